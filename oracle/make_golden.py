@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- regenerates tests/golden/ from the compiled reference.
+
+Runs oracle/_ref/ref_dump (the unmodified abPOA v1.4.1, built by oracle/Makefile with
+gcc -O3 -mavx2 -fno-strict-aliasing) over the reference's own test data and over seeded synthetic
+read-sets, and stores per-alignment containers (inputs + the reference's bands, planes or per-row
+plane checksums, best score, cigar) as tests/golden/<case>/aln_XXX.abpg.gz plus the reference's final
+consensus / MSA text.  Only runs where /root/reference exists; the fixtures it writes are data.
+
+usage: python oracle/make_golden.py
+"""
+import gzip
+import glob
+import os
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+from abpoa_amd import synth  # noqa: E402
+
+REF = H.REFERENCE_TREE
+AG = ["-O", "4,0", "-E", "2"]
+LG = ["-O", "0,0", "-E", "2"]
+CG = []
+MODES = {"gb": [], "gu": ["-b", "-1"], "loc": ["-m", "1"], "ext": ["-m", "2"], "extz": ["-m", "2", "-z", "5"]}
+
+
+def cases(tmp):
+    s1k = os.path.join(tmp, "s1k.fa")
+    synth.write_fasta(s1k, synth.make_read_set(1, 0, 12, 1000, 0.05))
+    s10k = os.path.join(tmp, "s10k.fa")
+    synth.write_fasta(s10k, synth.make_read_set(2, 0, 9, 10000, 0.15))
+    aa = os.path.join(tmp, "aa.fa")
+    synth.write_fasta(aa, synth.make_read_set(5, 0, 8, 500, alphabet=synth.AA, rates=(0.05, 0.03, 0.03)))
+    seq, het, tst = (os.path.join(REF, "test_data", f) for f in ("seq.fa", "heter.fa", "test.fa"))
+    out = []
+    for gname, g in (("ag", AG), ("cg", CG), ("lg", LG)):
+        for mname, mo in MODES.items():
+            out.append((f"seq_{gname}_{mname}", seq, g + mo, "1,5,9", 1, None))
+        out.append((f"test_{gname}_gb", tst, g, "all", 1, None))
+        out.append((f"heter_{gname}_gb", het, g, "7", 0, None))
+    out.append(("heter_cg_extz", het, CG + MODES["extz"], "5,12", 0, None))
+    out.append(("seq_ag_sub", seq, AG, "3,8", 1, (10, 40)))
+    out.append(("heter_cg_sub", het, CG, "9", 0, (100, 500)))
+    out.append(("s1k_ag_gb", s1k, AG, "11", 0, None))
+    out.append(("s1k_cg_gb", s1k, CG, "5", 0, None))
+    out.append(("s10k_cg_i32", s10k, CG, "8", 0, None))
+    out.append(("s10k_ag_i32", s10k, AG, "8", 0, None))
+    out.append(("aa_blosum_loc", aa, ["-m", "1", "-c", "-t", os.path.join(REF, "BLOSUM62.mtx"), "-r", "1"], "3,7", 0, None))
+    out.append(("aa_blosum_gb", aa, ["-c", "-t", os.path.join(REF, "BLOSUM62.mtx")], "7", 0, None))
+    # whole-pipeline text goldens (consensus / MSA) used by the host-layer tests
+    out.append(("out_seq_cons", seq, AG, "none", 0, None))
+    out.append(("out_test_msa", tst, ["-r", "1"], "none", 0, None))
+    out.append(("out_test_cons_msa", tst, ["-r", "2"], "none", 0, None))
+    out.append(("out_heter_cons", het, CG, "none", 0, None))
+    out.append(("out_s1k_cons", s1k, AG, "none", 0, None))
+    return out
+
+
+def main():
+    if not H.have_ref():
+        sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
+    tmp = tempfile.mkdtemp()
+    for name, fa, opts, reads, planes, sub in cases(tmp):
+        d = os.path.join(tmp, name)
+        H.run_ref_dump(fa, d, opts, reads, planes=planes, sub=sub)
+        dst = os.path.join(H.GOLDEN_DIR, name)
+        shutil.rmtree(dst, ignore_errors=True)
+        os.makedirs(dst)
+        for f in sorted(glob.glob(os.path.join(d, "*.abpg"))):
+            with open(f, "rb") as fi, gzip.GzipFile(os.path.join(dst, os.path.basename(f) + ".gz"), "wb", mtime=0) as fo:
+                fo.write(fi.read())
+        shutil.copy(os.path.join(d, "output.txt"), os.path.join(dst, "output.txt"))
+        with open(os.path.join(dst, "cmd.txt"), "w") as f:
+            f.write(" ".join(o.replace(REF, "$REF").replace(tmp, "$TMP") for o in opts) + f" | reads={reads} sub={sub} input={os.path.basename(fa)}\n")
+        if fa.startswith(tmp):
+            shutil.copy(fa, os.path.join(dst, "input.fa"))
+    # the reference's own small inputs and matrices are data fixtures too
+    fx = os.path.join(H.GOLDEN_DIR, "data")
+    os.makedirs(fx, exist_ok=True)
+    for f in ("test_data/seq.fa", "test_data/heter.fa", "test_data/test.fa", "BLOSUM62.mtx", "HOXD70.mtx", "PAM250.mtx"):
+        shutil.copy(os.path.join(REF, f), os.path.join(fx, os.path.basename(f)))
+    shutil.rmtree(tmp)
+    print("golden fixtures written to", H.GOLDEN_DIR)
+
+
+if __name__ == "__main__":
+    main()
