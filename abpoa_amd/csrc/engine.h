@@ -1,0 +1,69 @@
+// Internal interface between the host engine (engine.cpp) and the device code (dp_kernel.hip).
+// Not installed; the public C-ABI is include/abpoa_hip.h.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+namespace abpoa_hip {
+
+// Per-alignment descriptor, resident in HBM for the duration of a launch.
+struct AlnDesc {
+    int32_t n_rows, qlen;
+    int32_t bits;        // 16 | 32  (reference: simd_abpoa_align.c:1672-1683)
+    int32_t inf_min;
+    int32_t w;           // band half-width, reference :445
+    int32_t cigar_cap;   // entries
+    int64_t query_off;   // into query pool (bytes)
+    int64_t row0;        // index of DP row 0 in every per-row pool
+    int64_t poff0;       // index of pred_off[0] / out_off[0] in the (n_rows+1)-sized offset pools
+    int64_t pred0;       // index of this alignment's first entry in pred_row pool
+    int64_t out0;        // same for out_row pool
+    int64_t plane_off;   // BYTE offset of this alignment's score-plane arena
+    int64_t plane_cap;   // arena capacity in cells (of `bits` width)
+    int64_t cigar_off;   // index into cigar pool (uint64 words)
+};
+
+// Per-alignment result record.
+struct AlnOut {
+    int32_t status;
+    int32_t best_score, best_row, best_col;
+    int32_t node_s, node_e, query_s, query_e;
+    int32_t n_aln_bases, n_matched_bases;
+    int32_t n_cigar;
+    int32_t pad;
+    int64_t n_cells;      // sum (end_sn-beg_sn+1)*pn over rows 1..gn-2
+    int64_t cells_used;   // arena cells consumed (all rows incl. row 0, all planes)
+};
+
+#define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
+
+// Everything one launch needs; passed by value as the kernel argument.
+struct DevBatch {
+    int32_t n;
+    int32_t m;
+    int32_t o1, e1, o2, e2;
+    int32_t align_mode, gap_mode, wb, zdrop, ret_cigar, rev_cigar;
+    const int32_t *mat;          // [m*m]
+    const AlnDesc *aln;          // [n]
+    AlnOut *out;                 // [n]
+    const uint8_t *query;        // pool
+    const uint8_t *row_base;     // per-row pools ...
+    const int32_t *row_node_id;
+    const int32_t *row_remain;
+    const uint8_t *row_active;
+    const int32_t *pred_off;     // (n_rows+1) per alignment
+    const int32_t *pred_row;
+    const int32_t *out_off;
+    const int32_t *out_row;
+    int32_t *left, *right;       // in/out
+    int32_t *dp_beg_sn, *dp_end_sn;   // out, per row (-1 = never computed)
+    int64_t *row_cell_off;       // out, per row: first cell of the row inside the alignment's arena
+    int32_t *row_max_i;          // out, per row
+    uint8_t *planes;             // arena pool (bytes)
+    uint64_t *cigar;             // pool
+};
+
+// Launches the DP kernel for the whole batch on `stream`.
+hipError_t launch_dp(const DevBatch &b, hipStream_t stream);
+
+}  // namespace abpoa_hip

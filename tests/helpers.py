@@ -3,6 +3,7 @@ the oracle binding, and comparison helpers.  Nothing here is imported by the pro
 import ctypes as C
 import os
 import subprocess
+import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +11,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_DIR = os.path.join(ORACLE_DIR, "_ref")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 REFERENCE_TREE = "/root/reference"
+sys.path.insert(0, ROOT)
 
 _DT = {0: np.uint8, 1: np.int32, 2: np.int64, 3: np.float32, 4: np.int16, 5: np.uint64}
 
@@ -34,36 +36,7 @@ def read_abpg(path):
     return out
 
 
-# ---- ctypes mirrors of include/abpoa_hip.h ---------------------------------------------------------
-class Scoring(C.Structure):
-    _fields_ = [("m", C.c_int32), ("mat", C.POINTER(C.c_int32)), ("max_mat", C.c_int32), ("min_mis", C.c_int32),
-                ("gap_open1", C.c_int32), ("gap_ext1", C.c_int32), ("gap_open2", C.c_int32), ("gap_ext2", C.c_int32),
-                ("align_mode", C.c_int32), ("gap_mode", C.c_int32), ("wb", C.c_int32), ("wf", C.c_float),
-                ("zdrop", C.c_int32), ("ret_cigar", C.c_int32), ("rev_cigar", C.c_int32)]
-
-
-class Problem(C.Structure):
-    _fields_ = [("n_rows", C.c_int32), ("qlen", C.c_int32), ("query", C.POINTER(C.c_uint8)),
-                ("row_base", C.POINTER(C.c_uint8)), ("row_node_id", C.POINTER(C.c_int32)),
-                ("row_remain", C.POINTER(C.c_int32)), ("row_active", C.POINTER(C.c_uint8)),
-                ("pred_off", C.POINTER(C.c_int32)), ("pred_row", C.POINTER(C.c_int32)),
-                ("out_off", C.POINTER(C.c_int32)), ("out_row", C.POINTER(C.c_int32)),
-                ("max_pos_left", C.POINTER(C.c_int32)), ("max_pos_right", C.POINTER(C.c_int32))]
-
-
-class HipTrace(C.Structure):
-    _fields_ = [("bits", C.c_int32), ("n_planes", C.c_int32),
-                ("dp_beg", C.POINTER(C.c_int32)), ("dp_end", C.POINTER(C.c_int32)),
-                ("dp_beg_sn", C.POINTER(C.c_int32)), ("dp_end_sn", C.POINTER(C.c_int32)),
-                ("row_off", C.POINTER(C.c_int64)), ("planes", C.c_void_p), ("row_max_i", C.POINTER(C.c_int32))]
-
-
-class Result(C.Structure):
-    _fields_ = [("status", C.c_int32), ("bits", C.c_int32), ("best_score", C.c_int32), ("best_row", C.c_int32),
-                ("best_col", C.c_int32), ("node_s", C.c_int32), ("node_e", C.c_int32), ("query_s", C.c_int32),
-                ("query_e", C.c_int32), ("n_aln_bases", C.c_int32), ("n_matched_bases", C.c_int32),
-                ("n_cigar", C.c_int32), ("cigar", C.POINTER(C.c_uint64)), ("n_cells", C.c_int64),
-                ("trace", C.POINTER(HipTrace))]
+from abpoa_amd.ffi import Scoring, Problem, Result, Trace as HipTrace  # noqa: E402  (C-ABI structs)
 
 
 class OracleTrace(C.Structure):
@@ -268,3 +241,64 @@ def golden_cases(with_planes_only=False):
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*", "aln_*.abpg.gz"))):
         out.append((os.path.basename(os.path.dirname(f)) + "/" + os.path.basename(f)[:-8], f))
     return out
+
+
+def run_hip(cases, want_trace=True):
+    """Run FlatCases through the C-ABI (abpoa_hip_align_batch); returns a list of OracleOut-like objects."""
+    from abpoa_amd import ffi
+    lib = ffi.lib()
+    n = len(cases)
+    for c in cases:
+        c.reset()
+        assert c.sc.m == cases[0].sc.m
+    pbs = (Problem * n)(*[c.pb for c in cases])
+    res = (Result * n)()
+    rc = lib.abpoa_hip_align_batch(C.byref(cases[0].sc), n, pbs, res, ffi.FLAG_TRACE if want_trace else 0)
+    ffi.check(rc)
+    outs = []
+    for i, case in enumerate(cases):
+        r = res[i]
+        o = OracleOut()
+        o.rc, o.status, o.bits = rc, r.status, r.bits
+        for k in ("best_score", "best_row", "best_col", "node_s", "node_e", "query_s", "query_e", "n_aln_bases",
+                  "n_matched_bases", "n_cigar", "n_cells"):
+            setattr(o, k, getattr(r, k))
+        o.cigar = np.ctypeslib.as_array(r.cigar, (r.n_cigar,)).copy() if r.n_cigar > 0 else np.zeros(0, np.uint64)
+        o.left, o.right = case.left.copy(), case.right.copy()
+        if want_trace and r.trace:
+            t = r.trace.contents
+            nr = case.n_rows
+            o.P = t.n_planes
+            for k in ("dp_beg", "dp_end", "dp_beg_sn", "dp_end_sn", "row_max_i"):
+                setattr(o, k, np.ctypeslib.as_array(getattr(t, k), (nr,)).copy())
+            o.row_off = np.ctypeslib.as_array(t.row_off, (nr + 1,)).copy()
+            tot = int(o.row_off[-1])
+            dt = np.int16 if t.bits == 16 else np.int32
+            o.planes = np.frombuffer((C.c_char * (tot * dt().itemsize)).from_address(t.planes), dt).astype(np.int32) if tot else np.zeros(0, np.int32)
+        lib.abpoa_hip_free_result(C.byref(res[i]))
+        outs.append(o)
+    return outs
+
+
+def compare_outs(a, b, label=""):
+    """HIP vs oracle on the same problem (both OracleOut-like)."""
+    assert a.status == b.status == 0, f"{label}: status {a.status}/{b.status}"
+    for k in ("bits", "best_score", "best_row", "best_col", "n_cigar", "n_cells", "node_s", "node_e", "query_s",
+              "query_e", "n_aln_bases", "n_matched_bases"):
+        assert getattr(a, k) == getattr(b, k), f"{label}: {k} {getattr(a, k)} vs {getattr(b, k)}"
+    assert np.array_equal(a.cigar, b.cigar), f"{label}: cigar differs"
+    assert np.array_equal(a.left, b.left) and np.array_equal(a.right, b.right), f"{label}: band state differs"
+    if hasattr(a, "dp_beg") and hasattr(b, "dp_beg"):
+        for k in ("dp_beg", "dp_end", "dp_beg_sn", "dp_end_sn", "row_off"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), f"{label}: {k} differs"
+        m = b.dp_beg_sn >= 0
+        m[0] = False
+        assert np.array_equal(a.row_max_i[m], b.row_max_i[m]), f"{label}: row arg-max differs"
+        if not np.array_equal(a.planes, b.planes):
+            bad = int(np.nonzero(a.planes != b.planes)[0][0])
+            r = int(np.searchsorted(b.row_off, bad, side="right") - 1)
+            pn = 16 if b.bits == 16 else 8
+            wv = (int(b.dp_end_sn[r]) - int(b.dp_beg_sn[r]) + 1) * pn
+            rel = bad - int(b.row_off[r])
+            raise AssertionError(f"{label}: plane cell differs: row {r} plane {rel // wv} col "
+                                 f"{int(b.dp_beg_sn[r]) * pn + rel % wv}: {a.planes[bad]} vs {b.planes[bad]}")
