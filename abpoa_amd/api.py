@@ -1,0 +1,146 @@
+"""Host-side mirror of the reference's parameter block and thin wrappers over the C-ABI.
+
+`Params` mirrors abpoa_para_t (ref src/abpoa.h:62-81) with the defaults of abpoa_init_para
+(src/abpoa_align.c:93-141) and the derived fields of abpoa_post_set_para (:143-168)."""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi, seqio
+
+GLOBAL, LOCAL, EXTEND = 0, 1, 2
+LINEAR, AFFINE, CONVEX = 0, 1, 2
+OUT_CONS, OUT_MSA = 1, 2
+
+
+class ReadSet(C.Structure):          # abpoa_hip_readset_t
+    _fields_ = [("n_reads", C.c_int32), ("seqs", C.POINTER(C.POINTER(C.c_uint8))), ("lens", C.POINTER(C.c_int32))]
+
+
+class Msa(C.Structure):              # abpoa_hip_msa_t
+    _fields_ = [("status", C.c_int32), ("n_reads", C.c_int32), ("cons_len", C.c_int32),
+                ("cons_base", C.POINTER(C.c_uint8)), ("cons_cov", C.POINTER(C.c_int32)), ("cons_node_id", C.POINTER(C.c_int32)),
+                ("msa_len", C.c_int32), ("msa_rows", C.c_int32), ("msa_base", C.POINTER(C.c_uint8)), ("n_cells", C.c_int64)]
+
+
+class MsaTiming(C.Structure):        # abpoa_hip_msa_timing_t
+    _fields_ = [("host_sort_s", C.c_double), ("host_fuse_s", C.c_double), ("engine_s", C.c_double), ("cons_s", C.c_double),
+                ("total_s", C.c_double), ("n_rounds", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class Params:
+    def __init__(self, aln_mode=GLOBAL, is_aa=False, match=2, mismatch=4, score_matrix=None, gap_open1=4, gap_open2=24,
+                 gap_ext1=2, gap_ext2=1, extra_b=10, extra_f=0.01, zdrop=-1):
+        self.align_mode, self.m = aln_mode, (27 if is_aa else 5)
+        self.match, self.mismatch, self.mat_fn = match, mismatch, score_matrix
+        self.gap_open1, self.gap_open2, self.gap_ext1, self.gap_ext2 = gap_open1, gap_open2, gap_ext1, gap_ext2
+        self.wb, self.wf, self.zdrop = extra_b, extra_f, zdrop
+        self.finalize()
+
+    def finalize(self):
+        """abpoa_post_set_para: gap mode from the open penalties, LOCAL disables the band, matrix."""
+        if self.gap_open1 == 0:
+            self.gap_mode = LINEAR
+        elif self.gap_open1 > 0 and self.gap_open2 == 0:
+            self.gap_mode = AFFINE
+        else:
+            self.gap_mode = CONVEX
+        if self.align_mode == LOCAL:
+            self.wb = -1
+        if self.mat_fn:
+            self.mat, self.max_mat, self.min_mis = seqio.matrix_from_file(self.mat_fn, self.m)
+        else:
+            self.mat, self.max_mat, self.min_mis = seqio.simple_matrix(self.m, self.match, self.mismatch)
+        self.mat = np.ascontiguousarray(self.mat, np.int32)
+        return self
+
+    def scoring(self):
+        return ffi.Scoring(self.m, self.mat.ctypes.data_as(C.POINTER(C.c_int32)), self.max_mat, self.min_mis, self.gap_open1,
+                           self.gap_ext1, self.gap_open2, self.gap_ext2, self.align_mode, self.gap_mode, self.wb,
+                           float(self.wf), self.zdrop, 1, 0)
+
+
+class SetResult:
+    __slots__ = ("status", "cons_seq", "cons_cov", "cons_len", "msa_seq", "msa_len", "n_cells")
+
+
+def _bind_msa(lib):
+    if not getattr(lib, "_msa_bound", False):
+        lib.abpoa_hip_msa_batch.argtypes = [C.POINTER(ffi.Scoring), C.c_int, C.POINTER(ReadSet), C.POINTER(Msa), C.c_uint, C.c_int]
+        lib.abpoa_hip_msa_batch.restype = C.c_int
+        lib.abpoa_hip_free_msa.argtypes = [C.POINTER(Msa)]
+        lib.abpoa_hip_get_msa_timing.argtypes = [C.POINTER(MsaTiming)]
+        lib._msa_bound = True
+
+
+class EncodedSets:
+    """Read-sets encoded once into residue codes and laid out for abpoa_hip_msa_batch (kept alive on self)."""
+
+    def __init__(self, read_sets, m=5):
+        self.n = len(read_sets)
+        self.codes = [[np.ascontiguousarray(seqio.encode(r, m)) for r in rs] for rs in read_sets]
+        self.sets = (ReadSet * self.n)()
+        self._keep = []
+        for i, rs in enumerate(self.codes):
+            ptrs = (C.POINTER(C.c_uint8) * len(rs))(*[a.ctypes.data_as(C.POINTER(C.c_uint8)) for a in rs])
+            lens = (C.c_int32 * len(rs))(*[len(a) for a in rs])
+            self._keep.append((ptrs, lens))
+            self.sets[i] = ReadSet(len(rs), ptrs, lens)
+
+
+def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=None, encoded=None):
+    """Consensus / MSA of many independent read-sets (lists of strings) in one call.
+    Returns a list of SetResult.  `lib` defaults to the HIP engine (tests may pass the CPU shim)."""
+    lib = lib or ffi.lib()
+    _bind_msa(lib)
+    enc = encoded or EncodedSets(read_sets, params.m)
+    out = (Msa * enc.n)()
+    sc = params.scoring()
+    flags = (OUT_CONS if out_cons else 0) | (OUT_MSA if out_msa else 0)
+    rc = lib.abpoa_hip_msa_batch(C.byref(sc), enc.n, enc.sets, out, flags, n_threads)
+    if rc != 0:
+        raise ffi.EngineError(f"abpoa_hip_msa_batch failed ({rc}): {lib.abpoa_hip_last_error().decode() if hasattr(lib, 'abpoa_hip_last_error') else ''}")
+    res = []
+    for i in range(enc.n):
+        o, r = out[i], SetResult()
+        r.status, r.n_cells = o.status, o.n_cells
+        r.cons_len = o.cons_len
+        r.cons_seq = seqio.decode(np.ctypeslib.as_array(o.cons_base, (o.cons_len,)), params.m) if o.cons_len > 0 else ""
+        r.cons_cov = np.ctypeslib.as_array(o.cons_cov, (o.cons_len,)).tolist() if o.cons_len > 0 else []
+        r.msa_len = o.msa_len
+        r.msa_seq = []
+        if o.msa_len > 0:
+            mb = np.ctypeslib.as_array(o.msa_base, (o.msa_rows, o.msa_len))
+            r.msa_seq = [seqio.decode(row, params.m) for row in mb]
+        lib.abpoa_hip_free_msa(C.byref(out[i]))
+        res.append(r)
+    return res
+
+
+def msa_timing(lib=None):
+    lib = lib or ffi.lib()
+    _bind_msa(lib)
+    t = MsaTiming()
+    lib.abpoa_hip_get_msa_timing(C.byref(t))
+    return {k: getattr(t, k) for k, _ in MsaTiming._fields_}
+
+
+def format_output(result, names=None, out_cons=True, out_msa=False):
+    """Text exactly as the reference prints it: abpoa_output_rc_msa (src/abpoa_output.c:70-101) when MSA is
+    requested, else abpoa_output_fx_consensus (:495-512), single consensus."""
+    lines = []
+    if out_msa:
+        if result.msa_len <= 0:
+            return ""
+        n_reads = len(result.msa_seq) - (1 if out_cons else 0)
+        for i in range(n_reads):
+            nm = names[i] if names and i < len(names) and names[i] else None
+            lines.append(f">{nm}" if nm else f">Seq_{i + 1}")
+            lines.append(result.msa_seq[i])
+        if out_cons:
+            lines.append(">Consensus_sequence")
+            lines.append(result.msa_seq[-1])
+    elif out_cons:
+        lines.append(">Consensus_sequence")
+        lines.append(result.cons_seq)
+    return "\n".join(lines) + "\n"

@@ -1,0 +1,177 @@
+// Read-set batch driver (include/abpoa_hip.h section 3).  Reference counterpart per set:
+// abpoa_msa -> abpoa_poa -> {abpoa_align_sequence_to_graph, abpoa_add_graph_alignment} -> abpoa_output
+// (src/abpoa_align.c:302-437).  Here the per-read loop is turned inside out: all sets advance one read
+// per round so that one engine launch carries one alignment of every set.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+#include "msa_batch.h"
+#include "poa_graph.h"
+
+namespace abpoa_hip {
+
+namespace {
+// Minimal persistent fork-join pool: run(n, fn) executes fn(i) for i in [0,n) on all workers + caller.
+class Pool {
+  public:
+    explicit Pool(int n) : n_(n < 1 ? 1 : n) {
+        for (int t = 1; t < n_; ++t) th_.emplace_back([this] { worker(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void run(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        fn_ = &fn; total_ = n; next_.store(0); pending_.store(n_ - 1);
+        { std::lock_guard<std::mutex> lk(mu_); ++gen_; }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_.load() == 0; });
+    }
+  private:
+    void drain() { for (int i; (i = next_.fetch_add(1)) < total_;) (*fn_)(i); }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+            drain();
+            if (pending_.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(mu_); done_cv_.notify_all(); }
+        }
+    }
+    int n_; std::vector<std::thread> th_;
+    std::mutex mu_; std::condition_variable cv_, done_cv_;
+    uint64_t gen_ = 0; bool stop_ = false;
+    const std::function<void(int)> *fn_ = nullptr; int total_ = 0;
+    std::atomic<int> next_{0}, pending_{0};
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out,
+                  unsigned flags, int n_threads, AlignBatchFn align, abpoa_hip_msa_timing_t *tm) {
+    if (n_sets < 0 || !sc || (n_sets > 0 && (!sets || !out))) return ABPOA_HIP_EINVAL;
+    const double t_start = now_s();
+    if (tm) memset(tm, 0, sizeof(*tm));
+    for (int s = 0; s < n_sets; ++s) memset(&out[s], 0, sizeof(out[s]));
+    if (n_sets == 0) return ABPOA_HIP_OK;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_sets) n_threads = n_sets;
+    const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
+    const bool banded = sc->wb >= 0 && sc->align_mode != ABPOA_HIP_LOCAL_MODE;
+    abpoa_hip_scoring_t scoring = *sc;
+    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE) scoring.wb = -1;        // reference abpoa_post_set_para, abpoa_align.c:150
+    scoring.ret_cigar = 1; scoring.rev_cigar = 0;
+    int max_reads = 0;
+    for (int s = 0; s < n_sets; ++s) {
+        if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL;
+        for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL;
+        if (sets[s].n_reads > max_reads) max_reads = sets[s].n_reads;
+        out[s].n_reads = sets[s].n_reads;
+    }
+    Pool pool(n_threads);
+    std::vector<PoaGraph> graphs(n_sets);
+    std::vector<FlatProblem> flat(n_sets);
+    for (int s = 0; s < n_sets; ++s) graphs[s].reset(sets[s].n_reads, want_msa);
+    std::vector<int> active; active.reserve(n_sets);
+    std::vector<abpoa_hip_problem_t> problems; std::vector<abpoa_hip_result_t> results;
+    std::atomic<int> fail{0};
+    const bool with_remain = banded || scoring.zdrop > 0;
+    int rc = ABPOA_HIP_OK;
+    for (int k = 0; k < max_reads && rc == ABPOA_HIP_OK; ++k) {
+        active.clear();
+        for (int s = 0; s < n_sets; ++s) if (sets[s].n_reads > k && out[s].status == 0) active.push_back(s);
+        if (k == 0) {
+            pool.run((int)active.size(), [&](int a) {
+                const int s = active[a];
+                try { graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0); } catch (...) { fail.store(1); }
+            });
+            continue;
+        }
+        double t0 = now_s();
+        problems.resize(active.size()); results.resize(active.size());
+        pool.run((int)active.size(), [&](int a) {
+            const int s = active[a];
+            try {
+                graphs[s].topological_sort(with_remain);
+                graphs[s].flatten(scoring.wb >= 0, &flat[s]);
+                problems[a] = flat[s].view(sets[s].seqs[k], sets[s].lens[k]);
+            } catch (...) { fail.store(1); }
+        });
+        if (fail.load()) { rc = ABPOA_HIP_EINVAL; break; }
+        double t1 = now_s();
+        rc = align((const abpoa_hip_scoring_t *)&scoring, (int)active.size(), problems.data(), results.data(), 0);
+        double t2 = now_s();
+        if (rc != ABPOA_HIP_OK) break;
+        pool.run((int)active.size(), [&](int a) {
+            const int s = active[a];
+            abpoa_hip_result_t &r = results[a];
+            if (r.status != 0) out[s].status = r.status;
+            else {
+                out[s].n_cells += r.n_cells;
+                try { graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], r.cigar, r.n_cigar, k); } catch (...) { fail.store(1); }
+            }
+            free(r.cigar); r.cigar = nullptr;
+        });
+        double t3 = now_s();
+        if (tm) { tm->host_sort_s += t1 - t0; tm->engine_s += t2 - t1; tm->host_fuse_s += t3 - t2; tm->n_rounds += 1; }
+        if (fail.load()) { rc = ABPOA_HIP_EINVAL; break; }
+    }
+    if (rc == ABPOA_HIP_OK) {
+        double t0 = now_s();
+        pool.run(n_sets, [&](int s) {
+            if (out[s].status != 0 || graphs[s].empty()) return;
+            abpoa_hip_msa_t &o = out[s];
+            std::vector<int> ids, cov; std::vector<uint8_t> bases;
+            if (want_cons) {
+                graphs[s].consensus(&ids, &bases, &cov);
+                o.cons_len = (int)ids.size();
+                o.cons_base = (uint8_t *)malloc(ids.size() + 1); o.cons_cov = (int32_t *)malloc(4 * (ids.size() + 1)); o.cons_node_id = (int32_t *)malloc(4 * (ids.size() + 1));
+                memcpy(o.cons_base, bases.data(), bases.size()); memcpy(o.cons_cov, cov.data(), 4 * cov.size()); memcpy(o.cons_node_id, ids.data(), 4 * ids.size());
+            }
+            if (want_msa) {
+                int msa_len = 0; std::vector<std::vector<uint8_t>> rows; std::vector<int> col;
+                graphs[s].rc_msa(scoring.m, &msa_len, &rows, &col);
+                o.msa_len = msa_len; o.msa_rows = sets[s].n_reads + (want_cons ? 1 : 0);
+                o.msa_base = (uint8_t *)malloc((size_t)o.msa_rows * (msa_len > 0 ? msa_len : 1));
+                for (int r = 0; r < sets[s].n_reads; ++r) memcpy(o.msa_base + (size_t)r * msa_len, rows[r].data(), msa_len);
+                if (want_cons) {                                      // reference abpoa_output.c:151-164
+                    uint8_t *crow = o.msa_base + (size_t)sets[s].n_reads * msa_len;
+                    memset(crow, scoring.m, msa_len);
+                    for (size_t i = 0; i < ids.size(); ++i) crow[col[ids[i]]] = bases[i];
+                }
+            }
+        });
+        if (tm) tm->cons_s = now_s() - t0;
+    }
+    if (tm) { tm->total_s = now_s() - t_start; tm->n_threads = n_threads; }
+    if (rc != ABPOA_HIP_OK) for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]);
+    return rc;
+}
+
+static abpoa_hip_msa_timing_t g_timing;
+
+}  // namespace abpoa_hip
+
+extern "C" {
+int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
+                        abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
+    return abpoa_hip::run_msa_batch(sc, n_sets, sets, out, flags, n_threads, abpoa_hip_align_batch, &abpoa_hip::g_timing);
+}
+void abpoa_hip_free_msa(abpoa_hip_msa_t *r) {
+    if (!r) return;
+    free(r->cons_base); free(r->cons_cov); free(r->cons_node_id); free(r->msa_base);
+    r->cons_base = nullptr; r->cons_cov = nullptr; r->cons_node_id = nullptr; r->msa_base = nullptr;
+    r->cons_len = r->msa_len = r->msa_rows = 0;
+}
+void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
+}

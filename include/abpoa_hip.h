@@ -152,6 +152,44 @@ void abpoa_hip_free_result(abpoa_hip_result_t *r);   /* frees cigar + trace, zer
  * stores inf_min.  Pure host arithmetic, usable without a GPU. */
 int  abpoa_hip_score_bits(const abpoa_hip_scoring_t *sc, int n_rows, int qlen, int32_t *inf_min);
 
+/* ---- (3) read-set batch API -------------------------------------------------------------------- */
+/* Progressive POA of N independent read-sets in lock-step rounds: round k aligns read k of every
+ * set to that set's graph (one engine launch for all sets), then fuses the cigars on host threads.
+ * Per set this is the reference's abpoa_msa() (src/abpoa_align.c:373-437) with plain abpoa_poa()
+ * (:302-344): no seeding / guide tree, unit weights, no reverse-complement retry.  Graph fusion,
+ * row ordering and the consensus / MSA calls follow the reference so that outputs are identical.   */
+typedef struct abpoa_hip_readset_t {
+    int32_t n_reads;
+    const uint8_t *const *seqs;   /* [n_reads] residue codes 0..m-1                                  */
+    const int32_t *lens;          /* [n_reads] each > 0                                               */
+} abpoa_hip_readset_t;
+
+typedef struct abpoa_hip_msa_t {
+    int32_t  status;              /* ABPOA_HIP_OK or the first failing alignment's code              */
+    int32_t  n_reads;
+    int32_t  cons_len;            /* single heaviest-bundling consensus (abpoa_cons_t, n_cons = 1)   */
+    uint8_t *cons_base;           /* [cons_len]                                                       */
+    int32_t *cons_cov;            /* [cons_len]                                                       */
+    int32_t *cons_node_id;        /* [cons_len]                                                       */
+    int32_t  msa_len;             /* 0 unless ABPOA_HIP_OUT_MSA                                       */
+    int32_t  msa_rows;            /* n_reads (+1 consensus row when both outputs are requested)       */
+    uint8_t *msa_base;            /* [msa_rows*msa_len] row-major, gap = m (abpoa_cons_t.msa_base)    */
+    int64_t  n_cells;             /* DP cells over all alignments of the set                          */
+} abpoa_hip_msa_t;
+
+#define ABPOA_HIP_OUT_CONS 0x1u   /* abpoa_para_t.out_cons */
+#define ABPOA_HIP_OUT_MSA  0x2u   /* abpoa_para_t.out_msa  */
+
+/* n_threads <= 0: one host thread per online core.  Every out[i] must be released with
+ * abpoa_hip_free_msa.  Fails with ABPOA_HIP_ENODEV when no GPU is usable. */
+int  abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
+                         abpoa_hip_msa_t *out, unsigned flags, int n_threads);
+void abpoa_hip_free_msa(abpoa_hip_msa_t *r);
+
+/* Phase timers of the last abpoa_hip_msa_batch call (seconds): host graph work, engine calls. */
+typedef struct abpoa_hip_msa_timing_t { double host_sort_s, host_fuse_s, engine_s, cons_s, total_s; int32_t n_rounds, n_threads; } abpoa_hip_msa_timing_t;
+void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -302,3 +302,26 @@ def compare_outs(a, b, label=""):
             rel = bad - int(b.row_off[r])
             raise AssertionError(f"{label}: plane cell differs: row {r} plane {rel // wv} col "
                                  f"{int(b.dp_beg_sn[r]) * pn + rel % wv}: {a.planes[bad]} vs {b.planes[bad]}")
+
+
+_shim = None
+
+
+def cpu_shim_lib():
+    """CPU-only build of the product's host layer with an oracle-backed aligner (tests/cpu_shim.cpp)."""
+    global _shim
+    if _shim is None:
+        bdir = os.path.join(ROOT, "tests", "_build")
+        os.makedirs(bdir, exist_ok=True)
+        so = os.path.join(bdir, "libcpu_shim.so")
+        srcs = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.cpp"),
+                os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.cpp")]
+        deps = srcs + [os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.h"),
+                       os.path.join(ROOT, "include", "abpoa_hip.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+            obj = os.path.join(bdir, "oracle.o")
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-c", "-I" + os.path.join(ROOT, "include"), "-o", obj,
+                                   os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c")])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", so] + srcs + [obj])
+        _shim = C.CDLL(so)
+    return _shim
