@@ -1,13 +1,20 @@
 // Adaptive-banded sequence-to-graph DP for gfx950 (MI355X).
 //
-// One 64-lane wavefront owns one alignment and walks its graph rows in topological order (rows of one
-// alignment are strictly sequential: the band of row r depends on the arg-max of all its predecessor
-// rows, reference src/simd_abpoa_align.c:1059-1067).  Lanes map to consecutive band columns, 64 columns
-// ("chunk") at a time; inside a chunk the reference's SIMD register (pn = 16 int16 / 8 int32 lanes) is a
-// group of pn adjacent lanes, so its whole-register lane shifts become DPP row shifts and its
-// vector-to-vector carry ("first") is a wave-uniform scalar.  Score planes are stored band-compacted in
-// HBM: row r owns P*(end_sn-beg_sn+1)*pn cells, written once with coalesced stores and re-read by
-// successor rows and by the backtrack.
+// One 64-lane wavefront (= one workgroup) owns one alignment and walks its graph rows in topological
+// order; rows of one alignment are strictly sequential because the band of row r depends on the arg-max
+// of all its predecessor rows (reference src/simd_abpoa_align.c:1059-1067), so per-row LATENCY is what
+// the design minimises:
+//   * lanes map to consecutive band columns, 64 columns ("chunk") at a time; the reference's SIMD register
+//     (pn = 16 int16 / 8 int32 lanes) is a group of pn adjacent lanes, its whole-register lane shifts are
+//     DPP row shifts and its vector-to-vector carry ("first") is a wave-uniform scalar;
+//   * everything a row needs from earlier rows lives in LDS: a 64-row tile of static graph metadata
+//     (base, predecessor / successor lists, remaining length), a ring with the band geometry of the last
+//     256 rows, a look-ahead ring of max_pos_left/right for the next 256 rows and a ring with the H/E
+//     score rows of the last `ring_rows` rows (predecessor distance is 1-12 rows in practice).  Older
+//     predecessors and over-wide rows fall back to the HBM copy;
+//   * score planes are also streamed band-compacted to HBM (row r owns P*(end_sn-beg_sn+1)*pn cells,
+//     written once, coalesced) because the backtrack compares H/E/F by value; the backtrack then pulls
+//     64-row windows of that arena back into LDS with wide coalesced loads and walks them there.
 //
 // Bit-exactness contract: every add/sub is done in the score width with
 // two's-complement wrap, the masked log-step scan of SIMD_SET_F (:665-699) is reproduced step by step,
@@ -15,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <type_traits>
 #include "engine.h"
 #include "../../include/abpoa_hip.h"
 
@@ -29,6 +37,30 @@ namespace abpoa_hip {
 #define OP_F   0x18
 #define OP_ALL 0x1f
 
+constexpr int TS = 64;      // rows per static-metadata tile
+constexpr int TP = 256;     // predecessor / successor entries staged per tile
+constexpr int RB = 256;     // band-geometry ring depth (rows)
+constexpr int RL = 256;     // max_pos_left/right window (two halves of 128 rows)
+constexpr int RLH = RL / 2;
+constexpr int MAX_RING_ROWS = 32;
+constexpr int BTR = 64;     // backtrack tile: rows
+constexpr int BTP = 256;    // backtrack tile: predecessor entries
+
+struct DpLds {              // fixed part of the DP-phase LDS image
+    int32_t t_poff[TS + 1], t_ooff[TS + 1], t_remain[TS], t_pred[TP], t_out[TP];
+    int32_t b_bsn[RB], b_esn[RB]; uint32_t b_coff[RB];      // b_coff in units of PN cells
+    int32_t l_left[RL], l_right[RL];
+    int32_t ring_tag[MAX_RING_ROWS];
+    uint8_t t_base[TS], t_act[TS];
+};
+struct BtLds {              // fixed part of the backtrack-phase LDS image
+    long long coff[BTR + 1];
+    int32_t bsn[BTR], esn[BTR], poff[BTR + 1], nid[BTR], pred[BTP];
+    uint8_t base[BTR];
+};
+int lds_fixed_bytes_dp() { return (int)((sizeof(DpLds) + 15) & ~15u); }
+int lds_fixed_bytes_bt() { return (int)((sizeof(BtLds) + 15) & ~15u); }
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
@@ -40,7 +72,7 @@ __device__ __forceinline__ int row_shr(int old, int src) { return dpp_mov<0x110 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// wave-wide signed max; every lane must be active
+// wave-wide max; every lane must be active
 __device__ __forceinline__ int wave_max_i32(int x) {
     x = imax(x, row_shr<1>(x, x));
     x = imax(x, row_shr<2>(x, x));
@@ -60,6 +92,21 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
     unsigned c = __builtin_amdgcn_readlane((int)x, 47), d = __builtin_amdgcn_readlane((int)x, 63);
     return umax(umax(a, b), umax(c, d));
 }
+
+// Rare-path HBM loads.  They are written as inline asm on purpose: with ordinary loads hipcc merges the LDS load of
+// the common path and the global load of the fallback path into ONE flat load of a selected pointer, and a flat load
+// waits for vmcnt(0)+lgkmcnt(0), i.e. for every outstanding score-plane store of the wave (gfx9 counts stores in vmcnt).
+// Each helper waits for its own data (and, as a side effect, for this wave's earlier stores, which these paths need).
+__device__ __forceinline__ int gld_i32(const int32_t *p) { int v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ int gld_u8(const uint8_t *p) { int v; asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ long long gld_i64(const int64_t *p) { long long v; asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ int gld_cell(const int16_t *p) { int v; asm volatile("global_load_sshort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ int gld_cell(const int32_t *p) { return gld_i32(p); }
+
+// Moves a wave-uniform pointer into a VGPR pair and hides its uniformity from the compiler.  The kernel keeps ~20
+// per-alignment base pointers; left in SGPRs they (with the per-row uniforms) overflow the 102-SGPR budget and the hot
+// loop drowns in v_readlane/v_writelane spill traffic.  VGPRs are plentiful here (one wave per SIMD).
+template <typename Pt> __device__ __forceinline__ Pt *vgpr_ptr(Pt *p) { asm("" : "+v"(p)); return p; }
 
 template <typename T> struct Width;
 template <> struct Width<int16_t> { static constexpr int PN = 16, LOGN = 4; };
@@ -91,14 +138,14 @@ __device__ __forceinline__ T set_f(T f, int l, int set_num, T e, T inf) {
     return f;
 }
 
-template <typename T>
-struct RowMeta { int beg_sn, end_sn; long long off; };
+extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 // GAP: 0 linear, 1 affine, 2 convex (reference gap_mode)
 template <typename T, int GAP>
-__device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
+__device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
     constexpr int PN = Width<T>::PN, NV = 64 / PN;
     constexpr int P = GAP == 0 ? 1 : (GAP == 1 ? 3 : 5);
+    constexpr int NPR = GAP == 0 ? 1 : (GAP == 1 ? 2 : 3);        // planes kept in the LDS score ring: H, E1, E2
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
     const int lane = threadIdx.x & 63, l = lane % PN, vvl = lane / PN;
     const int gn = d.n_rows, qlen = d.qlen, m = b.m, w = d.w;
@@ -108,82 +155,168 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
     const T e1 = (T)b.e1, o1 = (T)b.o1, oe1 = (T)(b.o1 + b.e1), e2 = (T)b.e2, o2 = (T)b.o2, oe2 = (T)(b.o2 + b.e2);
     const int dp_sn = (qlen + PN) / PN;
 
-    const uint8_t *query = b.query + d.query_off;
-    const uint8_t *row_base = b.row_base + d.row0;
-    const int32_t *row_node_id = b.row_node_id + d.row0;
-    const int32_t *row_remain = b.row_remain + d.row0;
-    const uint8_t *row_active = b.row_active + d.row0;
-    const int32_t *pred_off = b.pred_off + d.poff0, *pred_row = b.pred_row + d.pred0;
-    const int32_t *out_off = b.out_off + d.poff0, *out_row = b.out_row + d.out0;
-    int32_t *left = b.left + d.row0, *right = b.right + d.row0;
-    int32_t *bsn = b.dp_beg_sn + d.row0, *esn = b.dp_end_sn + d.row0, *row_max_i = b.row_max_i + d.row0;
-    int64_t *cell_off = b.row_cell_off + d.row0;
+    const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
+    const uint8_t *row_base = vgpr_ptr(b.row_base + d.row0);
+    const int32_t *row_node_id = vgpr_ptr(b.row_node_id + d.row0);
+    const int32_t *row_remain = vgpr_ptr(b.row_remain + d.row0);
+    const uint8_t *row_active = vgpr_ptr(b.row_active + d.row0);
+    const int32_t *pred_off = vgpr_ptr(b.pred_off + d.poff0), *pred_row = vgpr_ptr(b.pred_row + d.pred0);
+    const int32_t *out_off = vgpr_ptr(b.out_off + d.poff0), *out_row = vgpr_ptr(b.out_row + d.out0);
+    int32_t *g_left = vgpr_ptr(b.left + d.row0), *g_right = vgpr_ptr(b.right + d.row0);
+    int32_t *g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0), *g_esn = vgpr_ptr(b.dp_end_sn + d.row0), *row_max_i = vgpr_ptr(b.row_max_i + d.row0);
+    int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
     T *planes = (T *)(b.planes + d.plane_off);
-    const int32_t *mat = b.mat;
+
+    // ---- LDS carve-up (engine.h LdsPlan)
+    uint8_t *s_query = lds_raw + b.lds.q_off;
+    int32_t *s_mat = (int32_t *)(lds_raw + b.lds.mat_off);
+    DpLds &S = *(DpLds *)(lds_raw + b.lds.phase_off);
+    T *s_ring = (T *)(lds_raw + b.lds.phase_off + b.lds.ring_off);
+    const int ring_rows = b.lds.ring_rows, ring_cols = b.lds.ring_cols;
+    const bool q_in_lds = qlen <= b.lds.q_cap;
+
+    { const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < m * m; i += 64) s_mat[i] = g_mat[i]; }
+    if (q_in_lds) for (int i = lane; i < qlen; i += 64) s_query[i] = g_query[i];
+    if (lane < MAX_RING_ROWS) S.ring_tag[lane] = -1;
 
     // dp_end as the reference stores it: vector-rounded when banded and for row 0, qlen otherwise
-    auto dp_end_of = [&](int row, int end_sn_row) { return (banded || row == 0) ? (end_sn_row + 1) * PN - 1 : qlen; };
+    auto dp_end_of = [&](int row, int end_sn_row) __attribute__((always_inline)) { return (banded || row == 0) ? (end_sn_row + 1) * PN - 1 : qlen; };
 
     long long cursor = 0;          // next free arena cell
     long long n_cells = 0;
     int status = 0;
 
     // ------------------------------------------------------------------ row 0, reference :553-662
+    int end_sn0 = 0;
     {
         int dp_end0;
         if (banded) {
-            if (lane == 0) { left[0] = 0; right[0] = 0; }
-            for (int t = out_off[0] + lane; t < out_off[1]; t += 64) {
-                int o = out_row[t];
-                if (o >= 0 && row_active[o]) { left[o] = 1; right[o] = 1; }
-            }
             int r = row_remain[0] - row_remain[gn - 1] - 1;
-            dp_end0 = imin(qlen, imax(0, qlen - r) + w);          // right[0] == 0
+            dp_end0 = imin(qlen, imax(0, qlen - r) + w);          // max_pos_right[begin] == 0
         } else dp_end0 = qlen;
-        int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
+        end_sn0 = dp_end0 / PN;
+        const int W0 = (end_sn0 + 1) * PN;
         if ((long long)W0 * P > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; }
         else {
-            if (lane == 0) { bsn[0] = 0; esn[0] = end_sn0; cell_off[0] = 0; row_max_i[0] = -2; }
+            if (lane == 0) { g_bsn[0] = 0; g_esn[0] = end_sn0; g_coff[0] = 0; S.b_bsn[0] = 0; S.b_esn[0] = end_sn0; S.b_coff[0] = 0; }
+            const bool ring0 = W0 <= ring_cols;
             for (int i = lane; i < W0; i += 64) {
-                if (local) { for (int p = 0; p < P; ++p) planes[(long long)p * W0 + i] = 0; }
-                else if (GAP == 0) planes[i] = (T)(-(int)e1 * i);
+                T h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
+                if (local) { h = 0; x1 = 0; x2 = 0; f1 = 0; f2 = 0; }
+                else if (GAP == 0) h = (T)(-(int)e1 * i);
                 else if (GAP == 1) {
                     T g = (T)(-(int)o1 - (int)e1 * i);
-                    planes[i] = i == 0 ? (T)0 : g;
-                    planes[(long long)PL_E1 * W0 + i] = i == 0 ? (T)(-(int)oe1) : inf;
-                    planes[(long long)PL_F1 * W0 + i] = i == 0 ? inf : g;
+                    h = i == 0 ? (T)0 : g; x1 = i == 0 ? (T)(-(int)oe1) : inf; f1 = i == 0 ? inf : g;
                 } else {
                     T g1 = (T)(-(int)o1 - (int)e1 * i), g2 = (T)(-(int)o2 - (int)e2 * i);
-                    planes[i] = i == 0 ? (T)0 : tmax<T>(g1, g2);
-                    planes[(long long)PL_E1 * W0 + i] = i == 0 ? (T)(-(int)oe1) : inf;
-                    planes[(long long)PL_E2 * W0 + i] = i == 0 ? (T)(-(int)oe2) : inf;
-                    planes[(long long)PL_F1 * W0 + i] = i == 0 ? inf : g1;
-                    planes[(long long)PL_F2 * W0 + i] = i == 0 ? inf : g2;
+                    h = i == 0 ? (T)0 : tmax<T>(g1, g2);
+                    x1 = i == 0 ? (T)(-(int)oe1) : inf; x2 = i == 0 ? (T)(-(int)oe2) : inf;
+                    f1 = i == 0 ? inf : g1; f2 = i == 0 ? inf : g2;
+                }
+                planes[i] = h;
+                if (GAP != 0) { planes[(long long)PL_E1 * W0 + i] = x1; planes[(long long)PL_F1 * W0 + i] = f1; }
+                if (GAP == 2) { planes[(long long)PL_E2 * W0 + i] = x2; planes[(long long)PL_F2 * W0 + i] = f2; }
+                if (ring0) {
+                    s_ring[i] = h;
+                    if (GAP != 0) s_ring[ring_cols + i] = x1;
+                    if (GAP == 2) s_ring[2 * ring_cols + i] = x2;
                 }
             }
+            if (ring0 && lane == 0) S.ring_tag[0] = 0;
             cursor = (long long)W0 * P;
+        }
+    }
+    // ---- max_pos_left/right look-ahead window: LDS holds rows [lr_blk, lr_blk + RL)
+    int lr_blk = 0;
+    if (banded && status == 0) {
+        for (int i = lane; i < RL; i += 64) { const int r = i; if (r < gn) { S.l_left[i] = g_left[r]; S.l_right[i] = g_right[r]; } }
+        __syncthreads();
+        if (lane == 0) { S.l_left[0] = 0; S.l_right[0] = 0; }                 // reference :556
+        for (int t = out_off[0] + lane; t < out_off[1]; t += 64) {            // reference :557-561
+            const int o = out_row[t];
+            if (o >= 0 && row_active[o]) {
+                if (o < RL) { S.l_left[o] = 1; S.l_right[o] = 1; } else { g_left[o] = 1; g_right[o] = 1; }
+            }
         }
     }
     __syncthreads();
 
+#ifdef ABPOA_HIP_PROFILE
+    long long seg[6] = {0, 0, 0, 0, 0, 0}, seg_last = 0;
+#define STAMP(I) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); long long t_ = (long long)__builtin_amdgcn_s_memtime(); seg[I] += t_ - seg_last; seg_last = t_; }
+#else
+#define STAMP(I)
+#endif
+    const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
+#ifdef ABPOA_HIP_PROFILE
+    seg_last = clk0;
+#endif
+    int rows_done = 0, bt_steps = 0;
     int best_score = d.inf_min, best_i = 0, best_j = 0, best_row_zd = 0;
     const int remain_end = (banded || b.zdrop > 0) ? row_remain[gn - 1] : 0;
     const bool need_max = local || extend || banded;
+    int tile_beg = 0, tile_end = 0, pbase = 0, obase = 0;     // static-metadata tile covers rows [tile_beg, tile_end)
+    int last_row = 0;                                         // last row whose left/right entry was consumed
+    int last_done = 0;                                        // last row the loop reached (z-drop may stop early)
 
     // ------------------------------------------------------------------ rows 1 .. gn-2, reference :1105
     for (int row = 1; row < gn - 1 && status == 0; ++row) {
-        if (!row_active[row]) { if (lane == 0) { bsn[row] = -1; esn[row] = -1; row_max_i[row] = -2; } continue; }
-        const int base = row_base[row];
-        const int ps = pred_off[row], np = pred_off[row + 1] - ps;
+        if (row >= tile_end) {                                // ---- stage the next 64 rows of graph metadata
+            __syncthreads();
+            // band geometry of the rows of the finished tile goes to HBM in one coalesced burst (backtrack + trace read it)
+            if (tile_end > tile_beg && tile_beg + lane < tile_end) {
+                const int r = tile_beg + lane;
+                g_bsn[r] = S.b_bsn[r % RB]; g_esn[r] = S.b_esn[r % RB]; g_coff[r] = (long long)S.b_coff[r % RB] * PN;
+            }
+            tile_beg = row; tile_end = imin(row + TS, gn);
+            for (int i = lane; i <= TS; i += 64) { const int rr = imin(tile_beg + i, gn); S.t_poff[i] = pred_off[rr]; S.t_ooff[i] = out_off[rr]; }
+            if (tile_beg + lane < tile_end) {
+                S.t_base[lane] = row_base[tile_beg + lane]; S.t_act[lane] = row_active[tile_beg + lane];
+                S.t_remain[lane] = (banded || b.zdrop > 0) ? row_remain[tile_beg + lane] : 0;
+            }
+            __syncthreads();
+            pbase = S.t_poff[0]; obase = S.t_ooff[0];
+            const int pn_t = imin(TP, S.t_poff[TS] - pbase), on_t = imin(TP, S.t_ooff[TS] - obase);
+            for (int i = lane; i < pn_t; i += 64) S.t_pred[i] = pred_row[pbase + i];
+            for (int i = lane; i < on_t; i += 64) S.t_out[i] = out_row[obase + i];
+            __syncthreads();
+        }
+        if (banded && row >= lr_blk + RLH) {                  // ---- slide the left/right window by half
+            // rows [lr_blk, lr_blk+RLH) are retired: write them back, then load rows [lr_blk+RL, lr_blk+RL+RLH)
+            __syncthreads();
+            for (int i = lane; i < RLH; i += 64) {
+                const int r = lr_blk + i;
+                if (r < gn) { g_left[r] = S.l_left[r % RL]; g_right[r] = S.l_right[r % RL]; }
+                const int nr = lr_blk + RL + i;
+                if (nr < gn) { S.l_left[nr % RL] = g_left[nr]; S.l_right[nr % RL] = g_right[nr]; }
+            }
+            lr_blk += RLH;
+            __syncthreads();
+        }
+        STAMP(5)
+        last_done = row;
+        const int ti = row - tile_beg;
+        if (!S.t_act[ti]) { if (lane == 0) { S.b_bsn[row % RB] = -1; S.b_esn[row % RB] = -1; S.b_coff[row % RB] = (uint32_t)(cursor / PN); } continue; }
+        const int base = S.t_base[ti];
+        const int ps = S.t_poff[ti], np = S.t_poff[ti + 1] - ps;
+        auto pred_at = [&](int idx) __attribute__((always_inline)) { const int t = idx - pbase; int v = S.t_pred[t < TP ? t : 0]; if (t >= TP) v = gld_i32(pred_row + idx); return v; };
+        // band geometry of an earlier row: LDS ring for the last RB rows, HBM copy otherwise
+        auto geom = [&](int p, int &pb, int &pe, long long &poff) __attribute__((always_inline)) {
+            pb = S.b_bsn[p % RB]; pe = S.b_esn[p % RB]; poff = (long long)S.b_coff[p % RB] * PN;
+            if (row - p >= RB) { pb = gld_i32(g_bsn + p); pe = gld_i32(g_esn + p); poff = gld_i64(g_coff + p); }
+        };
         int beg_sn, end_sn, max_pre_end_sn;
         if (!banded) { beg_sn = 0; end_sn = qlen / PN; max_pre_end_sn = end_sn; }        // reference :706-709
         else {                                                                          // reference :710-720
-            int r = row_remain[row] - remain_end - 1;
-            int beg = imax(0, imin(left[row], qlen - r) - w), end = imin(qlen, imax(right[row], qlen - r) + w);
+            const int r = S.t_remain[ti] - remain_end - 1;
+            const int lft = S.l_left[row % RL], rgt = S.l_right[row % RL];
+            last_row = row;
+            int beg = imax(0, imin(lft, qlen - r) - w), end = imin(qlen, imax(rgt, qlen - r) + w);
             beg_sn = beg / PN; int min_pre_beg_sn = INT_MAX; max_pre_end_sn = -1;
             for (int k = 0; k < np; ++k) {
-                int p = pred_row[ps + k];
-                min_pre_beg_sn = imin(min_pre_beg_sn, bsn[p]); max_pre_end_sn = imax(max_pre_end_sn, esn[p]);
+                const int p = pred_at(ps + k);
+                int pb, pe; long long po; geom(p, pb, pe, po);
+                min_pre_beg_sn = imin(min_pre_beg_sn, pb); max_pre_end_sn = imax(max_pre_end_sn, pe);
             }
             if (beg_sn < min_pre_beg_sn) beg_sn = min_pre_beg_sn;
             end_sn = end / PN;
@@ -192,14 +325,19 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
         const long long off = cursor;
         if (off + (long long)Wr * P > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
         cursor += (long long)Wr * P;
-        n_cells += Wr;
-        if (lane == 0) { bsn[row] = beg_sn; esn[row] = end_sn; cell_off[row] = off; }
+        n_cells += Wr; ++rows_done;
+        if (lane == 0) { S.b_bsn[row % RB] = beg_sn; S.b_esn[row % RB] = end_sn; S.b_coff[row % RB] = (uint32_t)(off / PN); }
         T *H = planes + off;
+        const bool to_ring = Wr <= ring_cols;
+        const int my_slot = row % ring_rows;
+        T *my_ring = s_ring + (long long)my_slot * NPR * ring_cols;
+        if (lane == 0) S.ring_tag[my_slot] = -1;              // slot is being overwritten
         const int nchunk = (Wr + 63) >> 6;
         T first = 0, first2 = 0;
         // running arg-max state of this lane (reference :1043-1057)
         int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false;
 
+        STAMP(0)
         for (int c = 0; c < nchunk; ++c) {
             const int rel = c * 64 + lane;
             const bool in_band = rel < Wr;
@@ -208,46 +346,57 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
             T Mv = inf, E1v = inf, E2v = inf;
             // query profile value, reference :504-510
             T q = 0;
-            if (in_band && col >= 1 && col <= qlen) q = (T)mat[base * m + query[col - 1]];
+            if (in_band && col >= 1 && col <= qlen) {
+                int qc = q_in_lds ? (int)s_query[col - 1] : 0;
+                if (!q_in_lds) qc = gld_u8(g_query + col - 1);
+                q = (T)s_mat[base * m + qc];
+            }
             // ---- predecessors, reference :722-761 / :803-852 / :912-969
             for (int k = 0; k < np; ++k) {
-                const int p = pred_row[ps + k];
-                const int pb = bsn[p], pe = esn[p];
-                const long long poff = cell_off[p];
+                const int p = pred_at(ps + k);
+                int pb, pe; long long poff; geom(p, pb, pe, poff);
                 const int Wp = (pe - pb + 1) * PN;
-                const T *Hp = planes + poff;
                 const int p_stored_end = (pe + 1) * PN - 1;          // last stored column of the predecessor row
-                int bs, es_h, es_e; T carry;
-                if (local) { bs = 0; es_h = end_sn; es_e = end_sn; carry = 0; }
+                const int pslot = p % ring_rows;
+                const bool in_ring = (row - p < ring_rows) && S.ring_tag[pslot] == p;
+                int bs, es_h, es_e;
+                if (local) { bs = 0; es_h = end_sn; es_e = end_sn; }
                 else {
-                    if (pb < beg_sn) { bs = beg_sn; carry = Hp[beg_sn * PN - 1 - pb * PN]; }
-                    else { bs = pb; carry = inf; }
+                    bs = pb < beg_sn ? beg_sn : pb;
                     es_h = imin(imin((dp_end_of(p, pe) + 1) / PN, end_sn), dp_sn - 1);
                     es_e = imin(pe, end_sn);
                 }
                 const bool inH = in_band && v >= bs && v <= es_h;
-                if (inH) {
-                    T hval;
-                    if (col == bs * PN) hval = carry;
-                    else hval = (col - 1 <= p_stored_end) ? Hp[col - 1 - pb * PN] : inf;
-                    if (GAP == 0) {
-                        T vert = (col <= p_stored_end) ? Hp[col - pb * PN] : inf;
-                        hval = tmax<T>(wadd<T>(hval, q), wsub<T>(vert, e1));
+                const bool inE = GAP != 0 && in_band && v >= bs && v <= es_e;
+                // The source row is read either from the LDS score ring or from its HBM copy; the two paths are
+                // instantiated separately so that no generic (flat) pointer is ever formed.
+                auto gather = [&](auto from_lds, const T *Hp, const long long pstride) __attribute__((always_inline)) {
+                    auto ld = [&](const T *p_) __attribute__((always_inline)) -> T { if constexpr (decltype(from_lds)::value) return *p_; else return (T)gld_cell(p_); };
+                    if (inH) {
+                        T hval;
+                        if (col == bs * PN) {
+                            if (local) hval = 0;
+                            else hval = (pb < beg_sn && beg_sn * PN - 1 <= p_stored_end) ? ld(Hp + beg_sn * PN - 1 - pb * PN) : inf;
+                        } else hval = (col - 1 <= p_stored_end) ? ld(Hp + col - 1 - pb * PN) : inf;
+                        if (GAP == 0) {
+                            T vert = (col <= p_stored_end) ? ld(Hp + col - pb * PN) : inf;
+                            hval = tmax<T>(wadd<T>(hval, q), wsub<T>(vert, e1));
+                        }
+                        Mv = (k == 0) ? hval : tmax<T>(Mv, hval);
                     }
-                    Mv = (k == 0) ? hval : tmax<T>(Mv, hval);
-                }
-                if (GAP != 0) {
-                    const bool inE = in_band && v >= bs && v <= es_e;
                     if (inE) {
-                        T ev = Hp[(long long)PL_E1 * Wp + col - pb * PN];
+                        T ev = ld(Hp + (long long)PL_E1 * pstride + col - pb * PN);
                         E1v = (k == 0) ? ev : tmax<T>(E1v, ev);
                         if (GAP == 2) {
-                            T ev2 = Hp[(long long)PL_E2 * Wp + col - pb * PN];
+                            T ev2 = ld(Hp + (long long)PL_E2 * pstride + col - pb * PN);
                             E2v = (k == 0) ? ev2 : tmax<T>(E2v, ev2);
                         }
                     }
-                }
+                };
+                if (in_ring) gather(std::true_type{}, s_ring + (long long)pslot * NPR * ring_cols, (long long)ring_cols);
+                else gather(std::false_type{}, planes + poff, (long long)Wp);       // HBM copy (older or over-wide row)
             }
+            STAMP(1)
             // ---- in-row part
             T Hout, E1out = 0, E2out = 0, F1 = inf, F2 = inf;
             if (GAP == 0) {
@@ -311,12 +460,18 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
                     Hout = hh;
                 }
             }
+            STAMP(2)
             if (in_band) {
                 H[rel] = Hout;
                 if (GAP != 0) {
                     H[(long long)PL_E1 * Wr + rel] = E1out;
                     H[(long long)PL_F1 * Wr + rel] = F1;
                     if (GAP == 2) { H[(long long)PL_E2 * Wr + rel] = E2out; H[(long long)PL_F2 * Wr + rel] = F2; }
+                }
+                if (to_ring) {
+                    my_ring[rel] = Hout;
+                    if (GAP != 0) my_ring[ring_cols + rel] = E1out;
+                    if (GAP == 2) my_ring[2 * ring_cols + rel] = E2out;
                 }
                 if (need_max) {
                     // per-lane candidate; columns past qlen only exist in vector qlen/PN and are masked there
@@ -326,7 +481,9 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
                     if (!am_any || (is_end ? cand >= am_val : cand > am_val)) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
                 }
             }
+            STAMP(3)
         }
+        if (to_ring && lane == 0) S.ring_tag[my_slot] = row;
         // ---- row arg-max, reference simd_abpoa_max_in_row :1043-1057 (tie-break: lowest lane, then the
         //      end_sn vector, then the lowest vector) and band hand-over :1059-1067
         int mx = d.inf_min, mi = -1;
@@ -340,87 +497,164 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
                 mx = vmax; mi = wv * PN + wl;
                 if (mi > qlen) mi = -1;          // cannot happen for a value above inf_min, kept for symmetry with qi[]
             }
-            if (lane == 0) row_max_i[row] = mi;
+            if (b.want_trace && lane == 0) row_max_i[row] = mi;
             if (local) { if (mx > best_score) { best_score = mx; best_i = row; best_j = mi; } }
             else if (extend) {
                 if (mx > best_score) { best_score = mx; best_i = row; best_j = mi; best_row_zd = row; }
                 else if (b.zdrop > 0) {
-                    int delta_index = row_remain[best_row_zd] - row_remain[row];
+                    int delta_index = gld_i32(row_remain + best_row_zd) - S.t_remain[ti];
                     int dd = delta_index - (mi - best_j); if (dd < 0) dd = -dd;
-                    if (best_score - mx > b.zdrop + (int)e1 * dd) { __syncthreads(); break; }
+                    if (best_score - mx > b.zdrop + (int)e1 * dd) break;
                 }
             }
             if (banded) {
                 const int out_i = mi + 1;
-                for (int t = out_off[row] + lane; t < out_off[row + 1]; t += 64) {
-                    int o = out_row[t];
+                const int os = S.t_ooff[ti], on = S.t_ooff[ti + 1] - os;
+                bool far = false;
+                for (int t = lane; t < on; t += 64) {
+                    const int tt = os + t - obase;
+                    int o = S.t_out[tt < TP ? tt : 0];
+                    if (tt >= TP) o = gld_i32(out_row + os + t);
                     if (o >= 0) {
-                        if (out_i > right[o]) right[o] = out_i;
-                        if (out_i < left[o]) left[o] = out_i;
+                        if (o < lr_blk + RL) {
+                            if (out_i > S.l_right[o % RL]) S.l_right[o % RL] = out_i;
+                            if (out_i < S.l_left[o % RL]) S.l_left[o % RL] = out_i;
+                        } else {                                       // beyond the LDS window: update the HBM copy
+                            if (out_i > gld_i32(g_right + o)) g_right[o] = out_i;
+                            if (out_i < gld_i32(g_left + o)) g_left[o] = out_i;
+                            far = true;
+                        }
                     }
                 }
+                if (__any(far)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-        } else if (lane == 0) row_max_i[row] = -2;
-        __syncthreads();    // this wave's stores (planes, band, left/right) before the next row's loads
+        } else if (b.want_trace && lane == 0) row_max_i[row] = -2;
+        STAMP(4)
     }
+    __syncthreads();
+    if (tile_end > tile_beg && tile_beg + lane < tile_end && status == 0) {      // band geometry of the last (partial) tile
+        const int r = tile_beg + lane;
+        if (r <= last_done) { g_bsn[r] = S.b_bsn[r % RB]; g_esn[r] = S.b_esn[r % RB]; g_coff[r] = (long long)S.b_coff[r % RB] * PN; }
+    }
+    const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
+    // ---- retire the left/right window to HBM (the arrays are in/out for the caller)
+    if (banded && status == 0) {
+        for (int i = lane; i < RL; i += 64) { const int r = lr_blk + i; if (r < gn) { g_left[r] = S.l_left[r % RL]; g_right[r] = S.l_right[r % RL]; } }
+    }
+    (void)last_row;
+    __syncthreads();       // all of this wave's plane / band stores have landed before the loads below
 
     // ------------------------------------------------------------------ global best, reference :1028-1041
     if (status == 0 && b.align_mode == ABPOA_HIP_GLOBAL_MODE) {
         for (int k = pred_off[gn - 1]; k < pred_off[gn]; ++k) {
             int in_row = pred_row[k];
-            int pe = esn[in_row], pb = bsn[in_row];
+            int pe = g_esn[in_row], pb = g_bsn[in_row];
             int dpe = dp_end_of(in_row, pe);
             int end = qlen > dpe ? dpe : qlen;
-            int score = (int)planes[cell_off[in_row] + end - pb * PN];
+            int score = (int)planes[g_coff[in_row] + end - pb * PN];
             if (score > best_score) { best_score = score; best_i = in_row; best_j = end; }
         }
     }
 
     // ------------------------------------------------------------------ backtrack, reference :109-429
+    // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
+    // refilled cooperatively; only lane 0 writes cigar words.
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
-    if (status == 0 && b.ret_cigar && lane == 0) {
-        uint64_t *cg = b.cigar + d.cigar_off;
+    if (status == 0 && b.ret_cigar) {
+        BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
+        T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
+        const long long bt_cells = b.lds.bt_bytes / (int)sizeof(T);
+        int bt_lo = 1, bt_hi = 0, bt_pbase = 0, bt_margin = 0;   // window = rows [bt_lo, bt_hi], empty at start
+        long long bt_c0 = 0;                                     // arena cell of B.coff[0]
+        uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
         const int cap = d.cigar_cap;
-        auto push = [&](int op, int len, int node_id, int query_id) {      // reference abpoa_align.h:54-73
+        uint64_t last_word = 0;
+        auto load_window = [&](int hi) __attribute__((always_inline)) {
+            __syncthreads();
+            int lo = imax(0, hi - BTR + 1);
+            const int r = lo + lane;
+            int my_b = -1, my_e = -1; long long my_c = 0;
+            if (r <= hi) { my_b = g_bsn[r]; my_e = g_esn[r]; my_c = g_coff[r]; }
+            // end of row hi = its offset + P * width (never-computed rows carry zero width)
+            const int hb = g_bsn[hi], he = g_esn[hi];
+            const long long c_end = g_coff[hi] + (hb >= 0 ? (long long)(he - hb + 1) * PN * P : 0);
+            // smallest lo' whose segment [coff[lo'], c_end) fits the LDS tile
+            const bool fits = (r <= hi) && (c_end - my_c) <= bt_cells;
+            const unsigned long long mk = __ballot(fits);
+            const int sh = mk ? __builtin_ctzll(mk) : (hi - lo);     // worst case: a single row (may still not fit -> HBM path)
+            lo += sh;
+            if (r >= lo && r <= hi) {
+                const int i = r - lo;
+                B.bsn[i] = my_b; B.esn[i] = my_e; B.coff[i] = my_c;
+                B.poff[i] = pred_off[r]; B.nid[i] = row_node_id[r]; B.base[i] = row_base[r];
+            }
+            if (lane == 0) { B.coff[hi - lo + 1] = c_end; B.poff[hi - lo + 1] = pred_off[hi + 1]; }
+            __syncthreads();
+            bt_lo = lo; bt_hi = hi; bt_c0 = B.coff[0]; bt_pbase = B.poff[0]; bt_margin = imin(4, (hi - lo) / 2);
+            const int pn_t = imin(BTP, B.poff[hi - lo + 1] - bt_pbase);
+            for (int i = lane; i < pn_t; i += 64) B.pred[i] = pred_row[bt_pbase + i];
+            long long ncell = c_end - bt_c0; if (ncell > bt_cells) ncell = 0;        // does not fit: leave the tile empty
+            if (ncell == 0) { bt_hi = bt_lo - 1; }
+            // 16-byte coalesced copy (arena offsets are multiples of PN cells = 32 bytes)
+            const int4 *src = (const int4 *)(planes + bt_c0); int4 *dst = (int4 *)bt;
+            const long long n16 = ncell * (long long)sizeof(T) / 16;
+            for (long long i = lane; i < n16; i += 64) dst[i] = src[i];
+            __syncthreads();
+        };
+        auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
             uint64_t L = (uint64_t)(int64_t)len;
-            if (n_cigar == 0 || op != ABPOA_HIP_CINS || op != (int)(cg[n_cigar - 1] & 0xf)) {
+            if (n_cigar == 0 || op != ABPOA_HIP_CINS || op != (int)(last_word & 0xf)) {
                 if (n_cigar >= cap) { status = ABPOA_HIP_EBACKTRACK; return; }
-                uint64_t n_id = (uint64_t)(int64_t)node_id, q_id = (uint64_t)(int64_t)query_id;
-                if (op == ABPOA_HIP_CMATCH) cg[n_cigar++] = n_id << 34 | q_id << 4 | (uint64_t)op;
-                else if (op == ABPOA_HIP_CINS) cg[n_cigar++] = q_id << 34 | L << 4 | (uint64_t)op;
-                else cg[n_cigar++] = n_id << 34 | L << 4 | (uint64_t)op;
-            } else cg[n_cigar - 1] += L << 4;
+                uint64_t n_id = (uint64_t)(int64_t)node_id, q_id = (uint64_t)(int64_t)query_id, wv;
+                if (op == ABPOA_HIP_CMATCH) wv = n_id << 34 | q_id << 4 | (uint64_t)op;
+                else if (op == ABPOA_HIP_CINS) wv = q_id << 34 | L << 4 | (uint64_t)op;
+                else wv = n_id << 34 | L << 4 | (uint64_t)op;
+                last_word = wv; ++n_cigar;
+            } else last_word += L << 4;
+            if (lane == 0) cg[n_cigar - 1] = last_word;      // the newest word lives in a register; memory is write-only here
         };
-        // cell (row, plane, col) with the row's band geometry
-        auto cell = [&](int row_, int plane, int col_) -> int {
-            int pb = bsn[row_], pe = esn[row_];
-            long long Wp = (long long)(pe - pb + 1) * PN;
-            return (int)planes[cell_off[row_] + plane * Wp + (col_ - pb * PN)];
+        struct Geo { int pb, pe; long long off; bool in_tile; };
+        auto geo_of = [&](int row_) __attribute__((always_inline)) {
+            Geo g;
+            g.in_tile = row_ >= bt_lo && row_ <= bt_hi;
+            const int i = g.in_tile ? row_ - bt_lo : 0;
+            g.pb = B.bsn[i]; g.pe = B.esn[i]; g.off = B.coff[i] - bt_c0;
+            if (!g.in_tile) { g.pb = gld_i32(g_bsn + row_); g.pe = gld_i32(g_esn + row_); g.off = gld_i64(g_coff + row_); }
+            return g;
         };
-        auto in_range = [&](int row_, int col_) {                            // dp_beg <= col <= dp_end
-            int pb = bsn[row_], pe = esn[row_];
-            return col_ >= pb * PN && col_ <= dp_end_of(row_, pe);
+        auto cell = [&](const Geo &g, int plane, int col_) __attribute__((always_inline)) -> int {
+            const long long Wp = (long long)(g.pe - g.pb + 1) * PN;
+            const long long idx = g.off + plane * Wp + (col_ - g.pb * PN);
+            int v = (int)bt[g.in_tile ? idx : 0];
+            if (!g.in_tile) v = gld_cell(planes + idx);
+            return v;
         };
-        auto stored = [&](int row_, int col_) {                              // column physically stored
-            int pb = bsn[row_], pe = esn[row_];
-            return col_ >= pb * PN && col_ <= (pe + 1) * PN - 1;
-        };
+        auto in_range = [&](const Geo &g, int row_, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= dp_end_of(row_, g.pe); };
+        auto stored = [&](const Geo &g, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= (g.pe + 1) * PN - 1; };
+        auto qcode = [&](int j_) __attribute__((always_inline)) { int v = (int)s_query[q_in_lds ? j_ : 0]; if (!q_in_lds) v = gld_u8(g_query + j_); return v; };
+
         int i = best_i, j = best_j, start_i = best_i, start_j = best_j, cur_op = OP_ALL, indel_first = 1;
         if (best_j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
         while (i > 0 && j > 0 && status == 0) {
-            const int Hij = cell(i, 0, j);
+            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
+            const Geo gi = geo_of(i);
+            const int Hij = cell(gi, 0, j);
             if (local && Hij == 0) break;
-            start_i = i; start_j = j;
-            const int ps = pred_off[i], np = pred_off[i + 1] - ps;
-            const int id = row_node_id[i];
-            const int s = mat[m * row_base[i] + query[j - 1]];
-            const int is_match = row_base[i] == query[j - 1];
+            start_i = i; start_j = j; ++bt_steps;
+            int ps, np, id, bs_;
+            { const int t = gi.in_tile ? i - bt_lo : 0; ps = B.poff[t]; np = B.poff[t + 1] - ps; id = B.nid[t]; bs_ = B.base[t]; }
+            if (!gi.in_tile) { ps = gld_i32(pred_off + i); np = gld_i32(pred_off + i + 1) - ps; id = gld_i32(row_node_id + i); bs_ = gld_u8(row_base + i); }
+            auto pred_bt = [&](int idx) __attribute__((always_inline)) { const int t = idx - bt_pbase; const bool ok = gi.in_tile && t >= 0 && t < BTP; int v = B.pred[ok ? t : 0]; if (!ok) v = gld_i32(pred_row + idx); return v; };
+            const int qc = qcode(j - 1);
+            const int s = s_mat[m * bs_ + qc];
+            const int is_match = bs_ == qc;
             int hit = 0;
-            auto try_match = [&](int set_indel) {
+            auto try_match = [&](int set_indel) __attribute__((always_inline)) {
                 for (int k = 0; k < np; ++k) {
-                    int pr = pred_row[ps + k];
-                    if (!in_range(pr, j - 1)) continue;
-                    if (cell(pr, 0, j - 1) + s == Hij) {
+                    const int pr = pred_bt(ps + k);
+                    const Geo gp = geo_of(pr);
+                    if (!in_range(gp, pr, j - 1)) continue;
+                    if (cell(gp, 0, j - 1) + s == Hij) {
                         cur_op = OP_ALL; hit = 1;
                         push(ABPOA_HIP_CMATCH, 1, id, j - 1);
                         i = pr; --j; ++n_aln; n_match += is_match;
@@ -433,27 +667,29 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
                 if (indel_first == 0) try_match(0);
                 if (!hit) {
                     for (int k = 0; k < np; ++k) {
-                        int pr = pred_row[ps + k];
-                        if (!in_range(pr, j)) continue;
-                        if (cell(pr, 0, j) - (int)e1 == Hij) { push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; hit = 1; break; }
+                        const int pr = pred_bt(ps + k);
+                        const Geo gp = geo_of(pr);
+                        if (!in_range(gp, pr, j)) continue;
+                        if (cell(gp, 0, j) - (int)e1 == Hij) { push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; hit = 1; break; }
                     }
                 }
-                if (!hit && stored(i, j - 1) && cell(i, 0, j - 1) - (int)e1 == Hij) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; hit = 1; ++n_aln; }
+                if (!hit && stored(gi, j - 1) && cell(gi, 0, j - 1) - (int)e1 == Hij) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; hit = 1; ++n_aln; }
                 if (!hit && indel_first == 1) try_match(1);
             } else {
                 if ((cur_op & OP_M) && indel_first == 0) try_match(0);
                 if (!hit && (cur_op & OP_E)) {
                     for (int k = 0; k < np && !hit; ++k) {
-                        int pr = pred_row[ps + k];
-                        if (!in_range(pr, j)) continue;
+                        const int pr = pred_bt(ps + k);
+                        const Geo gp = geo_of(pr);
+                        if (!in_range(gp, pr, j)) continue;
                         for (int x = 1; x <= (GAP == 2 ? 2 : 1); ++x) {
                             const int bit = x == 1 ? OP_E1 : OP_E2, pl = x == 1 ? PL_E1 : PL_E2;
                             const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
                             if (!(cur_op & bit)) continue;
-                            const int preE = cell(pr, pl, j);
-                            const bool ok = (cur_op & OP_M) ? (Hij == preE) : (cell(i, pl, j) == preE - ex);
+                            const int preE = cell(gp, pl, j);
+                            const bool ok = (cur_op & OP_M) ? (Hij == preE) : (cell(gi, pl, j) == preE - ex);
                             if (ok) {
-                                cur_op = (cell(pr, 0, j) - oex == preE) ? (OP_M | OP_F) : bit;
+                                cur_op = (cell(gp, 0, j) - oex == preE) ? (OP_M | OP_F) : bit;
                                 hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; break;
                             }
                         }
@@ -464,11 +700,11 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
                         const int bit = x == 1 ? OP_F1 : OP_F2, pl = x == 1 ? PL_F1 : PL_F2;
                         const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
                         if (!(cur_op & bit)) continue;
-                        const int Fij = cell(i, pl, j);
+                        const int Fij = cell(gi, pl, j);
                         if (!(cur_op & OP_M) || Hij == Fij) {
-                            if (stored(i, j - 1)) {
-                                if (cell(i, 0, j - 1) - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
-                                else if (cell(i, pl, j - 1) - ex == Fij) { cur_op = bit; hit = 1; }
+                            if (stored(gi, j - 1)) {
+                                if (cell(gi, 0, j - 1) - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
+                                else if (cell(gi, pl, j - 1) - ex == Fij) { cur_op = bit; hit = 1; }
                             }
                         }
                     }
@@ -480,17 +716,22 @@ __device__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) 
         }
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
-            if (!b.rev_cigar) for (int k = 0; k < n_cigar >> 1; ++k) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
+            __syncthreads();
+            if (!b.rev_cigar) for (int k = lane; k < n_cigar >> 1; k += 64) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
             node_e = row_node_id[best_i]; query_e = best_j - 1;
             node_s = row_node_id[start_i]; query_s = start_j - 1;
         }
     }
     if (lane == 0) {
-        AlnOut o;
+        AlnOut o; for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = 0;
         o.status = status; o.best_score = best_score; o.best_row = best_i; o.best_col = best_j;
         o.node_s = node_s; o.node_e = node_e; o.query_s = query_s; o.query_e = query_e;
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = 0;
         o.n_cells = n_cells; o.cells_used = cursor;
+#ifdef ABPOA_HIP_PROFILE
+        for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
+#endif
+        o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }
 }
@@ -507,11 +748,23 @@ __global__ void __launch_bounds__(64) dp_kernel(const DevBatch b) {
 hipError_t launch_dp(const DevBatch &b, hipStream_t stream) {
     if (b.n <= 0) return hipSuccess;
     dim3 grid(b.n), block(64);
+    const size_t lds = (size_t)b.lds.total;
+    hipError_t e = hipSuccess;
     switch (b.gap_mode) {
-        case ABPOA_HIP_LINEAR_GAP: hipLaunchKernelGGL(dp_kernel<0>, grid, block, 0, stream, b); break;
-        case ABPOA_HIP_AFFINE_GAP: hipLaunchKernelGGL(dp_kernel<1>, grid, block, 0, stream, b); break;
-        default: hipLaunchKernelGGL(dp_kernel<2>, grid, block, 0, stream, b); break;
+        case ABPOA_HIP_LINEAR_GAP:
+            if (lds > 65536) e = hipFuncSetAttribute((const void *)dp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL(dp_kernel<0>, grid, block, lds, stream, b);
+            break;
+        case ABPOA_HIP_AFFINE_GAP:
+            if (lds > 65536) e = hipFuncSetAttribute((const void *)dp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL(dp_kernel<1>, grid, block, lds, stream, b);
+            break;
+        default:
+            if (lds > 65536) e = hipFuncSetAttribute((const void *)dp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL(dp_kernel<2>, grid, block, lds, stream, b);
+            break;
     }
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -54,6 +54,7 @@ struct Engine {
 };
 static Engine g;
 
+long long g_dbg[10] = {0};
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 }  // namespace abpoa_hip
@@ -94,6 +95,7 @@ void abpoa_hip_shutdown(void) {
 
 const char *abpoa_hip_last_error(void) { return g_err; }
 void abpoa_hip_get_stats(abpoa_hip_stats_t *out) { std::lock_guard<std::mutex> lk(g.mu); *out = g.stats; }
+void abpoa_hip__debug_clocks(long long *out) { for (int i = 0; i < 10; ++i) { out[i] = g_dbg[i]; g_dbg[i] = 0; } }
 void abpoa_hip_reset_stats(void) { std::lock_guard<std::mutex> lk(g.mu); memset(&g.stats, 0, sizeof(g.stats)); }
 
 // reference src/simd_abpoa_align.c:1672-1683
@@ -230,8 +232,26 @@ int abpoa_hip_align_batch(const abpoa_hip_scoring_t *sc, int n, const abpoa_hip_
 
         DevBatch b; memset(&b, 0, sizeof(b));
         b.n = (int)pass.size(); b.m = sc->m;
+        {   // ---- LDS plan (engine.h LdsPlan): sized for the widest expected band / largest query of this pass
+            int max_qlen = 0, max_bits = 16; int64_t est_cols = 0;
+            for (const AlnDesc &d : pass) {
+                max_qlen = std::max(max_qlen, d.qlen); max_bits = std::max(max_bits, d.bits);
+                const int pn = d.bits == 16 ? 16 : 8; const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
+                est_cols = std::max<int64_t>(est_cols, banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width);
+            }
+            LdsPlan &L = b.lds; const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
+            L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
+            L.mat_off = L.q_cap; L.phase_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
+            L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
+            while ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024 && L.ring_rows > 4) L.ring_rows /= 2;
+            if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
+            const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
+            L.bt_off = lds_fixed_bytes_bt();
+            L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
+            L.total = L.phase_off + std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes);
+        }
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
-        b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
+        b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar; b.want_trace = trace ? 1 : 0;
         uint8_t *di = g.in.dev, *dout = g.outb.dev;
         b.mat = (const int32_t *)(di + o_mat); b.aln = (const AlnDesc *)(di + o_desc); b.out = (AlnOut *)(dout + o_rec);
         b.query = di + o_query; b.row_base = di + o_base; b.row_node_id = (const int32_t *)(di + o_nid); b.row_remain = (const int32_t *)(di + o_rem);
@@ -247,6 +267,7 @@ int abpoa_hip_align_batch(const abpoa_hip_scoring_t *sc, int n, const abpoa_hip_
             HIP_TRY(hipMemcpyAsync(dout + o_left, ho + o_left, (o_right - o_left) + 4 * rows_tot, hipMemcpyHostToDevice, g.stream), ABPOA_HIP_ELAUNCH);
         // -1 = "row never computed" (inactive rows, rows behind a z-drop break)
         HIP_TRY(hipMemsetAsync(dout + o_bsn, 0xFF, (o_esn - o_bsn) + 4 * rows_tot, g.stream), ABPOA_HIP_ELAUNCH);
+        if (trace) HIP_TRY(hipMemsetAsync(dout + o_rmi, 0xFE, 4 * rows_tot, g.stream), ABPOA_HIP_ELAUNCH);
         HIP_TRY(hipEventRecord(g.ev[1], g.stream), ABPOA_HIP_ELAUNCH);
         HIP_TRY(launch_dp(b, g.stream), ABPOA_HIP_ELAUNCH);
         HIP_TRY(hipEventRecord(g.ev[2], g.stream), ABPOA_HIP_ELAUNCH);
@@ -282,6 +303,7 @@ int abpoa_hip_align_batch(const abpoa_hip_scoring_t *sc, int n, const abpoa_hip_
             if (banded) { memcpy(p.max_pos_left, ho + o_left + 4 * d.row0, 4 * p.n_rows); memcpy(p.max_pos_right, ho + o_right + 4 * d.row0, 4 * p.n_rows); }
             const int pn = d.bits == 16 ? 16 : 8;
             g.stats.n_alignments += 1; g.stats.n_cells += r.n_cells;
+            g_dbg[0] += r.clk_dp; g_dbg[1] += r.clk_bt; g_dbg[2] += r.n_rows_done; g_dbg[3] += r.n_bt_steps; for (int q_ = 0; q_ < 6; ++q_) g_dbg[4 + q_] += r.seg[q_];
             g.stats.algo_bytes += r.n_cells * (d.bits / 8) * (P == 1 ? 2 : (P == 3 ? 5 : 8));
             if (trace) {
                 abpoa_hip_trace_t *T = (abpoa_hip_trace_t *)calloc(1, sizeof(abpoa_hip_trace_t));

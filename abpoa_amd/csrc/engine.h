@@ -33,9 +33,26 @@ struct AlnOut {
     int32_t pad;
     int64_t n_cells;      // sum (end_sn-beg_sn+1)*pn over rows 1..gn-2
     int64_t cells_used;   // arena cells consumed (all rows incl. row 0, all planes)
+    int64_t clk_dp, clk_bt; // shader-clock ticks spent in the row loop / in the backtrack (s_memtime)
+    int32_t n_rows_done, n_bt_steps;
+    int64_t seg[6];       // ABPOA_HIP_PROFILE builds: ticks per row-loop segment
 };
 
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
+
+// LDS carve-up of one wavefront (= one workgroup), chosen on the host per launch.  Byte offsets from the
+// dynamic-LDS base; every region is 16-byte aligned.
+struct LdsPlan {
+    int32_t q_off, q_cap;         // query codes (uint8), used when qlen <= q_cap
+    int32_t mat_off;              // int32 [m*m]
+    int32_t phase_off;            // start of the region shared by the DP phase and the backtrack phase
+    // --- DP phase (offsets from phase_off) ---
+    int32_t ring_rows, ring_cols; // recent-row score ring: [ring_rows][planes_in_ring][ring_cols] cells of 4 bytes max
+    int32_t ring_off;             // (relative to phase_off)
+    // --- backtrack phase ---
+    int32_t bt_off, bt_bytes;     // arena tile (relative to phase_off)
+    int32_t total;                // dynamic LDS bytes to request
+};
 
 // Everything one launch needs; passed by value as the kernel argument.
 struct DevBatch {
@@ -43,6 +60,8 @@ struct DevBatch {
     int32_t m;
     int32_t o1, e1, o2, e2;
     int32_t align_mode, gap_mode, wb, zdrop, ret_cigar, rev_cigar;
+    int32_t want_trace;          // also record the per-row arg-max column (tests)
+    LdsPlan lds;
     const int32_t *mat;          // [m*m]
     const AlnDesc *aln;          // [n]
     AlnOut *out;                 // [n]
@@ -62,6 +81,10 @@ struct DevBatch {
     uint8_t *planes;             // arena pool (bytes)
     uint64_t *cigar;             // pool
 };
+
+// Fixed LDS structures of the kernel (rows per metadata tile, ring depths); see dp_kernel.hip.
+int lds_fixed_bytes_dp();
+int lds_fixed_bytes_bt();
 
 // Launches the DP kernel for the whole batch on `stream`.
 hipError_t launch_dp(const DevBatch &b, hipStream_t stream);

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on BASELINE.json's workload.
+
+step      = one full pass of the lock-step read-set driver over this rank's batch of synthetic read-sets
+            (every read of every set aligned on the GPU by the banded POA DP kernel, cigars fused on the host,
+            consensus called) -- i.e. reads in, consensus out, nothing cached between steps.
+workload  = BASELINE.json configs[1]: 1000 read-sets x 50 reads x 1 kb, 5 % error, global / affine (-O 4,0 -E 2),
+            per GPU (weak scaling: every rank gets its own 1000 sets, no data-path collective; one tiny RCCL
+            all-reduce gathers the consensus digest).
+value     = read-sets/s over all ranks (end to end, host graph work included); the DP-kernel-only rate is
+            reported beside it as dp_gcells_per_s together with the roofline figures of that kernel.
+"""
+import argparse
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (synth cfg, Params kwargs, reference CLI options, description)
+    "cfg2": (2, dict(gap_open1=4, gap_open2=0, gap_ext1=2), ["-O", "4,0", "-E", "2"],
+             "50 reads x 1 kb, 5% err, global affine (-O 4,0 -E 2)"),
+    "cfg3": (3, dict(), [], "50 reads x 10 kb, 15% err, global convex defaults (-b 10 -f 0.01)"),
+    "cfg4": (4, dict(gap_open1=4, gap_open2=0, gap_ext1=2), ["-O", "4,0", "-E", "2"],
+             "50 reads x 10 kb, 5% err, global affine"),
+}
+
+
+def digest(results):
+    h = hashlib.sha256()
+    for r in results:
+        h.update(r.cons_seq.encode())
+        h.update(b"\n")
+    return h.hexdigest()
+
+
+def cpu_baseline(wl, sets, target_s=15.0):
+    """Time the compiled REFERENCE (oracle/_ref/abpoa_ref, built from /root/reference by oracle/Makefile with
+    gcc -O3 -mavx2 -fno-strict-aliasing) on a bounded sample of the same read-sets, one process per core.
+    Falls back to the repo's scalar port (oracle-backed host run) when the binary did not travel."""
+    _, pk, opts, _ = WORKLOADS[wl]
+    ref = os.path.join(ROOT, "oracle", "_ref", "abpoa_ref")
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from abpoa_amd import synth
+    if os.path.exists(ref):
+        tmp = tempfile.mkdtemp(prefix="abpoa_cpu_")
+        try:
+            n_files = min(len(sets), 16)
+            files = []
+            for i in range(n_files):
+                fn = os.path.join(tmp, f"s{i}.fa")
+                synth.write_fasta(fn, sets[i])
+                files.append(fn)
+            # calibrate on one set, then size the per-process list for ~target_s
+            t0 = time.time()
+            one = subprocess.run([ref] + opts + [files[0]], capture_output=True, text=True, check=True).stdout
+            t_one = max(time.time() - t0, 1e-3)
+            per_proc = max(1, min(int(target_s / t_one), 2000))
+            lst = os.path.join(tmp, "list.txt")
+            with open(lst, "w") as f:
+                for k in range(per_proc):
+                    f.write(files[k % n_files] + "\n")
+            nproc = ncores
+            env = dict(os.environ, GLIBC_TUNABLES="glibc.malloc.hugetlb=1")   # removes page-fault stalls
+            t0 = time.time()
+            procs = [subprocess.Popen([ref] + opts + ["-l", lst], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+                     for _ in range(nproc)]
+            for p in procs:
+                p.wait()
+            dt = time.time() - t0
+            return {"value": round(nproc * per_proc / dt, 3), "unit": "read-sets/s", "cores": nproc, "kind": "reference",
+                    "sample": f"{per_proc} read-sets per process x {nproc} processes of the same workload "
+                              f"({n_files} distinct sets, -l list), abPOA v1.4.1 AVX2 build, {dt:.1f} s wall",
+                    "per_core": round(per_proc / dt, 3)}, one
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    # scalar port
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from abpoa_amd import api
+    n = min(len(sets), 4)
+    t0 = time.time()
+    res = api.msa_batch(sets[:n], api.Params(**pk), lib=H.cpu_shim_lib(), n_threads=1)
+    dt = time.time() - t0
+    return {"value": round(n / dt, 3), "unit": "read-sets/s", "cores": 1, "kind": "port",
+            "sample": f"{n} read-sets, scalar C restatement (oracle), single thread, {dt:.1f} s"}, \
+        ">Consensus_sequence\n" + res[0].cons_seq + "\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--sets", type=int, default=0, help="read-sets per GPU (default: 1000 for cfg2, 32 for the 10 kb configs)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (default: online cores / ranks per node)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from abpoa_amd import api, ffi, synth
+    lib = ffi.lib()
+    if lib.abpoa_hip_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the DP engine has no CPU fallback")
+    ffi.check(lib.abpoa_hip_init(local_rank))
+    torch.cuda.set_device(local_rank)
+
+    cfg, pk, _, desc = WORKLOADS[args.workload]
+    n_sets = args.sets or (1000 if args.workload == "cfg2" else 32)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_threads = args.threads or max(1, ncores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    params = api.Params(**pk)
+    # every rank generates ITS OWN read-sets (set index = rank * n_sets + i): independent units, no exchange
+    sets = [synth.make_read_set(1, rank * n_sets + i, **synth.CONFIGS[cfg]) for i in range(n_sets)]
+    enc = api.EncodedSets(sets, params.m)
+
+    def step():
+        return api.msa_batch(None, params, encoded=enc, n_threads=n_threads)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    lib.abpoa_hip_reset_stats()
+    host_t = {"host_sort_s": 0.0, "host_fuse_s": 0.0, "engine_s": 0.0, "cons_s": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        tm = api.msa_timing()
+        for k in host_t:
+            host_t[k] += tm[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    st = ffi.stats()
+    assert all(r.status == 0 for r in res)
+    dig = digest(res)
+    cells_per_step = sum(r.n_cells for r in res)
+
+    # max time over ranks, totals over ranks
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        agg = torch.tensor([cells_per_step, int(dig[:15], 16), st["n_cells"], st["algo_bytes"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)          # the only collective: result/digest gather over RCCL
+        km = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        cells_all, dig_all = int(agg[0].item()), "%x" % int(agg[1].item())
+        kernel_ms_max = float(km.item())
+    else:
+        cells_all, dig_all, kernel_ms_max = cells_per_step, dig, st["kernel_ms"]
+
+    if rank == 0:
+        total_sets = n_sets * world
+        out = {
+            "metric": "read-sets/sec (consensus bit-exact) + DP Gcells/sec (dp_gcells_per_s)",
+            "value": round(total_sets * args.steps / dt, 3),
+            "unit": "read-sets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16" if args.workload == "cfg2" else "int16+int32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{cfg - 1}]: {n_sets} read-sets per GPU x {desc}",
+                       "read_sets_per_gpu": n_sets, "host_threads_per_rank": n_threads, "parallelism": f"{world} x independent read-set shards"},
+            "dp_gcells_per_s": round(cells_all * args.steps / (kernel_ms_max / 1e3) / 1e9, 3) if kernel_ms_max > 0 else None,
+            "gcells_per_s_end_to_end": round(cells_all * args.steps / dt / 1e9, 3),
+            "cells_per_step": cells_all,
+            "consensus_sha256": dig_all,
+            "time_split_s_rank0": {k: round(v, 4) for k, v in host_t.items()},
+        }
+        ach = st["algo_bytes"] / (st["kernel_ms"] / 1e3) / 1e9 if st["kernel_ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "kernel": "abpoa_hip::dp_kernel", "launches": st["n_launches"],
+                           "avg_launch_ms": round(st["kernel_ms"] / max(1, st["n_launches"]), 4),
+                           "algo_bytes_per_launch": int(st["algo_bytes"] / max(1, st["n_launches"]))}
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref_txt = cpu_baseline(args.workload, sets)
+            out["cpu_baseline"] = cb
+            out["parity_spot_check"] = bool(ref_txt == api.format_output(res[0]))
+            assert out["parity_spot_check"], "consensus of set 0 differs from the CPU baseline's"
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
