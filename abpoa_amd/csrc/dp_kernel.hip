@@ -229,7 +229,11 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     // ---- max_pos_left/right look-ahead window: LDS holds rows [lr_blk, lr_blk + RL)
     int lr_blk = 0;
     if (banded && status == 0) {
-        for (int i = lane; i < RL; i += 64) { const int r = i; if (r < gn) { S.l_left[i] = g_left[r]; S.l_right[i] = g_right[r]; } }
+        if (b.fresh_band) {       // reference abpoa_topological_sort resets them before every alignment (abpoa_graph.c:303-308)
+            for (int i = lane; i < gn; i += 64) { g_left[i] = gn; g_right[i] = 0; }
+            for (int i = lane; i < RL; i += 64) { S.l_left[i] = gn; S.l_right[i] = 0; }
+        } else
+            for (int i = lane; i < RL; i += 64) { const int r = i; if (r < gn) { S.l_left[i] = g_left[r]; S.l_right[i] = g_right[r]; } }
         __syncthreads();
         if (lane == 0) { S.l_left[0] = 0; S.l_right[0] = 0; }                 // reference :556
         for (int t = out_off[0] + lane; t < out_off[1]; t += 64) {            // reference :557-561

@@ -1,5 +1,5 @@
-// Host side of the flat batch API (include/abpoa_hip.h): validation, packing of N problems into one
-// pinned staging blob, one H2D copy, one kernel launch, result unpacking.  Compiled with hipcc.
+// Host side of the engine: device binding, BatchStream (pinned staging + HBM pools + launch) and the flat
+// batch API of include/abpoa_hip.h on top of it.  Compiled with hipcc.
 //
 // Replaces the per-alignment driver simd_abpoa_align_sequence_to_subgraph
 // (reference src/simd_abpoa_align.c:1645-1712) and the scratch owner simd_abpoa_realloc (:1178-1208):
@@ -14,48 +14,258 @@
 #include <mutex>
 #include <vector>
 #include <algorithm>
-#include "engine.h"
-#include "../../include/abpoa_hip.h"
+#include "batch_stream.h"
 
 namespace abpoa_hip {
 
 static thread_local char g_err[512] = "";
-static void set_err(const char *fmt, ...) {
+void set_err(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 #define HIP_TRY(expr, code)                                                                          \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                             \
         set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return code; } } while (0)
 
-// A device buffer with a pinned host mirror; grow-only.
-struct Blob {
-    uint8_t *dev = nullptr, *host = nullptr; size_t cap = 0; bool mirrored;
-    explicit Blob(bool m) : mirrored(m) {}
-    int reserve(size_t n) {
-        if (n <= cap) return 0;
-        size_t want = std::max(n, cap + cap / 2);
-        want = (want + 0xFFFFF) & ~(size_t)0xFFFFF;
-        release();
-        if (hipMalloc((void **)&dev, want) != hipSuccess) { dev = nullptr; set_err("hipMalloc(%zu) failed", want); return ABPOA_HIP_ENOMEM; }
-        if (mirrored && hipHostMalloc((void **)&host, want, hipHostMallocDefault) != hipSuccess) {
-            host = nullptr; set_err("hipHostMalloc(%zu) failed", want); return ABPOA_HIP_ENOMEM; }
-        cap = want; return 0;
-    }
-    void release() { if (dev) (void)hipFree(dev); if (host) (void)hipHostFree(host); dev = host = nullptr; cap = 0; }
-};
+int Blob::reserve(size_t n) {
+    if (n <= cap) return 0;
+    size_t want = std::max(n, cap + cap / 2);
+    want = (want + 0xFFFFF) & ~(size_t)0xFFFFF;
+    release();
+    if (hipMalloc((void **)&dev, want) != hipSuccess) { dev = nullptr; set_err("hipMalloc(%zu) failed", want); return ABPOA_HIP_ENOMEM; }
+    if (mirrored && hipHostMalloc((void **)&host, want, hipHostMallocDefault) != hipSuccess) {
+        host = nullptr; set_err("hipHostMalloc(%zu) failed", want); return ABPOA_HIP_ENOMEM; }
+    cap = want; return 0;
+}
+void Blob::release() { if (dev) (void)hipFree(dev); if (host) (void)hipHostFree(host); dev = host = nullptr; cap = 0; }
 
 struct Engine {
     bool ready = false; int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {};
-    Blob in{true}, outb{true}, planes{false};
+    BatchStream flat;                  // default stream of the flat C API
     abpoa_hip_stats_t stats{};
-    std::mutex mu;
+    std::mutex mu, stats_mu;
 };
 static Engine g;
-
 long long g_dbg[10] = {0};
+
+int engine_device() { return g.ready ? g.device : -1; }
+void add_global_stats(const StreamStats &s) {
+    std::lock_guard<std::mutex> lk(g.stats_mu);
+    g.stats.n_launches += s.n_launches; g.stats.n_alignments += s.n_alignments; g.stats.n_cells += s.n_cells;
+    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms;
+}
+
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------ BatchStream
+int BatchStream::open(int device) {
+    if (open_) return 0;
+    HIP_TRY(hipSetDevice(device), ABPOA_HIP_ENODEV);
+    HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), ABPOA_HIP_ENODEV);
+    for (auto &e : ev_) HIP_TRY(hipEventCreate(&e), ABPOA_HIP_ENODEV);
+    device_ = device; open_ = true; return 0;
+}
+void BatchStream::close() {
+    if (!open_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    in_.release(); out_.release(); planes_.release();
+    for (auto &e : ev_) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(stream_);
+    open_ = false;
+}
+
+int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *sh, unsigned flags) {
+    if (!open_) { set_err("stream not open"); return ABPOA_HIP_ENODEV; }
+    HIP_TRY(hipSetDevice(device_), ABPOA_HIP_ENODEV);
+    sc_ = *sc; mat_.assign(sc->mat, sc->mat + sc->m * sc->m); sc_.mat = mat_.data();
+    flags_ = flags; n_ = n;
+    P_ = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
+    const bool banded = sc->wb >= 0;
+    desc_.resize(n); recs_.resize(n); full_cells_.resize(n);
+    rows_tot_ = preds_tot_ = outs_tot_ = q_tot_ = cig_tot_ = 0;
+    for (int i = 0; i < n; ++i) {
+        AlnDesc &d = desc_[i];
+        d.n_rows = sh[i].n_rows; d.qlen = sh[i].qlen;
+        d.bits = abpoa_hip_score_bits(sc, d.n_rows, d.qlen, &d.inf_min);
+        d.w = sc->wb < 0 ? d.qlen : sc->wb + (int)(sc->wf * d.qlen);     // reference :445 (float32 product)
+        d.cigar_cap = d.n_rows + d.qlen + 8;
+        d.query_off = q_tot_; d.row0 = rows_tot_; d.poff0 = rows_tot_ + i; d.pred0 = preds_tot_; d.out0 = outs_tot_; d.cigar_off = cig_tot_;
+        q_tot_ += d.qlen; rows_tot_ += d.n_rows; preds_tot_ += sh[i].n_pred; outs_tot_ += sh[i].n_out; cig_tot_ += d.cigar_cap;
+        const int pn = d.bits == 16 ? 16 : 8;
+        const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
+        full_cells_[i] = width * P_ * d.n_rows;
+        const int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
+        d.plane_cap = std::min<int64_t>(full_cells_[i], width * P_ + est * P_ * (d.n_rows - 1));
+    }
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
+    o_desc_ = take(sizeof(AlnDesc) * n); o_mat_ = take(sizeof(int32_t) * sc->m * sc->m); o_query_ = take(q_tot_ + 1);
+    o_base_ = take(rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
+    o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1));
+    in_bytes_ = o;
+    o = 0;
+    o_rec_ = take(sizeof(AlnOut) * n); o_cig_ = take(8 * cig_tot_); o_left_ = take(4 * rows_tot_); o_right_ = take(4 * rows_tot_);
+    o_bsn_ = take(4 * rows_tot_); o_esn_ = take(4 * rows_tot_); o_coff_ = take(8 * rows_tot_); o_rmi_ = take(4 * rows_tot_);
+    out_bytes_ = o;
+    int rc;
+    if ((rc = in_.reserve(in_bytes_)) || (rc = out_.reserve(out_bytes_))) return rc;
+    memcpy(in_.host + o_mat_, sc->mat, sizeof(int32_t) * sc->m * sc->m);
+    memset(in_.host + o_act_, 1, rows_tot_);
+    return 0;
+}
+
+ProblemSlots BatchStream::slots(int i) const {
+    const AlnDesc &d = desc_[i]; uint8_t *hi = in_.host, *ho = out_.host; ProblemSlots s;
+    s.query = hi + o_query_ + d.query_off; s.row_base = hi + o_base_ + d.row0;
+    s.row_node_id = (int32_t *)(hi + o_nid_) + d.row0; s.row_remain = (int32_t *)(hi + o_rem_) + d.row0; s.row_active = hi + o_act_ + d.row0;
+    s.pred_off = (int32_t *)(hi + o_poff_) + d.poff0; s.pred_row = (int32_t *)(hi + o_pred_) + d.pred0;
+    s.out_off = (int32_t *)(hi + o_ooff_) + d.poff0; s.out_row = (int32_t *)(hi + o_out_) + d.out0;
+    s.left = (int32_t *)(ho + o_left_) + d.row0; s.right = (int32_t *)(ho + o_right_) + d.row0;
+    return s;
+}
+const uint64_t *BatchStream::cigar(int i) const { return (const uint64_t *)(out_.host + o_cig_) + desc_[i].cigar_off; }
+const int32_t *BatchStream::left(int i) const { return (const int32_t *)(out_.host + o_left_) + desc_[i].row0; }
+const int32_t *BatchStream::right(int i) const { return (const int32_t *)(out_.host + o_right_) + desc_[i].row0; }
+
+int BatchStream::run() {
+    HIP_TRY(hipSetDevice(device_), ABPOA_HIP_ENODEV);
+    const abpoa_hip_scoring_t *sc = &sc_;
+    const bool banded = sc->wb >= 0, trace = flags_ & BS_TRACE, fresh = flags_ & BS_FRESH_BAND;
+    const int P = P_, n = n_;
+    uint8_t *hi = in_.host, *ho = out_.host, *di = in_.dev, *dout = out_.dev;
+    std::vector<int> todo(n); for (int i = 0; i < n; ++i) todo[i] = i;
+    const size_t lr_words = (o_right_ - o_left_) / 4 + rows_tot_;
+    std::vector<int32_t> saved_lr;              // caller's band state, needed again if an alignment is retried
+    bool first_pass = true; int rc;
+    std::vector<AlnDesc> pass;
+    while (!todo.empty()) {
+        int64_t plane_bytes = 0;
+        pass.resize(todo.size());
+        for (size_t t = 0; t < todo.size(); ++t) {
+            AlnDesc &d = desc_[todo[t]];
+            if (!first_pass) d.plane_cap = full_cells_[todo[t]];
+            d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8));
+            pass[t] = d;
+        }
+        if ((rc = planes_.reserve((size_t)plane_bytes))) return rc;
+        memcpy(hi + o_desc_, pass.data(), sizeof(AlnDesc) * pass.size());
+
+        DevBatch b; memset(&b, 0, sizeof(b));
+        b.n = (int)pass.size(); b.m = sc->m;
+        {   // ---- LDS plan (engine.h LdsPlan): sized for the widest expected band / largest query of this pass
+            int max_qlen = 0, max_bits = 16; int64_t est_cols = 0;
+            for (const AlnDesc &d : pass) {
+                max_qlen = std::max(max_qlen, d.qlen); max_bits = std::max(max_bits, d.bits);
+                const int pn = d.bits == 16 ? 16 : 8; const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
+                est_cols = std::max<int64_t>(est_cols, banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width);
+            }
+            LdsPlan &L = b.lds; const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
+            L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
+            L.mat_off = L.q_cap; L.phase_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
+            L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
+            while ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024 && L.ring_rows > 4) L.ring_rows /= 2;
+            if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
+            const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
+            L.bt_off = lds_fixed_bytes_bt();
+            L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
+            L.total = L.phase_off + std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes);
+        }
+        b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
+        b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
+        b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
+        b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);
+        b.query = di + o_query_; b.row_base = di + o_base_; b.row_node_id = (const int32_t *)(di + o_nid_); b.row_remain = (const int32_t *)(di + o_rem_);
+        b.row_active = di + o_act_; b.pred_off = (const int32_t *)(di + o_poff_); b.pred_row = (const int32_t *)(di + o_pred_);
+        b.out_off = (const int32_t *)(di + o_ooff_); b.out_row = (const int32_t *)(di + o_out_);
+        b.left = (int32_t *)(dout + o_left_); b.right = (int32_t *)(dout + o_right_);
+        b.dp_beg_sn = (int32_t *)(dout + o_bsn_); b.dp_end_sn = (int32_t *)(dout + o_esn_); b.row_cell_off = (int64_t *)(dout + o_coff_);
+        b.row_max_i = (int32_t *)(dout + o_rmi_); b.planes = planes_.dev; b.cigar = (uint64_t *)(dout + o_cig_);
+
+        HIP_TRY(hipEventRecord(ev_[0], stream_), ABPOA_HIP_ELAUNCH);
+        HIP_TRY(hipMemcpyAsync(di, hi, first_pass ? in_bytes_ : o_mat_, hipMemcpyHostToDevice, stream_), ABPOA_HIP_ELAUNCH);
+        if (banded && !fresh) {
+            if (first_pass) {
+                saved_lr.assign((const int32_t *)(ho + o_left_), (const int32_t *)(ho + o_left_) + lr_words);
+                HIP_TRY(hipMemcpyAsync(dout + o_left_, ho + o_left_, lr_words * 4, hipMemcpyHostToDevice, stream_), ABPOA_HIP_ELAUNCH);
+            } else for (int i : todo) {      // only the retried alignments restart from the caller's band state
+                const AlnDesc &d = desc_[i]; const size_t ro = (o_right_ - o_left_) / 4;
+                HIP_TRY(hipMemcpyAsync(dout + o_left_ + 4 * d.row0, saved_lr.data() + d.row0, 4 * (size_t)d.n_rows, hipMemcpyHostToDevice, stream_), ABPOA_HIP_ELAUNCH);
+                HIP_TRY(hipMemcpyAsync(dout + o_right_ + 4 * d.row0, saved_lr.data() + ro + d.row0, 4 * (size_t)d.n_rows, hipMemcpyHostToDevice, stream_), ABPOA_HIP_ELAUNCH);
+            }
+        }
+        // -1 = "row never computed" (inactive rows, rows behind a z-drop break)
+        if (first_pass) HIP_TRY(hipMemsetAsync(dout + o_bsn_, 0xFF, (o_esn_ - o_bsn_) + 4 * rows_tot_, stream_), ABPOA_HIP_ELAUNCH);
+        else for (int i : todo) {
+            const AlnDesc &d = desc_[i];
+            HIP_TRY(hipMemsetAsync(dout + o_bsn_ + 4 * d.row0, 0xFF, 4 * (size_t)d.n_rows, stream_), ABPOA_HIP_ELAUNCH);
+            HIP_TRY(hipMemsetAsync(dout + o_esn_ + 4 * d.row0, 0xFF, 4 * (size_t)d.n_rows, stream_), ABPOA_HIP_ELAUNCH);
+        }
+        HIP_TRY(hipEventRecord(ev_[1], stream_), ABPOA_HIP_ELAUNCH);
+        HIP_TRY(launch_dp(b, stream_), ABPOA_HIP_ELAUNCH);
+        HIP_TRY(hipEventRecord(ev_[2], stream_), ABPOA_HIP_ELAUNCH);
+        // results: records + cigars are adjacent at the start of the output blob; band state / trace arrays on demand
+        size_t d2h = o_left_;
+        if (banded && (flags_ & BS_WANT_BAND_STATE)) d2h = o_bsn_;
+        if (trace) d2h = out_bytes_;
+        HIP_TRY(hipMemcpyAsync(ho, dout, d2h, hipMemcpyDeviceToHost, stream_), ABPOA_HIP_ELAUNCH);
+        HIP_TRY(hipEventRecord(ev_[3], stream_), ABPOA_HIP_ELAUNCH);
+        HIP_TRY(hipStreamSynchronize(stream_), ABPOA_HIP_ELAUNCH);
+        float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
+        (void)hipEventElapsedTime(&ms_h2d, ev_[0], ev_[1]); (void)hipEventElapsedTime(&ms_k, ev_[1], ev_[2]); (void)hipEventElapsedTime(&ms_d2h, ev_[2], ev_[3]);
+        stats_.n_launches += 1; stats_.kernel_ms += ms_k; stats_.h2d_ms += ms_h2d; stats_.d2h_ms += ms_d2h;
+
+        // records are indexed by position in this pass; cigar / per-row slots by alignment, so a retry pass cannot
+        // clobber the results of alignments that finished earlier
+        const AlnOut *got = (const AlnOut *)(ho + o_rec_);
+        std::vector<int> again;
+        for (size_t t = 0; t < todo.size(); ++t) {
+            const int i = todo[t]; const AlnOut &r = got[t]; const AlnDesc &d = desc_[i];
+            if (r.status == ABPOA_HIP_STATUS_OVERFLOW) {
+                if (d.plane_cap >= full_cells_[i]) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
+                again.push_back(i); continue;
+            }
+            recs_[i] = r;
+            stats_.n_alignments += 1; stats_.n_cells += r.n_cells;
+            stats_.algo_bytes += r.n_cells * (d.bits / 8) * (P == 1 ? 2 : (P == 3 ? 5 : 8));
+            g_dbg[0] += r.clk_dp; g_dbg[1] += r.clk_bt; g_dbg[2] += r.n_rows_done; g_dbg[3] += r.n_bt_steps; for (int q_ = 0; q_ < 6; ++q_) g_dbg[4 + q_] += r.seg[q_];
+        }
+        todo.swap(again); first_pass = false;
+    }
+    return ABPOA_HIP_OK;
+}
+
+int BatchStream::fetch_trace(int i, const uint8_t *row_active, abpoa_hip_trace_t *T) {
+    (void)row_active;
+    const AlnDesc &d = desc_[i]; const AlnOut &r = recs_[i]; const int gn = d.n_rows, P = P_;
+    const bool banded = sc_.wb >= 0; const int pn = d.bits == 16 ? 16 : 8;
+    uint8_t *ho = out_.host;
+    T->bits = d.bits; T->n_planes = P;
+    T->dp_beg = (int32_t *)malloc(4 * gn); T->dp_end = (int32_t *)malloc(4 * gn); T->dp_beg_sn = (int32_t *)malloc(4 * gn); T->dp_end_sn = (int32_t *)malloc(4 * gn);
+    T->row_off = (int64_t *)malloc(8 * (gn + 1)); T->row_max_i = (int32_t *)malloc(4 * gn);
+    const int32_t *bsn = (const int32_t *)(ho + o_bsn_) + d.row0, *esn = (const int32_t *)(ho + o_esn_) + d.row0;
+    const int64_t *coff = (const int64_t *)(ho + o_coff_) + d.row0;
+    memcpy(T->row_max_i, (const int32_t *)(ho + o_rmi_) + d.row0, 4 * gn);
+    std::vector<uint8_t> arena((size_t)r.cells_used * (d.bits / 8));
+    if (!arena.empty()) HIP_TRY(hipMemcpy(arena.data(), planes_.dev + d.plane_off, arena.size(), hipMemcpyDeviceToHost), ABPOA_HIP_ELAUNCH);
+    int64_t tot = 0;
+    for (int rr = 0; rr < gn; ++rr) {
+        T->row_off[rr] = tot;
+        const bool computed = rr < gn - 1 && bsn[rr] >= 0;
+        if (!computed) { T->dp_beg[rr] = T->dp_end[rr] = T->dp_beg_sn[rr] = T->dp_end_sn[rr] = -1; T->row_max_i[rr] = -2; continue; }
+        T->dp_beg_sn[rr] = bsn[rr]; T->dp_end_sn[rr] = esn[rr]; T->dp_beg[rr] = bsn[rr] * pn;
+        T->dp_end[rr] = (banded || rr == 0) ? (esn[rr] + 1) * pn - 1 : d.qlen;
+        if (rr == 0) T->row_max_i[rr] = -2;
+        tot += (int64_t)(esn[rr] - bsn[rr] + 1) * pn * P;
+    }
+    T->row_off[gn] = tot;
+    T->planes = malloc((size_t)std::max<int64_t>(tot, 1) * (d.bits / 8));
+    for (int rr = 0; rr < gn; ++rr) {
+        if (T->dp_beg_sn[rr] < 0) continue;
+        size_t nb = (size_t)(T->row_off[rr + 1] - T->row_off[rr]) * (d.bits / 8);
+        memcpy((uint8_t *)T->planes + T->row_off[rr] * (d.bits / 8), arena.data() + coff[rr] * (d.bits / 8), nb);
+    }
+    return 0;
+}
 
 }  // namespace abpoa_hip
 
@@ -76,9 +286,8 @@ int abpoa_hip_init(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err("no HIP device available (the DP has no CPU fallback)"); return ABPOA_HIP_ENODEV; }
     if (device < 0 || device >= n) { set_err("device %d out of range (0..%d)", device, n - 1); return ABPOA_HIP_ENODEV; }
-    HIP_TRY(hipSetDevice(device), ABPOA_HIP_ENODEV);
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV);
-    for (auto &e : g.ev) HIP_TRY(hipEventCreate(&e), ABPOA_HIP_ENODEV);
+    int rc = g.flat.open(device);
+    if (rc) return rc;
     g.device = device; g.ready = true; memset(&g.stats, 0, sizeof(g.stats));
     return ABPOA_HIP_OK;
 }
@@ -86,17 +295,14 @@ int abpoa_hip_init(int device) {
 void abpoa_hip_shutdown(void) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return;
-    (void)hipStreamSynchronize(g.stream);
-    g.in.release(); g.outb.release(); g.planes.release();
-    for (auto &e : g.ev) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(g.stream);
+    g.flat.close();
     g.ready = false; g.device = -1;
 }
 
 const char *abpoa_hip_last_error(void) { return g_err; }
-void abpoa_hip_get_stats(abpoa_hip_stats_t *out) { std::lock_guard<std::mutex> lk(g.mu); *out = g.stats; }
+void abpoa_hip_get_stats(abpoa_hip_stats_t *out) { std::lock_guard<std::mutex> lk(g.stats_mu); *out = g.stats; }
 void abpoa_hip__debug_clocks(long long *out) { for (int i = 0; i < 10; ++i) { out[i] = g_dbg[i]; g_dbg[i] = 0; } }
-void abpoa_hip_reset_stats(void) { std::lock_guard<std::mutex> lk(g.mu); memset(&g.stats, 0, sizeof(g.stats)); }
+void abpoa_hip_reset_stats(void) { std::lock_guard<std::mutex> lk(g.stats_mu); memset(&g.stats, 0, sizeof(g.stats)); }
 
 // reference src/simd_abpoa_align.c:1672-1683
 int abpoa_hip_score_bits(const abpoa_hip_scoring_t *sc, int n_rows, int qlen, int32_t *inf_min) {
@@ -126,7 +332,7 @@ static int validate(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p,
     if ((sc->wb >= 0 || sc->zdrop > 0) && !p->row_remain) { set_err("problem %d: row_remain required", idx); return ABPOA_HIP_EINVAL; }
     if (sc->wb >= 0 && (!p->max_pos_left || !p->max_pos_right)) { set_err("problem %d: max_pos_left/right required when banded", idx); return ABPOA_HIP_EINVAL; }
     const int gn = p->n_rows;
-    if (p->pred_off[0] < 0 || p->out_off[0] < 0) { set_err("problem %d: negative CSR offset", idx); return ABPOA_HIP_EINVAL; }
+    if (p->pred_off[0] != 0 || p->out_off[0] != 0) { set_err("problem %d: CSR offsets must start at 0", idx); return ABPOA_HIP_EINVAL; }
     for (int r = 0; r < gn; ++r) {
         if (p->pred_off[r + 1] < p->pred_off[r] || p->out_off[r + 1] < p->out_off[r]) { set_err("problem %d: CSR offsets not monotone at row %d", idx, r); return ABPOA_HIP_EINVAL; }
         if (p->row_base[r] >= sc->m) { set_err("problem %d: base code %d >= m at row %d", idx, p->row_base[r], r); return ABPOA_HIP_EINVAL; }
@@ -154,190 +360,42 @@ int abpoa_hip_align_batch(const abpoa_hip_scoring_t *sc, int n, const abpoa_hip_
     if (sc->m <= 0 || !sc->mat || sc->gap_mode < 0 || sc->gap_mode > 2 || sc->align_mode < 0 || sc->align_mode > 2) { set_err("bad scoring"); return ABPOA_HIP_EINVAL; }
     for (int i = 0; i < n; ++i) { int rc = validate(sc, &pb[i], i); if (rc) return rc; }
     std::lock_guard<std::mutex> lk(g.mu);
-    HIP_TRY(hipSetDevice(g.device), ABPOA_HIP_ENODEV);
-
-    const int P = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
-    const bool banded = sc->wb >= 0;
-    const bool trace = flags & ABPOA_HIP_FLAG_TRACE;
-
-    // ---- sizes and offsets ----
-    std::vector<AlnDesc> desc(n);
-    int64_t rows_tot = 0, preds_tot = 0, outs_tot = 0, q_tot = 0, cig_tot = 0;
-    std::vector<int64_t> full_cells(n);
+    const bool banded = sc->wb >= 0, trace = flags & ABPOA_HIP_FLAG_TRACE;
+    std::vector<BatchShape> sh(n);
+    for (int i = 0; i < n; ++i) sh[i] = BatchShape{pb[i].n_rows, pb[i].qlen, pb[i].pred_off[pb[i].n_rows], pb[i].out_off[pb[i].n_rows]};
+    BatchStream &S = g.flat;
+    int rc = S.prepare(sc, n, sh.data(), (trace ? BS_TRACE : 0) | BS_WANT_BAND_STATE);
+    if (rc) return rc;
     for (int i = 0; i < n; ++i) {
-        const abpoa_hip_problem_t &p = pb[i]; AlnDesc &d = desc[i];
-        d.n_rows = p.n_rows; d.qlen = p.qlen;
-        d.bits = abpoa_hip_score_bits(sc, p.n_rows, p.qlen, &d.inf_min);
-        d.w = sc->wb < 0 ? p.qlen : sc->wb + (int)(sc->wf * p.qlen);     // reference :445 (float32 product)
-        d.cigar_cap = p.n_rows + p.qlen + 8;
-        d.query_off = q_tot; d.row0 = rows_tot; d.poff0 = rows_tot + i; d.pred0 = preds_tot; d.out0 = outs_tot; d.cigar_off = cig_tot;
-        q_tot += p.qlen; rows_tot += p.n_rows; preds_tot += p.pred_off[p.n_rows]; outs_tot += p.out_off[p.n_rows]; cig_tot += d.cigar_cap;
-        const int pn = d.bits == 16 ? 16 : 8;
-        const int64_t width = (int64_t)((p.qlen + pn) / pn) * pn;
-        full_cells[i] = width * P * p.n_rows;
-        int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
-        d.plane_cap = std::min<int64_t>(full_cells[i], width * P + est * P * (p.n_rows - 1));
+        const abpoa_hip_problem_t &p = pb[i]; const int gn = p.n_rows; ProblemSlots s = S.slots(i);
+        if (p.qlen) memcpy(s.query, p.query, p.qlen);
+        memcpy(s.row_base, p.row_base, gn); memcpy(s.row_node_id, p.row_node_id, 4 * gn);
+        if (p.row_remain) memcpy(s.row_remain, p.row_remain, 4 * gn); else memset(s.row_remain, 0, 4 * gn);
+        if (p.row_active) memcpy(s.row_active, p.row_active, gn);
+        memcpy(s.pred_off, p.pred_off, 4 * (gn + 1)); memcpy(s.pred_row, p.pred_row, 4 * (size_t)p.pred_off[gn]);
+        memcpy(s.out_off, p.out_off, 4 * (gn + 1)); memcpy(s.out_row, p.out_row, 4 * (size_t)p.out_off[gn]);
+        if (banded) { memcpy(s.left, p.max_pos_left, 4 * gn); memcpy(s.right, p.max_pos_right, 4 * gn); }
     }
-    // input blob layout
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
-    const size_t o_desc = take(sizeof(AlnDesc) * n), o_mat = take(sizeof(int32_t) * sc->m * sc->m), o_query = take(q_tot + 1),
-                 o_base = take(rows_tot), o_nid = take(4 * rows_tot), o_rem = take(4 * rows_tot), o_act = take(rows_tot),
-                 o_poff = take(4 * (rows_tot + n)), o_pred = take(4 * (preds_tot + 1)), o_ooff = take(4 * (rows_tot + n)), o_out = take(4 * (outs_tot + 1));
-    const size_t in_bytes = o;
-    // output blob layout
-    o = 0;
-    const size_t o_rec = take(sizeof(AlnOut) * n), o_left = take(4 * rows_tot), o_right = take(4 * rows_tot), o_bsn = take(4 * rows_tot),
-                 o_esn = take(4 * rows_tot), o_coff = take(8 * rows_tot), o_rmi = take(4 * rows_tot), o_cig = take(8 * cig_tot);
-    const size_t out_bytes = o;
-    int rc;
-    if ((rc = g.in.reserve(in_bytes)) || (rc = g.outb.reserve(out_bytes))) return rc;
-
-    // ---- pack ----
-    uint8_t *hi = g.in.host, *ho = g.outb.host;
-    memcpy(hi + o_mat, sc->mat, sizeof(int32_t) * sc->m * sc->m);
+    rc = S.run();
+    if (rc) return rc;
     for (int i = 0; i < n; ++i) {
-        const abpoa_hip_problem_t &p = pb[i]; const AlnDesc &d = desc[i]; const int gn = p.n_rows;
-        if (p.qlen) memcpy(hi + o_query + d.query_off, p.query, p.qlen);
-        memcpy(hi + o_base + d.row0, p.row_base, gn);
-        memcpy(hi + o_nid + 4 * d.row0, p.row_node_id, 4 * gn);
-        if (p.row_remain) memcpy(hi + o_rem + 4 * d.row0, p.row_remain, 4 * gn); else memset(hi + o_rem + 4 * d.row0, 0, 4 * gn);
-        if (p.row_active) memcpy(hi + o_act + d.row0, p.row_active, gn); else memset(hi + o_act + d.row0, 1, gn);
-        memcpy(hi + o_poff + 4 * d.poff0, p.pred_off, 4 * (gn + 1));
-        memcpy(hi + o_pred + 4 * d.pred0, p.pred_row + 0, 4 * (size_t)(p.pred_off[gn]));
-        memcpy(hi + o_ooff + 4 * d.poff0, p.out_off, 4 * (gn + 1));
-        memcpy(hi + o_out + 4 * d.out0, p.out_row + 0, 4 * (size_t)(p.out_off[gn]));
-        if (p.pred_off[0] != 0 || p.out_off[0] != 0) { set_err("problem %d: CSR offsets must start at 0", i); return ABPOA_HIP_EINVAL; }
+        const AlnOut &r = S.rec(i); abpoa_hip_result_t &R = res[i]; const abpoa_hip_problem_t &p = pb[i];
+        R.status = r.status; R.bits = S.desc(i).bits; R.best_score = r.best_score; R.best_row = r.best_row; R.best_col = r.best_col;
+        R.node_s = r.node_s; R.node_e = r.node_e; R.query_s = r.query_s; R.query_e = r.query_e;
+        R.n_aln_bases = r.n_aln_bases; R.n_matched_bases = r.n_matched_bases; R.n_cells = r.n_cells;
+        R.n_cigar = r.status == 0 ? r.n_cigar : 0;
+        if (R.n_cigar > 0) {
+            R.cigar = (uint64_t *)malloc(sizeof(uint64_t) * R.n_cigar);
+            if (!R.cigar) { set_err("malloc failed"); return ABPOA_HIP_ENOMEM; }
+            memcpy(R.cigar, S.cigar(i), sizeof(uint64_t) * R.n_cigar);
+        }
+        if (banded) { memcpy(p.max_pos_left, S.left(i), 4 * p.n_rows); memcpy(p.max_pos_right, S.right(i), 4 * p.n_rows); }
+        if (trace) {
+            R.trace = (abpoa_hip_trace_t *)calloc(1, sizeof(abpoa_hip_trace_t));
+            if ((rc = S.fetch_trace(i, p.row_active, R.trace))) return rc;
+        }
     }
-
-    std::vector<int> todo(n); for (int i = 0; i < n; ++i) todo[i] = i;
-    bool first_pass = true;
-    while (!todo.empty()) {
-        // arena offsets for the alignments of this pass
-        int64_t plane_bytes = 0;
-        std::vector<AlnDesc> pass(todo.size());
-        for (size_t t = 0; t < todo.size(); ++t) {
-            AlnDesc &d = desc[todo[t]];
-            if (!first_pass) d.plane_cap = full_cells[todo[t]];
-            d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8));
-            pass[t] = d;
-        }
-        if ((rc = g.planes.reserve((size_t)plane_bytes))) return rc;
-        memcpy(hi + o_desc, pass.data(), sizeof(AlnDesc) * pass.size());
-        if (banded)   // max_pos_left/right are in/out: stage the caller's values (a retried alignment restarts from them)
-            for (int i : todo) {
-                memcpy(ho + o_left + 4 * desc[i].row0, pb[i].max_pos_left, 4 * pb[i].n_rows);
-                memcpy(ho + o_right + 4 * desc[i].row0, pb[i].max_pos_right, 4 * pb[i].n_rows);
-            }
-
-        DevBatch b; memset(&b, 0, sizeof(b));
-        b.n = (int)pass.size(); b.m = sc->m;
-        {   // ---- LDS plan (engine.h LdsPlan): sized for the widest expected band / largest query of this pass
-            int max_qlen = 0, max_bits = 16; int64_t est_cols = 0;
-            for (const AlnDesc &d : pass) {
-                max_qlen = std::max(max_qlen, d.qlen); max_bits = std::max(max_bits, d.bits);
-                const int pn = d.bits == 16 ? 16 : 8; const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
-                est_cols = std::max<int64_t>(est_cols, banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width);
-            }
-            LdsPlan &L = b.lds; const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
-            L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
-            L.mat_off = L.q_cap; L.phase_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
-            L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
-            while ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024 && L.ring_rows > 4) L.ring_rows /= 2;
-            if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
-            const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
-            L.bt_off = lds_fixed_bytes_bt();
-            L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
-            L.total = L.phase_off + std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes);
-        }
-        b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
-        b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar; b.want_trace = trace ? 1 : 0;
-        uint8_t *di = g.in.dev, *dout = g.outb.dev;
-        b.mat = (const int32_t *)(di + o_mat); b.aln = (const AlnDesc *)(di + o_desc); b.out = (AlnOut *)(dout + o_rec);
-        b.query = di + o_query; b.row_base = di + o_base; b.row_node_id = (const int32_t *)(di + o_nid); b.row_remain = (const int32_t *)(di + o_rem);
-        b.row_active = di + o_act; b.pred_off = (const int32_t *)(di + o_poff); b.pred_row = (const int32_t *)(di + o_pred);
-        b.out_off = (const int32_t *)(di + o_ooff); b.out_row = (const int32_t *)(di + o_out);
-        b.left = (int32_t *)(dout + o_left); b.right = (int32_t *)(dout + o_right);
-        b.dp_beg_sn = (int32_t *)(dout + o_bsn); b.dp_end_sn = (int32_t *)(dout + o_esn); b.row_cell_off = (int64_t *)(dout + o_coff);
-        b.row_max_i = (int32_t *)(dout + o_rmi); b.planes = g.planes.dev; b.cigar = (uint64_t *)(dout + o_cig);
-
-        HIP_TRY(hipEventRecord(g.ev[0], g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(hipMemcpyAsync(di, hi, first_pass ? in_bytes : o_mat, hipMemcpyHostToDevice, g.stream), ABPOA_HIP_ELAUNCH);
-        if (banded)
-            HIP_TRY(hipMemcpyAsync(dout + o_left, ho + o_left, (o_right - o_left) + 4 * rows_tot, hipMemcpyHostToDevice, g.stream), ABPOA_HIP_ELAUNCH);
-        // -1 = "row never computed" (inactive rows, rows behind a z-drop break)
-        HIP_TRY(hipMemsetAsync(dout + o_bsn, 0xFF, (o_esn - o_bsn) + 4 * rows_tot, g.stream), ABPOA_HIP_ELAUNCH);
-        if (trace) HIP_TRY(hipMemsetAsync(dout + o_rmi, 0xFE, 4 * rows_tot, g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(hipEventRecord(g.ev[1], g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(launch_dp(b, g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(hipEventRecord(g.ev[2], g.stream), ABPOA_HIP_ELAUNCH);
-        std::vector<AlnOut> recs(pass.size());
-        HIP_TRY(hipMemcpyAsync(ho + o_rec, dout + o_rec, sizeof(AlnOut) * pass.size(), hipMemcpyDeviceToHost, g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(hipStreamSynchronize(g.stream), ABPOA_HIP_ELAUNCH);
-        memcpy(recs.data(), ho + o_rec, sizeof(AlnOut) * pass.size());
-        // everything else the host needs: band state, per-row outputs, cigars
-        HIP_TRY(hipMemcpyAsync(ho + o_left, dout + o_left, out_bytes - o_left, hipMemcpyDeviceToHost, g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(hipEventRecord(g.ev[3], g.stream), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(hipStreamSynchronize(g.stream), ABPOA_HIP_ELAUNCH);
-        float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
-        (void)hipEventElapsedTime(&ms_h2d, g.ev[0], g.ev[1]); (void)hipEventElapsedTime(&ms_k, g.ev[1], g.ev[2]); (void)hipEventElapsedTime(&ms_d2h, g.ev[2], g.ev[3]);
-        g.stats.n_launches += 1; g.stats.kernel_ms += ms_k; g.stats.h2d_ms += ms_h2d; g.stats.d2h_ms += ms_d2h;
-
-        std::vector<int> again;
-        for (size_t t = 0; t < todo.size(); ++t) {
-            const int i = todo[t]; const AlnOut &r = recs[t]; const AlnDesc &d = desc[i]; const abpoa_hip_problem_t &p = pb[i];
-            if (r.status == ABPOA_HIP_STATUS_OVERFLOW) {
-                if (d.plane_cap >= full_cells[i]) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
-                again.push_back(i); continue;
-            }
-            abpoa_hip_result_t &R = res[i];
-            R.status = r.status; R.bits = d.bits; R.best_score = r.best_score; R.best_row = r.best_row; R.best_col = r.best_col;
-            R.node_s = r.node_s; R.node_e = r.node_e; R.query_s = r.query_s; R.query_e = r.query_e;
-            R.n_aln_bases = r.n_aln_bases; R.n_matched_bases = r.n_matched_bases; R.n_cells = r.n_cells;
-            R.n_cigar = r.status == 0 ? r.n_cigar : 0;
-            if (R.n_cigar > 0) {
-                R.cigar = (uint64_t *)malloc(sizeof(uint64_t) * R.n_cigar);
-                if (!R.cigar) { set_err("malloc failed"); return ABPOA_HIP_ENOMEM; }
-                memcpy(R.cigar, ho + o_cig + 8 * d.cigar_off, sizeof(uint64_t) * R.n_cigar);
-            }
-            if (banded) { memcpy(p.max_pos_left, ho + o_left + 4 * d.row0, 4 * p.n_rows); memcpy(p.max_pos_right, ho + o_right + 4 * d.row0, 4 * p.n_rows); }
-            const int pn = d.bits == 16 ? 16 : 8;
-            g.stats.n_alignments += 1; g.stats.n_cells += r.n_cells;
-            g_dbg[0] += r.clk_dp; g_dbg[1] += r.clk_bt; g_dbg[2] += r.n_rows_done; g_dbg[3] += r.n_bt_steps; for (int q_ = 0; q_ < 6; ++q_) g_dbg[4 + q_] += r.seg[q_];
-            g.stats.algo_bytes += r.n_cells * (d.bits / 8) * (P == 1 ? 2 : (P == 3 ? 5 : 8));
-            if (trace) {
-                abpoa_hip_trace_t *T = (abpoa_hip_trace_t *)calloc(1, sizeof(abpoa_hip_trace_t));
-                const int gn = p.n_rows;
-                T->bits = d.bits; T->n_planes = P;
-                T->dp_beg = (int32_t *)malloc(4 * gn); T->dp_end = (int32_t *)malloc(4 * gn); T->dp_beg_sn = (int32_t *)malloc(4 * gn); T->dp_end_sn = (int32_t *)malloc(4 * gn);
-                T->row_off = (int64_t *)malloc(8 * (gn + 1)); T->row_max_i = (int32_t *)malloc(4 * gn);
-                const int32_t *bsn = (const int32_t *)(ho + o_bsn) + d.row0, *esn = (const int32_t *)(ho + o_esn) + d.row0;
-                const int64_t *coff = (const int64_t *)(ho + o_coff) + d.row0;
-                memcpy(T->row_max_i, (const int32_t *)(ho + o_rmi) + d.row0, 4 * gn);
-                // host copy of the arena
-                std::vector<uint8_t> arena((size_t)r.cells_used * (d.bits / 8));
-                if (!arena.empty()) HIP_TRY(hipMemcpy(arena.data(), g.planes.dev + d.plane_off, arena.size(), hipMemcpyDeviceToHost), ABPOA_HIP_ELAUNCH);
-                int64_t tot = 0;
-                for (int rr = 0; rr < gn; ++rr) {
-                    T->row_off[rr] = tot;
-                    const bool computed = rr < gn - 1 && bsn[rr] >= 0;
-                    if (!computed) { T->dp_beg[rr] = T->dp_end[rr] = T->dp_beg_sn[rr] = T->dp_end_sn[rr] = -1; continue; }
-                    T->dp_beg_sn[rr] = bsn[rr]; T->dp_end_sn[rr] = esn[rr]; T->dp_beg[rr] = bsn[rr] * pn;
-                    T->dp_end[rr] = (banded || rr == 0) ? (esn[rr] + 1) * pn - 1 : p.qlen;
-                    tot += (int64_t)(esn[rr] - bsn[rr] + 1) * pn * P;
-                }
-                T->row_off[gn] = tot;
-                T->planes = malloc((size_t)std::max<int64_t>(tot, 1) * (d.bits / 8));
-                for (int rr = 0; rr < gn; ++rr) {
-                    if (T->dp_beg_sn[rr] < 0) continue;
-                    size_t nb = (size_t)(T->row_off[rr + 1] - T->row_off[rr]) * (d.bits / 8);
-                    memcpy((uint8_t *)T->planes + T->row_off[rr] * (d.bits / 8), arena.data() + coff[rr] * (d.bits / 8), nb);
-                }
-                R.trace = T;
-            }
-        }
-        todo.swap(again); first_pass = false;   // retried alignments keep their slots in the row pools
-    }
+    add_global_stats(S.take_stats());
     return ABPOA_HIP_OK;
 }
 

@@ -1,11 +1,14 @@
 // Read-set batch driver (include/abpoa_hip.h section 3).  Reference counterpart per set:
 // abpoa_msa -> abpoa_poa -> {abpoa_align_sequence_to_graph, abpoa_add_graph_alignment} -> abpoa_output
-// (src/abpoa_align.c:302-437).  Here the per-read loop is turned inside out: all sets advance one read
-// per round so that one engine launch carries one alignment of every set.
+// (src/abpoa_align.c:302-437).  Here the per-read loop is turned inside out: the sets are split into a few groups;
+// inside a group all sets advance one read per round so that one engine launch carries one alignment of every set
+// of the group, and the groups run out of phase on their own streams so that host graph work (fusion, row ordering,
+// flattening straight into pinned staging memory) of one group overlaps the DP kernel of another.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +33,7 @@ class Pool {
     }
     void run(int n, const std::function<void(int)> &fn) {
         if (n <= 0) return;
+        if (n_ == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
         fn_ = &fn; total_ = n; next_.store(0); pending_.store(n_ - 1);
         { std::lock_guard<std::mutex> lk(mu_); ++gen_; }
         cv_.notify_all();
@@ -54,10 +58,69 @@ class Pool {
     std::atomic<int> next_{0}, pending_{0};
 };
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct GroupTimes { double sort_s = 0, engine_s = 0, fuse_s = 0; int rounds = 0; };
 }  // namespace
 
+// One group of read-sets [s0, s1): the whole progressive POA, lock-step over reads.
+static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int s0, int s1,
+                     std::vector<PoaGraph> &graphs, int n_threads, GroupAligner *al, bool with_remain, GroupTimes *gt) {
+    Pool pool(n_threads);
+    int max_reads = 0;
+    for (int s = s0; s < s1; ++s) if (sets[s].n_reads > max_reads) max_reads = sets[s].n_reads;
+    std::vector<int> active; active.reserve(s1 - s0);
+    std::vector<BatchShape> shapes;
+    std::atomic<int> fail{0};
+    for (int k = 0; k < max_reads; ++k) {
+        active.clear();
+        for (int s = s0; s < s1; ++s) if (sets[s].n_reads > k && out[s].status == 0) active.push_back(s);
+        if (active.empty()) break;
+        if (k == 0) {       // first read of every set seeds its graph (reference: abpoa_align_sequence_to_graph returns -1, :186)
+            pool.run((int)active.size(), [&](int a) {
+                const int s = active[a];
+                try { graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0); } catch (...) { fail.store(1); }
+            });
+            if (fail.load()) return ABPOA_HIP_EINVAL;
+            continue;
+        }
+        const double t0 = now_s();
+        shapes.resize(active.size());
+        for (size_t a = 0; a < active.size(); ++a) {
+            const int s = active[a];
+            shapes[a] = BatchShape{graphs[s].n_nodes(), sets[s].lens[k], graphs[s].n_edges(), graphs[s].n_edges()};
+        }
+        int rc = al->prepare(&scoring, (int)active.size(), shapes.data());
+        if (rc) return rc;
+        pool.run((int)active.size(), [&](int a) {
+            const int s = active[a];
+            try {
+                graphs[s].topological_sort(with_remain);
+                ProblemSlots sl = al->slots(a);
+                memcpy(sl.query, sets[s].seqs[k], sets[s].lens[k]);
+                graphs[s].flatten_into(with_remain, sl.row_base, sl.row_node_id, sl.row_remain, sl.pred_off, sl.pred_row, sl.out_off, sl.out_row);
+            } catch (...) { fail.store(1); }
+        });
+        if (fail.load()) return ABPOA_HIP_EINVAL;
+        const double t1 = now_s();
+        rc = al->run();
+        if (rc) return rc;
+        const double t2 = now_s();
+        pool.run((int)active.size(), [&](int a) {
+            const int s = active[a];
+            const int st = al->status(a);
+            if (st != 0) { out[s].status = st; return; }
+            out[s].n_cells += al->n_cells(a);
+            try { graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], al->cigar(a), al->n_cigar(a), k); } catch (...) { fail.store(1); }
+        });
+        if (fail.load()) return ABPOA_HIP_EINVAL;
+        const double t3 = now_s();
+        gt->sort_s += t1 - t0; gt->engine_s += t2 - t1; gt->fuse_s += t3 - t2; gt->rounds += 1;
+    }
+    return ABPOA_HIP_OK;
+}
+
 int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out,
-                  unsigned flags, int n_threads, AlignBatchFn align, abpoa_hip_msa_timing_t *tm) {
+                  unsigned flags, int n_threads, int n_groups, AlignerFactory make, abpoa_hip_msa_timing_t *tm) {
     if (n_sets < 0 || !sc || (n_sets > 0 && (!sets || !out))) return ABPOA_HIP_EINVAL;
     const double t_start = now_s();
     if (tm) memset(tm, 0, sizeof(*tm));
@@ -66,68 +129,43 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_sets) n_threads = n_sets;
+    if (n_groups <= 0) n_groups = n_sets >= 512 ? 4 : (n_sets >= 128 ? 2 : 1);
+    if (n_groups > n_threads) n_groups = n_threads;
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
-    const bool banded = sc->wb >= 0 && sc->align_mode != ABPOA_HIP_LOCAL_MODE;
     abpoa_hip_scoring_t scoring = *sc;
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE) scoring.wb = -1;        // reference abpoa_post_set_para, abpoa_align.c:150
     scoring.ret_cigar = 1; scoring.rev_cigar = 0;
-    int max_reads = 0;
+    const bool with_remain = scoring.wb >= 0 || scoring.zdrop > 0;
     for (int s = 0; s < n_sets; ++s) {
         if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL;
         for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL;
-        if (sets[s].n_reads > max_reads) max_reads = sets[s].n_reads;
         out[s].n_reads = sets[s].n_reads;
     }
-    Pool pool(n_threads);
     std::vector<PoaGraph> graphs(n_sets);
-    std::vector<FlatProblem> flat(n_sets);
     for (int s = 0; s < n_sets; ++s) graphs[s].reset(sets[s].n_reads, want_msa);
-    std::vector<int> active; active.reserve(n_sets);
-    std::vector<abpoa_hip_problem_t> problems; std::vector<abpoa_hip_result_t> results;
-    std::atomic<int> fail{0};
-    const bool with_remain = banded || scoring.zdrop > 0;
+
+    // ---- groups run concurrently, each with its own aligner (stream) and worker pool
+    std::vector<std::unique_ptr<GroupAligner>> aligners;
+    for (int g = 0; g < n_groups; ++g) { aligners.emplace_back(make()); if (!aligners.back()) return ABPOA_HIP_ENODEV; }
+    std::vector<GroupTimes> gts(n_groups); std::vector<int> rcs(n_groups, 0);
+    std::vector<std::thread> drivers;
+    const int per_group_threads = n_threads / n_groups > 0 ? n_threads / n_groups : 1;
+    for (int g = 0; g < n_groups; ++g) {
+        const int s0 = (int)((int64_t)n_sets * g / n_groups), s1 = (int)((int64_t)n_sets * (g + 1) / n_groups);
+        auto body = [&, g, s0, s1] { rcs[g] = run_group(scoring, sets, out, s0, s1, graphs, per_group_threads, aligners[g].get(), with_remain, &gts[g]); };
+        if (g + 1 < n_groups) drivers.emplace_back(body); else body();
+    }
+    for (auto &t : drivers) t.join();
     int rc = ABPOA_HIP_OK;
-    for (int k = 0; k < max_reads && rc == ABPOA_HIP_OK; ++k) {
-        active.clear();
-        for (int s = 0; s < n_sets; ++s) if (sets[s].n_reads > k && out[s].status == 0) active.push_back(s);
-        if (k == 0) {
-            pool.run((int)active.size(), [&](int a) {
-                const int s = active[a];
-                try { graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0); } catch (...) { fail.store(1); }
-            });
-            continue;
-        }
-        double t0 = now_s();
-        problems.resize(active.size()); results.resize(active.size());
-        pool.run((int)active.size(), [&](int a) {
-            const int s = active[a];
-            try {
-                graphs[s].topological_sort(with_remain);
-                graphs[s].flatten(scoring.wb >= 0, &flat[s]);
-                problems[a] = flat[s].view(sets[s].seqs[k], sets[s].lens[k]);
-            } catch (...) { fail.store(1); }
-        });
-        if (fail.load()) { rc = ABPOA_HIP_EINVAL; break; }
-        double t1 = now_s();
-        rc = align((const abpoa_hip_scoring_t *)&scoring, (int)active.size(), problems.data(), results.data(), 0);
-        double t2 = now_s();
-        if (rc != ABPOA_HIP_OK) break;
-        pool.run((int)active.size(), [&](int a) {
-            const int s = active[a];
-            abpoa_hip_result_t &r = results[a];
-            if (r.status != 0) out[s].status = r.status;
-            else {
-                out[s].n_cells += r.n_cells;
-                try { graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], r.cigar, r.n_cigar, k); } catch (...) { fail.store(1); }
-            }
-            free(r.cigar); r.cigar = nullptr;
-        });
-        double t3 = now_s();
-        if (tm) { tm->host_sort_s += t1 - t0; tm->engine_s += t2 - t1; tm->host_fuse_s += t3 - t2; tm->n_rounds += 1; }
-        if (fail.load()) { rc = ABPOA_HIP_EINVAL; break; }
+    for (int g = 0; g < n_groups; ++g) if (rcs[g] != 0 && rc == 0) rc = rcs[g];
+    aligners.clear();
+    if (tm) for (int g = 0; g < n_groups; ++g) {
+        tm->host_sort_s += gts[g].sort_s / n_groups; tm->engine_s += gts[g].engine_s / n_groups; tm->host_fuse_s += gts[g].fuse_s / n_groups;
+        if (gts[g].rounds > tm->n_rounds) tm->n_rounds = gts[g].rounds;
     }
     if (rc == ABPOA_HIP_OK) {
-        double t0 = now_s();
+        const double t0 = now_s();
+        Pool pool(n_threads);
         pool.run(n_sets, [&](int s) {
             if (out[s].status != 0 || graphs[s].empty()) return;
             abpoa_hip_msa_t &o = out[s];
@@ -158,20 +196,13 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     return rc;
 }
 
-static abpoa_hip_msa_timing_t g_timing;
-
 }  // namespace abpoa_hip
 
 extern "C" {
-int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
-                        abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
-    return abpoa_hip::run_msa_batch(sc, n_sets, sets, out, flags, n_threads, abpoa_hip_align_batch, &abpoa_hip::g_timing);
-}
 void abpoa_hip_free_msa(abpoa_hip_msa_t *r) {
     if (!r) return;
     free(r->cons_base); free(r->cons_cov); free(r->cons_node_id); free(r->msa_base);
     r->cons_base = nullptr; r->cons_cov = nullptr; r->cons_node_id = nullptr; r->msa_base = nullptr;
     r->cons_len = r->msa_len = r->msa_rows = 0;
 }
-void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
 }

@@ -23,7 +23,7 @@ void PoaGraph::reset(int tot_reads, bool use_read_ids) {
     tot_reads_ = tot_reads; use_read_ids_ = use_read_ids;
     words_ = use_read_ids ? 1 + ((tot_reads > 0 ? tot_reads : 1) - 1) / 64 : 0;   // reference abpoa_graph.c:599
     if (use_read_ids_) read_ids_.resize(2);
-    sorted_ = false;
+    sorted_ = false; n_edges_ = 0;
 }
 
 int PoaGraph::add_node(uint8_t base) {                        // reference abpoa_graph.c:409-416
@@ -40,7 +40,7 @@ void PoaGraph::add_edge(int from, int to, bool check_edge, int w, bool add_read_
     }
     if (edge_i < 0) {
         nodes_[to].in_id.push_back(from);
-        f.out_id.push_back(to); f.out_w.push_back(w);
+        f.out_id.push_back(to); f.out_w.push_back(w); ++n_edges_;
         edge_i = f.out_id.size() - 1;
         if (use_read_ids_) read_ids_[from].resize((size_t)f.out_id.size() * words_, 0);
     }
@@ -171,6 +171,20 @@ void PoaGraph::flatten(bool banded, FlatProblem *fp) const {
     fp->pred_off[n] = (int)fp->pred_row.size(); fp->out_off[n] = (int)fp->out_row.size();
     if (fp->pred_row.empty()) fp->pred_row.push_back(0);
     if (fp->out_row.empty()) fp->out_row.push_back(0);
+}
+
+void PoaGraph::flatten_into(bool with_remain, uint8_t *row_base, int32_t *row_node_id, int32_t *row_remain, int32_t *pred_off,
+                            int32_t *pred_row, int32_t *out_off, int32_t *out_row) const {
+    const int n = (int)nodes_.size();
+    int np = 0, no = 0;
+    for (int r = 0; r < n; ++r) {
+        const int id = index_to_node_[r]; const PoaNode &nd = nodes_[id];
+        row_base[r] = nd.base; row_node_id[r] = id; row_remain[r] = with_remain ? remain_[id] : 0;
+        pred_off[r] = np; out_off[r] = no;
+        for (int j = 0; j < nd.in_id.size(); ++j) pred_row[np++] = node_to_index_[nd.in_id[j]];
+        for (int j = 0; j < nd.out_id.size(); ++j) out_row[no++] = node_to_index_[nd.out_id[j]];
+    }
+    pred_off[n] = np; out_off[n] = no;
 }
 
 void PoaGraph::consensus(std::vector<int> *node_ids, std::vector<uint8_t> *bases, std::vector<int> *cov) const {

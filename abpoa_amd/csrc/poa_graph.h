@@ -81,6 +81,10 @@ class PoaGraph {
     void topological_sort(bool with_remain);
     // Snapshot of the whole graph (row 0 = source, last row = sink) for the engine.
     void flatten(bool banded, FlatProblem *out) const;
+    // Same snapshot written straight into the engine's pinned staging slots (sizes: n_nodes(), n_edges()).
+    void flatten_into(bool with_remain, uint8_t *row_base, int32_t *row_node_id, int32_t *row_remain, int32_t *pred_off,
+                      int32_t *pred_row, int32_t *out_off, int32_t *out_row) const;
+    int n_edges() const { return n_edges_; }
 
     // Single heaviest-bundling consensus: node ids of the path, bases and per-base coverage.
     void consensus(std::vector<int> *node_ids, std::vector<uint8_t> *bases, std::vector<int> *cov) const;
@@ -101,7 +105,7 @@ class PoaGraph {
     std::vector<std::vector<uint64_t>> read_ids_;   // per node: out_edge * words_ + w   (only if use_read_ids_)
     std::vector<int> index_to_node_, node_to_index_, remain_;
     mutable std::vector<int> scratch_deg_, scratch_q_;
-    int tot_reads_ = 0, words_ = 0;
+    int tot_reads_ = 0, words_ = 0, n_edges_ = 0;
     bool use_read_ids_ = false, sorted_ = false;
 };
 

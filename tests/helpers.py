@@ -316,7 +316,7 @@ def cpu_shim_lib():
         so = os.path.join(bdir, "libcpu_shim.so")
         srcs = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.cpp"),
                 os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.cpp")]
-        deps = srcs + [os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.h"),
+        deps = srcs + [os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "batch_types.h"),
                        os.path.join(ROOT, "include", "abpoa_hip.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
             obj = os.path.join(bdir, "oracle.o")
