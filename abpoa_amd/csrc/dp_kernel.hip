@@ -28,6 +28,7 @@
 
 namespace abpoa_hip {
 
+#define GLOBAL_AS __attribute__((address_space(1)))
 #define OP_M   0x1
 #define OP_E1  0x2
 #define OP_E2  0x4
@@ -46,12 +47,11 @@ constexpr int MAX_RING_ROWS = 32;
 constexpr int BTR = 64;     // backtrack tile: rows
 constexpr int BTP = 256;    // backtrack tile: predecessor entries
 
-struct DpLds {              // fixed part of the DP-phase LDS image
-    int32_t t_poff[TS + 1], t_ooff[TS + 1], t_remain[TS], t_pred[TP], t_out[TP];
-    int32_t b_bsn[RB], b_esn[RB]; uint32_t b_coff[RB];      // b_coff in units of PN cells
-    int32_t l_left[RL], l_right[RL];
-    int32_t ring_tag[MAX_RING_ROWS];
-    uint8_t t_base[TS], t_act[TS];
+struct __attribute__((aligned(16))) DpLds {   // fixed part of the DP-phase LDS image; 16-byte records = one ds_read_b128 each
+    int4 t_rec[TS + 1];     // static tile, per row: {pred_off, out_off, remain, base | active << 8}; entry [TS] = end offsets
+    int4 b_rec[RB];         // band ring: {beg_sn, end_sn, cell_off / PN, row id while its H/E rows sit in the score ring else -1}
+    int2 l_lr[RL];          // look-ahead window: {max_pos_left, max_pos_right}
+    int32_t t_pred[TP], t_out[TP];
 };
 struct BtLds {              // fixed part of the backtrack-phase LDS image
     long long coff[BTR + 1];
@@ -97,16 +97,18 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
 // the common path and the global load of the fallback path into ONE flat load of a selected pointer, and a flat load
 // waits for vmcnt(0)+lgkmcnt(0), i.e. for every outstanding score-plane store of the wave (gfx9 counts stores in vmcnt).
 // Each helper waits for its own data (and, as a side effect, for this wave's earlier stores, which these paths need).
-__device__ __forceinline__ int gld_i32(const int32_t *p) { int v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ int gld_u8(const uint8_t *p) { int v; asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ long long gld_i64(const int64_t *p) { long long v; asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ int gld_cell(const int16_t *p) { int v; asm volatile("global_load_sshort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ int gld_cell(const int32_t *p) { return gld_i32(p); }
+__device__ __forceinline__ int gld_i32(GLOBAL_AS const int32_t *p) { int v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ int gld_u8(GLOBAL_AS const uint8_t *p) { int v; asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ long long gld_i64(GLOBAL_AS const int64_t *p) { long long v; asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ int gld_cell(GLOBAL_AS const int16_t *p) { int v; asm volatile("global_load_sshort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ int gld_cell(GLOBAL_AS const int32_t *p) { return gld_i32(p); }
 
 // Moves a wave-uniform pointer into a VGPR pair and hides its uniformity from the compiler.  The kernel keeps ~20
 // per-alignment base pointers; left in SGPRs they (with the per-row uniforms) overflow the 102-SGPR budget and the hot
 // loop drowns in v_readlane/v_writelane spill traffic.  VGPRs are plentiful here (one wave per SIMD).
-template <typename Pt> __device__ __forceinline__ Pt *vgpr_ptr(Pt *p) { asm("" : "+v"(p)); return p; }
+template <typename Pt> __device__ __forceinline__ GLOBAL_AS Pt *vgpr_ptr(Pt *p) { asm("" : "+v"(p)); return (GLOBAL_AS Pt *)p; }
+// (the result stays typed as a GLOBAL pointer: a generic pointer would turn every access into a flat load, and an
+//  outstanding flat load also blocks s_waitcnt lgkmcnt(0), i.e. every LDS wait of the row loop)
 
 template <typename T> struct Width;
 template <> struct Width<int16_t> { static constexpr int PN = 16, LOGN = 4; };
@@ -138,6 +140,47 @@ __device__ __forceinline__ T set_f(T f, int l, int set_num, T e, T inf) {
     return f;
 }
 
+// Distance (in lanes) to the nearest "inf" injection of the reference's log-step scan (zero-filled shift | PRE_MIN):
+// after the scan lane l holds max( clean prefix scan , inf - INJ[l]*e ); -1 = no injection reaches the lane.
+template <int PN> __device__ __forceinline__ int inj_dist(int l);
+template <> __device__ __forceinline__ int inj_dist<16>(int l) { return l < 8 ? 0 : (l < 12 ? 8 : (l < 14 ? 12 : (l == 14 ? 14 : -1))); }
+template <> __device__ __forceinline__ int inj_dist<8>(int l) { return l < 4 ? 0 : (l < 6 ? 4 : (l == 6 ? 6 : -1)); }
+
+// Closed form of "F = (H<<1 | first) - oe; SIMD_SET_F(F); first = max(H[pn-1], F[pn-1] + o)" (reference :870-874) for the
+// first `nfast` vectors of a chunk at once, valid when no subtraction can wrap (the caller checks hs >= MIN + oe + pn*e):
+// then max-plus arithmetic distributes and  F[l] = max( scan of the vector's own H , first - oe - l*e , inf - INJ[l]*e ),
+// and the vector-to-vector carry is first' = max(H[pn-1], ownscan[pn-1] + o, first - pn*e).  Plain int arithmetic.
+template <typename T>
+__device__ __forceinline__ int fast_f_chain(int hs, int &first, int nfast, int l, int vvl, int oe, int e, int o, int cl, int inj) {
+    constexpr int PN = Width<T>::PN, NV = 64 / PN;
+    int f = row_shr<1>(hs, hs) - oe;                 // own sources: F0[l] = H[l-1] - oe for l >= 1 (lane 0 has none)
+    if (PN == 16) {
+        f = (l == 0) ? -(1 << 30) : f;               // int16 values in 32-bit registers: a plain sentinel survives the scan
+        f = imax(f, row_shr<1>(f, f) - e);
+        f = imax(f, row_shr<2>(f, f) - 2 * e);
+        f = imax(f, row_shr<4>(f, f) - 4 * e);
+        f = imax(f, row_shr<8>(f, f) - 8 * e);
+    } else {                                         // int32: no room for a sentinel, lane l only takes from lanes l-s >= 1
+        int t;
+        t = row_shr<1>(f, f) - e;     f = (l > 1) ? imax(f, t) : f;
+        t = row_shr<2>(f, f) - 2 * e; f = (l > 2) ? imax(f, t) : f;
+        t = row_shr<4>(f, f) - 4 * e; f = (l > 4) ? imax(f, t) : f;
+    }
+    const int cv = imax(hs, f + o);                  // at lane pn-1 of a vector: max(H[pn-1], ownscan[pn-1] + o)
+    int fc[NV + 1]; fc[0] = first;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c_v = __builtin_amdgcn_readlane(cv, v * PN + PN - 1);
+        fc[v + 1] = (v < nfast) ? imax(c_v, fc[v] - PN * e) : fc[v];
+    }
+    int fv = fc[0];
+#pragma unroll
+    for (int v = 1; v < NV; ++v) fv = (vvl >= v) ? fc[v] : fv;
+    first = fc[NV];
+    const int own = (l == 0) ? INT_MIN : f;
+    return imax(imax(own, fv - cl), inj);
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 // GAP: 0 linear, 1 affine, 2 convex (reference gap_mode)
@@ -154,17 +197,23 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     const T inf = (T)d.inf_min;
     const T e1 = (T)b.e1, o1 = (T)b.o1, oe1 = (T)(b.o1 + b.e1), e2 = (T)b.e2, o2 = (T)b.o2, oe2 = (T)(b.o2 + b.e2);
     const int dp_sn = (qlen + PN) / PN;
+    // fast F path (fast_f_chain): per-lane constants and the no-wrap threshold
+    const int idist = inj_dist<PN>(l);
+    const int cl1 = (int)oe1 + l * (int)e1, cl2 = (int)oe2 + l * (int)e2;
+    const int inj1 = idist >= 0 ? (int)inf - idist * (int)e1 : INT_MIN, inj2 = idist >= 0 ? (int)inf - idist * (int)e2 : INT_MIN;
+    const long long lo_ll = (long long)(sizeof(T) == 2 ? INT16_MIN : INT32_MIN) + imax((int)oe1, (int)oe2) + (long long)PN * imax((int)e1, (int)e2);
+    const int fast_lo = (int)lo_ll;
 
-    const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
-    const uint8_t *row_base = vgpr_ptr(b.row_base + d.row0);
-    const int32_t *row_node_id = vgpr_ptr(b.row_node_id + d.row0);
-    const int32_t *row_remain = vgpr_ptr(b.row_remain + d.row0);
-    const uint8_t *row_active = vgpr_ptr(b.row_active + d.row0);
-    const int32_t *pred_off = vgpr_ptr(b.pred_off + d.poff0), *pred_row = vgpr_ptr(b.pred_row + d.pred0);
-    const int32_t *out_off = vgpr_ptr(b.out_off + d.poff0), *out_row = vgpr_ptr(b.out_row + d.out0);
-    int32_t *g_left = vgpr_ptr(b.left + d.row0), *g_right = vgpr_ptr(b.right + d.row0);
-    int32_t *g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0), *g_esn = vgpr_ptr(b.dp_end_sn + d.row0), *row_max_i = vgpr_ptr(b.row_max_i + d.row0);
-    int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
+    GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
+    GLOBAL_AS const uint8_t *row_base = vgpr_ptr(b.row_base + d.row0);
+    GLOBAL_AS const int32_t *row_node_id = vgpr_ptr(b.row_node_id + d.row0);
+    GLOBAL_AS const int32_t *row_remain = vgpr_ptr(b.row_remain + d.row0);
+    GLOBAL_AS const uint8_t *row_active = vgpr_ptr(b.row_active + d.row0);
+    GLOBAL_AS const int32_t *pred_off = vgpr_ptr(b.pred_off + d.poff0), *pred_row = vgpr_ptr(b.pred_row + d.pred0);
+    GLOBAL_AS const int32_t *out_off = vgpr_ptr(b.out_off + d.poff0), *out_row = vgpr_ptr(b.out_row + d.out0);
+    GLOBAL_AS int32_t *g_left = vgpr_ptr(b.left + d.row0), *g_right = vgpr_ptr(b.right + d.row0);
+    GLOBAL_AS int32_t *g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0), *g_esn = vgpr_ptr(b.dp_end_sn + d.row0), *row_max_i = vgpr_ptr(b.row_max_i + d.row0);
+    GLOBAL_AS int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
     T *planes = (T *)(b.planes + d.plane_off);
 
     // ---- LDS carve-up (engine.h LdsPlan)
@@ -175,9 +224,8 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     const int ring_rows = b.lds.ring_rows, ring_cols = b.lds.ring_cols;
     const bool q_in_lds = qlen <= b.lds.q_cap;
 
-    { const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < m * m; i += 64) s_mat[i] = g_mat[i]; }
+    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < m * m; i += 64) s_mat[i] = g_mat[i]; }
     if (q_in_lds) for (int i = lane; i < qlen; i += 64) s_query[i] = g_query[i];
-    if (lane < MAX_RING_ROWS) S.ring_tag[lane] = -1;
 
     // dp_end as the reference stores it: vector-rounded when banded and for row 0, qlen otherwise
     auto dp_end_of = [&](int row, int end_sn_row) __attribute__((always_inline)) { return (banded || row == 0) ? (end_sn_row + 1) * PN - 1 : qlen; };
@@ -198,8 +246,8 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         const int W0 = (end_sn0 + 1) * PN;
         if ((long long)W0 * P > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; }
         else {
-            if (lane == 0) { g_bsn[0] = 0; g_esn[0] = end_sn0; g_coff[0] = 0; S.b_bsn[0] = 0; S.b_esn[0] = end_sn0; S.b_coff[0] = 0; }
             const bool ring0 = W0 <= ring_cols;
+            if (lane == 0) { g_bsn[0] = 0; g_esn[0] = end_sn0; g_coff[0] = 0; S.b_rec[0] = make_int4(0, end_sn0, 0, ring0 ? 0 : -1); }
             for (int i = lane; i < W0; i += 64) {
                 T h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
                 if (local) { h = 0; x1 = 0; x2 = 0; f1 = 0; f2 = 0; }
@@ -222,7 +270,6 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                     if (GAP == 2) s_ring[2 * ring_cols + i] = x2;
                 }
             }
-            if (ring0 && lane == 0) S.ring_tag[0] = 0;
             cursor = (long long)W0 * P;
         }
     }
@@ -231,15 +278,15 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     if (banded && status == 0) {
         if (b.fresh_band) {       // reference abpoa_topological_sort resets them before every alignment (abpoa_graph.c:303-308)
             for (int i = lane; i < gn; i += 64) { g_left[i] = gn; g_right[i] = 0; }
-            for (int i = lane; i < RL; i += 64) { S.l_left[i] = gn; S.l_right[i] = 0; }
+            for (int i = lane; i < RL; i += 64) S.l_lr[i] = make_int2(gn, 0);
         } else
-            for (int i = lane; i < RL; i += 64) { const int r = i; if (r < gn) { S.l_left[i] = g_left[r]; S.l_right[i] = g_right[r]; } }
+            for (int i = lane; i < RL; i += 64) { const int r = i; if (r < gn) S.l_lr[i] = make_int2(g_left[r], g_right[r]); }
         __syncthreads();
-        if (lane == 0) { S.l_left[0] = 0; S.l_right[0] = 0; }                 // reference :556
+        if (lane == 0) S.l_lr[0] = make_int2(0, 0);                            // reference :556
         for (int t = out_off[0] + lane; t < out_off[1]; t += 64) {            // reference :557-561
             const int o = out_row[t];
             if (o >= 0 && row_active[o]) {
-                if (o < RL) { S.l_left[o] = 1; S.l_right[o] = 1; } else { g_left[o] = 1; g_right[o] = 1; }
+                if (o < RL) S.l_lr[o] = make_int2(1, 1); else { g_left[o] = 1; g_right[o] = 1; }
             }
         }
     }
@@ -264,64 +311,89 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     int last_done = 0;                                        // last row the loop reached (z-drop may stop early)
 
     // ------------------------------------------------------------------ rows 1 .. gn-2, reference :1105
+    // next-tile prefetch registers (static graph metadata of rows [nt_t0, nt_t0 + TS))
+    int4 nt_rec0 = make_int4(0, 0, 0, 0), nt_rec1 = make_int4(0, 0, 0, 0); int nt_pred[TP / 64], nt_out[TP / 64];
+    int nt_t0 = 1, nt_pb0 = 0, nt_ob0 = 0; bool far_seen = false;
+    if (gn > 2) {
+        nt_pb0 = gld_i32(pred_off + 1); nt_ob0 = gld_i32(out_off + 1);
+        const int tend = imin(nt_t0 + TS, gn);
+        const int rr = imin(nt_t0 + lane, gn), rc = imin(rr, gn - 1), r2 = imin(nt_t0 + TS, gn);
+        nt_rec0.x = pred_off[rr]; nt_rec0.y = out_off[rr];
+        const int rem_ = (banded || b.zdrop > 0) ? row_remain[rc] : 0; const int ba_ = (int)row_base[rc] | ((int)row_active[rc] << 8);
+        nt_rec0.z = rr < tend ? rem_ : 0; nt_rec0.w = rr < tend ? ba_ : 0;
+        nt_rec1.x = pred_off[r2]; nt_rec1.y = out_off[r2];
+#pragma unroll
+        for (int j = 0; j < TP / 64; ++j) { nt_pred[j] = pred_row[nt_pb0 + j * 64 + lane]; nt_out[j] = out_row[nt_ob0 + j * 64 + lane]; }
+    }
+    int qc_beg_sn = -1; int qc_cache[2] = {0, 0};            // query codes of this lane's columns for chunks 0/1 of band start qc_beg_sn
     for (int row = 1; row < gn - 1 && status == 0; ++row) {
-        if (row >= tile_end) {                                // ---- stage the next 64 rows of graph metadata
-            __syncthreads();
+        if (row >= tile_end) {                                // ---- switch to the next 64-row metadata tile (prefetched in registers)
             // band geometry of the rows of the finished tile goes to HBM in one coalesced burst (backtrack + trace read it)
             if (tile_end > tile_beg && tile_beg + lane < tile_end) {
-                const int r = tile_beg + lane;
-                g_bsn[r] = S.b_bsn[r % RB]; g_esn[r] = S.b_esn[r % RB]; g_coff[r] = (long long)S.b_coff[r % RB] * PN;
+                const int r = tile_beg + lane; const int4 br = S.b_rec[r % RB];
+                g_bsn[r] = br.x; g_esn[r] = br.y; g_coff[r] = (long long)(uint32_t)br.z * PN;
             }
-            tile_beg = row; tile_end = imin(row + TS, gn);
-            for (int i = lane; i <= TS; i += 64) { const int rr = imin(tile_beg + i, gn); S.t_poff[i] = pred_off[rr]; S.t_ooff[i] = out_off[rr]; }
-            if (tile_beg + lane < tile_end) {
-                S.t_base[lane] = row_base[tile_beg + lane]; S.t_act[lane] = row_active[tile_beg + lane];
-                S.t_remain[lane] = (banded || b.zdrop > 0) ? row_remain[tile_beg + lane] : 0;
+            S.t_rec[lane] = nt_rec0; if (lane == 0) S.t_rec[TS] = nt_rec1;
+#pragma unroll
+            for (int j = 0; j < TP / 64; ++j) { S.t_pred[j * 64 + lane] = nt_pred[j]; S.t_out[j * 64 + lane] = nt_out[j]; }
+            tile_beg = nt_t0; tile_end = imin(nt_t0 + TS, gn); pbase = nt_pb0; obase = nt_ob0;
+            // issue the loads of the tile after this one right away; they complete while this tile is being processed
+            nt_t0 = tile_end; nt_pb0 = __builtin_amdgcn_readfirstlane(nt_rec1.x); nt_ob0 = __builtin_amdgcn_readfirstlane(nt_rec1.y);
+            if (nt_t0 < gn - 1) {
+                const int tend = imin(nt_t0 + TS, gn);
+                const int rr = imin(nt_t0 + lane, gn), rc = imin(rr, gn - 1), r2 = imin(nt_t0 + TS, gn);
+                nt_rec0.x = pred_off[rr]; nt_rec0.y = out_off[rr];
+                const int rem_ = (banded || b.zdrop > 0) ? row_remain[rc] : 0; const int ba_ = (int)row_base[rc] | ((int)row_active[rc] << 8);
+                nt_rec0.z = rr < tend ? rem_ : 0; nt_rec0.w = rr < tend ? ba_ : 0;
+                nt_rec1.x = pred_off[r2]; nt_rec1.y = out_off[r2]; nt_rec1.z = 0; nt_rec1.w = 0;
+#pragma unroll
+                for (int j = 0; j < TP / 64; ++j) { nt_pred[j] = pred_row[nt_pb0 + j * 64 + lane]; nt_out[j] = out_row[nt_ob0 + j * 64 + lane]; }
             }
-            __syncthreads();
-            pbase = S.t_poff[0]; obase = S.t_ooff[0];
-            const int pn_t = imin(TP, S.t_poff[TS] - pbase), on_t = imin(TP, S.t_ooff[TS] - obase);
-            for (int i = lane; i < pn_t; i += 64) S.t_pred[i] = pred_row[pbase + i];
-            for (int i = lane; i < on_t; i += 64) S.t_out[i] = out_row[obase + i];
-            __syncthreads();
         }
         if (banded && row >= lr_blk + RLH) {                  // ---- slide the left/right window by half
-            // rows [lr_blk, lr_blk+RLH) are retired: write them back, then load rows [lr_blk+RL, lr_blk+RL+RLH)
-            __syncthreads();
+            // rows [lr_blk, lr_blk+RLH) are retired: write them back, then bring in rows [lr_blk+RL, lr_blk+RL+RLH)
             for (int i = lane; i < RLH; i += 64) {
                 const int r = lr_blk + i;
-                if (r < gn) { g_left[r] = S.l_left[r % RL]; g_right[r] = S.l_right[r % RL]; }
+                if (r < gn) { const int2 v2 = S.l_lr[r % RL]; g_left[r] = v2.x; g_right[r] = v2.y; }
                 const int nr = lr_blk + RL + i;
-                if (nr < gn) { S.l_left[nr % RL] = g_left[nr]; S.l_right[nr % RL] = g_right[nr]; }
+                if (nr < gn) {
+                    if (b.fresh_band && !far_seen) S.l_lr[nr % RL] = make_int2(gn, 0);       // untouched so far: known without a load
+                    else S.l_lr[nr % RL] = make_int2(gld_i32(g_left + nr), gld_i32(g_right + nr));
+                }
             }
             lr_blk += RLH;
-            __syncthreads();
         }
         STAMP(5)
         last_done = row;
         const int ti = row - tile_beg;
-        if (!S.t_act[ti]) { if (lane == 0) { S.b_bsn[row % RB] = -1; S.b_esn[row % RB] = -1; S.b_coff[row % RB] = (uint32_t)(cursor / PN); } continue; }
-        const int base = S.t_base[ti];
-        const int ps = S.t_poff[ti], np = S.t_poff[ti + 1] - ps;
+        const int4 rec = S.t_rec[ti], recn = S.t_rec[ti + 1];
+        const int2 lr = S.l_lr[row % RL];
+        if (!((rec.w >> 8) & 1)) { if (lane == 0) S.b_rec[row % RB] = make_int4(-1, -1, (int)(uint32_t)(cursor / PN), -1); continue; }
+        const int base = rec.w & 0xff;
+        const int ps = rec.x, np = recn.x - ps;
         auto pred_at = [&](int idx) __attribute__((always_inline)) { const int t = idx - pbase; int v = S.t_pred[t < TP ? t : 0]; if (t >= TP) v = gld_i32(pred_row + idx); return v; };
-        // band geometry of an earlier row: LDS ring for the last RB rows, HBM copy otherwise
-        auto geom = [&](int p, int &pb, int &pe, long long &poff) __attribute__((always_inline)) {
-            pb = S.b_bsn[p % RB]; pe = S.b_esn[p % RB]; poff = (long long)S.b_coff[p % RB] * PN;
-            if (row - p >= RB) { pb = gld_i32(g_bsn + p); pe = gld_i32(g_esn + p); poff = gld_i64(g_coff + p); }
+        // band geometry of an earlier row: LDS ring for the last RB rows, HBM copy otherwise (w = -1: never in the score ring)
+        auto geom4 = [&](int p) __attribute__((always_inline)) {
+            int4 g4 = S.b_rec[p % RB];
+            if (row - p >= RB) { g4.x = gld_i32(g_bsn + p); g4.y = gld_i32(g_esn + p); g4.z = (int)(uint32_t)(gld_i64(g_coff + p) / PN); g4.w = -1; }
+            return g4;
         };
+        // the first (up to) four predecessors are fetched in one batch; np <= 4 covers practically every POA node
+        int pid[4]; int4 pg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pid[k] = pred_at(ps + imin(k, np - 1));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pg[k] = geom4(pid[k]);
         int beg_sn, end_sn, max_pre_end_sn;
         if (!banded) { beg_sn = 0; end_sn = qlen / PN; max_pre_end_sn = end_sn; }        // reference :706-709
         else {                                                                          // reference :710-720
-            const int r = S.t_remain[ti] - remain_end - 1;
-            const int lft = S.l_left[row % RL], rgt = S.l_right[row % RL];
+            const int r = rec.z - remain_end - 1;
             last_row = row;
-            int beg = imax(0, imin(lft, qlen - r) - w), end = imin(qlen, imax(rgt, qlen - r) + w);
-            beg_sn = beg / PN; int min_pre_beg_sn = INT_MAX; max_pre_end_sn = -1;
-            for (int k = 0; k < np; ++k) {
-                const int p = pred_at(ps + k);
-                int pb, pe; long long po; geom(p, pb, pe, po);
-                min_pre_beg_sn = imin(min_pre_beg_sn, pb); max_pre_end_sn = imax(max_pre_end_sn, pe);
-            }
+            int beg = imax(0, imin(lr.x, qlen - r) - w), end = imin(qlen, imax(lr.y, qlen - r) + w);
+            beg_sn = beg / PN;
+            int min_pre_beg_sn = imin(imin(pg[0].x, pg[1].x), imin(pg[2].x, pg[3].x));          // duplicates of the last one are harmless
+            max_pre_end_sn = imax(imax(pg[0].y, pg[1].y), imax(pg[2].y, pg[3].y));
+            for (int k = 4; k < np; ++k) { const int4 g4 = geom4(pred_at(ps + k)); min_pre_beg_sn = imin(min_pre_beg_sn, g4.x); max_pre_end_sn = imax(max_pre_end_sn, g4.y); }
             if (beg_sn < min_pre_beg_sn) beg_sn = min_pre_beg_sn;
             end_sn = end / PN;
         }
@@ -330,16 +402,24 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         if (off + (long long)Wr * P > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
         cursor += (long long)Wr * P;
         n_cells += Wr; ++rows_done;
-        if (lane == 0) { S.b_bsn[row % RB] = beg_sn; S.b_esn[row % RB] = end_sn; S.b_coff[row % RB] = (uint32_t)(off / PN); }
-        T *H = planes + off;
         const bool to_ring = Wr <= ring_cols;
+        if (lane == 0) S.b_rec[row % RB] = make_int4(beg_sn, end_sn, (int)(uint32_t)(off / PN), -1);   // score-ring tag set when the row is complete
+        T *H = planes + off;
         const int my_slot = row % ring_rows;
         T *my_ring = s_ring + (long long)my_slot * NPR * ring_cols;
-        if (lane == 0) S.ring_tag[my_slot] = -1;              // slot is being overwritten
         const int nchunk = (Wr + 63) >> 6;
         T first = 0, first2 = 0;
         // running arg-max state of this lane (reference :1043-1057)
         int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false;
+        // fast gather: every predecessor's H/E row is in the LDS score ring -> straight-line, batched LDS reads
+        bool all_ring = np <= 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) all_ring = all_ring && (row - pid[k] < ring_rows) && (pg[k].w == pid[k]);
+        if (q_in_lds && beg_sn != qc_beg_sn) {                // band start moved: refresh this lane's cached query codes
+            qc_beg_sn = beg_sn;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) { const int cc = beg_sn * PN + c2 * 64 + lane; qc_cache[c2] = (cc >= 1 && cc <= qlen) ? (int)s_query[cc - 1] : -1; }
+        }
 
         STAMP(0)
         for (int c = 0; c < nchunk; ++c) {
@@ -350,19 +430,61 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             T Mv = inf, E1v = inf, E2v = inf;
             // query profile value, reference :504-510
             T q = 0;
-            if (in_band && col >= 1 && col <= qlen) {
-                int qc = q_in_lds ? (int)s_query[col - 1] : 0;
-                if (!q_in_lds) qc = gld_u8(g_query + col - 1);
-                q = (T)s_mat[base * m + qc];
+            {
+                int qc;
+                if (q_in_lds) qc = c == 0 ? qc_cache[0] : c == 1 ? qc_cache[1] : ((col >= 1 && col <= qlen) ? (int)s_query[col - 1] : -1);
+                else qc = (in_band && col >= 1 && col <= qlen) ? gld_u8(g_query + col - 1) : -1;
+                const int qv = s_mat[base * m + (qc >= 0 ? qc : 0)];
+                q = (in_band && qc >= 0) ? (T)qv : (T)0;
             }
             // ---- predecessors, reference :722-761 / :803-852 / :912-969
+            if (all_ring) {
+                auto gather_ring = [&](auto npc) __attribute__((always_inline)) {
+                    constexpr int N = decltype(npc)::value;
+                    int hraw[N], e1raw[N], e2raw[N], vraw[N]; bool inHk[N], inEk[N], srcok[N], vok[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {                      // issue every LDS read first (clamped addresses), select afterwards
+                        const int pb = pg[k].x, pe = pg[k].y;
+                        const int p_stored_end = (pe + 1) * PN - 1;
+                        int bs, es_h, es_e;
+                        if (local) { bs = 0; es_h = end_sn; es_e = end_sn; }
+                        else {
+                            bs = pb < beg_sn ? beg_sn : pb;
+                            es_h = imin(imin((dp_end_of(pid[k], pe) + 1) / PN, end_sn), dp_sn - 1);
+                            es_e = imin(pe, end_sn);
+                        }
+                        inHk[k] = in_band && v >= bs && v <= es_h;
+                        inEk[k] = GAP != 0 && in_band && v >= bs && v <= es_e;
+                        const T *rp = s_ring + (long long)(pid[k] % ring_rows) * NPR * ring_cols;
+                        const int x = col - 1 - pb * PN;                // column col-1 relative to the source row's band start
+                        srcok[k] = x >= 0 && col - 1 <= p_stored_end;
+                        hraw[k] = (int)rp[srcok[k] ? x : 0];
+                        if (GAP == 0) { vok[k] = col <= p_stored_end; vraw[k] = (int)rp[vok[k] ? x + 1 : 0]; }
+                        if (GAP != 0) e1raw[k] = (int)rp[ring_cols + (inEk[k] ? x + 1 : 0)];
+                        if (GAP == 2) e2raw[k] = (int)rp[2 * ring_cols + (inEk[k] ? x + 1 : 0)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        T hval = srcok[k] ? (T)hraw[k] : (local ? (T)0 : inf);
+                        if (GAP == 0) { const T vert = vok[k] ? (T)vraw[k] : inf; hval = tmax<T>(wadd<T>(hval, q), wsub<T>(vert, e1)); }
+                        if (k == 0) Mv = inHk[k] ? hval : inf; else Mv = inHk[k] ? tmax<T>(Mv, hval) : Mv;
+                        if (GAP != 0) { if (k == 0) E1v = inEk[k] ? (T)e1raw[k] : inf; else E1v = inEk[k] ? tmax<T>(E1v, (T)e1raw[k]) : E1v; }
+                        if (GAP == 2) { if (k == 0) E2v = inEk[k] ? (T)e2raw[k] : inf; else E2v = inEk[k] ? tmax<T>(E2v, (T)e2raw[k]) : E2v; }
+                    }
+                };
+                if (np == 1) gather_ring(std::integral_constant<int, 1>{});
+                else if (np == 2) gather_ring(std::integral_constant<int, 2>{});
+                else if (np == 3) gather_ring(std::integral_constant<int, 3>{});
+                else gather_ring(std::integral_constant<int, 4>{});
+            } else
             for (int k = 0; k < np; ++k) {
                 const int p = pred_at(ps + k);
-                int pb, pe; long long poff; geom(p, pb, pe, poff);
+                const int4 g4 = geom4(p);
+                const int pb = g4.x, pe = g4.y; const long long poff = (long long)(uint32_t)g4.z * PN;
                 const int Wp = (pe - pb + 1) * PN;
                 const int p_stored_end = (pe + 1) * PN - 1;          // last stored column of the predecessor row
                 const int pslot = p % ring_rows;
-                const bool in_ring = (row - p < ring_rows) && S.ring_tag[pslot] == p;
+                const bool in_ring = (row - p < ring_rows) && g4.w == p;
                 int bs, es_h, es_e;
                 if (local) { bs = 0; es_h = end_sn; es_e = end_sn; }
                 else {
@@ -375,7 +497,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                 // The source row is read either from the LDS score ring or from its HBM copy; the two paths are
                 // instantiated separately so that no generic (flat) pointer is ever formed.
                 auto gather = [&](auto from_lds, const T *Hp, const long long pstride) __attribute__((always_inline)) {
-                    auto ld = [&](const T *p_) __attribute__((always_inline)) -> T { if constexpr (decltype(from_lds)::value) return *p_; else return (T)gld_cell(p_); };
+                    auto ld = [&](const T *p_) __attribute__((always_inline)) -> T { if constexpr (decltype(from_lds)::value) return *p_; else return (T)gld_cell((GLOBAL_AS const T *)p_); };
                     if (inH) {
                         T hval;
                         if (col == bs * PN) {
@@ -425,10 +547,26 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                 T hs = h;                                               // value the F recurrence opens from
                 if (GAP == 2) hs = tmax<T>(tmax<T>(h, E1v), E2v);       // reference :988
                 if (c == 0) { first = (T)__builtin_amdgcn_readlane((int)h, 0); first2 = first; }   // :858 / :976-977
+                // leading vectors that use the plain scan (set_num == pn) go through the closed form when nothing can wrap
+                const int nvec = imin(NV, end_sn - (beg_sn + c * NV) + 1);
+                int nfast = local ? nvec : imin(nvec, max_pre_end_sn - (beg_sn + c * NV) + 1);
+                if (nfast < 0) nfast = 0;
+                if (nfast > 0 && __any(vvl < nfast && (int)h < fast_lo)) nfast = 0;
+                if (b.dbg & 4) nfast = 0;
+                if (nfast > 0) {
+                    int fi = (int)first;
+                    F1 = (T)fast_f_chain<T>((int)hs, fi, nfast, l, vvl, (int)oe1, (int)e1, (int)o1, cl1, inj1);
+                    first = (T)fi;
+                    if (GAP == 2) {
+                        int fi2 = (int)first2;
+                        F2 = (T)fast_f_chain<T>((int)hs, fi2, nfast, l, vvl, (int)oe2, (int)e2, (int)o2, cl2, inj2);
+                        first2 = (T)fi2;
+                    }
+                }
 #pragma unroll
                 for (int vv = 0; vv < NV; ++vv) {
                     const int vg = beg_sn + c * NV + vv;
-                    if (vg <= end_sn) {
+                    if (vv >= nfast && vg <= end_sn) {
                         int set_num = PN;
                         if (!local && vg > max_pre_end_sn) set_num = (vg == max_pre_end_sn + 1) ? 2 : 1;
                         T prev = (T)row_shr<1>((int)first, (int)hs);
@@ -465,13 +603,15 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                 }
             }
             STAMP(2)
-            if (in_band) {
+            if (in_band && !(b.dbg & 1)) {
                 H[rel] = Hout;
                 if (GAP != 0) {
                     H[(long long)PL_E1 * Wr + rel] = E1out;
                     H[(long long)PL_F1 * Wr + rel] = F1;
                     if (GAP == 2) { H[(long long)PL_E2 * Wr + rel] = E2out; H[(long long)PL_F2 * Wr + rel] = F2; }
                 }
+            }
+            if (in_band) {
                 if (to_ring) {
                     my_ring[rel] = Hout;
                     if (GAP != 0) my_ring[ring_cols + rel] = E1out;
@@ -487,11 +627,12 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             }
             STAMP(3)
         }
-        if (to_ring && lane == 0) S.ring_tag[my_slot] = row;
+        if (to_ring && lane == 0) S.b_rec[row % RB].w = row;      // H/E of this row are now readable from the score ring
         // ---- row arg-max, reference simd_abpoa_max_in_row :1043-1057 (tie-break: lowest lane, then the
         //      end_sn vector, then the lowest vector) and band hand-over :1059-1067
         int mx = d.inf_min, mi = -1;
-        if (need_max) {
+        if (need_max && (b.dbg & 2)) { mx = 0; mi = imin(qlen, row + 1); }
+        else if (need_max) {
             int vmax = wave_max_i32(am_any ? am_val : INT_MIN);
             if (vmax > d.inf_min) {
                 unsigned key = 0;
@@ -506,14 +647,14 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             else if (extend) {
                 if (mx > best_score) { best_score = mx; best_i = row; best_j = mi; best_row_zd = row; }
                 else if (b.zdrop > 0) {
-                    int delta_index = gld_i32(row_remain + best_row_zd) - S.t_remain[ti];
+                    int delta_index = gld_i32(row_remain + best_row_zd) - rec.z;
                     int dd = delta_index - (mi - best_j); if (dd < 0) dd = -dd;
                     if (best_score - mx > b.zdrop + (int)e1 * dd) break;
                 }
             }
             if (banded) {
                 const int out_i = mi + 1;
-                const int os = S.t_ooff[ti], on = S.t_ooff[ti + 1] - os;
+                const int os = rec.y, on = recn.y - os;
                 bool far = false;
                 for (int t = lane; t < on; t += 64) {
                     const int tt = os + t - obase;
@@ -521,8 +662,9 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                     if (tt >= TP) o = gld_i32(out_row + os + t);
                     if (o >= 0) {
                         if (o < lr_blk + RL) {
-                            if (out_i > S.l_right[o % RL]) S.l_right[o % RL] = out_i;
-                            if (out_i < S.l_left[o % RL]) S.l_left[o % RL] = out_i;
+                            int2 v2 = S.l_lr[o % RL];
+                            v2.x = imin(v2.x, out_i); v2.y = imax(v2.y, out_i);
+                            S.l_lr[o % RL] = v2;
                         } else {                                       // beyond the LDS window: update the HBM copy
                             if (out_i > gld_i32(g_right + o)) g_right[o] = out_i;
                             if (out_i < gld_i32(g_left + o)) g_left[o] = out_i;
@@ -530,7 +672,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                         }
                     }
                 }
-                if (__any(far)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (__any(far)) { far_seen = true; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             }
         } else if (b.want_trace && lane == 0) row_max_i[row] = -2;
         STAMP(4)
@@ -538,12 +680,12 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     __syncthreads();
     if (tile_end > tile_beg && tile_beg + lane < tile_end && status == 0) {      // band geometry of the last (partial) tile
         const int r = tile_beg + lane;
-        if (r <= last_done) { g_bsn[r] = S.b_bsn[r % RB]; g_esn[r] = S.b_esn[r % RB]; g_coff[r] = (long long)S.b_coff[r % RB] * PN; }
+        if (r <= last_done) { const int4 br = S.b_rec[r % RB]; g_bsn[r] = br.x; g_esn[r] = br.y; g_coff[r] = (long long)(uint32_t)br.z * PN; }
     }
     const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
     // ---- retire the left/right window to HBM (the arrays are in/out for the caller)
     if (banded && status == 0) {
-        for (int i = lane; i < RL; i += 64) { const int r = lr_blk + i; if (r < gn) { g_left[r] = S.l_left[r % RL]; g_right[r] = S.l_right[r % RL]; } }
+        for (int i = lane; i < RL; i += 64) { const int r = lr_blk + i; if (r < gn) { const int2 v2 = S.l_lr[r % RL]; g_left[r] = v2.x; g_right[r] = v2.y; } }
     }
     (void)last_row;
     __syncthreads();       // all of this wave's plane / band stores have landed before the loads below
@@ -570,7 +712,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         const long long bt_cells = b.lds.bt_bytes / (int)sizeof(T);
         int bt_lo = 1, bt_hi = 0, bt_pbase = 0, bt_margin = 0;   // window = rows [bt_lo, bt_hi], empty at start
         long long bt_c0 = 0;                                     // arena cell of B.coff[0]
-        uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
+        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
         const int cap = d.cigar_cap;
         uint64_t last_word = 0;
         auto load_window = [&](int hi) __attribute__((always_inline)) {
@@ -630,7 +772,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             const long long Wp = (long long)(g.pe - g.pb + 1) * PN;
             const long long idx = g.off + plane * Wp + (col_ - g.pb * PN);
             int v = (int)bt[g.in_tile ? idx : 0];
-            if (!g.in_tile) v = gld_cell(planes + idx);
+            if (!g.in_tile) v = gld_cell((GLOBAL_AS const T *)(planes + idx));
             return v;
         };
         auto in_range = [&](const Geo &g, int row_, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= dp_end_of(row_, g.pe); };

@@ -101,7 +101,7 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
     o_desc_ = take(sizeof(AlnDesc) * n); o_mat_ = take(sizeof(int32_t) * sc->m * sc->m); o_query_ = take(q_tot_ + 1);
     o_base_ = take(rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
-    o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1));
+    o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1) + 4 * 512);   // slack: tile prefetch over-reads up to TP entries
     in_bytes_ = o;
     o = 0;
     o_rec_ = take(sizeof(AlnOut) * n); o_cig_ = take(8 * cig_tot_); o_left_ = take(4 * rows_tot_); o_right_ = take(4 * rows_tot_);
@@ -173,6 +173,7 @@ int BatchStream::run() {
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
+        { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
         b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);
         b.query = di + o_query_; b.row_base = di + o_base_; b.row_node_id = (const int32_t *)(di + o_nid_); b.row_remain = (const int32_t *)(di + o_rem_);
         b.row_active = di + o_act_; b.pred_off = (const int32_t *)(di + o_poff_); b.pred_row = (const int32_t *)(di + o_pred_);

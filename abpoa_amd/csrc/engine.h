@@ -61,6 +61,7 @@ struct DevBatch {
     int32_t o1, e1, o2, e2;
     int32_t align_mode, gap_mode, wb, zdrop, ret_cigar, rev_cigar;
     int32_t want_trace;          // also record the per-row arg-max column (tests)
+    int32_t dbg;                 // ablation switches for timing experiments (env ABPOA_HIP_DBG); 0 in production
     int32_t fresh_band;          // max_pos_left/right start as (n_rows, 0): initialise them on the device
     LdsPlan lds;
     const int32_t *mat;          // [m*m]
