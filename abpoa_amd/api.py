@@ -25,7 +25,7 @@ class Msa(C.Structure):              # abpoa_hip_msa_t
 
 class MsaTiming(C.Structure):        # abpoa_hip_msa_timing_t
     _fields_ = [("host_sort_s", C.c_double), ("host_fuse_s", C.c_double), ("engine_s", C.c_double), ("cons_s", C.c_double),
-                ("total_s", C.c_double), ("n_rounds", C.c_int32), ("n_threads", C.c_int32)]
+                ("total_s", C.c_double), ("n_rounds", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32), ("pad", C.c_int32)]
 
 
 class Params:

@@ -51,6 +51,7 @@ struct __attribute__((aligned(16))) DpLds {   // fixed part of the DP-phase LDS 
     int4 t_rec[TS + 1];     // static tile, per row: {pred_off, out_off, remain, base | active << 8}; entry [TS] = end offsets
     int4 b_rec[RB];         // band ring: {beg_sn, end_sn, cell_off / PN, row id while its H/E rows sit in the score ring else -1}
     int2 l_lr[RL];          // look-ahead window: {max_pos_left, max_pos_right}
+    int4 t_fast[TS];        // fast-row record: {flag<<31 | base<<16 | dist(pred1)<<8 | dist(pred0), rterm, out0, out1}
     int32_t t_pred[TP], t_out[TP];
 };
 struct BtLds {              // fixed part of the backtrack-phase LDS image
@@ -110,6 +111,18 @@ template <typename Pt> __device__ __forceinline__ GLOBAL_AS Pt *vgpr_ptr(Pt *p) 
 // (the result stays typed as a GLOBAL pointer: a generic pointer would turn every access into a flat load, and an
 //  outstanding flat load also blocks s_waitcnt lgkmcnt(0), i.e. every LDS wait of the row loop)
 
+// wave-wide unsigned max with a single v_readlane: 4 in-row steps, then row_bcast:15 / row_bcast:31 fold the four DPP rows
+__device__ __forceinline__ unsigned wave_max_u32_b(unsigned x) {
+    auto umax = [](unsigned p, unsigned q) { return p > q ? p : q; };
+    x = umax(x, (unsigned)row_shr<1>((int)x, (int)x));
+    x = umax(x, (unsigned)row_shr<2>((int)x, (int)x));
+    x = umax(x, (unsigned)row_shr<4>((int)x, (int)x));
+    x = umax(x, (unsigned)row_shr<8>((int)x, (int)x));
+    x = umax(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false));   // rows 1,3 <- lane 15 of the row before
+    x = umax(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false));   // rows 2,3 <- lane 31
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 template <typename T> struct Width;
 template <> struct Width<int16_t> { static constexpr int PN = 16, LOGN = 4; };
 template <> struct Width<int32_t> { static constexpr int PN = 8, LOGN = 3; };
@@ -151,7 +164,7 @@ template <> __device__ __forceinline__ int inj_dist<8>(int l) { return l < 4 ? 0
 // then max-plus arithmetic distributes and  F[l] = max( scan of the vector's own H , first - oe - l*e , inf - INJ[l]*e ),
 // and the vector-to-vector carry is first' = max(H[pn-1], ownscan[pn-1] + o, first - pn*e).  Plain int arithmetic.
 template <typename T>
-__device__ __forceinline__ int fast_f_chain(int hs, int &first, int nfast, int l, int vvl, int oe, int e, int o, int cl, int inj) {
+__device__ __forceinline__ int fast_f_chain(int hs, int &first, int nfast, int l, int vvl, int oe, int e, int o, int cl, int inj, int *dbg_cv = nullptr) {
     constexpr int PN = Width<T>::PN, NV = 64 / PN;
     int f = row_shr<1>(hs, hs) - oe;                 // own sources: F0[l] = H[l-1] - oe for l >= 1 (lane 0 has none)
     if (PN == 16) {
@@ -167,6 +180,7 @@ __device__ __forceinline__ int fast_f_chain(int hs, int &first, int nfast, int l
         t = row_shr<4>(f, f) - 4 * e; f = (l > 4) ? imax(f, t) : f;
     }
     const int cv = imax(hs, f + o);                  // at lane pn-1 of a vector: max(H[pn-1], ownscan[pn-1] + o)
+    if (dbg_cv) *dbg_cv = cv;
     int fc[NV + 1]; fc[0] = first;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -180,6 +194,12 @@ __device__ __forceinline__ int fast_f_chain(int hs, int &first, int nfast, int l
     const int own = (l == 0) ? INT_MIN : f;
     return imax(imax(own, fv - cl), inj);
 }
+
+// wave-uniform LDS records: tell the compiler (values land in SGPRs, branches on them become scalar branches)
+__device__ __forceinline__ int4 uniform4(int4 v) {
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+}
+__device__ __forceinline__ int2 uniform2(int2 v) { return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y)); }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -229,6 +249,33 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
 
     // dp_end as the reference stores it: vector-rounded when banded and for row 0, qlen otherwise
     auto dp_end_of = [&](int row, int end_sn_row) __attribute__((always_inline)) { return (banded || row == 0) ? (end_sn_row + 1) * PN - 1 : qlen; };
+
+    // literal (wrap-exact) F recurrence for the vectors [nfast_, ...) of chunk c: reference :859-875 / :978-997
+    auto slow_f_tail = [&](int c, int beg_sn_, int end_sn_, int max_pre_, int nfast_, T hs, T &F1, T &F2, T &first, T &first2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int vv = 0; vv < NV; ++vv) {
+            const int vg = beg_sn_ + c * NV + vv;
+            if (vv >= nfast_ && vg <= end_sn_) {
+                int set_num = PN;
+                if (!local && vg > max_pre_) set_num = (vg == max_pre_ + 1) ? 2 : 1;
+                T prev = (T)row_shr<1>((int)first, (int)hs);
+                if (PN == 8) prev = (l == 0) ? first : prev;
+                T f = wsub<T>(prev, oe1);                        // reference :870 / :990
+                f = set_f<T>(f, l, set_num, e1, inf);
+                const T hlast = (T)__builtin_amdgcn_readlane((int)hs, vv * PN + PN - 1);
+                first = tmax<T>(hlast, wadd<T>((T)__builtin_amdgcn_readlane((int)f, vv * PN + PN - 1), o1));  // :874 / :996
+                if (vvl == vv) F1 = f;
+                if (GAP == 2) {
+                    T prev2 = (T)row_shr<1>((int)first2, (int)hs);
+                    if (PN == 8) prev2 = (l == 0) ? first2 : prev2;
+                    T g = wsub<T>(prev2, oe2);                   // reference :991
+                    g = set_f<T>(g, l, set_num, e2, inf);
+                    first2 = tmax<T>(hlast, wadd<T>((T)__builtin_amdgcn_readlane((int)g, vv * PN + PN - 1), o2));  // :997
+                    if (vvl == vv) F2 = g;
+                }
+            }
+        }
+    };
 
     long long cursor = 0;          // next free arena cell
     long long n_cells = 0;
@@ -314,6 +361,9 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     // next-tile prefetch registers (static graph metadata of rows [nt_t0, nt_t0 + TS))
     int4 nt_rec0 = make_int4(0, 0, 0, 0), nt_rec1 = make_int4(0, 0, 0, 0); int nt_pred[TP / 64], nt_out[TP / 64];
     int nt_t0 = 1, nt_pb0 = 0, nt_ob0 = 0; bool far_seen = false;
+    // per-lane copy of the CURRENT tile's metadata (lane i <-> row tile_beg + i): the row loop fetches a field with one
+    // v_readlane instead of an LDS round trip.  tv_meta = base | active<<8 | fast<<9 | np<<16 | n_out<<24
+    int tv_meta = 0, tv_rterm = 0, tv_ps = 0, tv_os = 0, tv_pid[4] = {0, 0, 0, 0}, tv_o[2] = {-1, -1};
     if (gn > 2) {
         nt_pb0 = gld_i32(pred_off + 1); nt_ob0 = gld_i32(out_off + 1);
         const int tend = imin(nt_t0 + TS, gn);
@@ -337,6 +387,29 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
 #pragma unroll
             for (int j = 0; j < TP / 64; ++j) { S.t_pred[j * 64 + lane] = nt_pred[j]; S.t_out[j * 64 + lane] = nt_out[j]; }
             tile_beg = nt_t0; tile_end = imin(nt_t0 + TS, gn); pbase = nt_pb0; obase = nt_ob0;
+            {
+                const int my_ps = nt_rec0.x, my_os = nt_rec0.y;
+                const int4 nx = S.t_rec[lane + 1];
+                const int np_ = nx.x - my_ps, on_ = nx.y - my_os;
+                bool ok = np_ >= 1 && np_ <= 4 && on_ >= 0 && on_ <= 2;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int idx = my_ps - pbase + imin(kk, imax(np_ - 1, 0));
+                    ok = ok && idx >= 0 && idx < TP; tv_pid[kk] = S.t_pred[(idx >= 0 && idx < TP) ? idx : 0];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int idx = my_os - obase + kk; const bool has = kk < on_;
+                    ok = ok && (!has || (idx >= 0 && idx < TP)); tv_o[kk] = has ? S.t_out[(idx >= 0 && idx < TP) ? idx : 0] : -1;
+                }
+                tv_meta = (nt_rec0.w & 0x1ff) | (ok ? (1 << 9) : 0) | (imin(imax(np_, 0), 255) << 16) | (imin(imax(on_, 0), 255) << 24);
+                tv_rterm = qlen - (nt_rec0.z - remain_end - 1); tv_ps = my_ps; tv_os = my_os;
+                // fast-row record (static eligibility: active, 1-2 predecessors within score-ring distance, 1-2 successors)
+                const int myrow = tile_beg + lane;
+                const int d0 = myrow - tv_pid[0], d1 = myrow - tv_pid[np_ >= 2 ? 1 : 0];
+                const bool fok = ok && ((nt_rec0.w >> 8) & 1) && np_ <= 2 && on_ >= 1 && d0 >= 1 && d1 >= 1 && d0 < ring_rows && d1 < ring_rows && d0 < 256 && d1 < 256;
+                S.t_fast[lane] = make_int4((fok ? (int)0x80000000u : 0) | ((nt_rec0.w & 0xff) << 16) | ((d1 & 0xff) << 8) | (d0 & 0xff), tv_rterm, tv_o[0], tv_o[1]);
+            }
             // issue the loads of the tile after this one right away; they complete while this tile is being processed
             nt_t0 = tile_end; nt_pb0 = __builtin_amdgcn_readfirstlane(nt_rec1.x); nt_ob0 = __builtin_amdgcn_readfirstlane(nt_rec1.y);
             if (nt_t0 < gn - 1) {
@@ -366,11 +439,142 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         STAMP(5)
         last_done = row;
         const int ti = row - tile_beg;
-        const int4 rec = S.t_rec[ti], recn = S.t_rec[ti + 1];
+        // ====================================================================================================
+        // FAST ROW (the common case of a POA graph): global + banded + affine/convex, one or two predecessors whose H/E
+        // rows are still in the score ring, band <= 128 columns, successors inside the left/right window.  Straight-line:
+        // one record read, two geometry reads, one batch of score reads per chunk, one reduction.  Same arithmetic as the
+        // general row below (which handles everything else), so the results are identical.
+        if (GAP != 0 && banded && !local && !extend && !(b.dbg & 64)) {
+            const int4 fr = uniform4(S.t_fast[ti]);
+            if (fr.x < 0) {
+                const int2 lr = uniform2(S.l_lr[row % RL]);
+                const int fp0 = row - (fr.x & 0xff), fp1 = row - ((fr.x >> 8) & 0xff), fbase = (fr.x >> 16) & 0xff;
+                const int4 g0 = uniform4(S.b_rec[fp0 % RB]), g1 = uniform4(S.b_rec[fp1 % RB]);
+                const int so0 = fr.z, so1 = fr.w;      // successor rows (-1 = none)
+                const int fbeg = imax(0, imin(lr.x, fr.y) - w), fend = imin(qlen, imax(lr.y, fr.y) + w);      // reference :711
+                const int fmin_pre = imin(g0.x, g1.x), fmax_pre = imax(g0.y, g1.y);
+                const int fbeg_sn = imax(fbeg / PN, fmin_pre), fend_sn = fend / PN;
+                const int fWr = (fend_sn - fbeg_sn + 1) * PN;
+                const bool feasible = g0.w == fp0 && g1.w == fp1 && fWr <= 128 && fWr <= ring_cols && so0 < lr_blk + RL && so1 < lr_blk + RL &&
+                                      q_in_lds && cursor + (long long)fWr * P <= d.plane_cap;
+                if (feasible) {
+                    const long long off = cursor; cursor += (long long)fWr * P; n_cells += fWr; ++rows_done; last_row = row;
+                    if (lane == 0) S.b_rec[row % RB] = make_int4(fbeg_sn, fend_sn, (int)(uint32_t)(off / PN), -1);
+                    T *H = planes + off;
+                    T *my_ring = s_ring + (long long)(row % ring_rows) * NPR * ring_cols;
+                    const T *rp0 = s_ring + (long long)(fp0 % ring_rows) * NPR * ring_cols, *rp1 = s_ring + (long long)(fp1 % ring_rows) * NPR * ring_cols;
+                    if (fbeg_sn != qc_beg_sn) {
+                        qc_beg_sn = fbeg_sn;
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) { const int cc = fbeg_sn * PN + c2 * 64 + lane; qc_cache[c2] = (cc >= 1 && cc <= qlen) ? (int)s_query[cc - 1] : -1; }
+                    }
+                    const int pb0 = g0.x * PN, pse0 = (g0.y + 1) * PN - 1, pb1 = g1.x * PN, pse1 = (g1.y + 1) * PN - 1;   // stored column ranges
+                    const int bs0 = imax(g0.x, fbeg_sn), bs1 = imax(g1.x, fbeg_sn);
+                    const int esh0 = imin(imin(g0.y + 1, fend_sn), dp_sn - 1), esh1 = imin(imin(g1.y + 1, fend_sn), dp_sn - 1);
+                    const int ese0 = imin(g0.y, fend_sn), ese1 = imin(g1.y, fend_sn);
+                    T first = 0, first2 = 0; int dbgv = 0;
+                    int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false; unsigned am_key = 0;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (c == 1 && fWr <= 64) break;
+                        const int rel = c * 64 + lane;
+                        const bool in_band = rel < fWr;
+                        const int col = fbeg_sn * PN + rel, v = fbeg_sn + c * NV + vvl;
+                        const int qc = c == 0 ? qc_cache[0] : qc_cache[1];
+                        const int qv = s_mat[fbase * m + (qc >= 0 ? qc : 0)];
+                        const int x0 = col - 1 - pb0, x1 = col - 1 - pb1;
+                        const bool ok0 = x0 >= 0 && col - 1 <= pse0, ok1 = x1 >= 0 && col - 1 <= pse1;
+                        const bool inH0 = in_band && v >= bs0 && v <= esh0, inH1 = in_band && v >= bs1 && v <= esh1;
+                        const bool inE0 = in_band && v >= bs0 && v <= ese0, inE1 = in_band && v >= bs1 && v <= ese1;
+                        const T h0 = rp0[ok0 ? x0 : 0], h1 = rp1[ok1 ? x1 : 0];
+                        const T a0 = rp0[ring_cols + (inE0 ? x0 + 1 : 0)], a1 = rp1[ring_cols + (inE1 ? x1 + 1 : 0)];
+                        T c0 = 0, c1 = 0;
+                        if (GAP == 2) { c0 = rp0[2 * ring_cols + (inE0 ? x0 + 1 : 0)]; c1 = rp1[2 * ring_cols + (inE1 ? x1 + 1 : 0)]; }
+                        const T q = (in_band && qc >= 0) ? (T)qv : (T)0;
+                        T Mv = inH0 ? (ok0 ? h0 : inf) : inf;
+                        Mv = inH1 ? tmax<T>(Mv, ok1 ? h1 : inf) : Mv;
+                        T E1v = inE0 ? a0 : inf; E1v = inE1 ? tmax<T>(E1v, a1) : E1v;
+                        T E2v = inf; if (GAP == 2) { E2v = inE0 ? c0 : inf; E2v = inE1 ? tmax<T>(E2v, c1) : E2v; }
+                        const T h = wadd<T>(Mv, q);
+                        T hs = h; if (GAP == 2) hs = tmax<T>(tmax<T>(h, E1v), E2v);
+                        if (c == 0) { first = (T)__builtin_amdgcn_readlane((int)h, 0); first2 = first; }
+                        const int nvec = imin(NV, fend_sn - (fbeg_sn + c * NV) + 1);
+                        int nfast = imin(nvec, fmax_pre - (fbeg_sn + c * NV) + 1);
+                        if (nfast < 0) nfast = 0;
+                        if (nfast > 0 && __any(vvl < nfast && (int)h < fast_lo)) nfast = 0;
+                        if (b.dbg & 4) nfast = 0;
+                        T F1 = inf, F2 = inf;
+                        if (nfast > 0) {
+                            int fi = (int)first;
+                            int dcv = 0;
+                            F1 = (T)fast_f_chain<T>((int)hs, fi, nfast, l, vvl, (int)oe1, (int)e1, (int)o1, cl1, inj1, &dcv);
+                            if (b.dbg & 512) F1 = (T)dcv;
+                            first = (T)fi;
+                            if (GAP == 2) { int fi2 = (int)first2; F2 = (T)fast_f_chain<T>((int)hs, fi2, nfast, l, vvl, (int)oe2, (int)e2, (int)o2, cl2, inj2); first2 = (T)fi2; }
+                        }
+                        if ((b.dbg & 256) && c == 0) dbgv = ((int)first & 0xffff) | (nfast << 16) | (nvec << 20) | ((__builtin_amdgcn_readlane((int)hs, 15) & 0xff) << 24);
+                        if (nfast < nvec) slow_f_tail(c, fbeg_sn, fend_sn, fmax_pre, nfast, hs, F1, F2, first, first2);
+                        T Hout, E1out, E2out = 0;
+                        if (GAP == 1) {                                          // reference :876-883
+                            const T tmp = tmax<T>(h, E1v);
+                            Hout = tmax<T>(tmp, F1);
+                            const T en = tmax<T>(wsub<T>(E1v, e1), wsub<T>(Hout, oe1));
+                            E1out = (Hout == tmp) ? en : inf;
+                        } else {                                                 // reference :1004-1007
+                            Hout = tmax<T>(hs, tmax<T>(F1, F2));
+                            E1out = tmax<T>(wsub<T>(E1v, e1), wsub<T>(Hout, oe1));
+                            E2out = tmax<T>(wsub<T>(E2v, e2), wsub<T>(Hout, oe2));
+                        }
+                        if (in_band) {
+                            H[rel] = Hout; H[PL_E1 * fWr + rel] = E1out; H[PL_F1 * fWr + rel] = F1;
+                            if (GAP == 2) { H[PL_E2 * fWr + rel] = E2out; H[PL_F2 * fWr + rel] = F2; }
+                            my_ring[rel] = Hout; my_ring[ring_cols + rel] = E1out;
+                            if (GAP == 2) my_ring[2 * ring_cols + rel] = E2out;
+                            const bool is_end = (v == fend_sn);
+                            int cand = (int)Hout;
+                            if (is_end && fend_sn == qlen / PN && col > qlen) cand = (int)inf;
+                            if (sizeof(T) == 2) {
+                                const unsigned key = ((unsigned)(cand + 32768) << 16) | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)is_end << 11) | (unsigned)(2047 - v);
+                                am_key = key > am_key ? key : am_key;
+                            } else if (!am_any || (is_end ? cand >= am_val : cand > am_val)) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
+                        }
+                    }
+                    if (lane == 0) S.b_rec[row % RB].w = row;
+                    int mi = -1;
+                    if (sizeof(T) == 2) {
+                        const unsigned kb = (b.dbg & 128) ? wave_max_u32(am_key) : wave_max_u32_b(am_key);
+                        const int vmax = (int)(kb >> 16) - 32768;
+                        if (vmax > d.inf_min) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+                    } else {
+                        const int vmax = wave_max_i32(am_any ? am_val : INT_MIN);
+                        if (vmax > d.inf_min) {
+                            unsigned key = 0;
+                            if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
+                            const unsigned kb = wave_max_u32_b(key);
+                            mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
+                            if (mi > qlen) mi = -1;
+                        }
+                    }
+                    if (b.want_trace && lane == 0) row_max_i[row] = (b.dbg & 256) ? dbgv : mi;
+                    {                                                            // reference :1059-1067
+                        const int out_i = mi + 1;
+                        int2 a2 = S.l_lr[(so0 >= 0 ? so0 : 0) % RL], b2 = S.l_lr[(so1 >= 0 ? so1 : 0) % RL];
+                        a2.x = imin(a2.x, out_i); a2.y = imax(a2.y, out_i); b2.x = imin(b2.x, out_i); b2.y = imax(b2.y, out_i);
+                        if (so0 >= 0 && lane == 0) S.l_lr[so0 % RL] = a2;
+                        if (so1 >= 0 && lane == 0) S.l_lr[so1 % RL] = b2;
+                    }
+                    continue;
+                }
+            }
+        }
+        // ==================================================================================================== general row
+        const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
+        if (!((meta >> 8) & 1)) { if (lane == 0) S.b_rec[row % RB] = make_int4(-1, -1, (int)(uint32_t)(cursor / PN), -1); continue; }
         const int2 lr = S.l_lr[row % RL];
-        if (!((rec.w >> 8) & 1)) { if (lane == 0) S.b_rec[row % RB] = make_int4(-1, -1, (int)(uint32_t)(cursor / PN), -1); continue; }
-        const int base = rec.w & 0xff;
-        const int ps = rec.x, np = recn.x - ps;
+        const int base = meta & 0xff;
+        const bool fastmeta = (meta >> 9) & 1;
+        const int rterm = __builtin_amdgcn_readlane(tv_rterm, ti);       // qlen - (remain[row] - remain[end] - 1), reference abpoa_align.h:34-35
+        const int ps = __builtin_amdgcn_readlane(tv_ps, ti), os = __builtin_amdgcn_readlane(tv_os, ti);
         auto pred_at = [&](int idx) __attribute__((always_inline)) { const int t = idx - pbase; int v = S.t_pred[t < TP ? t : 0]; if (t >= TP) v = gld_i32(pred_row + idx); return v; };
         // band geometry of an earlier row: LDS ring for the last RB rows, HBM copy otherwise (w = -1: never in the score ring)
         auto geom4 = [&](int p) __attribute__((always_inline)) {
@@ -378,18 +582,24 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             if (row - p >= RB) { g4.x = gld_i32(g_bsn + p); g4.y = gld_i32(g_esn + p); g4.z = (int)(uint32_t)(gld_i64(g_coff + p) / PN); g4.w = -1; }
             return g4;
         };
-        // the first (up to) four predecessors are fetched in one batch; np <= 4 covers practically every POA node
-        int pid[4]; int4 pg[4];
+        // the first (up to) four predecessors are handled in one batch; np <= 4 covers practically every POA node
+        int np, on, pid[4]; int4 pg[4];
+        if (fastmeta) {
+            np = (meta >> 16) & 0xff; on = (meta >> 24) & 0xff;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pid[k] = pred_at(ps + imin(k, np - 1));
+            for (int k = 0; k < 4; ++k) pid[k] = __builtin_amdgcn_readlane(tv_pid[k], ti);
+        } else {
+            np = S.t_rec[ti + 1].x - ps; on = S.t_rec[ti + 1].y - os;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pid[k] = pred_at(ps + imin(k, np - 1));
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pg[k] = geom4(pid[k]);
         int beg_sn, end_sn, max_pre_end_sn;
         if (!banded) { beg_sn = 0; end_sn = qlen / PN; max_pre_end_sn = end_sn; }        // reference :706-709
         else {                                                                          // reference :710-720
-            const int r = rec.z - remain_end - 1;
             last_row = row;
-            int beg = imax(0, imin(lr.x, qlen - r) - w), end = imin(qlen, imax(lr.y, qlen - r) + w);
+            int beg = imax(0, imin(lr.x, rterm) - w), end = imin(qlen, imax(lr.y, rterm) + w);
             beg_sn = beg / PN;
             int min_pre_beg_sn = imin(imin(pg[0].x, pg[1].x), imin(pg[2].x, pg[3].x));          // duplicates of the last one are harmless
             max_pre_end_sn = imax(imax(pg[0].y, pg[1].y), imax(pg[2].y, pg[3].y));
@@ -407,10 +617,11 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         T *H = planes + off;
         const int my_slot = row % ring_rows;
         T *my_ring = s_ring + (long long)my_slot * NPR * ring_cols;
-        const int nchunk = (Wr + 63) >> 6;
+        const int nchunk = (b.dbg & 8) ? 0 : (Wr + 63) >> 6;
         T first = 0, first2 = 0;
         // running arg-max state of this lane (reference :1043-1057)
         int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false;
+        unsigned am_key = 0;          // int16: value and tie-break priority packed into one word (value<<16 | 15-lane<<12 | is_end<<11 | 2047-vector)
         // fast gather: every predecessor's H/E row is in the LDS score ring -> straight-line, batched LDS reads
         bool all_ring = np <= 4;
 #pragma unroll
@@ -430,7 +641,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             T Mv = inf, E1v = inf, E2v = inf;
             // query profile value, reference :504-510
             T q = 0;
-            {
+            if (!(b.dbg & 32)) {
                 int qc;
                 if (q_in_lds) qc = c == 0 ? qc_cache[0] : c == 1 ? qc_cache[1] : ((col >= 1 && col <= qlen) ? (int)s_query[col - 1] : -1);
                 else qc = (in_band && col >= 1 && col <= qlen) ? gld_u8(g_query + col - 1) : -1;
@@ -438,7 +649,8 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                 q = (in_band && qc >= 0) ? (T)qv : (T)0;
             }
             // ---- predecessors, reference :722-761 / :803-852 / :912-969
-            if (all_ring) {
+            if (b.dbg & 16) { Mv = (T)(col & 15); E1v = inf; }
+            else if (all_ring) {
                 auto gather_ring = [&](auto npc) __attribute__((always_inline)) {
                     constexpr int N = decltype(npc)::value;
                     int hraw[N], e1raw[N], e2raw[N], vraw[N]; bool inHk[N], inEk[N], srcok[N], vok[N];
@@ -563,29 +775,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                         first2 = (T)fi2;
                     }
                 }
-#pragma unroll
-                for (int vv = 0; vv < NV; ++vv) {
-                    const int vg = beg_sn + c * NV + vv;
-                    if (vv >= nfast && vg <= end_sn) {
-                        int set_num = PN;
-                        if (!local && vg > max_pre_end_sn) set_num = (vg == max_pre_end_sn + 1) ? 2 : 1;
-                        T prev = (T)row_shr<1>((int)first, (int)hs);
-                        if (PN == 8) prev = (l == 0) ? first : prev;
-                        T f = wsub<T>(prev, oe1);                        // reference :870 / :990
-                        f = set_f<T>(f, l, set_num, e1, inf);
-                        const T hlast = (T)__builtin_amdgcn_readlane((int)hs, vv * PN + PN - 1);
-                        first = tmax<T>(hlast, wadd<T>((T)__builtin_amdgcn_readlane((int)f, vv * PN + PN - 1), o1));  // :874 / :996
-                        if (vvl == vv) F1 = f;
-                        if (GAP == 2) {
-                            T prev2 = (T)row_shr<1>((int)first2, (int)hs);
-                            if (PN == 8) prev2 = (l == 0) ? first2 : prev2;
-                            T g = wsub<T>(prev2, oe2);                   // reference :991
-                            g = set_f<T>(g, l, set_num, e2, inf);
-                            first2 = tmax<T>(hlast, wadd<T>((T)__builtin_amdgcn_readlane((int)g, vv * PN + PN - 1), o2));  // :997
-                            if (vvl == vv) F2 = g;
-                        }
-                    }
-                }
+                if (nfast < nvec) slow_f_tail(c, beg_sn, end_sn, max_pre_end_sn, nfast, hs, F1, F2, first, first2);
                 if (GAP == 1) {                                          // reference :876-883
                     T tmp = tmax<T>(h, E1v);
                     T hh = tmax<T>(tmp, F1);
@@ -622,7 +812,10 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                     const bool is_end = (v == end_sn);
                     int cand = (int)Hout;
                     if (is_end && end_sn == qlen / PN && col > qlen) cand = (int)inf;
-                    if (!am_any || (is_end ? cand >= am_val : cand > am_val)) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
+                    if (sizeof(T) == 2) {
+                        const unsigned key = ((unsigned)(cand + 32768) << 16) | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)is_end << 11) | (unsigned)(2047 - v);
+                        am_key = key > am_key ? key : am_key;
+                    } else if (!am_any || (is_end ? cand >= am_val : cand > am_val)) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
                 }
             }
             STAMP(3)
@@ -633,6 +826,11 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         int mx = d.inf_min, mi = -1;
         if (need_max && (b.dbg & 2)) { mx = 0; mi = imin(qlen, row + 1); }
         else if (need_max) {
+            if (sizeof(T) == 2) {
+                const unsigned kb = wave_max_u32(am_key);
+                const int vmax = (int)(kb >> 16) - 32768;
+                if (vmax > d.inf_min) { mx = vmax; mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+            } else {
             int vmax = wave_max_i32(am_any ? am_val : INT_MIN);
             if (vmax > d.inf_min) {
                 unsigned key = 0;
@@ -642,19 +840,26 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                 mx = vmax; mi = wv * PN + wl;
                 if (mi > qlen) mi = -1;          // cannot happen for a value above inf_min, kept for symmetry with qi[]
             }
+            }
             if (b.want_trace && lane == 0) row_max_i[row] = mi;
             if (local) { if (mx > best_score) { best_score = mx; best_i = row; best_j = mi; } }
             else if (extend) {
                 if (mx > best_score) { best_score = mx; best_i = row; best_j = mi; best_row_zd = row; }
                 else if (b.zdrop > 0) {
-                    int delta_index = gld_i32(row_remain + best_row_zd) - rec.z;
+                    int delta_index = gld_i32(row_remain + best_row_zd) - (qlen - rterm + remain_end + 1);
                     int dd = delta_index - (mi - best_j); if (dd < 0) dd = -dd;
                     if (best_score - mx > b.zdrop + (int)e1 * dd) break;
                 }
             }
             if (banded) {
                 const int out_i = mi + 1;
-                const int os = rec.y, on = recn.y - os;
+                const int o0 = fastmeta ? __builtin_amdgcn_readlane(tv_o[0], ti) : -1, o1 = fastmeta ? __builtin_amdgcn_readlane(tv_o[1], ti) : -1;
+                if (fastmeta && o0 < lr_blk + RL && o1 < lr_blk + RL) {      // at most two successors, both inside the LDS window
+                    int2 a2 = S.l_lr[(o0 >= 0 ? o0 : 0) % RL], b2 = S.l_lr[(o1 >= 0 ? o1 : 0) % RL];
+                    a2.x = imin(a2.x, out_i); a2.y = imax(a2.y, out_i); b2.x = imin(b2.x, out_i); b2.y = imax(b2.y, out_i);
+                    if (o0 >= 0 && lane == 0) S.l_lr[o0 % RL] = a2;
+                    if (o1 >= 0 && lane == 0) S.l_lr[o1 % RL] = b2;
+                } else {
                 bool far = false;
                 for (int t = lane; t < on; t += 64) {
                     const int tt = os + t - obase;
@@ -673,6 +878,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                     }
                 }
                 if (__any(far)) { far_seen = true; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                }
             }
         } else if (b.want_trace && lane == 0) row_max_i[row] = -2;
         STAMP(4)

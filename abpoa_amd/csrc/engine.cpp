@@ -284,6 +284,8 @@ int abpoa_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (g.ready && g.device == device) return ABPOA_HIP_OK;
     if (g.ready) { set_err("engine already bound to device %d", g.device); return ABPOA_HIP_EINVAL; }
+    // the read-set driver runs one stream per group; give the runtime enough hardware queues for them to overlap
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err("no HIP device available (the DP has no CPU fallback)"); return ABPOA_HIP_ENODEV; }
     if (device < 0 || device >= n) { set_err("device %d out of range (0..%d)", device, n - 1); return ABPOA_HIP_ENODEV; }

@@ -129,6 +129,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_sets) n_threads = n_sets;
+    if (n_groups <= 0) { const char *e_ = getenv("ABPOA_HIP_GROUPS"); if (e_) n_groups = atoi(e_); }
     if (n_groups <= 0) n_groups = n_sets >= 512 ? 4 : (n_sets >= 128 ? 2 : 1);
     if (n_groups > n_threads) n_groups = n_threads;
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
@@ -191,7 +192,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
         });
         if (tm) tm->cons_s = now_s() - t0;
     }
-    if (tm) { tm->total_s = now_s() - t_start; tm->n_threads = n_threads; }
+    if (tm) { tm->total_s = now_s() - t_start; tm->n_threads = n_threads; tm->n_groups = n_groups; }
     if (rc != ABPOA_HIP_OK) for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]);
     return rc;
 }

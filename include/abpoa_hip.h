@@ -187,7 +187,10 @@ int  abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_
 void abpoa_hip_free_msa(abpoa_hip_msa_t *r);
 
 /* Phase timers of the last abpoa_hip_msa_batch call (seconds): host graph work, engine calls. */
-typedef struct abpoa_hip_msa_timing_t { double host_sort_s, host_fuse_s, engine_s, cons_s, total_s; int32_t n_rounds, n_threads; } abpoa_hip_msa_timing_t;
+typedef struct abpoa_hip_msa_timing_t {
+    double host_sort_s, host_fuse_s, engine_s, cons_s, total_s;   /* per-group averages for the first three */
+    int32_t n_rounds, n_threads, n_groups, pad;                   /* n_groups = read-set groups run concurrently (one stream each) */
+} abpoa_hip_msa_timing_t;
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out);
 
 #ifdef __cplusplus

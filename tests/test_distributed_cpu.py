@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path of bench.py shards independent read-sets across ranks with no
+data-path collective and gathers only a digest.  Here each rank runs the host driver (oracle-backed CPU shim) on its
+shard; the union must equal the single-process result and the all-reduced digest must be identical on both ranks."""
+import hashlib
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+from abpoa_amd import api, synth
+
+AG = dict(gap_open1=4, gap_open2=0, gap_ext1=2)
+N_SETS = 6
+
+
+def _shard_sets(rank, world, n_per_rank):
+    """same rule as bench.py: rank r owns set indices [r*n, (r+1)*n)"""
+    return [synth.make_read_set(1, rank * n_per_rank + i, 6, 150, 0.05) for i in range(n_per_rank)]
+
+
+def _digest_int(results):
+    h = hashlib.sha256()
+    for r in results:
+        h.update(r.cons_seq.encode())
+        h.update(b"\n")
+    return int(h.hexdigest()[:15], 16)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sets = _shard_sets(rank, world, N_SETS // world)
+    res = api.msa_batch(sets, api.Params(**AG), lib=H.cpu_shim_lib(), n_threads=2)
+    agg = torch.tensor([_digest_int(res), sum(r.n_cells for r in res)], dtype=torch.int64)
+    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{int(agg[0])} {int(agg[1])} {float(t[0])}\n" + "\n".join(r.cons_seq for r in res) + "\n")
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_equal_single_process(tmp_path):
+    H.cpu_shim_lib()          # build once before forking
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    lines = [open(tmp_path / f"rank{r}.txt").read().split("\n") for r in range(2)]
+    assert lines[0][0] == lines[1][0]                       # identical all-reduced digest / cells / max-time on both ranks
+    single = api.msa_batch(_shard_sets(0, 1, N_SETS), api.Params(**AG), lib=H.cpu_shim_lib(), n_threads=2)
+    union = [c for ln in lines for c in ln[1:] if c]
+    assert union == [r.cons_seq for r in single]
+    want = _digest_int(single[:N_SETS // 2]) + _digest_int(single[N_SETS // 2:])
+    assert int(lines[0][0].split()[0]) == want
+    assert int(lines[0][0].split()[1]) == sum(r.n_cells for r in single)
