@@ -123,6 +123,21 @@ __device__ __forceinline__ unsigned wave_max_u32_b(unsigned x) {
     return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+
+// inclusive prefix max over the 64 lanes (Hillis-Steele inside each 16-lane DPP row, then row_bcast:15 / row_bcast:31)
+__device__ __forceinline__ int wave_scan_max_i32(int x) {
+    x = imax(x, row_shr<1>(x, x));
+    x = imax(x, row_shr<2>(x, x));
+    x = imax(x, row_shr<4>(x, x));
+    x = imax(x, row_shr<8>(x, x));
+    x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));   // rows 1,3 <- lane 15 of the row before
+    x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));   // rows 2,3 <- lane 31
+    return x;
+}
+// value of lane-1 (whole wave, DPP wave_shr:1); lane 0 receives `lane0`
+__device__ __forceinline__ int wave_shr1(int lane0, int src) { return __builtin_amdgcn_update_dpp(lane0, src, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int med3i(int a, int lo, int hi) { return imin(imax(a, lo), hi); }
+
 template <typename T> struct Width;
 template <> struct Width<int16_t> { static constexpr int PN = 16, LOGN = 4; };
 template <> struct Width<int32_t> { static constexpr int PN = 8, LOGN = 3; };
@@ -203,6 +218,604 @@ __device__ __forceinline__ int2 uniform2(int2 v) { return make_int2(__builtin_am
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
+// =====================================================================================================================
+// Register-resident row loop ("fast loop") for the production case: global alignment, adaptive band, affine / convex
+// gaps, every row active, band state at its reset value.  Same cells, bands and arg-max as the general loop in
+// align_one() (and therefore as the reference), organised to minimise the INSTRUCTION COUNT of one row, because with
+// one wavefront per SIMD a row costs (instructions x ~4 cycles) + exposed latency:
+//   * max_pos_left/right are PULLED: left/right of row r = min/max over its predecessors p of (argmax_p + 1) (what the
+//     reference's push at :1059-1067 leaves there once every predecessor is done), so the band needs no window at all;
+//   * band geometry, arg-max and arena offset of the last 64 rows live in three VGPRs (lane = row & 63) and are read /
+//     written with v_readlane / v_writelane -- no LDS round trip between a row and its successor;
+//   * static per-row metadata (base, first four predecessors, remaining length) sits in VGPRs per 64-row tile
+//     (lane = row & 63), loaded from the CSR arrays two tiles ahead;
+//   * the H/E rows of the last fr_rows rows sit in an LDS ring as packed words (int16: H | E1 << 16), fr_cols columns per
+//     row with "inf" guard cells on both sides and "inf" padding after the band: the first predecessor needs no range
+//     masks at all (reading outside its stored band yields exactly what the reference reads or assigns there), further
+//     predecessors need one unsigned compare per plane; one ds_read2_b32 fetches H[col-1], H|E[col];
+//   * F is one 64-lane prefix-max scan: with g[c] = hs[c] + c*e,  F[c] = max_{c' < c} g[c'] - (oe - e) - c*e  whenever no
+//     subtraction can wrap (same condition as fast_f_chain), then max with the lane-constant "inf injection" term of
+//     the reference's zero-filled shifts;  vectors beyond max_pre_end_sn use the literal masked scan (set_f);
+//   * rows that do not fit (predecessor further back than the ring, > 4 predecessors, band wider than the ring) take
+//     the general gather (exact range masks, HBM copies) but share everything else.
+template <typename T> struct FastIO {
+    GLOBAL_AS const uint8_t *row_base; GLOBAL_AS const int32_t *row_remain, *pred_off, *pred_row;
+    GLOBAL_AS int32_t *g_bsn, *g_esn, *row_max_i, *g_left, *g_right; GLOBAL_AS int64_t *g_coff;
+    T *planes;
+};
+
+// literal SIMD_SET_F for the vectors [nfast, ...) of one 64-lane chunk (global mode), reference :859-875 / :978-997
+template <typename T, int GAP>
+__device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pre, int nfast, int l, int vvl, T hs, T inf,
+                                               T e1, T oe1, T o1, T e2, T oe2, T o2, T &F1, T &F2, T &first, T &first2) {
+    constexpr int PN = Width<T>::PN, NV = 64 / PN;
+#pragma unroll
+    for (int vv = 0; vv < NV; ++vv) {
+        const int vg = vbase + vv;
+        if (vv >= nfast && vg <= end_sn) {
+            int set_num = PN;
+            if (vg > max_pre) set_num = (vg == max_pre + 1) ? 2 : 1;
+            T prev = (T)row_shr<1>((int)first, (int)hs);
+            if (PN == 8) prev = (l == 0) ? first : prev;
+            T f = wsub<T>(prev, oe1);
+            f = set_f<T>(f, l, set_num, e1, inf);
+            const T hlast = (T)__builtin_amdgcn_readlane((int)hs, vv * PN + PN - 1);
+            first = tmax<T>(hlast, wadd<T>((T)__builtin_amdgcn_readlane((int)f, vv * PN + PN - 1), o1));
+            if (vvl == vv) F1 = f;
+            if (GAP == 2) {
+                T prev2 = (T)row_shr<1>((int)first2, (int)hs);
+                if (PN == 8) prev2 = (l == 0) ? first2 : prev2;
+                T g = wsub<T>(prev2, oe2);
+                g = set_f<T>(g, l, set_num, e2, inf);
+                first2 = tmax<T>(hlast, wadd<T>((T)__builtin_amdgcn_readlane((int)g, vv * PN + PN - 1), o2));
+                if (vvl == vv) F2 = g;
+            }
+        }
+    }
+}
+
+template <typename T, int GAP>
+__device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, const FastIO<T> &io, const uint8_t *s_query,
+                                          long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done) {
+    constexpr int PN = Width<T>::PN, NV = 64 / PN;
+    constexpr int P = GAP == 1 ? 3 : 5;
+    constexpr bool I16 = sizeof(T) == 2;
+    constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? 3 : 2);
+    constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
+    constexpr int GEO_RING = 1 << 24;
+    const int lane = threadIdx.x & 63, l = lane % PN, vvl = lane / PN;
+    const int gn = d.n_rows, qlen = d.qlen, m = b.m, m1 = b.m + 1, w = d.w;
+    const int inf = d.inf_min;
+    const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
+    const int RR = b.lds.fr_rows, RC = b.lds.fr_cols, RCS = RC + 4;
+    int *fr = (int *)(lds_raw + b.lds.phase_off + b.lds.fr_off);
+    int *s_mx = (int *)(lds_raw + b.lds.mx_off);
+    const int infw = I16 ? (int)(((unsigned)inf & 0xffffu) | ((unsigned)inf << 16)) : inf;
+    const int qlen_sn = qlen / PN;
+    auto wr = [](int x) __attribute__((always_inline)) { return (int)(T)x; };          // wrap to the score width
+
+    // per-lane constants of the F scan and of the arg-max key
+    const int idist = inj_dist<PN>(l);
+    const int inj1 = idist >= 0 ? inf - idist * e1 : INT_MIN, inj2 = idist >= 0 ? inf - idist * e2 : INT_MIN;
+    const int le1 = lane * e1, le2 = lane * e2;
+    const int cf1 = oe1 - e1 + le1, cf2 = oe2 - e2 + le2;                               // F[c] = S[c] - cf
+    const long long lo_ll = (long long)(I16 ? INT16_MIN : INT32_MIN) + imax(oe1, oe2) + (long long)PN * imax(e1, e2);
+    const int fast_lo = (int)lo_ll;
+    const int kconst = I16 ? (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (unsigned)(2047 - vvl)) : 0;
+
+    // ---- LDS: extended score matrix (column m = 0) and the score ring, everything "inf"
+    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < m * m1; i += 64) { const int bb = i / m1, qc = i - bb * m1; s_mx[i] = qc < m ? g_mat[bb * m + qc] : 0; } }
+    for (int i = lane; i < RR * NPW * RCS; i += 64) { const int pl = (i / RCS) % NPW; fr[i] = (I16 && pl == 0) ? infw : inf; }
+    __syncthreads();
+    auto ring_put = [&](int slot, int x, int H, int E1, int E2) __attribute__((always_inline)) {
+        int *q = fr + slot * (NPW * RCS) + 2 + x;
+        if (I16) { q[0] = (int)(((unsigned)H & 0xffffu) | ((unsigned)E1 << 16)); if (GAP == 2) q[RCS] = E2; }
+        else { q[0] = H; q[RCS] = E1; if (GAP == 2) q[2 * RCS] = E2; }
+    };
+
+    int cur = 0, n_vec = 0, rows_done = 0;          // arena cursor and cell count in units of PN cells (one reference SIMD vector)
+    const int cap_pn = (int)(d.plane_cap / PN > 0x7fffffffLL ? 0x7fffffffLL : d.plane_cap / PN);
+    const int remain_end = __builtin_amdgcn_readfirstlane(io.row_remain[gn - 1]);
+    // ------------------------------------------------------------------ row 0, reference :553-662
+    int vg_geo = 0, vg_mi = 0, vg_off = 0;          // lane = row & 63: beg_sn | end_sn << 12 | in-ring << 24, arg-max column, arena offset / PN
+    {
+        const int r = __builtin_amdgcn_readfirstlane(io.row_remain[0]) - remain_end - 1;
+        const int dp_end0 = imin(qlen, imax(0, qlen - r) + w);
+        const int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
+        if ((long long)W0 * P > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
+        const bool ring0 = W0 <= RC;
+        T *H = io.planes;
+        for (int i = lane; i < W0; i += 64) {
+            int h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
+            if (GAP == 1) { const int g = wr(-o1 - e1 * i); h = i == 0 ? 0 : g; x1 = i == 0 ? wr(-oe1) : inf; f1 = i == 0 ? inf : g; }
+            else {
+                const int g1 = wr(-o1 - e1 * i), g2 = wr(-o2 - e2 * i);
+                h = i == 0 ? 0 : imax(g1, g2); x1 = i == 0 ? wr(-oe1) : inf; x2 = i == 0 ? wr(-oe2) : inf; f1 = i == 0 ? inf : g1; f2 = i == 0 ? inf : g2;
+            }
+            H[i] = (T)h; H[(long long)PL_E1 * W0 + i] = (T)x1; H[(long long)PL_F1 * W0 + i] = (T)f1;
+            if (GAP == 2) { H[(long long)PL_E2 * W0 + i] = (T)x2; H[(long long)PL_F2 * W0 + i] = (T)f2; }
+            if (ring0) ring_put(0, i, h, x1, x2);
+        }
+        cur = (end_sn0 + 1) * P;
+        if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = 0; }     // source: successors get left = right = 1 (:556-561)
+    }
+
+    // ------------------------------------------------------------------ static metadata, two tiles ahead
+    struct MetaA { int ps, pe, base, rem; };
+    struct MetaB { int p[4]; };
+    auto load_a = [&](int t0) __attribute__((always_inline)) {
+        MetaA a; const int r = imin(t0 + lane, gn - 1);
+        a.ps = io.pred_off[r]; a.pe = io.pred_off[r + 1]; a.base = io.row_base[r]; a.rem = io.row_remain[r];
+        return a;
+    };
+    auto load_b = [&](const MetaA &a) __attribute__((always_inline)) {
+        MetaB q; const int np = a.pe - a.ps;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q.p[k] = io.pred_row[a.ps + imin(k, imax(np - 1, 0))];
+        return q;
+    };
+    MetaA a1 = load_a(0); MetaB b1 = load_b(a1); MetaA a2 = load_a(64);
+    int tv_meta = 0, tv_rterm = 0, tv_ps = 0, tv_p0 = 0, tv_p1 = 0, tv_p2 = 0, tv_p3 = 0;
+    auto switch_tile = [&](int t0) __attribute__((always_inline)) {
+        const int myrow = t0 + lane, np = a1.pe - a1.ps;
+        bool fastrow = np >= 1 && np <= 4 && myrow < gn - 1 && myrow >= 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int dk = myrow - b1.p[k]; fastrow = fastrow && dk >= 1 && dk < RR; }
+        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0);
+        tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
+        tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
+        a1 = a2; b1 = load_b(a1); a2 = load_a(t0 + 128);
+    };
+    switch_tile(0);
+
+    int qc_beg_sn = -1, qoff0 = 0, qoff1 = 0;        // cached (query code of this lane's column) for chunks 0/1 of band start qc_beg_sn
+    auto geo_of = [&](int p, int row, int &geo, int &mi, int &off) __attribute__((always_inline)) {
+        if (row - p < 64) { const int sl = p & 63; geo = __builtin_amdgcn_readlane(vg_geo, sl); mi = __builtin_amdgcn_readlane(vg_mi, sl); off = __builtin_amdgcn_readlane(vg_off, sl); }
+        else {
+            geo = __builtin_amdgcn_readfirstlane(gld_i32(io.g_bsn + p) | (gld_i32(io.g_esn + p) << 12)); mi = __builtin_amdgcn_readfirstlane(gld_i32(io.row_max_i + p));
+            off = __builtin_amdgcn_readfirstlane((int)(uint32_t)(gld_i64(io.g_coff + p) / PN));
+        }
+    };
+
+    for (int row = 1; row < gn - 1; ++row) {
+        const int ti = row & 63;
+        if (ti == 0) {
+            { const int rb = row - 64 + lane; io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
+            switch_tile(row);
+        }
+        last_done = row;
+        const int meta = __builtin_amdgcn_readlane(tv_meta, ti), rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
+        const int base = meta & 0xff, np = (meta >> 8) & 0xff;
+        const bool fastrow = (meta >> 16) & 1;
+        int pr[4], pgeo[4], pmi[4], poffs[4];
+        pr[0] = __builtin_amdgcn_readlane(tv_p0, ti); pr[1] = __builtin_amdgcn_readlane(tv_p1, ti);
+        pr[2] = __builtin_amdgcn_readlane(tv_p2, ti); pr[3] = __builtin_amdgcn_readlane(tv_p3, ti);
+        // ---- band, reference :710-720 with max_pos_left/right pulled from the predecessors' arg-max
+        int mn_mi, mx_mi, min_pb, max_pe, allring;
+        if (fastrow) {
+            { const int sl = pr[0] & 63; pgeo[0] = __builtin_amdgcn_readlane(vg_geo, sl); pmi[0] = __builtin_amdgcn_readlane(vg_mi, sl); poffs[0] = 0; }
+            mn_mi = pmi[0]; mx_mi = pmi[0]; min_pb = pgeo[0] & 0xfff; max_pe = (pgeo[0] >> 12) & 0xfff; allring = pgeo[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                pgeo[k] = pgeo[0]; pmi[k] = pmi[0]; poffs[k] = 0;
+                if (k < np) {
+                    const int sl = pr[k] & 63; pgeo[k] = __builtin_amdgcn_readlane(vg_geo, sl); pmi[k] = __builtin_amdgcn_readlane(vg_mi, sl);
+                    mn_mi = imin(mn_mi, pmi[k]); mx_mi = imax(mx_mi, pmi[k]);
+                    min_pb = imin(min_pb, pgeo[k] & 0xfff); max_pe = imax(max_pe, (pgeo[k] >> 12) & 0xfff); allring &= pgeo[k];
+                }
+            }
+        } else {
+            const int ps = __builtin_amdgcn_readlane(tv_ps, ti);
+            mn_mi = gn; mx_mi = -1; min_pb = 4095; max_pe = -1; allring = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pgeo[k] = 0; pmi[k] = 0; poffs[k] = 0;
+                if (k < np) {
+                    geo_of(pr[k], row, pgeo[k], pmi[k], poffs[k]);
+                    mn_mi = imin(mn_mi, pmi[k]); mx_mi = imax(mx_mi, pmi[k]); min_pb = imin(min_pb, pgeo[k] & 0xfff); max_pe = imax(max_pe, (pgeo[k] >> 12) & 0xfff);
+                }
+            }
+            for (int k = 4; k < np; ++k) {
+                int g_, mi_, off_; geo_of(__builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)), row, g_, mi_, off_);
+                mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff);
+            }
+            if (np == 0) min_pb = 0;
+        }
+        const int left = imin(gn, mn_mi + 1), right = imax(0, mx_mi + 1);
+        const int beg = imax(0, imin(left, rterm) - w), end = imin(qlen, imax(right, rterm) + w);
+        const int beg_sn = imax(beg / PN, min_pb), end_sn = end / PN;
+        const int Wr = (end_sn - beg_sn + 1) * PN;
+        const int off_pn = cur, nvr = end_sn - beg_sn + 1;
+        if (off_pn + nvr * P > cap_pn) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+        cur += nvr * P; n_vec += nvr; ++rows_done;
+        const bool to_ring = Wr <= RC;
+        const bool fast = fastrow && (allring & GEO_RING) && to_ring;
+        if (fastrow && !fast) {                       // rare: statically fast row that must take the general gather after all
+#pragma unroll
+            for (int k = 0; k < 4; ++k) poffs[k] = __builtin_amdgcn_readlane(vg_off, pr[k] & 63);
+        }
+        T *H = io.planes + (long long)off_pn * PN;
+        const int my_slot = (row & (RR - 1)) * (NPW * RCS);
+        const int nch = (Wr + 63) >> 6;
+        if (beg_sn != qc_beg_sn) {                 // band start moved: refresh this lane's cached query codes (as byte offsets into a matrix row)
+            qc_beg_sn = beg_sn;
+            const int c0 = beg_sn * PN + lane, c1 = c0 + 64;
+            qoff0 = (c0 >= 1 && c0 <= qlen) ? (int)s_query[c0 - 1] : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? (int)s_query[c1 - 1] : m;
+        }
+        const int *mrow = s_mx + base * m1;
+        int first = 0, first2 = 0;
+        unsigned am_key = 0; int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false;
+        if (!fast) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // HBM gathers below read cells this wave stored earlier
+        for (int c = 0; c < nch; ++c) {
+            const int rel = c * 64 + lane, col = beg_sn * PN + rel, vb = beg_sn + c * NV, v = vb + vvl;
+            const bool in_band = rel < Wr;
+            int qc = c == 0 ? qoff0 : qoff1;
+            if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
+            const int q = mrow[qc];
+            int Mv = inf, E1v = inf, E2v = inf;
+            // ---- predecessors
+            auto from_ring = [&](int k, int p, int g_) __attribute__((always_inline)) {
+                const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
+                const int x = col - pb * PN;
+                const int *src = fr + (p & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+                int hm1, ev1, ev2 = inf;
+                if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
+                else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
+                if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; }
+                else {
+                    const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
+                    Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
+                }
+            };
+            auto from_hbm = [&](int k, int g_, int off_) __attribute__((always_inline)) {
+                const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
+                const int x = col - pb * PN;
+                const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
+                const T *Hp = io.planes + (long long)(uint32_t)off_ * PN;
+                int hval = inf, ev1 = inf, ev2 = inf;
+                if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + x - 1));
+                if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E1 * Wp + x)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E2 * Wp + x)); }
+                if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; }
+                else { Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
+            };
+            if (fast) {
+                from_ring(0, pr[0], pgeo[0]);
+                if (np > 1) from_ring(1, pr[1], pgeo[1]);
+                if (np > 2) from_ring(2, pr[2], pgeo[2]);
+                if (np > 3) from_ring(3, pr[3], pgeo[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < np) {
+                    if ((pgeo[k] & GEO_RING) && row - pr[k] < RR) from_ring(k, pr[k], pgeo[k]); else from_hbm(k, pgeo[k], poffs[k]);
+                }
+                if (np > 4) {
+                    const int ps = __builtin_amdgcn_readlane(tv_ps, ti);
+                    for (int k = 4; k < np; ++k) {
+                        int g_, mi_, off_; const int p = __builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)); geo_of(p, row, g_, mi_, off_);
+                        if ((g_ & GEO_RING) && row - p < RR) from_ring(k, p, g_); else from_hbm(k, g_, off_);
+                    }
+                }
+            }
+            // ---- in-row part, reference :854-883 / :972-1008
+            const int h = wr(Mv + q);
+            int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
+            if (c == 0) { first = __builtin_amdgcn_readlane(h, 0); first2 = first; }
+            const int nvec = imin(NV, end_sn - vb + 1);
+            int nfast = imin(nvec, max_pe - vb + 1);
+            if (nfast < 0) nfast = 0;
+            if (nfast > 0 && __any(vvl < nfast && h < fast_lo)) nfast = 0;
+            int F1 = inf, F2 = inf;
+            if (nfast > 0) {
+                const int g1 = hs + le1;
+                const int S1 = wave_scan_max_i32(wave_shr1(first - e1, g1));
+                F1 = imax(S1 - cf1, inj1);
+                if (GAP == 2) { const int g2 = hs + le2; const int S2 = wave_scan_max_i32(wave_shr1(first2 - e2, g2)); F2 = imax(S2 - cf2, inj2);
+                                if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first2 = __builtin_amdgcn_readlane(imax(S2, g2), lastl) - lastl * e2; } }
+                if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first = __builtin_amdgcn_readlane(imax(S1, g1), lastl) - lastl * e1; }
+            }
+            if (nfast < nvec) {
+                T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
+                slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
+                F1 = (int)f1t; F2 = (int)f2t; first = (int)fi; first2 = (int)fi2;
+            }
+            int Hout, E1out, E2out = inf;
+            if (GAP == 1) {
+                const int tmp = imax(h, E1v);
+                Hout = imax(tmp, F1);
+                const int en = imax(wr(E1v - e1), wr(Hout - oe1));
+                E1out = (Hout == tmp) ? en : inf;
+            } else {
+                Hout = imax(hs, imax(F1, F2));
+                E1out = imax(wr(E1v - e1), wr(Hout - oe1));
+                E2out = imax(wr(E2v - e2), wr(Hout - oe2));
+            }
+            if (in_band) {
+                H[rel] = (T)Hout; H[PL_E1 * Wr + rel] = (T)E1out; H[PL_F1 * Wr + rel] = (T)F1;
+                if (GAP == 2) { H[PL_E2 * Wr + rel] = (T)E2out; H[PL_F2 * Wr + rel] = (T)F2; }
+            }
+            if (to_ring) {
+                int *qd = fr + my_slot + 2 + rel;
+                if (I16) { qd[0] = in_band ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16)) : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
+                else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
+            }
+            // ---- running arg-max candidate of this lane, reference :1043-1057
+            {
+                const bool is_end = (v == end_sn);
+                int cand = Hout;
+                if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
+                if (I16) {
+                    const unsigned key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
+                    am_key = (in_band && key > am_key) ? key : am_key;
+                } else if (in_band && (!am_any || (is_end ? cand >= am_val : cand > am_val))) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
+            }
+        }
+        if (to_ring) for (int c = nch; c < (RC >> 6); ++c) {        // "inf" padding after the band, up to the ring width
+            int *qd = fr + my_slot + 2 + c * 64 + lane;
+            qd[0] = infw; if (NPW > 1) qd[RCS] = inf; if (NPW > 2) qd[2 * RCS] = inf;
+        }
+        // ---- row arg-max (tie-break: lowest lane residue, then the end_sn vector, then the lowest vector), reference :1043-1057
+        int mi = -1;
+        if (I16) {
+            const unsigned kb = wave_max_u32_b(am_key);
+            const int vmax = (int)(kb >> 16) - 32768;
+            if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+        } else {
+            const int vmax = wave_max_i32(am_any ? am_val : INT_MIN);
+            if (vmax > inf) {
+                unsigned key = 0;
+                if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
+                const unsigned kb = wave_max_u32_b(key);
+                mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
+                if (mi > qlen) mi = -1;
+            }
+        }
+        {   // v_writelane x3 (no clang builtin here); the operands are SALU results, the s_nop covers the lane-select hazard regardless
+            const int geo_new = beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0), off_new = off_pn;
+            asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+                         : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
+        }
+    }
+    // ---- geometry of the last (partial) tile
+    if (status == 0) {
+        const int tb = last_done & ~63, rb = tb + lane;
+        if (rb <= last_done) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
+    }
+    __syncthreads();
+    // ---- max_pos_left/right as the reference leaves them (only when the caller reads them back)
+    if (status == 0 && b.want_lr) {
+        for (int r = lane; r < gn; r += 64) {
+            int lf = gn, rt = 0;
+            if (r == 0) { lf = 0; rt = 0; }
+            else for (int k = io.pred_off[r]; k < io.pred_off[r + 1]; ++k) {
+                const int p = io.pred_row[k]; const int oi = (p == 0 ? 0 : io.row_max_i[p]) + 1;
+                lf = imin(lf, oi); rt = imax(rt, oi);
+            }
+            io.g_left[r] = lf; io.g_right[r] = rt;
+        }
+    }
+    cursor_out = (long long)cur * PN; n_cells_out = (long long)n_vec * PN; rows_done_out = rows_done;
+}
+
+// Everything after the row loop: global best (reference :1028-1041), backtrack (:109-429) and the result record.  Shared by the
+// general kernel and the fast-loop kernel; reads only what the row loops left in HBM (planes, per-row band geometry).
+struct TailState { long long cursor, n_cells, clk0, clk1, seg[6]; int status, rows_done, best_score, best_i, best_j; };
+
+template <typename T, int GAP>
+__device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts) {
+    constexpr int PN = Width<T>::PN;
+    constexpr int P = GAP == 0 ? 1 : (GAP == 1 ? 3 : 5);
+    constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
+    const int lane = threadIdx.x & 63;
+    const int gn = d.n_rows, qlen = d.qlen, m = b.m;
+    const bool local = b.align_mode == ABPOA_HIP_LOCAL_MODE;
+    const bool banded = b.wb >= 0;
+    const T e1 = (T)b.e1, oe1 = (T)(b.o1 + b.e1), e2 = (T)b.e2, oe2 = (T)(b.o2 + b.e2);
+    GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
+    GLOBAL_AS const uint8_t *row_base = vgpr_ptr(b.row_base + d.row0);
+    GLOBAL_AS const int32_t *row_node_id = vgpr_ptr(b.row_node_id + d.row0);
+    GLOBAL_AS const int32_t *pred_off = vgpr_ptr(b.pred_off + d.poff0), *pred_row = vgpr_ptr(b.pred_row + d.pred0);
+    GLOBAL_AS int32_t *g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0), *g_esn = vgpr_ptr(b.dp_end_sn + d.row0);
+    GLOBAL_AS int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
+    T *planes = (T *)(b.planes + d.plane_off);
+    uint8_t *s_query = lds_raw + b.lds.q_off;
+    int32_t *s_mat = (int32_t *)(lds_raw + b.lds.mat_off);
+    const bool q_in_lds = qlen <= b.lds.q_cap;
+    auto dp_end_of = [&](int row, int end_sn_row) __attribute__((always_inline)) { return (banded || row == 0) ? (end_sn_row + 1) * PN - 1 : qlen; };
+    int status = ts.status, best_score = ts.best_score, best_i = ts.best_i, best_j = ts.best_j, bt_steps = 0;
+    const long long cursor = ts.cursor, n_cells = ts.n_cells, clk0 = ts.clk0, clk1 = ts.clk1; const int rows_done = ts.rows_done;
+    const long long *seg = ts.seg;
+    __syncthreads();       // all of this wave's plane / band stores have landed before the loads below
+
+    // ------------------------------------------------------------------ global best, reference :1028-1041
+    if (status == 0 && b.align_mode == ABPOA_HIP_GLOBAL_MODE) {
+        for (int k = pred_off[gn - 1]; k < pred_off[gn]; ++k) {
+            int in_row = pred_row[k];
+            int pe = g_esn[in_row], pb = g_bsn[in_row];
+            int dpe = dp_end_of(in_row, pe);
+            int end = qlen > dpe ? dpe : qlen;
+            int score = (int)planes[g_coff[in_row] + end - pb * PN];
+            if (score > best_score) { best_score = score; best_i = in_row; best_j = end; }
+        }
+    }
+
+    // ------------------------------------------------------------------ backtrack, reference :109-429
+    // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
+    // refilled cooperatively; only lane 0 writes cigar words.
+    int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
+    if (status == 0 && b.ret_cigar) {
+        BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
+        T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
+        const long long bt_cells = b.lds.bt_bytes / (int)sizeof(T);
+        int bt_lo = 1, bt_hi = 0, bt_pbase = 0, bt_margin = 0;   // window = rows [bt_lo, bt_hi], empty at start
+        long long bt_c0 = 0;                                     // arena cell of B.coff[0]
+        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
+        const int cap = d.cigar_cap;
+        uint64_t last_word = 0;
+        auto load_window = [&](int hi) __attribute__((always_inline)) {
+            __syncthreads();
+            int lo = imax(0, hi - BTR + 1);
+            const int r = lo + lane;
+            int my_b = -1, my_e = -1; long long my_c = 0;
+            if (r <= hi) { my_b = g_bsn[r]; my_e = g_esn[r]; my_c = g_coff[r]; }
+            // end of row hi = its offset + P * width (never-computed rows carry zero width)
+            const int hb = g_bsn[hi], he = g_esn[hi];
+            const long long c_end = g_coff[hi] + (hb >= 0 ? (long long)(he - hb + 1) * PN * P : 0);
+            // smallest lo' whose segment [coff[lo'], c_end) fits the LDS tile
+            const bool fits = (r <= hi) && (c_end - my_c) <= bt_cells;
+            const unsigned long long mk = __ballot(fits);
+            const int sh = mk ? __builtin_ctzll(mk) : (hi - lo);     // worst case: a single row (may still not fit -> HBM path)
+            lo += sh;
+            if (r >= lo && r <= hi) {
+                const int i = r - lo;
+                B.bsn[i] = my_b; B.esn[i] = my_e; B.coff[i] = my_c;
+                B.poff[i] = pred_off[r]; B.nid[i] = row_node_id[r]; B.base[i] = row_base[r];
+            }
+            if (lane == 0) { B.coff[hi - lo + 1] = c_end; B.poff[hi - lo + 1] = pred_off[hi + 1]; }
+            __syncthreads();
+            bt_lo = lo; bt_hi = hi; bt_c0 = B.coff[0]; bt_pbase = B.poff[0]; bt_margin = imin(4, (hi - lo) / 2);
+            const int pn_t = imin(BTP, B.poff[hi - lo + 1] - bt_pbase);
+            for (int i = lane; i < pn_t; i += 64) B.pred[i] = pred_row[bt_pbase + i];
+            long long ncell = c_end - bt_c0; if (ncell > bt_cells) ncell = 0;        // does not fit: leave the tile empty
+            if (ncell == 0) { bt_hi = bt_lo - 1; }
+            // 16-byte coalesced copy (arena offsets are multiples of PN cells = 32 bytes)
+            const int4 *src = (const int4 *)(planes + bt_c0); int4 *dst = (int4 *)bt;
+            const long long n16 = ncell * (long long)sizeof(T) / 16;
+            for (long long i = lane; i < n16; i += 64) dst[i] = src[i];
+            __syncthreads();
+        };
+        auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
+            uint64_t L = (uint64_t)(int64_t)len;
+            if (n_cigar == 0 || op != ABPOA_HIP_CINS || op != (int)(last_word & 0xf)) {
+                if (n_cigar >= cap) { status = ABPOA_HIP_EBACKTRACK; return; }
+                uint64_t n_id = (uint64_t)(int64_t)node_id, q_id = (uint64_t)(int64_t)query_id, wv;
+                if (op == ABPOA_HIP_CMATCH) wv = n_id << 34 | q_id << 4 | (uint64_t)op;
+                else if (op == ABPOA_HIP_CINS) wv = q_id << 34 | L << 4 | (uint64_t)op;
+                else wv = n_id << 34 | L << 4 | (uint64_t)op;
+                last_word = wv; ++n_cigar;
+            } else last_word += L << 4;
+            if (lane == 0) cg[n_cigar - 1] = last_word;      // the newest word lives in a register; memory is write-only here
+        };
+        struct Geo { int pb, pe; long long off; bool in_tile; };
+        auto geo_of = [&](int row_) __attribute__((always_inline)) {
+            Geo g;
+            g.in_tile = row_ >= bt_lo && row_ <= bt_hi;
+            const int i = g.in_tile ? row_ - bt_lo : 0;
+            g.pb = B.bsn[i]; g.pe = B.esn[i]; g.off = B.coff[i] - bt_c0;
+            if (!g.in_tile) { g.pb = gld_i32(g_bsn + row_); g.pe = gld_i32(g_esn + row_); g.off = gld_i64(g_coff + row_); }
+            return g;
+        };
+        auto cell = [&](const Geo &g, int plane, int col_) __attribute__((always_inline)) -> int {
+            const long long Wp = (long long)(g.pe - g.pb + 1) * PN;
+            const long long idx = g.off + plane * Wp + (col_ - g.pb * PN);
+            int v = (int)bt[g.in_tile ? idx : 0];
+            if (!g.in_tile) v = gld_cell((GLOBAL_AS const T *)(planes + idx));
+            return v;
+        };
+        auto in_range = [&](const Geo &g, int row_, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= dp_end_of(row_, g.pe); };
+        auto stored = [&](const Geo &g, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= (g.pe + 1) * PN - 1; };
+        auto qcode = [&](int j_) __attribute__((always_inline)) { int v = (int)s_query[q_in_lds ? j_ : 0]; if (!q_in_lds) v = gld_u8(g_query + j_); return v; };
+
+        int i = best_i, j = best_j, start_i = best_i, start_j = best_j, cur_op = OP_ALL, indel_first = 1;
+        if (best_j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
+        while (i > 0 && j > 0 && status == 0) {
+            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
+            const Geo gi = geo_of(i);
+            const int Hij = cell(gi, 0, j);
+            if (local && Hij == 0) break;
+            start_i = i; start_j = j; ++bt_steps;
+            int ps, np, id, bs_;
+            { const int t = gi.in_tile ? i - bt_lo : 0; ps = B.poff[t]; np = B.poff[t + 1] - ps; id = B.nid[t]; bs_ = B.base[t]; }
+            if (!gi.in_tile) { ps = gld_i32(pred_off + i); np = gld_i32(pred_off + i + 1) - ps; id = gld_i32(row_node_id + i); bs_ = gld_u8(row_base + i); }
+            auto pred_bt = [&](int idx) __attribute__((always_inline)) { const int t = idx - bt_pbase; const bool ok = gi.in_tile && t >= 0 && t < BTP; int v = B.pred[ok ? t : 0]; if (!ok) v = gld_i32(pred_row + idx); return v; };
+            const int qc = qcode(j - 1);
+            const int s = s_mat[m * bs_ + qc];
+            const int is_match = bs_ == qc;
+            int hit = 0;
+            auto try_match = [&](int set_indel) __attribute__((always_inline)) {
+                for (int k = 0; k < np; ++k) {
+                    const int pr = pred_bt(ps + k);
+                    const Geo gp = geo_of(pr);
+                    if (!in_range(gp, pr, j - 1)) continue;
+                    if (cell(gp, 0, j - 1) + s == Hij) {
+                        cur_op = OP_ALL; hit = 1;
+                        push(ABPOA_HIP_CMATCH, 1, id, j - 1);
+                        i = pr; --j; ++n_aln; n_match += is_match;
+                        if (set_indel) indel_first = 0;
+                        break;
+                    }
+                }
+            };
+            if (GAP == 0) {
+                if (indel_first == 0) try_match(0);
+                if (!hit) {
+                    for (int k = 0; k < np; ++k) {
+                        const int pr = pred_bt(ps + k);
+                        const Geo gp = geo_of(pr);
+                        if (!in_range(gp, pr, j)) continue;
+                        if (cell(gp, 0, j) - (int)e1 == Hij) { push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; hit = 1; break; }
+                    }
+                }
+                if (!hit && stored(gi, j - 1) && cell(gi, 0, j - 1) - (int)e1 == Hij) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; hit = 1; ++n_aln; }
+                if (!hit && indel_first == 1) try_match(1);
+            } else {
+                if ((cur_op & OP_M) && indel_first == 0) try_match(0);
+                if (!hit && (cur_op & OP_E)) {
+                    for (int k = 0; k < np && !hit; ++k) {
+                        const int pr = pred_bt(ps + k);
+                        const Geo gp = geo_of(pr);
+                        if (!in_range(gp, pr, j)) continue;
+                        for (int x = 1; x <= (GAP == 2 ? 2 : 1); ++x) {
+                            const int bit = x == 1 ? OP_E1 : OP_E2, pl = x == 1 ? PL_E1 : PL_E2;
+                            const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
+                            if (!(cur_op & bit)) continue;
+                            const int preE = cell(gp, pl, j);
+                            const bool ok = (cur_op & OP_M) ? (Hij == preE) : (cell(gi, pl, j) == preE - ex);
+                            if (ok) {
+                                cur_op = (cell(gp, 0, j) - oex == preE) ? (OP_M | OP_F) : bit;
+                                hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; break;
+                            }
+                        }
+                    }
+                }
+                if (!hit && (cur_op & OP_F)) {
+                    for (int x = 1; x <= (GAP == 2 ? 2 : 1) && !hit; ++x) {
+                        const int bit = x == 1 ? OP_F1 : OP_F2, pl = x == 1 ? PL_F1 : PL_F2;
+                        const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
+                        if (!(cur_op & bit)) continue;
+                        const int Fij = cell(gi, pl, j);
+                        if (!(cur_op & OP_M) || Hij == Fij) {
+                            if (stored(gi, j - 1)) {
+                                if (cell(gi, 0, j - 1) - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
+                                else if (cell(gi, pl, j - 1) - ex == Fij) { cur_op = bit; hit = 1; }
+                            }
+                        }
+                    }
+                    if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
+                }
+                if (!hit && (cur_op & OP_M) && indel_first == 1) try_match(1);
+            }
+            if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
+        }
+        if (status == 0) {
+            if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
+            __syncthreads();
+            if (!b.rev_cigar) for (int k = lane; k < n_cigar >> 1; k += 64) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
+            node_e = row_node_id[best_i]; query_e = best_j - 1;
+            node_s = row_node_id[start_i]; query_s = start_j - 1;
+        }
+    }
+    if (lane == 0) {
+        AlnOut o; for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = 0;
+        o.status = status; o.best_score = best_score; o.best_row = best_i; o.best_col = best_j;
+        o.node_s = node_s; o.node_e = node_e; o.query_s = query_s; o.query_e = query_e;
+        o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = 0;
+        o.n_cells = n_cells; o.cells_used = cursor;
+        for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
+        o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
+        *out_rec = o;
+    }
+}
+
 // GAP: 0 linear, 1 affine, 2 convex (reference gap_mode)
 template <typename T, int GAP>
 __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
@@ -280,7 +893,14 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     long long cursor = 0;          // next free arena cell
     long long n_cells = 0;
     int status = 0;
-
+    int rows_done = 0, bt_steps = 0;
+    int best_score = d.inf_min, best_i = 0, best_j = 0, best_row_zd = 0;
+    int last_done = 0;                                        // last row the loop reached (z-drop may stop early)
+    long long clk0 = 0, clk1 = 0;
+#ifdef ABPOA_HIP_PROFILE
+    long long seg_keep[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    {
     // ------------------------------------------------------------------ row 0, reference :553-662
     int end_sn0 = 0;
     {
@@ -345,17 +965,14 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
 #else
 #define STAMP(I)
 #endif
-    const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
+    clk0 = (long long)__builtin_amdgcn_s_memtime();
 #ifdef ABPOA_HIP_PROFILE
     seg_last = clk0;
 #endif
-    int rows_done = 0, bt_steps = 0;
-    int best_score = d.inf_min, best_i = 0, best_j = 0, best_row_zd = 0;
     const int remain_end = (banded || b.zdrop > 0) ? row_remain[gn - 1] : 0;
     const bool need_max = local || extend || banded;
     int tile_beg = 0, tile_end = 0, pbase = 0, obase = 0;     // static-metadata tile covers rows [tile_beg, tile_end)
     int last_row = 0;                                         // last row whose left/right entry was consumed
-    int last_done = 0;                                        // last row the loop reached (z-drop may stop early)
 
     // ------------------------------------------------------------------ rows 1 .. gn-2, reference :1105
     // next-tile prefetch registers (static graph metadata of rows [nt_t0, nt_t0 + TS))
@@ -888,204 +1505,30 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         const int r = tile_beg + lane;
         if (r <= last_done) { const int4 br = S.b_rec[r % RB]; g_bsn[r] = br.x; g_esn[r] = br.y; g_coff[r] = (long long)(uint32_t)br.z * PN; }
     }
-    const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
+    clk1 = (long long)__builtin_amdgcn_s_memtime();
     // ---- retire the left/right window to HBM (the arrays are in/out for the caller)
     if (banded && status == 0) {
         for (int i = lane; i < RL; i += 64) { const int r = lr_blk + i; if (r < gn) { const int2 v2 = S.l_lr[r % RL]; g_left[r] = v2.x; g_right[r] = v2.y; } }
     }
     (void)last_row;
-    __syncthreads();       // all of this wave's plane / band stores have landed before the loads below
-
-    // ------------------------------------------------------------------ global best, reference :1028-1041
-    if (status == 0 && b.align_mode == ABPOA_HIP_GLOBAL_MODE) {
-        for (int k = pred_off[gn - 1]; k < pred_off[gn]; ++k) {
-            int in_row = pred_row[k];
-            int pe = g_esn[in_row], pb = g_bsn[in_row];
-            int dpe = dp_end_of(in_row, pe);
-            int end = qlen > dpe ? dpe : qlen;
-            int score = (int)planes[g_coff[in_row] + end - pb * PN];
-            if (score > best_score) { best_score = score; best_i = in_row; best_j = end; }
-        }
-    }
-
-    // ------------------------------------------------------------------ backtrack, reference :109-429
-    // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
-    // refilled cooperatively; only lane 0 writes cigar words.
-    int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
-    if (status == 0 && b.ret_cigar) {
-        BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
-        T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
-        const long long bt_cells = b.lds.bt_bytes / (int)sizeof(T);
-        int bt_lo = 1, bt_hi = 0, bt_pbase = 0, bt_margin = 0;   // window = rows [bt_lo, bt_hi], empty at start
-        long long bt_c0 = 0;                                     // arena cell of B.coff[0]
-        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
-        const int cap = d.cigar_cap;
-        uint64_t last_word = 0;
-        auto load_window = [&](int hi) __attribute__((always_inline)) {
-            __syncthreads();
-            int lo = imax(0, hi - BTR + 1);
-            const int r = lo + lane;
-            int my_b = -1, my_e = -1; long long my_c = 0;
-            if (r <= hi) { my_b = g_bsn[r]; my_e = g_esn[r]; my_c = g_coff[r]; }
-            // end of row hi = its offset + P * width (never-computed rows carry zero width)
-            const int hb = g_bsn[hi], he = g_esn[hi];
-            const long long c_end = g_coff[hi] + (hb >= 0 ? (long long)(he - hb + 1) * PN * P : 0);
-            // smallest lo' whose segment [coff[lo'], c_end) fits the LDS tile
-            const bool fits = (r <= hi) && (c_end - my_c) <= bt_cells;
-            const unsigned long long mk = __ballot(fits);
-            const int sh = mk ? __builtin_ctzll(mk) : (hi - lo);     // worst case: a single row (may still not fit -> HBM path)
-            lo += sh;
-            if (r >= lo && r <= hi) {
-                const int i = r - lo;
-                B.bsn[i] = my_b; B.esn[i] = my_e; B.coff[i] = my_c;
-                B.poff[i] = pred_off[r]; B.nid[i] = row_node_id[r]; B.base[i] = row_base[r];
-            }
-            if (lane == 0) { B.coff[hi - lo + 1] = c_end; B.poff[hi - lo + 1] = pred_off[hi + 1]; }
-            __syncthreads();
-            bt_lo = lo; bt_hi = hi; bt_c0 = B.coff[0]; bt_pbase = B.poff[0]; bt_margin = imin(4, (hi - lo) / 2);
-            const int pn_t = imin(BTP, B.poff[hi - lo + 1] - bt_pbase);
-            for (int i = lane; i < pn_t; i += 64) B.pred[i] = pred_row[bt_pbase + i];
-            long long ncell = c_end - bt_c0; if (ncell > bt_cells) ncell = 0;        // does not fit: leave the tile empty
-            if (ncell == 0) { bt_hi = bt_lo - 1; }
-            // 16-byte coalesced copy (arena offsets are multiples of PN cells = 32 bytes)
-            const int4 *src = (const int4 *)(planes + bt_c0); int4 *dst = (int4 *)bt;
-            const long long n16 = ncell * (long long)sizeof(T) / 16;
-            for (long long i = lane; i < n16; i += 64) dst[i] = src[i];
-            __syncthreads();
-        };
-        auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
-            uint64_t L = (uint64_t)(int64_t)len;
-            if (n_cigar == 0 || op != ABPOA_HIP_CINS || op != (int)(last_word & 0xf)) {
-                if (n_cigar >= cap) { status = ABPOA_HIP_EBACKTRACK; return; }
-                uint64_t n_id = (uint64_t)(int64_t)node_id, q_id = (uint64_t)(int64_t)query_id, wv;
-                if (op == ABPOA_HIP_CMATCH) wv = n_id << 34 | q_id << 4 | (uint64_t)op;
-                else if (op == ABPOA_HIP_CINS) wv = q_id << 34 | L << 4 | (uint64_t)op;
-                else wv = n_id << 34 | L << 4 | (uint64_t)op;
-                last_word = wv; ++n_cigar;
-            } else last_word += L << 4;
-            if (lane == 0) cg[n_cigar - 1] = last_word;      // the newest word lives in a register; memory is write-only here
-        };
-        struct Geo { int pb, pe; long long off; bool in_tile; };
-        auto geo_of = [&](int row_) __attribute__((always_inline)) {
-            Geo g;
-            g.in_tile = row_ >= bt_lo && row_ <= bt_hi;
-            const int i = g.in_tile ? row_ - bt_lo : 0;
-            g.pb = B.bsn[i]; g.pe = B.esn[i]; g.off = B.coff[i] - bt_c0;
-            if (!g.in_tile) { g.pb = gld_i32(g_bsn + row_); g.pe = gld_i32(g_esn + row_); g.off = gld_i64(g_coff + row_); }
-            return g;
-        };
-        auto cell = [&](const Geo &g, int plane, int col_) __attribute__((always_inline)) -> int {
-            const long long Wp = (long long)(g.pe - g.pb + 1) * PN;
-            const long long idx = g.off + plane * Wp + (col_ - g.pb * PN);
-            int v = (int)bt[g.in_tile ? idx : 0];
-            if (!g.in_tile) v = gld_cell((GLOBAL_AS const T *)(planes + idx));
-            return v;
-        };
-        auto in_range = [&](const Geo &g, int row_, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= dp_end_of(row_, g.pe); };
-        auto stored = [&](const Geo &g, int col_) __attribute__((always_inline)) { return col_ >= g.pb * PN && col_ <= (g.pe + 1) * PN - 1; };
-        auto qcode = [&](int j_) __attribute__((always_inline)) { int v = (int)s_query[q_in_lds ? j_ : 0]; if (!q_in_lds) v = gld_u8(g_query + j_); return v; };
-
-        int i = best_i, j = best_j, start_i = best_i, start_j = best_j, cur_op = OP_ALL, indel_first = 1;
-        if (best_j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
-        while (i > 0 && j > 0 && status == 0) {
-            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
-            const Geo gi = geo_of(i);
-            const int Hij = cell(gi, 0, j);
-            if (local && Hij == 0) break;
-            start_i = i; start_j = j; ++bt_steps;
-            int ps, np, id, bs_;
-            { const int t = gi.in_tile ? i - bt_lo : 0; ps = B.poff[t]; np = B.poff[t + 1] - ps; id = B.nid[t]; bs_ = B.base[t]; }
-            if (!gi.in_tile) { ps = gld_i32(pred_off + i); np = gld_i32(pred_off + i + 1) - ps; id = gld_i32(row_node_id + i); bs_ = gld_u8(row_base + i); }
-            auto pred_bt = [&](int idx) __attribute__((always_inline)) { const int t = idx - bt_pbase; const bool ok = gi.in_tile && t >= 0 && t < BTP; int v = B.pred[ok ? t : 0]; if (!ok) v = gld_i32(pred_row + idx); return v; };
-            const int qc = qcode(j - 1);
-            const int s = s_mat[m * bs_ + qc];
-            const int is_match = bs_ == qc;
-            int hit = 0;
-            auto try_match = [&](int set_indel) __attribute__((always_inline)) {
-                for (int k = 0; k < np; ++k) {
-                    const int pr = pred_bt(ps + k);
-                    const Geo gp = geo_of(pr);
-                    if (!in_range(gp, pr, j - 1)) continue;
-                    if (cell(gp, 0, j - 1) + s == Hij) {
-                        cur_op = OP_ALL; hit = 1;
-                        push(ABPOA_HIP_CMATCH, 1, id, j - 1);
-                        i = pr; --j; ++n_aln; n_match += is_match;
-                        if (set_indel) indel_first = 0;
-                        break;
-                    }
-                }
-            };
-            if (GAP == 0) {
-                if (indel_first == 0) try_match(0);
-                if (!hit) {
-                    for (int k = 0; k < np; ++k) {
-                        const int pr = pred_bt(ps + k);
-                        const Geo gp = geo_of(pr);
-                        if (!in_range(gp, pr, j)) continue;
-                        if (cell(gp, 0, j) - (int)e1 == Hij) { push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; hit = 1; break; }
-                    }
-                }
-                if (!hit && stored(gi, j - 1) && cell(gi, 0, j - 1) - (int)e1 == Hij) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; hit = 1; ++n_aln; }
-                if (!hit && indel_first == 1) try_match(1);
-            } else {
-                if ((cur_op & OP_M) && indel_first == 0) try_match(0);
-                if (!hit && (cur_op & OP_E)) {
-                    for (int k = 0; k < np && !hit; ++k) {
-                        const int pr = pred_bt(ps + k);
-                        const Geo gp = geo_of(pr);
-                        if (!in_range(gp, pr, j)) continue;
-                        for (int x = 1; x <= (GAP == 2 ? 2 : 1); ++x) {
-                            const int bit = x == 1 ? OP_E1 : OP_E2, pl = x == 1 ? PL_E1 : PL_E2;
-                            const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
-                            if (!(cur_op & bit)) continue;
-                            const int preE = cell(gp, pl, j);
-                            const bool ok = (cur_op & OP_M) ? (Hij == preE) : (cell(gi, pl, j) == preE - ex);
-                            if (ok) {
-                                cur_op = (cell(gp, 0, j) - oex == preE) ? (OP_M | OP_F) : bit;
-                                hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); i = pr; break;
-                            }
-                        }
-                    }
-                }
-                if (!hit && (cur_op & OP_F)) {
-                    for (int x = 1; x <= (GAP == 2 ? 2 : 1) && !hit; ++x) {
-                        const int bit = x == 1 ? OP_F1 : OP_F2, pl = x == 1 ? PL_F1 : PL_F2;
-                        const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
-                        if (!(cur_op & bit)) continue;
-                        const int Fij = cell(gi, pl, j);
-                        if (!(cur_op & OP_M) || Hij == Fij) {
-                            if (stored(gi, j - 1)) {
-                                if (cell(gi, 0, j - 1) - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
-                                else if (cell(gi, pl, j - 1) - ex == Fij) { cur_op = bit; hit = 1; }
-                            }
-                        }
-                    }
-                    if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
-                }
-                if (!hit && (cur_op & OP_M) && indel_first == 1) try_match(1);
-            }
-            if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
-        }
-        if (status == 0) {
-            if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
-            __syncthreads();
-            if (!b.rev_cigar) for (int k = lane; k < n_cigar >> 1; k += 64) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
-            node_e = row_node_id[best_i]; query_e = best_j - 1;
-            node_s = row_node_id[start_i]; query_s = start_j - 1;
-        }
-    }
-    if (lane == 0) {
-        AlnOut o; for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = 0;
-        o.status = status; o.best_score = best_score; o.best_row = best_i; o.best_col = best_j;
-        o.node_s = node_s; o.node_e = node_e; o.query_s = query_s; o.query_e = query_e;
-        o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = 0;
-        o.n_cells = n_cells; o.cells_used = cursor;
 #ifdef ABPOA_HIP_PROFILE
-        for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
+    for (int i_ = 0; i_ < 6; ++i_) seg_keep[i_] = seg[i_];
 #endif
-        o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
-        *out_rec = o;
-    }
+    }   // general row loop
+    TailState ts; ts.cursor = cursor; ts.n_cells = n_cells; ts.status = status; ts.rows_done = rows_done; ts.best_score = best_score; ts.best_i = best_i; ts.best_j = best_j;
+    ts.clk0 = clk0; ts.clk1 = clk1;
+#ifdef ABPOA_HIP_PROFILE
+    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = seg_keep[i_];
+#else
+    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = 0;
+#endif
+    finish_alignment<T, GAP>(b, d, out_rec, ts);
+}
+
+// Which row loop an alignment takes (must agree between the two kernels and with engine.cpp's count).
+__device__ __forceinline__ bool takes_fast(const DevBatch &b, const AlnDesc &d) {
+    return b.gap_mode != ABPOA_HIP_LINEAR_GAP && b.wb >= 0 && b.align_mode == ABPOA_HIP_GLOBAL_MODE && (d.flags & ALN_FAST_OK) && b.lds.fr_cols > 0 &&
+           d.qlen <= b.lds.q_cap && !(b.dbg & 64);
 }
 
 template <int GAP>
@@ -1093,31 +1536,72 @@ __global__ void __launch_bounds__(64) dp_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
+    if (takes_fast(b, d)) return;            // dp_fast_kernel's
     if (d.bits == 16) align_one<int16_t, GAP>(b, d, b.out + a);
     else align_one<int32_t, GAP>(b, d, b.out + a);
 }
 
-hipError_t launch_dp(const DevBatch &b, hipStream_t stream) {
-    if (b.n <= 0) return hipSuccess;
+template <typename T, int GAP>
+__device__ __forceinline__ void align_fast(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
+    const int lane = threadIdx.x & 63;
+    FastIO<T> io;
+    io.row_base = vgpr_ptr(b.row_base + d.row0); io.row_remain = vgpr_ptr(b.row_remain + d.row0);
+    io.pred_off = vgpr_ptr(b.pred_off + d.poff0); io.pred_row = vgpr_ptr(b.pred_row + d.pred0);
+    io.g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0); io.g_esn = vgpr_ptr(b.dp_end_sn + d.row0); io.row_max_i = vgpr_ptr(b.row_max_i + d.row0);
+    io.g_left = vgpr_ptr(b.left + d.row0); io.g_right = vgpr_ptr(b.right + d.row0); io.g_coff = vgpr_ptr(b.row_cell_off + d.row0);
+    io.planes = (T *)(b.planes + d.plane_off);
+    uint8_t *s_query = lds_raw + b.lds.q_off;
+    int32_t *s_mat = (int32_t *)(lds_raw + b.lds.mat_off);
+    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < b.m * b.m; i += 64) s_mat[i] = g_mat[i]; }
+    { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = lane; i < d.qlen; i += 64) s_query[i] = g_query[i]; }
+    __syncthreads();
+    TailState ts; ts.cursor = 0; ts.n_cells = 0; ts.status = 0; ts.rows_done = 0; ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;
+    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = 0;
+    int last_done = 0;
+    ts.clk0 = (long long)__builtin_amdgcn_s_memtime();
+    rows_fast<T, GAP>(b, d, io, s_query, ts.cursor, ts.n_cells, ts.status, ts.rows_done, last_done);
+    ts.clk1 = (long long)__builtin_amdgcn_s_memtime();
+    __syncthreads();
+    finish_alignment<T, GAP>(b, d, out_rec, ts);
+}
+
+template <int GAP>
+__global__ void __launch_bounds__(64) dp_fast_kernel(const DevBatch b) {
+    const int a = blockIdx.x;
+    if (a >= b.n) return;
+    const AlnDesc d = b.aln[a];
+    if (!takes_fast(b, d)) return;           // dp_kernel's
+    if (d.bits == 16) align_fast<int16_t, GAP>(b, d, b.out + a);
+    else align_fast<int32_t, GAP>(b, d, b.out + a);
+}
+
+template <typename K>
+static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream) {
     dim3 grid(b.n), block(64);
     const size_t lds = (size_t)b.lds.total;
-    hipError_t e = hipSuccess;
-    switch (b.gap_mode) {
-        case ABPOA_HIP_LINEAR_GAP:
-            if (lds > 65536) e = hipFuncSetAttribute((const void *)dp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) hipLaunchKernelGGL(dp_kernel<0>, grid, block, lds, stream, b);
-            break;
-        case ABPOA_HIP_AFFINE_GAP:
-            if (lds > 65536) e = hipFuncSetAttribute((const void *)dp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) hipLaunchKernelGGL(dp_kernel<1>, grid, block, lds, stream, b);
-            break;
-        default:
-            if (lds > 65536) e = hipFuncSetAttribute((const void *)dp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) hipLaunchKernelGGL(dp_kernel<2>, grid, block, lds, stream, b);
-            break;
-    }
-    if (e != hipSuccess) return e;
+    if (lds > 65536) { hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, b);
     return hipGetLastError();
+}
+
+// n_fast: how many alignments of the batch take the fast row loop (engine.cpp applies takes_fast() on the host); a kernel
+// with nothing to do is not launched.
+hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream) {
+    if (b.n <= 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (n_fast > 0) {
+        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) e = launch_one(dp_fast_kernel<1>, b, stream);
+        else e = launch_one(dp_fast_kernel<2>, b, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (n_fast < b.n) {
+        switch (b.gap_mode) {
+            case ABPOA_HIP_LINEAR_GAP: e = launch_one(dp_kernel<0>, b, stream); break;
+            case ABPOA_HIP_AFFINE_GAP: e = launch_one(dp_kernel<1>, b, stream); break;
+            default: e = launch_one(dp_kernel<2>, b, stream); break;
+        }
+    }
+    return e;
 }
 
 }  // namespace abpoa_hip

@@ -138,6 +138,16 @@ int BatchStream::run() {
     std::vector<int32_t> saved_lr;              // caller's band state, needed again if an alignment is retried
     bool first_pass = true; int rc;
     std::vector<AlnDesc> pass;
+    // alignment-level eligibility for the register-resident row loop: every row active, band state at its reset value
+    for (int i = 0; i < n; ++i) {
+        AlnDesc &d = desc_[i]; bool ok = banded;
+        if (ok && memchr(hi + o_act_ + d.row0, 0, (size_t)d.n_rows)) ok = false;
+        if (ok && !fresh) {
+            const int32_t *l = (const int32_t *)(ho + o_left_) + d.row0, *r = (const int32_t *)(ho + o_right_) + d.row0;
+            for (int k = 0; k < d.n_rows && ok; ++k) ok = l[k] == d.n_rows && r[k] == 0;
+        }
+        d.flags = ok ? ALN_FAST_OK : 0; d.pad0 = 0;
+    }
     while (!todo.empty()) {
         int64_t plane_bytes = 0;
         pass.resize(todo.size());
@@ -161,18 +171,29 @@ int BatchStream::run() {
             }
             LdsPlan &L = b.lds; const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
             L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
-            L.mat_off = L.q_cap; L.phase_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
+            L.mat_off = L.q_cap; L.mx_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
+            L.phase_off = L.mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
             L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
             while ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024 && L.ring_rows > 4) L.ring_rows /= 2;
             if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
             const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
             L.bt_off = lds_fixed_bytes_bt();
             L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
-            L.total = L.phase_off + std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes);
+            // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
+            const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
+            L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? (int)align_up((size_t)est_cols, 64) : 0;
+            const int fr_budget = 36 * 1024 - L.phase_off;
+            while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
+            if (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget) L.fr_cols = 0;
+            if (L.q_cap == 0 || est_cols > 1024) L.fr_cols = 0;
+            { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
+            const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
+            L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
         }
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
+        b.want_lr = (trace || (flags_ & BS_WANT_BAND_STATE)) ? 1 : 0;
         { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
         b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);
         b.query = di + o_query_; b.row_base = di + o_base_; b.row_node_id = (const int32_t *)(di + o_nid_); b.row_remain = (const int32_t *)(di + o_rem_);
@@ -202,7 +223,10 @@ int BatchStream::run() {
             HIP_TRY(hipMemsetAsync(dout + o_esn_ + 4 * d.row0, 0xFF, 4 * (size_t)d.n_rows, stream_), ABPOA_HIP_ELAUNCH);
         }
         HIP_TRY(hipEventRecord(ev_[1], stream_), ABPOA_HIP_ELAUNCH);
-        HIP_TRY(launch_dp(b, stream_), ABPOA_HIP_ELAUNCH);
+        int n_fast = 0;       // mirrors takes_fast() in dp_kernel.hip
+        if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && b.lds.fr_cols > 0 && !(b.dbg & 64))
+            for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.qlen <= b.lds.q_cap) ? 1 : 0;
+        HIP_TRY(launch_dp(b, n_fast, stream_), ABPOA_HIP_ELAUNCH);
         HIP_TRY(hipEventRecord(ev_[2], stream_), ABPOA_HIP_ELAUNCH);
         // results: records + cigars are adjacent at the start of the output blob; band state / trace arrays on demand
         size_t d2h = o_left_;

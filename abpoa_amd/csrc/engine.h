@@ -13,6 +13,8 @@ struct AlnDesc {
     int32_t inf_min;
     int32_t w;           // band half-width, reference :445
     int32_t cigar_cap;   // entries
+    int32_t flags;       // ALN_FAST_OK: every row active and max_pos_left/right start as (n_rows, 0) -> the register-resident row loop may be used
+    int32_t pad0;
     int64_t query_off;   // into query pool (bytes)
     int64_t row0;        // index of DP row 0 in every per-row pool
     int64_t poff0;       // index of pred_off[0] / out_off[0] in the (n_rows+1)-sized offset pools
@@ -38,6 +40,7 @@ struct AlnOut {
     int64_t seg[6];       // ABPOA_HIP_PROFILE builds: ticks per row-loop segment
 };
 
+#define ALN_FAST_OK 1
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
 
 // LDS carve-up of one wavefront (= one workgroup), chosen on the host per launch.  Byte offsets from the
@@ -51,6 +54,9 @@ struct LdsPlan {
     int32_t ring_off;             // (relative to phase_off)
     // --- backtrack phase ---
     int32_t bt_off, bt_bytes;     // arena tile (relative to phase_off)
+    // --- fast row loop (dp_kernel.hip rows_fast): packed H|E score ring [fr_rows][words][fr_cols + 4] dwords at phase_off + fr_off
+    int32_t fr_off, fr_rows, fr_cols;   // fr_rows: power of two <= 64; fr_cols: multiple of 64, 0 = fast loop disabled
+    int32_t mx_off;               // int32 [m*(m+1)]: score matrix with an extra all-zero query column (code m = "no query base")
     int32_t total;                // dynamic LDS bytes to request
 };
 
@@ -63,6 +69,7 @@ struct DevBatch {
     int32_t want_trace;          // also record the per-row arg-max column (tests)
     int32_t dbg;                 // ablation switches for timing experiments (env ABPOA_HIP_DBG); 0 in production
     int32_t fresh_band;          // max_pos_left/right start as (n_rows, 0): initialise them on the device
+    int32_t want_lr;             // the caller reads max_pos_left/right back (the fast row loop derives them in a post-pass)
     LdsPlan lds;
     const int32_t *mat;          // [m*m]
     const AlnDesc *aln;          // [n]
@@ -89,6 +96,6 @@ int lds_fixed_bytes_dp();
 int lds_fixed_bytes_bt();
 
 // Launches the DP kernel for the whole batch on `stream`.
-hipError_t launch_dp(const DevBatch &b, hipStream_t stream);
+hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream);
 
 }  // namespace abpoa_hip
