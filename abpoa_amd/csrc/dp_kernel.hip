@@ -124,16 +124,23 @@ __device__ __forceinline__ unsigned wave_max_u32_b(unsigned x) {
 }
 
 
-// inclusive prefix max over the 64 lanes (Hillis-Steele inside each 16-lane DPP row, then row_bcast:15 / row_bcast:31)
-__device__ __forceinline__ int wave_scan_max_i32(int x) {
-    x = imax(x, row_shr<1>(x, x));
-    x = imax(x, row_shr<2>(x, x));
-    x = imax(x, row_shr<4>(x, x));
-    x = imax(x, row_shr<8>(x, x));
-    x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));   // rows 1,3 <- lane 15 of the row before
-    x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));   // rows 2,3 <- lane 31
-    return x;
-}
+// inclusive prefix max over the 64 lanes (Hillis-Steele inside each 16-lane DPP row, then row_bcast:15 / row_bcast:31).
+// Written as asm: hipcc does not fold update_dpp(old = x, src = x) into the max and emits 4 instructions per step.
+// s_nop 1 = the two wait states a DPP read needs after a VALU write of the same VGPR.
+#define DPP_SCAN6(OP)                                                                                                    \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                        \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+__device__ __forceinline__ int wave_scan_max_i32(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return x; }
+// wave-wide unsigned max, result valid in lane 63 only (the same six steps), returned as a wave-uniform value
+__device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) { asm(DPP_SCAN6("v_max_u32_dpp") : "+v"(x)); return (unsigned)__builtin_amdgcn_readlane((int)x, 63); }
+__device__ __forceinline__ int wave_max_i32_s(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return __builtin_amdgcn_readlane(x, 63); }
+// keeps a wave-uniform value in an SGPR and hides it from pattern matching (hipcc otherwise turns scalar min/max chains
+// into VALU v_min3/v_max3 + v_readfirstlane)
+__device__ __forceinline__ int sgpr(int x) { x = __builtin_amdgcn_readfirstlane(x); asm("" : "+s"(x)); return x; }
 // value of lane-1 (whole wave, DPP wave_shr:1); lane 0 receives `lane0`
 __device__ __forceinline__ int wave_shr1(int lane0, int src) { return __builtin_amdgcn_update_dpp(lane0, src, 0x138, 0xF, 0xF, false); }
 __device__ __forceinline__ int med3i(int a, int lo, int hi) { return imin(imax(a, lo), hi); }
@@ -366,9 +373,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
         a1 = a2; b1 = load_b(a1); a2 = load_a(t0 + 128);
     };
-    switch_tile(0);
-
-    int qc_beg_sn = -1, qoff0 = 0, qoff1 = 0;        // cached (query code of this lane's column) for chunks 0/1 of band start qc_beg_sn
+    int qc_beg_sn = -1, qoff0 = 0, qoff1 = 0;        // cached query code of this lane's column for chunks 0/1 of band start qc_beg_sn
     auto geo_of = [&](int p, int row, int &geo, int &mi, int &off) __attribute__((always_inline)) {
         if (row - p < 64) { const int sl = p & 63; geo = __builtin_amdgcn_readlane(vg_geo, sl); mi = __builtin_amdgcn_readlane(vg_mi, sl); off = __builtin_amdgcn_readlane(vg_off, sl); }
         else {
@@ -376,203 +381,243 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             off = __builtin_amdgcn_readfirstlane((int)(uint32_t)(gld_i64(io.g_coff + p) / PN));
         }
     };
+    // ---- per-row working set shared by the two row bodies and the epilogue
+    int beg_sn = 0, end_sn = 0, off_pn = 0, max_pe = 0, rterm = 0, base = 0, np = 0;
+    bool to_ring = false;
+    unsigned am_key = 0; int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false;
 
-    for (int row = 1; row < gn - 1; ++row) {
-        const int ti = row & 63;
-        if (ti == 0) {
-            { const int rb = row - 64 + lane; io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
-            switch_tile(row);
-        }
-        last_done = row;
-        const int meta = __builtin_amdgcn_readlane(tv_meta, ti), rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
-        const int base = meta & 0xff, np = (meta >> 8) & 0xff;
-        const bool fastrow = (meta >> 16) & 1;
-        int pr[4], pgeo[4], pmi[4], poffs[4];
-        pr[0] = __builtin_amdgcn_readlane(tv_p0, ti); pr[1] = __builtin_amdgcn_readlane(tv_p1, ti);
-        pr[2] = __builtin_amdgcn_readlane(tv_p2, ti); pr[3] = __builtin_amdgcn_readlane(tv_p3, ti);
-        // ---- band, reference :710-720 with max_pos_left/right pulled from the predecessors' arg-max
-        int mn_mi, mx_mi, min_pb, max_pe, allring;
-        if (fastrow) {
-            { const int sl = pr[0] & 63; pgeo[0] = __builtin_amdgcn_readlane(vg_geo, sl); pmi[0] = __builtin_amdgcn_readlane(vg_mi, sl); poffs[0] = 0; }
-            mn_mi = pmi[0]; mx_mi = pmi[0]; min_pb = pgeo[0] & 0xfff; max_pe = (pgeo[0] >> 12) & 0xfff; allring = pgeo[0];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                pgeo[k] = pgeo[0]; pmi[k] = pmi[0]; poffs[k] = 0;
-                if (k < np) {
-                    const int sl = pr[k] & 63; pgeo[k] = __builtin_amdgcn_readlane(vg_geo, sl); pmi[k] = __builtin_amdgcn_readlane(vg_mi, sl);
-                    mn_mi = imin(mn_mi, pmi[k]); mx_mi = imax(mx_mi, pmi[k]);
-                    min_pb = imin(min_pb, pgeo[k] & 0xfff); max_pe = imax(max_pe, (pgeo[k] >> 12) & 0xfff); allring &= pgeo[k];
-                }
-            }
-        } else {
-            const int ps = __builtin_amdgcn_readlane(tv_ps, ti);
-            mn_mi = gn; mx_mi = -1; min_pb = 4095; max_pe = -1; allring = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pgeo[k] = 0; pmi[k] = 0; poffs[k] = 0;
-                if (k < np) {
-                    geo_of(pr[k], row, pgeo[k], pmi[k], poffs[k]);
-                    mn_mi = imin(mn_mi, pmi[k]); mx_mi = imax(mx_mi, pmi[k]); min_pb = imin(min_pb, pgeo[k] & 0xfff); max_pe = imax(max_pe, (pgeo[k] >> 12) & 0xfff);
-                }
-            }
-            for (int k = 4; k < np; ++k) {
-                int g_, mi_, off_; geo_of(__builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)), row, g_, mi_, off_);
-                mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff);
-            }
-            if (np == 0) min_pb = 0;
-        }
-        const int left = imin(gn, mn_mi + 1), right = imax(0, mx_mi + 1);
-        const int beg = imax(0, imin(left, rterm) - w), end = imin(qlen, imax(right, rterm) + w);
-        const int beg_sn = imax(beg / PN, min_pb), end_sn = end / PN;
-        const int Wr = (end_sn - beg_sn + 1) * PN;
-        const int off_pn = cur, nvr = end_sn - beg_sn + 1;
-        if (off_pn + nvr * P > cap_pn) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
-        cur += nvr * P; n_vec += nvr; ++rows_done;
-        const bool to_ring = Wr <= RC;
-        const bool fast = fastrow && (allring & GEO_RING) && to_ring;
-        if (fastrow && !fast) {                       // rare: statically fast row that must take the general gather after all
-#pragma unroll
-            for (int k = 0; k < 4; ++k) poffs[k] = __builtin_amdgcn_readlane(vg_off, pr[k] & 63);
-        }
-        T *H = io.planes + (long long)off_pn * PN;
-        const int my_slot = (row & (RR - 1)) * (NPW * RCS);
-        const int nch = (Wr + 63) >> 6;
-        if (beg_sn != qc_beg_sn) {                 // band start moved: refresh this lane's cached query codes (as byte offsets into a matrix row)
+    // band of the row from (min, max) predecessor arg-max and predecessor geometry, reference :710-720
+    auto set_band = [&](auto pin, int mn_mi, int mx_mi, int min_pb) __attribute__((always_inline)) {
+        auto S = [](int x) __attribute__((always_inline)) { if constexpr (decltype(pin)::value) return sgpr(x); else return x; };
+        const int left = S(imin(gn, mn_mi + 1)), right = S(imax(0, mx_mi + 1));
+        const int lo = S(imin(left, rterm) - w), hi = S(imax(right, rterm) + w);
+        const int beg = S(imax(0, lo)), end = S(imin(qlen, hi));
+        beg_sn = imax(beg / PN, min_pb); end_sn = end / PN;
+    };
+    auto refresh_qc = [&]() __attribute__((always_inline)) {
+        if (beg_sn != qc_beg_sn) {                 // band start moved: refresh this lane's cached query codes
             qc_beg_sn = beg_sn;
             const int c0 = beg_sn * PN + lane, c1 = c0 + 64;
             qoff0 = (c0 >= 1 && c0 <= qlen) ? (int)s_query[c0 - 1] : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? (int)s_query[c1 - 1] : m;
         }
+    };
+    // one predecessor's contribution from the score ring (k == 0: unmasked, see the header comment)
+    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v) __attribute__((always_inline)) {
+        const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
+        const int x = col - pb * PN;
+        const int *src = fr + (p & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+        int hm1, ev1, ev2 = inf;
+        if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
+        else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
+        if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; }
+        else {
+            const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
+            Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
+        }
+    };
+    // everything of a chunk after the predecessor gather: F, H, E, stores, ring, arg-max candidate (reference :854-883 / :972-1008)
+    auto chunk_tail = [&](int c, int nch, int Wr, int Mv, int E1v, int E2v, int q, int &first, int &first2, T *H, int my_slot) __attribute__((always_inline)) {
+        const int rel = c * 64 + lane, col = beg_sn * PN + rel, vb = beg_sn + c * NV, v = vb + vvl;
+        const bool in_band = rel < Wr;
+        const int h = wr(Mv + q);
+        int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
+        if (c == 0) { first = __builtin_amdgcn_readlane(h, 0); first2 = first; }
+        const int nvec = imin(NV, end_sn - vb + 1);
+        int nfast = imin(nvec, max_pe - vb + 1);
+        if (nfast < 0) nfast = 0;
+        if (nfast > 0 && __any(vvl < nfast && h < fast_lo)) nfast = 0;
+        int F1 = inf, F2 = inf;
+        if (nfast > 0) {
+            const int g1 = hs + le1;
+            const int S1 = wave_scan_max_i32(wave_shr1(first - e1, g1));
+            F1 = imax(S1 - cf1, inj1);
+            if (GAP == 2) { const int g2 = hs + le2; const int S2 = wave_scan_max_i32(wave_shr1(first2 - e2, g2)); F2 = imax(S2 - cf2, inj2);
+                            if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first2 = __builtin_amdgcn_readlane(imax(S2, g2), lastl) - lastl * e2; } }
+            if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first = __builtin_amdgcn_readlane(imax(S1, g1), lastl) - lastl * e1; }
+        }
+        if (nfast < nvec) {
+            T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
+            slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
+            F1 = (int)f1t; F2 = (int)f2t; first = (int)fi; first2 = (int)fi2;
+        }
+        int Hout, E1out, E2out = inf;
+        if (GAP == 1) {
+            const int tmp = imax(h, E1v);
+            Hout = imax(tmp, F1);
+            const int en = imax(wr(E1v - e1), wr(Hout - oe1));
+            E1out = (Hout == tmp) ? en : inf;
+        } else {
+            Hout = imax(hs, imax(F1, F2));
+            E1out = imax(wr(E1v - e1), wr(Hout - oe1));
+            E2out = imax(wr(E2v - e2), wr(Hout - oe2));
+        }
+        if (in_band) {
+            H[rel] = (T)Hout; H[PL_E1 * Wr + rel] = (T)E1out; H[PL_F1 * Wr + rel] = (T)F1;
+            if (GAP == 2) { H[PL_E2 * Wr + rel] = (T)E2out; H[PL_F2 * Wr + rel] = (T)F2; }
+        }
+        if (to_ring) {
+            int *qd = fr + my_slot + 2 + rel;
+            if (I16) { qd[0] = in_band ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16)) : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
+            else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
+        }
+        {   // running arg-max candidate of this lane, reference :1043-1057
+            const bool is_end = (v == end_sn);
+            int cand = Hout;
+            if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
+            if (I16) {
+                const unsigned key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
+                am_key = (in_band && key > am_key) ? key : am_key;
+            } else if (in_band && (!am_any || (is_end ? cand >= am_val : cand > am_val))) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
+        }
+    };
+    auto pad_ring = [&](int nch, int my_slot) __attribute__((always_inline)) {        // "inf" after the band, up to the ring width
+        for (int c = nch; c < (RC >> 6); ++c) {
+            int *qd = fr + my_slot + 2 + c * 64 + lane;
+            qd[0] = infw; if (NPW > 1) qd[RCS] = inf; if (NPW > 2) qd[2 * RCS] = inf;
+        }
+    };
+    // reserve the row's arena cells; false = overflow
+    auto reserve = [&]() __attribute__((always_inline)) {
+        const int nvr = end_sn - beg_sn + 1;
+        if (cur + nvr * P > cap_pn) return false;
+        off_pn = cur; cur += nvr * P; n_vec += nvr; ++rows_done;
+        return true;
+    };
+
+    // ---- FAST body: NP (1, 2, or up to 4 with run-time count) predecessors, all in the 64-row geometry ring and the score ring.
+    //      Returns 0 = not applicable (nothing touched), 1 = done, 2 = arena overflow.
+    auto fast_body = [&](auto npc, int row, int ti) __attribute__((always_inline)) -> int {
+        constexpr int NPC = decltype(npc)::value;
+        int pr[4], pgeo[4];
+        pr[0] = __builtin_amdgcn_readlane(tv_p0, ti);
+        pgeo[0] = __builtin_amdgcn_readlane(vg_geo, pr[0] & 63);
+        int mn_mi = __builtin_amdgcn_readlane(vg_mi, pr[0] & 63), mx_mi = mn_mi, min_pb = pgeo[0] & 0xfff, allring = pgeo[0];
+        max_pe = (pgeo[0] >> 12) & 0xfff;
+        auto more = [&](int k, int tvp) __attribute__((always_inline)) {
+            pr[k] = __builtin_amdgcn_readlane(tvp, ti); pgeo[k] = __builtin_amdgcn_readlane(vg_geo, pr[k] & 63);
+            const int mi_ = __builtin_amdgcn_readlane(vg_mi, pr[k] & 63);
+            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, pgeo[k] & 0xfff); max_pe = imax(max_pe, (pgeo[k] >> 12) & 0xfff); allring &= pgeo[k];
+        };
+        if (NPC >= 2) more(1, tv_p1);
+        if (NPC >= 4) { pr[2] = pr[1]; pgeo[2] = pgeo[1]; pr[3] = pr[1]; pgeo[3] = pgeo[1]; if (np > 2) more(2, tv_p2); if (np > 3) more(3, tv_p3); }
+        set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
+        const int Wr = (end_sn - beg_sn + 1) * PN;
+        if (!(allring & GEO_RING) || Wr > RC) return 0;
+        if (!reserve()) return 2;
+        to_ring = true;
+        T *H = io.planes + (long long)off_pn * PN;
+        const int my_slot = (row & (RR - 1)) * (NPW * RCS);
+        const int nch = (Wr + 63) >> 6;
+        refresh_qc();
         const int *mrow = s_mx + base * m1;
         int first = 0, first2 = 0;
-        unsigned am_key = 0; int am_val = INT_MIN, am_v = 0, am_isend = 0; bool am_any = false;
-        if (!fast) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // HBM gathers below read cells this wave stored earlier
         for (int c = 0; c < nch; ++c) {
-            const int rel = c * 64 + lane, col = beg_sn * PN + rel, vb = beg_sn + c * NV, v = vb + vvl;
+            const int col = beg_sn * PN + c * 64 + lane;
+            int qc = c == 0 ? qoff0 : qoff1;
+            if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
+            const int q = mrow[qc];
+            int Mv, E1v, E2v;
+            from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v);
+            if (NPC >= 2) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v);
+            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v); }
+            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, first, first2, H, my_slot);
+        }
+        pad_ring(nch, my_slot);
+        return 1;
+    };
+
+    // ---- GENERAL body: any number of predecessors, any distance (HBM copies of geometry and score rows), any band width.
+    //      Returns 1 = done, 2 = arena overflow.
+    auto general_body = [&](int row, int ti) __attribute__((always_inline)) -> int {
+        const int ps = __builtin_amdgcn_readlane(tv_ps, ti);
+        int mn_mi = gn, mx_mi = -1, min_pb = 4095; max_pe = -1;
+        for (int k = 0; k < np; ++k) {
+            int g_, mi_, off_; geo_of(__builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)), row, g_, mi_, off_);
+            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff);
+        }
+        if (np == 0) min_pb = 0;
+        set_band(std::false_type{}, mn_mi, mx_mi, min_pb);
+        const int Wr = (end_sn - beg_sn + 1) * PN;
+        if (!reserve()) return 2;
+        to_ring = Wr <= RC;
+        T *H = io.planes + (long long)off_pn * PN;
+        const int my_slot = (row & (RR - 1)) * (NPW * RCS);
+        const int nch = (Wr + 63) >> 6;
+        refresh_qc();
+        const int *mrow = s_mx + base * m1;
+        int first = 0, first2 = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // HBM gathers below read cells this wave stored earlier
+        for (int c = 0; c < nch; ++c) {
+            const int rel = c * 64 + lane, col = beg_sn * PN + rel;
             const bool in_band = rel < Wr;
             int qc = c == 0 ? qoff0 : qoff1;
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
             const int q = mrow[qc];
             int Mv = inf, E1v = inf, E2v = inf;
-            // ---- predecessors
-            auto from_ring = [&](int k, int p, int g_) __attribute__((always_inline)) {
-                const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
-                const int x = col - pb * PN;
-                const int *src = fr + (p & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
-                int hm1, ev1, ev2 = inf;
-                if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
-                else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
-                if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; }
-                else {
-                    const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
-                    Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
+            for (int k = 0; k < np; ++k) {
+                int g_, mi_, off_; const int p = __builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)); geo_of(p, row, g_, mi_, off_);
+                if ((g_ & GEO_RING) && row - p < RR) {
+                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v); else from_ring(1, p, g_, col, Mv, E1v, E2v);
+                } else {
+                    const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
+                    const int x = col - pb * PN;
+                    const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
+                    const T *Hp = io.planes + (long long)(uint32_t)off_ * PN;
+                    int hval = inf, ev1 = inf, ev2 = inf;
+                    if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + x - 1));
+                    if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E1 * Wp + x)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E2 * Wp + x)); }
+                    if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; }
+                    else { Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
                 }
-            };
-            auto from_hbm = [&](int k, int g_, int off_) __attribute__((always_inline)) {
-                const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
-                const int x = col - pb * PN;
-                const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
-                const T *Hp = io.planes + (long long)(uint32_t)off_ * PN;
-                int hval = inf, ev1 = inf, ev2 = inf;
-                if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + x - 1));
-                if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E1 * Wp + x)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E2 * Wp + x)); }
-                if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; }
-                else { Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
-            };
-            if (fast) {
-                from_ring(0, pr[0], pgeo[0]);
-                if (np > 1) from_ring(1, pr[1], pgeo[1]);
-                if (np > 2) from_ring(2, pr[2], pgeo[2]);
-                if (np > 3) from_ring(3, pr[3], pgeo[3]);
+            }
+            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, first, first2, H, my_slot);
+        }
+        if (to_ring) pad_ring(nch, my_slot);
+        return 1;
+    };
+
+    for (int t0 = 0; t0 < gn - 1 && status == 0; t0 += 64) {
+        if (t0 > 0) {       // geometry of the finished tile goes to HBM in one coalesced burst (older predecessors, backtrack, trace)
+            const int rb = t0 - 64 + lane; io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi;
+        }
+        switch_tile(t0);
+        const int r_hi = imin(t0 + 64, gn - 1);
+        for (int row = imax(t0, 1); row < r_hi; ++row) {
+            const int ti = row & 63;
+            last_done = row;
+            const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
+            rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
+            base = meta & 0xff; np = (meta >> 8) & 0xff;
+            am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
+            int rc = 0;
+            if ((meta >> 16) & 1) {
+                if (np == 1) rc = fast_body(std::integral_constant<int, 1>{}, row, ti);
+                else if (np == 2) rc = fast_body(std::integral_constant<int, 2>{}, row, ti);
+                else rc = fast_body(std::integral_constant<int, 4>{}, row, ti);
+            }
+            if (rc == 0) rc = general_body(row, ti);
+            if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+            // ---- row arg-max (tie-break: lowest lane residue, then the end_sn vector, then the lowest vector), reference :1043-1057
+            int mi = -1;
+            if (I16) {
+                const unsigned kb = wave_max_u32_s(am_key);
+                const int vmax = (int)(kb >> 16) - 32768;
+                if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
             } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k < np) {
-                    if ((pgeo[k] & GEO_RING) && row - pr[k] < RR) from_ring(k, pr[k], pgeo[k]); else from_hbm(k, pgeo[k], poffs[k]);
-                }
-                if (np > 4) {
-                    const int ps = __builtin_amdgcn_readlane(tv_ps, ti);
-                    for (int k = 4; k < np; ++k) {
-                        int g_, mi_, off_; const int p = __builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)); geo_of(p, row, g_, mi_, off_);
-                        if ((g_ & GEO_RING) && row - p < RR) from_ring(k, p, g_); else from_hbm(k, g_, off_);
-                    }
+                const int vmax = wave_max_i32_s(am_any ? am_val : INT_MIN);
+                if (vmax > inf) {
+                    unsigned key = 0;
+                    if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
+                    const unsigned kb = wave_max_u32_s(key);
+                    mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
+                    if (mi > qlen) mi = -1;
                 }
             }
-            // ---- in-row part, reference :854-883 / :972-1008
-            const int h = wr(Mv + q);
-            int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
-            if (c == 0) { first = __builtin_amdgcn_readlane(h, 0); first2 = first; }
-            const int nvec = imin(NV, end_sn - vb + 1);
-            int nfast = imin(nvec, max_pe - vb + 1);
-            if (nfast < 0) nfast = 0;
-            if (nfast > 0 && __any(vvl < nfast && h < fast_lo)) nfast = 0;
-            int F1 = inf, F2 = inf;
-            if (nfast > 0) {
-                const int g1 = hs + le1;
-                const int S1 = wave_scan_max_i32(wave_shr1(first - e1, g1));
-                F1 = imax(S1 - cf1, inj1);
-                if (GAP == 2) { const int g2 = hs + le2; const int S2 = wave_scan_max_i32(wave_shr1(first2 - e2, g2)); F2 = imax(S2 - cf2, inj2);
-                                if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first2 = __builtin_amdgcn_readlane(imax(S2, g2), lastl) - lastl * e2; } }
-                if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first = __builtin_amdgcn_readlane(imax(S1, g1), lastl) - lastl * e1; }
+            {   // v_writelane x3 (no clang builtin here); M0 holds the lane select (two different SGPRs would violate the constant-bus limit)
+                const int geo_new = sgpr(beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
+                asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+                             : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
             }
-            if (nfast < nvec) {
-                T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
-                slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
-                F1 = (int)f1t; F2 = (int)f2t; first = (int)fi; first2 = (int)fi2;
-            }
-            int Hout, E1out, E2out = inf;
-            if (GAP == 1) {
-                const int tmp = imax(h, E1v);
-                Hout = imax(tmp, F1);
-                const int en = imax(wr(E1v - e1), wr(Hout - oe1));
-                E1out = (Hout == tmp) ? en : inf;
-            } else {
-                Hout = imax(hs, imax(F1, F2));
-                E1out = imax(wr(E1v - e1), wr(Hout - oe1));
-                E2out = imax(wr(E2v - e2), wr(Hout - oe2));
-            }
-            if (in_band) {
-                H[rel] = (T)Hout; H[PL_E1 * Wr + rel] = (T)E1out; H[PL_F1 * Wr + rel] = (T)F1;
-                if (GAP == 2) { H[PL_E2 * Wr + rel] = (T)E2out; H[PL_F2 * Wr + rel] = (T)F2; }
-            }
-            if (to_ring) {
-                int *qd = fr + my_slot + 2 + rel;
-                if (I16) { qd[0] = in_band ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16)) : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
-                else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
-            }
-            // ---- running arg-max candidate of this lane, reference :1043-1057
-            {
-                const bool is_end = (v == end_sn);
-                int cand = Hout;
-                if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
-                if (I16) {
-                    const unsigned key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
-                    am_key = (in_band && key > am_key) ? key : am_key;
-                } else if (in_band && (!am_any || (is_end ? cand >= am_val : cand > am_val))) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
-            }
-        }
-        if (to_ring) for (int c = nch; c < (RC >> 6); ++c) {        // "inf" padding after the band, up to the ring width
-            int *qd = fr + my_slot + 2 + c * 64 + lane;
-            qd[0] = infw; if (NPW > 1) qd[RCS] = inf; if (NPW > 2) qd[2 * RCS] = inf;
-        }
-        // ---- row arg-max (tie-break: lowest lane residue, then the end_sn vector, then the lowest vector), reference :1043-1057
-        int mi = -1;
-        if (I16) {
-            const unsigned kb = wave_max_u32_b(am_key);
-            const int vmax = (int)(kb >> 16) - 32768;
-            if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
-        } else {
-            const int vmax = wave_max_i32(am_any ? am_val : INT_MIN);
-            if (vmax > inf) {
-                unsigned key = 0;
-                if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
-                const unsigned kb = wave_max_u32_b(key);
-                mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
-                if (mi > qlen) mi = -1;
-            }
-        }
-        {   // v_writelane x3 (no clang builtin here); the operands are SALU results, the s_nop covers the lane-select hazard regardless
-            const int geo_new = beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0), off_new = off_pn;
-            asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
-                         : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
         }
     }
     // ---- geometry of the last (partial) tile
@@ -1541,8 +1586,10 @@ __global__ void __launch_bounds__(64) dp_kernel(const DevBatch b) {
     else align_one<int32_t, GAP>(b, d, b.out + a);
 }
 
+// The fast path is two kernels -- row loop, then global best + backtrack -- so that the row loop's register allocation
+// (its SGPR budget above all) is not shared with the tail; the hand-over is the AlnOut record in HBM.
 template <typename T, int GAP>
-__device__ __forceinline__ void align_fast(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
+__device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
     const int lane = threadIdx.x & 63;
     FastIO<T> io;
     io.row_base = vgpr_ptr(b.row_base + d.row0); io.row_remain = vgpr_ptr(b.row_remain + d.row0);
@@ -1551,18 +1598,13 @@ __device__ __forceinline__ void align_fast(const DevBatch &b, const AlnDesc &d, 
     io.g_left = vgpr_ptr(b.left + d.row0); io.g_right = vgpr_ptr(b.right + d.row0); io.g_coff = vgpr_ptr(b.row_cell_off + d.row0);
     io.planes = (T *)(b.planes + d.plane_off);
     uint8_t *s_query = lds_raw + b.lds.q_off;
-    int32_t *s_mat = (int32_t *)(lds_raw + b.lds.mat_off);
-    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < b.m * b.m; i += 64) s_mat[i] = g_mat[i]; }
     { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = lane; i < d.qlen; i += 64) s_query[i] = g_query[i]; }
     __syncthreads();
-    TailState ts; ts.cursor = 0; ts.n_cells = 0; ts.status = 0; ts.rows_done = 0; ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;
-    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = 0;
-    int last_done = 0;
-    ts.clk0 = (long long)__builtin_amdgcn_s_memtime();
-    rows_fast<T, GAP>(b, d, io, s_query, ts.cursor, ts.n_cells, ts.status, ts.rows_done, last_done);
-    ts.clk1 = (long long)__builtin_amdgcn_s_memtime();
-    __syncthreads();
-    finish_alignment<T, GAP>(b, d, out_rec, ts);
+    long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
+    const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
+    rows_fast<T, GAP>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done);
+    const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
+    if (lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; }
 }
 
 template <int GAP>
@@ -1571,8 +1613,34 @@ __global__ void __launch_bounds__(64) dp_fast_kernel(const DevBatch b) {
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
     if (!takes_fast(b, d)) return;           // dp_kernel's
-    if (d.bits == 16) align_fast<int16_t, GAP>(b, d, b.out + a);
-    else align_fast<int32_t, GAP>(b, d, b.out + a);
+    if (d.bits == 16) align_fast_rows<int16_t, GAP>(b, d, b.out + a);
+    else align_fast_rows<int32_t, GAP>(b, d, b.out + a);
+}
+
+template <typename T, int GAP>
+__device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
+    const int lane = threadIdx.x & 63;
+    uint8_t *s_query = lds_raw + b.lds.q_off;
+    int32_t *s_mat = (int32_t *)(lds_raw + b.lds.mat_off);
+    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < b.m * b.m; i += 64) s_mat[i] = g_mat[i]; }
+    { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = lane; i < d.qlen; i += 64) s_query[i] = g_query[i]; }
+    TailState ts;
+    ts.status = out_rec->status; ts.n_cells = out_rec->n_cells; ts.cursor = out_rec->cells_used; ts.rows_done = out_rec->n_rows_done;
+    ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;
+    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = 0;
+    ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
+    __syncthreads();
+    finish_alignment<T, GAP>(b, d, out_rec, ts);
+}
+
+template <int GAP>
+__global__ void __launch_bounds__(64) dp_fast_tail_kernel(const DevBatch b) {
+    const int a = blockIdx.x;
+    if (a >= b.n) return;
+    const AlnDesc d = b.aln[a];
+    if (!takes_fast(b, d)) return;
+    if (d.bits == 16) align_fast_tail<int16_t, GAP>(b, d, b.out + a);
+    else align_fast_tail<int32_t, GAP>(b, d, b.out + a);
 }
 
 template <typename K>
@@ -1590,8 +1658,8 @@ hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream) {
     if (b.n <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
     if (n_fast > 0) {
-        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) e = launch_one(dp_fast_kernel<1>, b, stream);
-        else e = launch_one(dp_fast_kernel<2>, b, stream);
+        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) { e = launch_one(dp_fast_kernel<1>, b, stream); if (e == hipSuccess) e = launch_one(dp_fast_tail_kernel<1>, b, stream); }
+        else { e = launch_one(dp_fast_kernel<2>, b, stream); if (e == hipSuccess) e = launch_one(dp_fast_tail_kernel<2>, b, stream); }
         if (e != hipSuccess) return e;
     }
     if (n_fast < b.n) {
