@@ -245,6 +245,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 //     the reference's zero-filled shifts;  vectors beyond max_pre_end_sn use the literal masked scan (set_f);
 //   * rows that do not fit (predecessor further back than the ring, > 4 predecessors, band wider than the ring) take
 //     the general gather (exact range masks, HBM copies) but share everything else.
+// Arena format of the fast loop: one record of CW values per column -- {H, E1, F1, -} (affine) or {H, E1, E2, F1, F2, -, -, -}
+// (convex), plane id = index in the record -- so that a row chunk is ONE wide store per lane instead of 3-5 two-byte ones
+// (vector-memory instruction issue, not bytes, is what a lone wave pays for).
+template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 1 ? 4 : 8; };
 template <typename T> struct FastIO {
     GLOBAL_AS const uint8_t *row_base; GLOBAL_AS const int32_t *row_remain, *pred_off, *pred_row;
     GLOBAL_AS int32_t *g_bsn, *g_esn, *row_max_i, *g_left, *g_right; GLOBAL_AS int64_t *g_coff;
@@ -281,11 +285,25 @@ __device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pr
     }
 }
 
+#ifdef ABPOA_HIP_PROFILE
+#define FSTAMP(I) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); long long t_ = (long long)__builtin_amdgcn_s_memtime(); fseg[I] += t_ - fseg_last; fseg_last = t_; }
+#else
+#define FSTAMP(I)
+#endif
+// Timing-only ablation switches (tools/kernel_bench.py with ABPOA_HIP_DBG=bits on the "prof" build): results are wrong on purpose.
+#ifdef ABPOA_HIP_ABLATE
+#define ABL(BIT) (b.dbg & (BIT))
+#else
+#define ABL(BIT) false
+#endif
 template <typename T, int GAP>
 __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, const FastIO<T> &io, const uint8_t *s_query,
-                                          long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done) {
+                                          long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done, long long *fseg) {
+#ifdef ABPOA_HIP_PROFILE
+    long long fseg_last = 0;
+#endif
     constexpr int PN = Width<T>::PN, NV = 64 / PN;
-    constexpr int P = GAP == 1 ? 3 : 5;
+    constexpr int CW = FastFmt<T, GAP>::CW;          // values per arena cell record
     constexpr bool I16 = sizeof(T) == 2;
     constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? 3 : 2);
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
@@ -329,7 +347,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r = __builtin_amdgcn_readfirstlane(io.row_remain[0]) - remain_end - 1;
         const int dp_end0 = imin(qlen, imax(0, qlen - r) + w);
         const int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
-        if ((long long)W0 * P > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
+        if ((long long)W0 * CW > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
         const bool ring0 = W0 <= RC;
         T *H = io.planes;
         for (int i = lane; i < W0; i += 64) {
@@ -339,11 +357,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int g1 = wr(-o1 - e1 * i), g2 = wr(-o2 - e2 * i);
                 h = i == 0 ? 0 : imax(g1, g2); x1 = i == 0 ? wr(-oe1) : inf; x2 = i == 0 ? wr(-oe2) : inf; f1 = i == 0 ? inf : g1; f2 = i == 0 ? inf : g2;
             }
-            H[i] = (T)h; H[(long long)PL_E1 * W0 + i] = (T)x1; H[(long long)PL_F1 * W0 + i] = (T)f1;
-            if (GAP == 2) { H[(long long)PL_E2 * W0 + i] = (T)x2; H[(long long)PL_F2 * W0 + i] = (T)f2; }
+            T *cellp = H + (long long)i * CW;
+            cellp[0] = (T)h; cellp[PL_E1] = (T)x1; cellp[PL_F1] = (T)f1;
+            if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
             if (ring0) ring_put(0, i, h, x1, x2);
         }
-        cur = (end_sn0 + 1) * P;
+        cur = (end_sn0 + 1) * CW;
         if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = 0; }     // source: successors get left = right = 1 (:556-561)
     }
 
@@ -363,12 +382,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     };
     MetaA a1 = load_a(0); MetaB b1 = load_b(a1); MetaA a2 = load_a(64);
     int tv_meta = 0, tv_rterm = 0, tv_ps = 0, tv_p0 = 0, tv_p1 = 0, tv_p2 = 0, tv_p3 = 0;
+    int tv_tb = 0;          // turbo rows: dist(pred 0) | dist(pred 1) << 8 | (base * (m + 1) * 4) << 16
     auto switch_tile = [&](int t0) __attribute__((always_inline)) {
         const int myrow = t0 + lane, np = a1.pe - a1.ps;
         bool fastrow = np >= 1 && np <= 4 && myrow < gn - 1 && myrow >= 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int dk = myrow - b1.p[k]; fastrow = fastrow && dk >= 1 && dk < RR; }
-        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0);
+        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0) | ((fastrow && np <= 2) ? (1 << 17) : 0);
+        tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
         tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
         a1 = a2; b1 = load_b(a1); a2 = load_a(t0 + 128);
@@ -392,7 +413,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int left = S(imin(gn, mn_mi + 1)), right = S(imax(0, mx_mi + 1));
         const int lo = S(imin(left, rterm) - w), hi = S(imax(right, rterm) + w);
         const int beg = S(imax(0, lo)), end = S(imin(qlen, hi));
-        beg_sn = imax(beg / PN, min_pb); end_sn = end / PN;
+        beg_sn = imax((int)((unsigned)beg / PN), min_pb); end_sn = (int)((unsigned)end / PN);
     };
     auto refresh_qc = [&]() __attribute__((always_inline)) {
         if (beg_sn != qc_beg_sn) {                 // band start moved: refresh this lane's cached query codes
@@ -427,7 +448,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (nfast < 0) nfast = 0;
         if (nfast > 0 && __any(vvl < nfast && h < fast_lo)) nfast = 0;
         int F1 = inf, F2 = inf;
-        if (nfast > 0) {
+        if (nfast > 0 && !ABL(8)) {
             const int g1 = hs + le1;
             const int S1 = wave_scan_max_i32(wave_shr1(first - e1, g1));
             F1 = imax(S1 - cf1, inj1);
@@ -435,11 +456,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                             if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first2 = __builtin_amdgcn_readlane(imax(S2, g2), lastl) - lastl * e2; } }
             if (nfast < nvec || c + 1 < nch) { const int lastl = nfast * PN - 1; first = __builtin_amdgcn_readlane(imax(S1, g1), lastl) - lastl * e1; }
         }
-        if (nfast < nvec) {
+        if (nfast < nvec && !ABL(32)) {
             T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
             slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
             F1 = (int)f1t; F2 = (int)f2t; first = (int)fi; first2 = (int)fi2;
         }
+        FSTAMP(2)
         int Hout, E1out, E2out = inf;
         if (GAP == 1) {
             const int tmp = imax(h, E1v);
@@ -451,16 +473,20 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             E1out = imax(wr(E1v - e1), wr(Hout - oe1));
             E2out = imax(wr(E2v - e2), wr(Hout - oe2));
         }
-        if (in_band) {
-            H[rel] = (T)Hout; H[PL_E1 * Wr + rel] = (T)E1out; H[PL_F1 * Wr + rel] = (T)F1;
-            if (GAP == 2) { H[PL_E2 * Wr + rel] = (T)E2out; H[PL_F2 * Wr + rel] = (T)F2; }
-        }
-        if (to_ring) {
+        // one record store per lane, all 64 lanes (lanes past the band write into cells the NEXT row overwrites: same wave,
+        // program order; the arena carries 64 records of slack at its end)
+        const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));      // int16: also the score-ring word
+        if (ABL(1)) {}
+        else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = F1 & 0xffff; *(int2 *)(H + (long long)rel * CW) = rec; }
+        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = 0; *(int4 *)(H + (long long)rel * CW) = rec; }
+        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = 0; *(int4 *)(H + (long long)rel * CW) = rec; }
+        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = 0; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + (long long)rel * CW); dst[0] = r0; dst[1] = r1; }
+        if (to_ring && !ABL(2)) {
             int *qd = fr + my_slot + 2 + rel;
-            if (I16) { qd[0] = in_band ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16)) : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
+            if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
             else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
         }
-        {   // running arg-max candidate of this lane, reference :1043-1057
+        if (!ABL(4)) {   // running arg-max candidate of this lane, reference :1043-1057
             const bool is_end = (v == end_sn);
             int cand = Hout;
             if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
@@ -471,7 +497,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
     };
     auto pad_ring = [&](int nch, int my_slot) __attribute__((always_inline)) {        // "inf" after the band, up to the ring width
-        for (int c = nch; c < (RC >> 6); ++c) {
+        if (!ABL(2)) for (int c = nch; c < (RC >> 6); ++c) {
             int *qd = fr + my_slot + 2 + c * 64 + lane;
             qd[0] = infw; if (NPW > 1) qd[RCS] = inf; if (NPW > 2) qd[2 * RCS] = inf;
         }
@@ -479,9 +505,109 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // reserve the row's arena cells; false = overflow
     auto reserve = [&]() __attribute__((always_inline)) {
         const int nvr = end_sn - beg_sn + 1;
-        if (cur + nvr * P > cap_pn) return false;
-        off_pn = cur; cur += nvr * P; n_vec += nvr; ++rows_done;
+        if (cur + nvr * CW > cap_pn) return false;
+        off_pn = cur; cur += nvr * CW; n_vec += nvr; ++rows_done;
         return true;
+    };
+
+
+    // ---- TURBO body: the dominant row shape as straight-line code -- 1 or 2 predecessors (both in the rings), band of at
+    //      most 64 columns (one chunk), every vector takes the closed-form F scan (end_sn <= max_pre_end_sn), not the last
+    //      query vector, and no value near the wrap limit.  Exactly two rarely-taken exits, both before any side effect.
+    //      Returns 1 = done (mi set), 0 = not applicable.
+    int mi = -1;
+    const int lane4 = lane * 4;
+    const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (unsigned)(NV - 1 - vvl)), kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | 8u);     // arg-max key constants: normal / end_sn vector
+    auto turbo_body = [&](auto npc, int row, int ti) __attribute__((always_inline)) -> int {
+        constexpr int NPC = decltype(npc)::value;
+        const int tb = __builtin_amdgcn_readlane(tv_tb, ti);
+        const int p0 = row - (tb & 0xff);
+        const int g0 = __builtin_amdgcn_readlane(vg_geo, p0 & 63), m0 = __builtin_amdgcn_readlane(vg_mi, p0 & 63);
+        const int pb0 = g0 & 0xfff, pe0 = (g0 >> 12) & 0xfff;
+        int mn = m0, mx = m0, min_pb = pb0, ring = g0; max_pe = pe0;
+        int p1 = p0, g1 = g0;
+        if (NPC == 2) {
+            p1 = row - ((tb >> 8) & 0xff);
+            g1 = __builtin_amdgcn_readlane(vg_geo, p1 & 63); const int m1_ = __builtin_amdgcn_readlane(vg_mi, p1 & 63);
+            mn = sgpr(imin(m0, m1_)); mx = sgpr(imax(m0, m1_)); min_pb = imin(pb0, g1 & 0xfff); max_pe = imax(pe0, (g1 >> 12) & 0xfff); ring &= g1;
+        }
+        set_band(std::true_type{}, mn, mx, min_pb);
+        const int nvr = end_sn - beg_sn + 1;
+        // all conditions as sign bits: (x <= y) <=> (x - y - 1) < 0
+        const int okbits = (nvr - NV - 1) & (end_sn - max_pe - 1) & (cur + nvr * CW - cap_pn - 1) & (ring << 7);      // GEO_RING (bit 24) -> bit 31
+        if (__builtin_expect(okbits >= 0 || end_sn == qlen_sn, 0)) return 0;
+        const int Wr = nvr * PN;
+        if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
+            qc_beg_sn = beg_sn;
+            const int c0 = beg_sn * PN + lane, c1 = c0 + 64;
+            qoff0 = (c0 >= 1 && c0 <= qlen) ? (int)s_query[c0 - 1] : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? (int)s_query[c1 - 1] : m;
+        }
+        const int q = *(const int *)((const char *)s_mx + (tb >> 16) + qoff0 * 4);
+        const int colrel = beg_sn * PN + lane;                     // this lane's column
+        int Mv, E1v, E2v = inf;
+        {
+            const int x = colrel - pb0 * PN;
+            const int *src = fr + (p0 & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+            if (I16) { const int w0 = src[0], w1 = src[1]; Mv = (int)(short)w0; E1v = w1 >> 16; if (GAP == 2) E2v = src[RCS + 1]; }
+            else { Mv = src[0]; E1v = src[RCS + 1]; if (GAP == 2) E2v = src[2 * RCS + 1]; }
+        }
+        if (NPC == 2) {
+            const int pb1 = g1 & 0xfff, Wp = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
+            const int x = colrel - pb1 * PN;
+            const int *src = fr + (p1 & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+            int hm1, ev1, ev2 = inf;
+            if (I16) { int w0 = src[0], w1 = src[1]; asm volatile("" : "+v"(w0), "+v"(w1)); hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) { ev2 = src[RCS + 1]; asm volatile("" : "+v"(ev2)); } }
+            else { hm1 = src[0]; ev1 = src[RCS + 1]; asm volatile("" : "+v"(hm1), "+v"(ev1)); if (GAP == 2) { ev2 = src[2 * RCS + 1]; asm volatile("" : "+v"(ev2)); } }      // (loads stay unconditional)
+            const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
+            Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
+        }
+        const int h = Mv + q;                                      // no wrap possible once the check below passes
+        const bool in_band = lane < Wr;
+        int lowest = imin(h, E1v); if (GAP == 2) lowest = imin(lowest, E2v);
+        if (__builtin_expect(__any(in_band && lowest < fast_lo), 0)) return 0;
+        // ---- from here on the row is committed
+        off_pn = cur; cur += nvr * CW; n_vec += nvr; ++rows_done; to_ring = true;
+        int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
+        const int first = __builtin_amdgcn_readlane(h, 0);
+        const int g1s = hs + le1;
+        int F1 = imax(wave_scan_max_i32(wave_shr1(first - e1, g1s)) - cf1, inj1), F2 = inf;
+        if (GAP == 2) { const int g2s = hs + le2; F2 = imax(wave_scan_max_i32(wave_shr1(first - e2, g2s)) - cf2, inj2); }
+        int Hout, E1out, E2out = inf;
+        if (GAP == 1) {
+            const int tmp = imax(h, E1v);
+            Hout = imax(tmp, F1);
+            E1out = (Hout == tmp) ? imax(E1v - e1, Hout - oe1) : inf;
+        } else {
+            Hout = imax(hs, imax(F1, F2));
+            E1out = imax(E1v - e1, Hout - oe1); E2out = imax(E2v - e2, Hout - oe2);
+        }
+        T *H = io.planes + (long long)off_pn * PN;
+        const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
+        if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = F1; *(int2 *)(H + lane * CW) = rec; }
+        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = 0; *(int4 *)(H + lane * CW) = rec; }
+        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = 0; *(int4 *)(H + lane * CW) = rec; }
+        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = 0; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + lane * CW); dst[0] = r0; dst[1] = r1; }
+        {
+            int *qd = fr + (row & (RR - 1)) * (NPW * RCS) + 2 + lane;
+            if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
+            else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
+            qd[64] = infw; if (NPW > 1) qd[RCS + 64] = inf; if (NPW > 2) qd[2 * RCS + 64] = inf;
+            if (__builtin_expect(RC > 128, 0)) for (int c = 2; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; }
+        }
+        // ---- arg-max, reference :1043-1057: value, then lowest lane residue, then the end_sn vector, then the lowest vector
+        if (I16) {
+            const unsigned key = ((unsigned)Hout << 16) + (unsigned)((vvl == nvr - 1) ? kE : kN);
+            const unsigned kb = wave_max_u32_s(in_band ? key : 0u);
+            const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
+            mi = ((int)(kb >> 16) - 32768 > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
+        } else {
+            const int vmax = wave_max_i32_s(in_band ? Hout : INT_MIN);
+            const unsigned key = (in_band && Hout == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
+            const unsigned kb = wave_max_u32_s(key);
+            const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
+            mi = (vmax > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
+        }
+        return 1;
     };
 
     // ---- FAST body: NP (1, 2, or up to 4 with run-time count) predecessors, all in the 64-row geometry ring and the score ring.
@@ -503,6 +629,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
         const int Wr = (end_sn - beg_sn + 1) * PN;
         if (!(allring & GEO_RING) || Wr > RC) return 0;
+        FSTAMP(0)
         if (!reserve()) return 2;
         to_ring = true;
         T *H = io.planes + (long long)off_pn * PN;
@@ -516,10 +643,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int qc = c == 0 ? qoff0 : qoff1;
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
             const int q = mrow[qc];
-            int Mv, E1v, E2v;
-            from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v);
-            if (NPC >= 2) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v);
+            int Mv = lane, E1v = inf, E2v = inf;
+            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v);
+            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v);
             if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v); }
+            FSTAMP(1)
             chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, first, first2, H, my_slot);
         }
         pad_ring(nch, my_slot);
@@ -564,8 +692,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
                     const T *Hp = io.planes + (long long)(uint32_t)off_ * PN;
                     int hval = inf, ev1 = inf, ev2 = inf;
-                    if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + x - 1));
-                    if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E1 * Wp + x)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)PL_E2 * Wp + x)); }
+                    if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CW));
+                    if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E2)); }
                     if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; }
                     else { Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
                 }
@@ -576,6 +704,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         return 1;
     };
 
+#ifdef ABPOA_HIP_PROFILE
+    fseg_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int t0 = 0; t0 < gn - 1 && status == 0; t0 += 64) {
         if (t0 > 0) {       // geometry of the finished tile goes to HBM in one coalesced burst (older predecessors, backtrack, trace)
             const int rb = t0 - 64 + lane; io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi;
@@ -589,35 +720,44 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
             am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
-            int rc = 0;
-            if ((meta >> 16) & 1) {
-                if (np == 1) rc = fast_body(std::integral_constant<int, 1>{}, row, ti);
-                else if (np == 2) rc = fast_body(std::integral_constant<int, 2>{}, row, ti);
-                else rc = fast_body(std::integral_constant<int, 4>{}, row, ti);
-            }
-            if (rc == 0) rc = general_body(row, ti);
-            if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
-            // ---- row arg-max (tie-break: lowest lane residue, then the end_sn vector, then the lowest vector), reference :1043-1057
-            int mi = -1;
-            if (I16) {
-                const unsigned kb = wave_max_u32_s(am_key);
-                const int vmax = (int)(kb >> 16) - 32768;
-                if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
-            } else {
-                const int vmax = wave_max_i32_s(am_any ? am_val : INT_MIN);
-                if (vmax > inf) {
-                    unsigned key = 0;
-                    if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
-                    const unsigned kb = wave_max_u32_s(key);
-                    mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
-                    if (mi > qlen) mi = -1;
-                }
-            }
-            {   // v_writelane x3 (no clang builtin here); M0 holds the lane select (two different SGPRs would violate the constant-bus limit)
+            auto commit_row = [&]() __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
                 const int geo_new = sgpr(beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
                 asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
                              : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
+            };
+            if (__builtin_expect((meta >> 17) & 1, 1)) {
+                if (np == 1) { if (__builtin_expect(turbo_body(std::integral_constant<int, 1>{}, row, ti), 1)) { commit_row(); continue; } }
+                else if (__builtin_expect(turbo_body(std::integral_constant<int, 2>{}, row, ti), 1)) { commit_row(); continue; }
             }
+            int rc = 0;
+            {
+                if ((meta >> 16) & 1) {
+                    if (np == 1) rc = fast_body(std::integral_constant<int, 1>{}, row, ti);
+                    else if (np == 2) rc = fast_body(std::integral_constant<int, 2>{}, row, ti);
+                    else rc = fast_body(std::integral_constant<int, 4>{}, row, ti);
+                }
+                if (rc == 0) rc = general_body(row, ti);
+                if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                FSTAMP(3)
+                // ---- row arg-max (tie-break: lowest lane residue, then the end_sn vector, then the lowest vector), reference :1043-1057
+                mi = -1;
+                if (I16) {
+                    const unsigned kb = wave_max_u32_s(am_key);
+                    const int vmax = (int)(kb >> 16) - 32768;
+                    if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+                } else {
+                    const int vmax = wave_max_i32_s(am_any ? am_val : INT_MIN);
+                    if (vmax > inf) {
+                        unsigned key = 0;
+                        if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
+                        const unsigned kb = wave_max_u32_s(key);
+                        mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
+                        if (mi > qlen) mi = -1;
+                    }
+                }
+            }
+            commit_row();
+            FSTAMP(4)
         }
     }
     // ---- geometry of the last (partial) tile
@@ -645,10 +785,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 // general kernel and the fast-loop kernel; reads only what the row loops left in HBM (planes, per-row band geometry).
 struct TailState { long long cursor, n_cells, clk0, clk1, seg[6]; int status, rows_done, best_score, best_i, best_j; };
 
-template <typename T, int GAP>
+// CW = 0: plane-major arena rows (general kernel); CW > 0: cell records of CW values (fast loop, see rows_fast)
+template <typename T, int GAP, int CW = 0>
 __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts) {
     constexpr int PN = Width<T>::PN;
-    constexpr int P = GAP == 0 ? 1 : (GAP == 1 ? 3 : 5);
+    constexpr int P = CW > 0 ? CW : (GAP == 0 ? 1 : (GAP == 1 ? 3 : 5));      // values per column in the arena
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
     const int lane = threadIdx.x & 63;
     const int gn = d.n_rows, qlen = d.qlen, m = b.m;
@@ -678,7 +819,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             int pe = g_esn[in_row], pb = g_bsn[in_row];
             int dpe = dp_end_of(in_row, pe);
             int end = qlen > dpe ? dpe : qlen;
-            int score = (int)planes[g_coff[in_row] + end - pb * PN];
+            int score = (int)planes[g_coff[in_row] + (long long)(end - pb * PN) * (CW > 0 ? CW : 1)];
             if (score > best_score) { best_score = score; best_i = in_row; best_j = end; }
         }
     }
@@ -751,7 +892,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         };
         auto cell = [&](const Geo &g, int plane, int col_) __attribute__((always_inline)) -> int {
             const long long Wp = (long long)(g.pe - g.pb + 1) * PN;
-            const long long idx = g.off + plane * Wp + (col_ - g.pb * PN);
+            const long long idx = CW > 0 ? g.off + (long long)(col_ - g.pb * PN) * CW + plane : g.off + plane * Wp + (col_ - g.pb * PN);
             int v = (int)bt[g.in_tile ? idx : 0];
             if (!g.in_tile) v = gld_cell((GLOBAL_AS const T *)(planes + idx));
             return v;
@@ -853,7 +994,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         AlnOut o; for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = 0;
         o.status = status; o.best_score = best_score; o.best_row = best_i; o.best_col = best_j;
         o.node_s = node_s; o.node_e = node_e; o.query_s = query_s; o.query_e = query_e;
-        o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = 0;
+        o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = CW;      // pad = arena cell stride (0: plane-major)
         o.n_cells = n_cells; o.cells_used = cursor;
         for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
         o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
@@ -1602,9 +1743,10 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     __syncthreads();
     long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
     const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
-    rows_fast<T, GAP>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done);
+    long long fseg[6] = {0, 0, 0, 0, 0, 0};
+    rows_fast<T, GAP>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
     const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
-    if (lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; }
+    if (lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
 }
 
 template <int GAP>
@@ -1627,10 +1769,10 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     TailState ts;
     ts.status = out_rec->status; ts.n_cells = out_rec->n_cells; ts.cursor = out_rec->cells_used; ts.rows_done = out_rec->n_rows_done;
     ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;
-    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = 0;
+    for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = out_rec->seg[i_];
     ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
     __syncthreads();
-    finish_alignment<T, GAP>(b, d, out_rec, ts);
+    finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
 }
 
 template <int GAP>

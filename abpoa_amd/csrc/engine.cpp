@@ -93,9 +93,11 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
         q_tot_ += d.qlen; rows_tot_ += d.n_rows; preds_tot_ += sh[i].n_pred; outs_tot_ += sh[i].n_out; cig_tot_ += d.cigar_cap;
         const int pn = d.bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
-        full_cells_[i] = width * P_ * d.n_rows;
+        // values per DP column in the arena: P planes (general kernel) or one padded cell record (fast loop: 4 / 8 values)
+        const int pv = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
+        full_cells_[i] = width * pv * d.n_rows;
         const int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
-        d.plane_cap = std::min<int64_t>(full_cells_[i], width * P_ + est * P_ * (d.n_rows - 1));
+        d.plane_cap = std::min<int64_t>(full_cells_[i], width * pv + est * pv * (d.n_rows - 1));
     }
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
@@ -154,7 +156,7 @@ int BatchStream::run() {
         for (size_t t = 0; t < todo.size(); ++t) {
             AlnDesc &d = desc_[todo[t]];
             if (!first_pass) d.plane_cap = full_cells_[todo[t]];
-            d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8));
+            d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8) + 64 * 8 * 4);   // + 64 records of slack (fast loop stores whole 64-lane chunks)
             pass[t] = d;
         }
         if ((rc = planes_.reserve((size_t)plane_bytes))) return rc;
@@ -181,7 +183,7 @@ int BatchStream::run() {
             L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
             // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
             const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
-            L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? (int)align_up((size_t)est_cols, 64) : 0;
+            L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally
             const int fr_budget = 36 * 1024 - L.phase_off;
             while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
             if (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget) L.fr_cols = 0;
@@ -284,10 +286,17 @@ int BatchStream::fetch_trace(int i, const uint8_t *row_active, abpoa_hip_trace_t
     }
     T->row_off[gn] = tot;
     T->planes = malloc((size_t)std::max<int64_t>(tot, 1) * (d.bits / 8));
+    const int cw = r.pad;          // arena cell stride: 0 = plane-major rows (general kernel), else cell records (fast loop)
     for (int rr = 0; rr < gn; ++rr) {
         if (T->dp_beg_sn[rr] < 0) continue;
-        size_t nb = (size_t)(T->row_off[rr + 1] - T->row_off[rr]) * (d.bits / 8);
-        memcpy((uint8_t *)T->planes + T->row_off[rr] * (d.bits / 8), arena.data() + coff[rr] * (d.bits / 8), nb);
+        const int64_t nv = T->row_off[rr + 1] - T->row_off[rr];
+        if (cw == 0) { memcpy((uint8_t *)T->planes + T->row_off[rr] * (d.bits / 8), arena.data() + coff[rr] * (d.bits / 8), (size_t)nv * (d.bits / 8)); continue; }
+        const int64_t W = nv / P;
+        for (int pl = 0; pl < P; ++pl) for (int64_t x = 0; x < W; ++x) {
+            const int64_t src = coff[rr] + x * cw + pl, dst = T->row_off[rr] + pl * W + x;
+            if (d.bits == 16) ((int16_t *)T->planes)[dst] = ((const int16_t *)arena.data())[src];
+            else ((int32_t *)T->planes)[dst] = ((const int32_t *)arena.data())[src];
+        }
     }
     return 0;
 }

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabpoa_hip.so")
+LIB_PATH = os.environ.get("ABPOA_HIP_LIB") or os.path.join(_HERE, "libabpoa_hip.so")   # env override: profiling builds (tools/)
 
 
 class Scoring(C.Structure):          # abpoa_hip_scoring_t
