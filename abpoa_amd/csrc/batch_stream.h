@@ -28,7 +28,7 @@ struct Blob {                   // device buffer with optional pinned host mirro
     void release();
 };
 
-struct StreamStats { int64_t n_launches = 0, n_alignments = 0, n_cells = 0, algo_bytes = 0; double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0; };
+struct StreamStats { int64_t n_launches = 0, n_alignments = 0, n_cells = 0, algo_bytes = 0; double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0, tail_ms = 0; };
 
 class BatchStream {
   public:
@@ -50,7 +50,7 @@ class BatchStream {
 
   private:
     bool open_ = false; int device_ = -1;
-    hipStream_t stream_ = nullptr; hipEvent_t ev_[4] = {};
+    hipStream_t stream_ = nullptr; hipEvent_t ev_[5] = {};
     Blob in_, out_, planes_;
     abpoa_hip_scoring_t sc_{}; std::vector<int32_t> mat_;
     unsigned flags_ = 0; int n_ = 0, P_ = 1;
@@ -62,6 +62,7 @@ class BatchStream {
 };
 
 void set_err(const char *fmt, ...);
+void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, LdsPlan *L);
 int engine_device();            // device the process is bound to, or -1
 void add_global_stats(const StreamStats &s);
 

@@ -1796,12 +1796,13 @@ static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream) {
 
 // n_fast: how many alignments of the batch take the fast row loop (engine.cpp applies takes_fast() on the host); a kernel
 // with nothing to do is not launched.
-hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream) {
+hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent_t after_rows) {
     if (b.n <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
     if (n_fast > 0) {
-        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) { e = launch_one(dp_fast_kernel<1>, b, stream); if (e == hipSuccess) e = launch_one(dp_fast_tail_kernel<1>, b, stream); }
-        else { e = launch_one(dp_fast_kernel<2>, b, stream); if (e == hipSuccess) e = launch_one(dp_fast_tail_kernel<2>, b, stream); }
+        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) e = launch_one(dp_fast_kernel<1>, b, stream); else e = launch_one(dp_fast_kernel<2>, b, stream);
+        if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
+        if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream) : launch_one(dp_fast_tail_kernel<2>, b, stream);
         if (e != hipSuccess) return e;
     }
     if (n_fast < b.n) {
@@ -1811,6 +1812,15 @@ hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream) {
             default: e = launch_one(dp_kernel<2>, b, stream); break;
         }
     }
+    return e;
+}
+
+// the two fast-path kernels alone (device-resident driver: every alignment of the batch is fast-eligible or skipped)
+hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows) {
+    if (b.n <= 0) return hipSuccess;
+    hipError_t e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_kernel<1>, b, stream) : launch_one(dp_fast_kernel<2>, b, stream);
+    if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
+    if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream) : launch_one(dp_fast_tail_kernel<2>, b, stream);
     return e;
 }
 

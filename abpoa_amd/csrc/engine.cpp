@@ -51,7 +51,7 @@ int engine_device() { return g.ready ? g.device : -1; }
 void add_global_stats(const StreamStats &s) {
     std::lock_guard<std::mutex> lk(g.stats_mu);
     g.stats.n_launches += s.n_launches; g.stats.n_alignments += s.n_alignments; g.stats.n_cells += s.n_cells;
-    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms;
+    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms; g.stats.tail_ms += s.tail_ms;
 }
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -72,6 +72,33 @@ void BatchStream::close() {
     for (auto &e : ev_) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(stream_);
     open_ = false;
+}
+
+// LDS carve-up of one wavefront (engine.h LdsPlan) for a launch whose largest query is max_qlen, widest score type max_bits
+// and widest expected band est_cols columns.
+void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, LdsPlan *Lp) {
+    LdsPlan &L = *Lp;
+    const int P = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
+    const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
+    L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
+    L.mat_off = L.q_cap; L.mx_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
+    L.phase_off = L.mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
+    L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
+    while ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024 && L.ring_rows > 4) L.ring_rows /= 2;
+    if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
+    const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
+    L.bt_off = lds_fixed_bytes_bt();
+    L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
+    // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
+    const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
+    L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally
+    const int fr_budget = 36 * 1024 - L.phase_off;
+    while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
+    if (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget) L.fr_cols = 0;
+    if (L.q_cap == 0 || est_cols > 1024) L.fr_cols = 0;
+    { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
+    const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
+    L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
 }
 
 int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *sh, unsigned flags) {
@@ -171,26 +198,7 @@ int BatchStream::run() {
                 const int pn = d.bits == 16 ? 16 : 8; const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
                 est_cols = std::max<int64_t>(est_cols, banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width);
             }
-            LdsPlan &L = b.lds; const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
-            L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
-            L.mat_off = L.q_cap; L.mx_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
-            L.phase_off = L.mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
-            L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
-            while ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024 && L.ring_rows > 4) L.ring_rows /= 2;
-            if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
-            const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
-            L.bt_off = lds_fixed_bytes_bt();
-            L.bt_bytes = std::max(16 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;
-            // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
-            const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
-            L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally
-            const int fr_budget = 36 * 1024 - L.phase_off;
-            while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
-            if (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget) L.fr_cols = 0;
-            if (L.q_cap == 0 || est_cols > 1024) L.fr_cols = 0;
-            { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
-            const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
-            L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
+            make_lds_plan(sc, max_qlen, max_bits, est_cols, &b.lds);
         }
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
@@ -228,7 +236,7 @@ int BatchStream::run() {
         int n_fast = 0;       // mirrors takes_fast() in dp_kernel.hip
         if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && b.lds.fr_cols > 0 && !(b.dbg & 64))
             for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.qlen <= b.lds.q_cap) ? 1 : 0;
-        HIP_TRY(launch_dp(b, n_fast, stream_), ABPOA_HIP_ELAUNCH);
+        HIP_TRY(launch_dp(b, n_fast, stream_, ev_[4]), ABPOA_HIP_ELAUNCH);
         HIP_TRY(hipEventRecord(ev_[2], stream_), ABPOA_HIP_ELAUNCH);
         // results: records + cigars are adjacent at the start of the output blob; band state / trace arrays on demand
         size_t d2h = o_left_;
@@ -239,7 +247,9 @@ int BatchStream::run() {
         HIP_TRY(hipStreamSynchronize(stream_), ABPOA_HIP_ELAUNCH);
         float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
         (void)hipEventElapsedTime(&ms_h2d, ev_[0], ev_[1]); (void)hipEventElapsedTime(&ms_k, ev_[1], ev_[2]); (void)hipEventElapsedTime(&ms_d2h, ev_[2], ev_[3]);
-        stats_.n_launches += 1; stats_.kernel_ms += ms_k; stats_.h2d_ms += ms_h2d; stats_.d2h_ms += ms_d2h;
+        float ms_tail = 0;                    // pure fast-path batches: ev_[4] sits between the row-loop kernel and the tail kernel
+        if (n_fast == b.n) { (void)hipEventElapsedTime(&ms_tail, ev_[4], ev_[2]); ms_k -= ms_tail; }
+        stats_.n_launches += 1; stats_.kernel_ms += ms_k; stats_.tail_ms += ms_tail; stats_.h2d_ms += ms_h2d; stats_.d2h_ms += ms_d2h;
 
         // records are indexed by position in this pass; cigar / per-row slots by alignment, so a retry pass cannot
         // clobber the results of alignments that finished earlier

@@ -96,6 +96,7 @@ int lds_fixed_bytes_dp();
 int lds_fixed_bytes_bt();
 
 // Launches the DP kernel for the whole batch on `stream`.
-hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream);
+hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent_t after_rows);
+hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows);
 
 }  // namespace abpoa_hip

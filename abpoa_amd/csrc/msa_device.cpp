@@ -1,0 +1,335 @@
+// Host side of the device-resident read-set driver (poa_device.h): pool allocation, one upload of the reads, the per-round
+// kernel sequence (prepare -> DP rows -> backtrack -> fuse) queued back to back with NO host work or synchronisation in
+// between, one download of the finished graphs, heaviest-bundling consensus on host threads.  Sets that exceed a device
+// capacity (edge slots, nodes, arena) are reported back and redone by the host driver (msa_batch.cpp).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <limits.h>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "batch_stream.h"
+#include "msa_device.h"
+#include "poa_device.h"
+#include "poa_graph.h"
+
+namespace abpoa_hip {
+
+namespace {
+#define HIP_OK(expr, code) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+        set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return code; } } while (0)
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+size_t up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Arena {                 // grow-only device / pinned-host buffers kept across calls (one job at a time, see g_mu)
+    uint8_t *dev = nullptr, *host = nullptr; size_t dev_cap = 0, host_cap = 0;
+    int need_dev(size_t n) {
+        if (n <= dev_cap) return 0;
+        if (dev) (void)hipFree(dev);
+        dev = nullptr; dev_cap = 0;
+        HIP_OK(hipMalloc((void **)&dev, n), ABPOA_HIP_ENOMEM); dev_cap = n; return 0;
+    }
+    int need_host(size_t n) {
+        if (n <= host_cap) return 0;
+        if (host) (void)hipHostFree(host);
+        host = nullptr; host_cap = 0;
+        HIP_OK(hipHostMalloc((void **)&host, n, hipHostMallocDefault), ABPOA_HIP_ENOMEM); host_cap = n; return 0;
+    }
+};
+struct Cache { Arena in, graph, rows, planes, out; hipStream_t stream = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
+Cache g_c; std::mutex g_mu;
+
+struct Layout {                // byte offsets inside the three device blobs
+    // in blob (uploaded): sets, read tables, reads, score matrix
+    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, in_bytes;
+    // graph blob (device only, the tail of it downloaded at the end): per-node pools
+    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
+    // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
+    size_t o_aln_desc, o_out_rec, o_rbase, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
+};
+
+// Heaviest-bundling consensus (reference src/abpoa_output.c:361-415, :343-356) straight from the flat device arrays, walking
+// the rows in reverse topological order instead of the reference's reverse Kahn queue: every quantity is a function of the
+// successors' values only, so the visiting order does not matter as long as successors come first.
+void consensus_flat(int n, const int32_t *order, const uint8_t *base, const uint8_t *nout, const int32_t *out_id, const int32_t *out_w,
+                    const int32_t *n_read, std::vector<int> *ids, std::vector<uint8_t> *bases, std::vector<int> *cov, std::vector<int> &score, std::vector<int> &max_out) {
+    ids->clear(); bases->clear(); cov->clear();
+    if (n <= 2) return;
+    score.assign(n, 0); max_out.assign(n, -1);
+    for (int r = n - 1; r >= 0; --r) {
+        const int cur = order[r];
+        const int32_t *oi = out_id + (size_t)cur * POA_OUT_CAP, *ow = out_w + (size_t)cur * POA_OUT_CAP; const int no = nout[cur];
+        if (cur == 1) { max_out[cur] = -1; score[cur] = 0; }
+        else if (cur == 0) {
+            int path_score = -1, path_max_w = -1, max_id = -1;
+            for (int i = 0; i < no; ++i) if (ow[i] > path_max_w || (ow[i] == path_max_w && score[oi[i]] > path_score)) { max_id = oi[i]; path_score = score[oi[i]]; path_max_w = ow[i]; }
+            max_out[cur] = max_id;
+        } else {
+            int max_w = INT_MIN, max_id = -1;
+            for (int i = 0; i < no; ++i) {
+                if (max_w < ow[i]) { max_w = ow[i]; max_id = oi[i]; }
+                else if (max_w == ow[i] && score[max_id] <= score[oi[i]]) max_id = oi[i];
+            }
+            score[cur] = max_w + score[max_id]; max_out[cur] = max_id;
+        }
+    }
+    for (int cur = max_out[0]; cur != 1 && cur >= 0; cur = max_out[cur]) { ids->push_back(cur); bases->push_back(base[cur]); cov->push_back(n_read[cur]); }
+}
+}  // namespace
+
+bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
+    const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
+    if (e && atoi(e)) return false;
+    return sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0 && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && !(flags & ABPOA_HIP_OUT_MSA) &&
+           sc->m - 1 <= POA_ALN_CAP && sc->zdrop <= 0;
+}
+
+int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
+                   std::vector<int> *fallback, DeviceRunStats *stats) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Cache &C = g_c;
+    const int device = engine_device();
+    if (device < 0) { set_err("engine not initialised"); return ABPOA_HIP_ENODEV; }
+    HIP_OK(hipSetDevice(device), ABPOA_HIP_ENODEV);
+    if (C.device != device) { if (!C.stream) HIP_OK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV); C.device = device; }
+    fallback->clear();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const double t_begin = now_s();
+    const int P = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5, CW = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8;
+
+    // ---- sizes
+    int max_reads = 0, max_qlen = 0; int64_t tot_reads = 0, tot_bases = 0;
+    for (int s = 0; s < n_sets; ++s) {
+        max_reads = std::max(max_reads, sets[s].n_reads); tot_reads += sets[s].n_reads;
+        for (int r = 0; r < sets[s].n_reads; ++r) { max_qlen = std::max(max_qlen, sets[s].lens[r]); tot_bases += sets[s].lens[r]; }
+    }
+    std::vector<PoaSet> ps(n_sets);
+    int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0; int max_node_cap = 0;
+    const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
+    for (int s = 0; s < n_sets; ++s) {
+        PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
+        int64_t sum = 0; int mx = 0;
+        for (int r = 0; r < sets[s].n_reads; ++r) { sum += sets[s].lens[r]; mx = std::max(mx, sets[s].lens[r]); }
+        const int64_t cap = std::min<int64_t>(2 + sum, 2 + 5LL * mx + 1024);
+        S.n_reads = sets[s].n_reads; S.node_cap = (int)cap; S.pred_cap = (int)(4 * cap);
+        S.read0 = read_i; read_i += sets[s].n_reads;
+        S.node0 = node_tot; node_tot += cap + 1;
+        S.pred0 = pred_tot; pred_tot += S.pred_cap;
+        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += S.cigar_cap;
+        S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + cap + 1;
+        // arena: the widest score type the set can reach decides the cell size; columns per row as the band estimate of engine.cpp
+        int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
+        const int64_t width = (int64_t)((mx + pn) / pn) * pn;
+        const int w = sc->wb + (int)(sc->wf * (float)mx);
+        const int64_t est = std::min<int64_t>(width, 2LL * w + 3 * pn + 32);
+        const int64_t bytes = (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
+        S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
+        max_node_cap = std::max(max_node_cap, (int)cap);
+    }
+    {   // the whole job must fit (the caller splits very large jobs)
+        size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t need = (size_t)plane_tot + (size_t)node_tot * 200 + (size_t)pred_tot * 4 + (size_t)cig_tot * 8 + (size_t)scr_tot * 4 + (size_t)tot_bases;
+        if (need > free_b + C.planes.dev_cap + C.graph.dev_cap + C.rows.dev_cap) { set_err("device-resident job needs %zu bytes, %zu free", need, free_b); return ABPOA_HIP_ENOMEM; }
+    }
+    Layout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
+    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_reads = take(tot_bases + 64);
+    L.o_mat = take(4 * sc->m * sc->m); L.in_bytes = o;
+    o = 0;
+    L.o_state = take(sizeof(PoaState) * n_sets);
+    // downloaded part first (consensus needs it), contiguous
+    L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
+    L.o_out = take(4 * node_tot * POA_OUT_CAP); L.o_outw = take(4 * node_tot * POA_OUT_CAP); L.o_nread = take(4 * node_tot);
+    const size_t dl_bytes = o;
+    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_IN_CAP); L.o_aln = take(4 * node_tot * POA_ALN_CAP); L.o_row = take(4 * node_tot);
+    L.graph_bytes = o;
+    o = 0;
+    L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
+    L.o_rbase = take(node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
+    L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
+    L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot); L.rows_bytes = o;
+
+    int rc;
+    if ((rc = C.in.need_dev(L.in_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc = C.graph.need_host(dl_bytes)) ||
+        (rc = C.rows.need_dev(L.rows_bytes)) || (rc = C.planes.need_dev((size_t)plane_tot))) return rc;
+    const int n_ev = 4 * max_reads + 8;
+    while ((int)C.ev.size() < n_ev) { hipEvent_t e; HIP_OK(hipEventCreate(&e), ABPOA_HIP_ENODEV); C.ev.push_back(e); }
+
+    // ---- upload: set table, reads (already residue codes), score matrix
+    uint8_t *hi = C.in.host;
+    memcpy(hi + L.o_sets, ps.data(), sizeof(PoaSet) * n_sets);
+    {
+        int64_t *roff = (int64_t *)(hi + L.o_roff); int32_t *rlen = (int32_t *)(hi + L.o_rlen); uint8_t *rd = hi + L.o_reads; int64_t at = 0, ri = 0;
+        for (int s = 0; s < n_sets; ++s) for (int r = 0; r < sets[s].n_reads; ++r) { roff[ri] = at; rlen[ri] = sets[s].lens[r]; memcpy(rd + at, sets[s].seqs[r], sets[s].lens[r]); at += sets[s].lens[r]; ++ri; }
+        roff[ri] = at;
+    }
+    memcpy(hi + L.o_mat, sc->mat, 4 * sc->m * sc->m);
+    hipStream_t st = C.stream;
+    HIP_OK(hipMemcpyAsync(C.in.dev, hi, L.in_bytes, hipMemcpyHostToDevice, st), ABPOA_HIP_ELAUNCH);
+
+    // ---- kernel arguments
+    uint8_t *di = C.in.dev, *dg = C.graph.dev, *dr = C.rows.dev;
+    PoaDev p; memset(&p, 0, sizeof(p));
+    p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2; p.e2 = sc->gap_ext2;
+    p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
+    p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
+    p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;
+    p.nd_base = dg + L.o_base; p.nd_nin = dg + L.o_nin; p.nd_nout = dg + L.o_nout; p.nd_naln = dg + L.o_naln;
+    p.nd_in = (int32_t *)(dg + L.o_in); p.nd_out = (int32_t *)(dg + L.o_out); p.nd_outw = (int32_t *)(dg + L.o_outw); p.nd_aln = (int32_t *)(dg + L.o_aln);
+    p.nd_nread = (int32_t *)(dg + L.o_nread); p.nd_row = (int32_t *)(dg + L.o_row);
+    p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
+    p.scratch = (int32_t *)(dr + L.o_scratch);
+    p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
+    p.row_base = dr + L.o_rbase; p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
+    p.pred_off = (int32_t *)(dr + L.o_poff); p.pred_row = (int32_t *)(dr + L.o_pred); p.cigar = (uint64_t *)(dr + L.o_cigar);
+
+    DevBatch b; memset(&b, 0, sizeof(b));
+    b.n = n_sets; b.m = sc->m;
+    {
+        int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
+        const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
+        make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(width, 2LL * w_max + 3 * pn + 32), &b.lds);
+    }
+    if (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
+    b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
+    b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
+    b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
+    b.mat = (const int32_t *)(di + L.o_mat); b.aln = p.aln; b.out = p.out;
+    b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
+    b.pred_off = p.pred_off; b.pred_row = p.pred_row; b.out_off = p.pred_off; b.out_row = p.pred_row;
+    b.left = p.scratch; b.right = p.scratch;
+    b.dp_beg_sn = (int32_t *)(dr + L.o_bsn); b.dp_end_sn = (int32_t *)(dr + L.o_esn); b.row_cell_off = (int64_t *)(dr + L.o_coff); b.row_max_i = (int32_t *)(dr + L.o_rmi);
+    b.planes = C.planes.dev; b.cigar = p.cigar;
+
+    // ---- the whole progressive alignment, queued back to back (ABPOA_HIP_DEVSYNC=1: synchronise and report after every kernel)
+    const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
+    auto stage = [&](const char *what, int k) -> int {
+        if (!dbg_sync) return 0;
+        fprintf(stderr, "[poa-device] round %d: %s queued\n", k, what); fflush(stderr);
+        hipError_t e_ = hipStreamSynchronize(st);
+        fprintf(stderr, "[poa-device] round %d: %s -> %s\n", k, what, hipGetErrorString(e_)); fflush(stderr);
+        return e_ == hipSuccess ? 0 : 1;
+    };
+    // debug (ABPOA_HIP_DEVSYNC=1): after every fuse, check set 0..3 structurally and against the host graph fed with the same cigars
+    std::vector<PoaGraph> dbg_graphs; if (dbg_sync) { dbg_graphs.resize(std::min(n_sets, 4)); for (auto &g_ : dbg_graphs) g_.reset(0, false); }
+    auto dbg_check = [&](int k) {
+        if (!dbg_sync) return;
+        for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
+            if (k >= sets[s].n_reads) continue;
+            PoaState hst; (void)hipMemcpy(&hst, (uint8_t *)p.state + sizeof(PoaState) * s, sizeof(hst), hipMemcpyDeviceToHost);
+            const PoaSet &S = ps[s]; const int n = hst.n_nodes;
+            // host graph: same cigar
+            if (k == 0) dbg_graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0);
+            else {
+                AlnOut ao; (void)hipMemcpy(&ao, (uint8_t *)p.out + sizeof(AlnOut) * s, sizeof(ao), hipMemcpyDeviceToHost);
+                std::vector<uint64_t> cg(std::max(1, ao.n_cigar)); (void)hipMemcpy(cg.data(), (uint8_t *)p.cigar + 8 * S.cigar_off, 8 * (size_t)ao.n_cigar, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[poa-device]   set %d round %d: dp status %d score %d n_cigar %d rows %d; device state status %d reason %d nodes %d\n", s, k, ao.status, ao.best_score, ao.n_cigar, ao.n_rows_done, hst.status, hst.pad, n);
+                if (ao.status != 0) continue;
+                dbg_graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], cg.data(), ao.n_cigar, k);
+            }
+            if (hst.status != POA_ST_OK) continue;
+            std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln(n * POA_ALN_CAP), nread(n), row(n), order(n);
+            auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
+            dl(base.data(), p.nd_base, 1, 1); dl(nin.data(), p.nd_nin, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl(naln.data(), p.nd_naln, 1, 1);
+            dl(in.data(), p.nd_in, 4, POA_IN_CAP); dl(outv.data(), p.nd_out, 4, POA_OUT_CAP); dl(outw.data(), p.nd_outw, 4, POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, POA_ALN_CAP);
+            dl(nread.data(), p.nd_nread, 4, 1); dl(row.data(), p.nd_row, 4, 1); dl(order.data(), p.row_node[hst.order_buf], 4, 1);
+            int bad = 0;
+            auto complain = [&](const char *what, int a, int b_) { if (bad++ < 8) fprintf(stderr, "[poa-device]   set %d round %d: %s (%d, %d)\n", s, k, what, a, b_); };
+            const PoaGraph &G = dbg_graphs[s];
+            if (G.n_nodes() != n) complain("node count differs from host graph", n, G.n_nodes());
+            for (int r = 0; r < n; ++r) { if (order[r] < 0 || order[r] >= n) { complain("order entry out of range", r, order[r]); continue; } if (row[order[r]] != r) complain("nd_row / order mismatch", r, order[r]); }
+            for (int u = 0; u < n && u < G.n_nodes(); ++u) {
+                const PoaNode &h = G.node(u);
+                if (h.base != base[u]) complain("base differs", u, base[u]);
+                if (h.in_id.size() != nin[u]) complain("in-degree differs", u, nin[u]);
+                else for (int t = 0; t < nin[u]; ++t) { if (h.in_id[t] != in[u * POA_IN_CAP + t]) complain("in edge differs", u, t); if (row[in[u * POA_IN_CAP + t]] >= row[u]) complain("order violated (pred row >= row)", in[u * POA_IN_CAP + t], u); }
+                if (h.out_id.size() != nout[u]) complain("out-degree differs", u, nout[u]);
+                else for (int t = 0; t < nout[u]; ++t) { if (h.out_id[t] != outv[u * POA_OUT_CAP + t]) complain("out edge differs", u, t); if (h.out_w[t] != outw[u * POA_OUT_CAP + t]) complain("out weight differs", u, t); }
+                if (h.aligned.size() != naln[u]) complain("aligned count differs", u, naln[u]);
+                else for (int t = 0; t < naln[u]; ++t) if (h.aligned[t] != aln[u * POA_ALN_CAP + t]) complain("aligned node differs", u, t);
+                if (h.n_read != nread[u]) complain("n_read differs", u, nread[u]);
+            }
+            fprintf(stderr, "[poa-device]   set %d round %d: graph check %s (%d nodes)\n", s, k, bad ? "FAILED" : "ok", n);
+        }
+    };
+    const double t_queue = now_s();
+    HIP_OK(hipEventRecord(C.ev[0], st), ABPOA_HIP_ELAUNCH);
+    if (stage("upload", 0)) return ABPOA_HIP_ELAUNCH;
+    HIP_OK(launch_poa_init(p, st), ABPOA_HIP_ELAUNCH);
+    if (stage("init", 0)) return ABPOA_HIP_ELAUNCH;
+    dbg_check(0);
+    HIP_OK(hipEventRecord(C.ev[1], st), ABPOA_HIP_ELAUNCH);
+    for (int k = 1; k < max_reads; ++k) {
+        p.round = k;
+        hipEvent_t *e = C.ev.data() + 4 * k;
+        HIP_OK(launch_poa_prepare(p, st), ABPOA_HIP_ELAUNCH);
+        if (stage("prepare", k)) return ABPOA_HIP_ELAUNCH;
+        HIP_OK(hipEventRecord(e[0], st), ABPOA_HIP_ELAUNCH);
+        HIP_OK(launch_dp_fast(b, st, e[1]), ABPOA_HIP_ELAUNCH);
+        if (stage("dp rows + tail", k)) return ABPOA_HIP_ELAUNCH;
+        HIP_OK(hipEventRecord(e[2], st), ABPOA_HIP_ELAUNCH);
+        HIP_OK(launch_poa_fuse(p, st), ABPOA_HIP_ELAUNCH);
+        if (stage("fuse", k)) return ABPOA_HIP_ELAUNCH;
+        dbg_check(k);
+        HIP_OK(hipEventRecord(e[3], st), ABPOA_HIP_ELAUNCH);
+    }
+    // ---- results: per-set state + the node arrays the consensus reads
+    uint8_t *hg = C.graph.host;
+    HIP_OK(hipMemcpyAsync(hg, dg, dl_bytes, hipMemcpyDeviceToHost, st), ABPOA_HIP_ELAUNCH);
+    HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
+    const double t_done = now_s();
+    if (stats) {
+        float ms = 0;
+        hipEvent_t prev = C.ev[1];
+        for (int k = 1; k < max_reads; ++k) {
+            hipEvent_t *e = C.ev.data() + 4 * k;
+            (void)hipEventElapsedTime(&ms, prev, e[0]); stats->prepare_ms += ms;
+            (void)hipEventElapsedTime(&ms, e[0], e[1]); stats->rows_ms += ms;
+            (void)hipEventElapsedTime(&ms, e[1], e[2]); stats->tail_ms += ms;
+            (void)hipEventElapsedTime(&ms, e[2], e[3]); stats->fuse_ms += ms;
+            prev = e[3];
+        }
+        stats->n_rounds = max_reads > 0 ? max_reads - 1 : 0; stats->device_s = t_done - t_queue;
+    }
+
+    // ---- consensus on host threads
+    const PoaState *hs = (const PoaState *)(hg + L.o_state);
+    const int32_t *h_order[2] = {(const int32_t *)(hg + L.o_order0), (const int32_t *)(hg + L.o_order1)};
+    const uint8_t *h_base = hg + L.o_base, *h_nout = hg + L.o_nout;
+    const int32_t *h_out = (const int32_t *)(hg + L.o_out), *h_outw = (const int32_t *)(hg + L.o_outw), *h_nread = (const int32_t *)(hg + L.o_nread);
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<int> next{0};
+    std::vector<char> need_fb(n_sets, 0);
+    auto worker = [&]() {
+        std::vector<int> ids, cov, score, mo; std::vector<uint8_t> bases;
+        for (int s; (s = next.fetch_add(1)) < n_sets;) {
+            abpoa_hip_msa_t &o_ = out[s];
+            memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
+            if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
+            const int64_t N0 = ps[s].node0;
+            consensus_flat(hs[s].n_nodes, h_order[hs[s].order_buf] + N0, h_base + N0, h_nout + N0, h_out + N0 * POA_OUT_CAP, h_outw + N0 * POA_OUT_CAP, h_nread + N0,
+                           &ids, &bases, &cov, score, mo);
+            o_.n_cells = hs[s].n_cells; o_.cons_len = (int)ids.size();
+            o_.cons_base = (uint8_t *)malloc(ids.size() + 1); o_.cons_cov = (int32_t *)malloc(4 * (ids.size() + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (ids.size() + 1));
+            memcpy(o_.cons_base, bases.data(), bases.size()); memcpy(o_.cons_cov, cov.data(), 4 * cov.size()); memcpy(o_.cons_node_id, ids.data(), 4 * ids.size());
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(s);
+    if (stats) {
+        stats->cons_s = now_s() - t_done; stats->total_s = now_s() - t_begin;
+        for (int s = 0; s < n_sets; ++s) if (!need_fb[s]) { stats->n_cells += hs[s].n_cells; stats->algo_bytes += hs[s].algo_bytes; stats->n_alignments += std::max(0, sets[s].n_reads - 1); }
+    }
+    return ABPOA_HIP_OK;
+}
+
+}  // namespace abpoa_hip

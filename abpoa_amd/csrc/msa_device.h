@@ -1,0 +1,25 @@
+// Device-resident read-set driver (msa_device.cpp / poa_device.hip): the graph of every read-set stays in HBM for the whole
+// progressive alignment; the host only uploads the reads and downloads the finished graphs.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "../../include/abpoa_hip.h"
+
+namespace abpoa_hip {
+
+struct DeviceRunStats {
+    double prepare_ms, rows_ms, tail_ms, fuse_ms;     // summed kernel durations (hipEvents on the job's stream)
+    double device_s, cons_s, total_s;                 // wall: first launch -> graphs on the host; consensus; whole call
+    int64_t n_cells, algo_bytes, n_alignments; int32_t n_rounds, pad;
+};
+
+// true when the scoring / output options can run on the device-resident path (global, banded, affine or convex gaps,
+// consensus only, nucleotide-sized alphabet); env ABPOA_HIP_HOSTGRAPH=1 forces the host driver
+bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
+
+// Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
+// them) and must be redone by the host driver.  ABPOA_HIP_ENOMEM / EINVAL: nothing was computed, use the host driver.
+int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
+                   std::vector<int> *fallback, DeviceRunStats *stats);
+
+}  // namespace abpoa_hip

@@ -1,8 +1,12 @@
 // The product's binding of the read-set driver to the HIP engine: every group gets its own BatchStream.
 #include <memory>
+#include <thread>
 #include <mutex>
 #include "batch_stream.h"
 #include "msa_batch.h"
+#include "msa_device.h"
+#include <string.h>
+#include <vector>
 
 namespace abpoa_hip {
 namespace {
@@ -32,8 +36,33 @@ abpoa_hip_msa_timing_t g_timing;
 extern "C" {
 int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
                         abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
-    if (abpoa_hip::engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
-    return abpoa_hip::run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, abpoa_hip::make_hip_aligner, &abpoa_hip::g_timing);
+    using namespace abpoa_hip;
+    if (engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
+    if (n_sets > 0 && sc && sets && out && msa_device_eligible(sc, flags)) {
+        // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
+        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL; }
+        std::vector<int> fb; DeviceRunStats ds;
+        const int rc = run_msa_device(sc, n_sets, sets, out, n_threads, &fb, &ds);
+        if (rc == ABPOA_HIP_OK) {
+            StreamStats ss; ss.n_launches = ds.n_rounds; ss.n_alignments = ds.n_alignments; ss.n_cells = ds.n_cells; ss.algo_bytes = ds.algo_bytes;
+            ss.kernel_ms = ds.rows_ms; ss.tail_ms = ds.tail_ms; add_global_stats(ss);
+            memset(&g_timing, 0, sizeof(g_timing));
+            g_timing.engine_s = ds.device_s; g_timing.cons_s = ds.cons_s; g_timing.total_s = ds.total_s; g_timing.n_rounds = ds.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = 1;
+            g_timing.host_sort_s = ds.prepare_ms / 1e3; g_timing.host_fuse_s = ds.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
+            if (fb.empty()) return ABPOA_HIP_OK;
+            std::vector<abpoa_hip_readset_t> sub(fb.size()); std::vector<abpoa_hip_msa_t> sub_out(fb.size());
+            for (size_t i = 0; i < fb.size(); ++i) sub[i] = sets[fb[i]];
+            abpoa_hip_msa_timing_t t2;
+            const int rc2 = run_msa_batch(sc, (int)fb.size(), sub.data(), sub_out.data(), flags, n_threads, 0, make_hip_aligner, &t2);
+            if (rc2 != ABPOA_HIP_OK) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); return rc2; }
+            for (size_t i = 0; i < fb.size(); ++i) out[fb[i]] = sub_out[i];
+            g_timing.pad = (int32_t)fb.size();           // how many sets took the host driver
+            return ABPOA_HIP_OK;
+        }
+        if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) return rc;
+    }
+    return run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &g_timing);
 }
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
 }

@@ -1,0 +1,63 @@
+// Device-resident progressive POA: the partial-order graph of every read-set lives in HBM for the whole job and the
+// per-read loop of the reference (abpoa_poa, src/abpoa_align.c:302-344) runs as four kernels per round with no host
+// work in between:
+//     poa_prepare_kernel   graph -> DP rows (remaining length, row-order CSR, alignment descriptor)   [poa_device.hip]
+//     dp_fast_kernel       banded DP row loop                                                          [dp_kernel.hip]
+//     dp_fast_tail_kernel  global best + backtrack -> graph cigar                                      [dp_kernel.hip]
+//     poa_fuse_kernel      cigar -> graph (abpoa_add_graph_alignment) + incremental row order          [poa_device.hip]
+// One wavefront (= one workgroup) owns one read-set.  Internal interface between msa_device.cpp and the kernels.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "engine.h"
+
+namespace abpoa_hip {
+
+constexpr int POA_IN_CAP = 8;      // in-edges per node kept on the device (more -> the set falls back to the host driver)
+constexpr int POA_OUT_CAP = 8;     // out-edges per node
+constexpr int POA_ALN_CAP = 4;     // aligned (mismatch-alternative) nodes per node: enough for nucleotides (m = 5)
+
+#define POA_ST_OK        0
+#define POA_ST_FALLBACK  100       // capacity exceeded somewhere (nodes, edges, arena, cigar): redo this set on the host driver
+
+struct PoaSet {                    // immutable per read-set
+    int32_t n_reads, node_cap;     // node_cap: slots in every per-node / per-row pool
+    int32_t pred_cap, pad;         // entries of this set's pred_row slice
+    int64_t read0;                 // first read in the read tables
+    int64_t node0;                 // first slot in the node / row pools
+    int64_t pred0;                 // first slot in pred_row
+    int64_t plane_off, plane_cap;  // arena: byte offset, capacity in bytes
+    int64_t cigar_off; int32_t cigar_cap, pad2;
+    int64_t scratch0;              // first slot of this set's int32 scratch (2 * max_qlen + node_cap entries)
+};
+
+struct PoaState {                  // mutable per read-set
+    int32_t n_nodes, status, order_buf, pad;     // order_buf: which row_node buffer is current
+    int64_t n_cells;               // DP cells over all alignments so far
+    int64_t algo_bytes;            // cells * algorithmic bytes per cell (affine 5S, convex 8S; S = 2 | 4)
+};
+
+struct PoaDev {                    // everything the poa_* kernels need; passed by value
+    int32_t n_sets, m;
+    int32_t max_mat, min_mis, o1, e1, o2, e2, wb; float wf;
+    int32_t gap_mode, round;       // round k: read k of every set is aligned / fused
+    int32_t max_qlen, pad;
+    const PoaSet *sets; PoaState *state;
+    const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
+    // graph, indexed node0 + node id
+    uint8_t *nd_base, *nd_nin, *nd_nout, *nd_naln;
+    int32_t *nd_in, *nd_out, *nd_outw, *nd_aln;     // [node][CAP]
+    int32_t *nd_nread, *nd_row;
+    int32_t *row_node[2];          // row order (double buffered), indexed node0 + row
+    int32_t *scratch;
+    // DP inputs produced by the prepare kernel (same arrays DevBatch points at)
+    AlnDesc *aln; AlnOut *out;
+    uint8_t *row_base; int32_t *row_node_id, *row_remain, *pred_off, *pred_row;
+    uint64_t *cigar;
+};
+
+hipError_t launch_poa_init(const PoaDev &p, hipStream_t s);
+hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s);
+hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s);
+
+}  // namespace abpoa_hip

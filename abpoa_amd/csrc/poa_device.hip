@@ -1,0 +1,318 @@
+// Device-resident partial-order graph for the read-set batch driver (see poa_device.h): graph fusion, row order and the
+// "remaining length" of the adaptive band, one wavefront per read-set, graph state resident in HBM between kernels.
+//
+// Reference behaviour restated here (all tie-breaks and insertion orders matter for consensus identity):
+//   fusion            src/abpoa_graph.c:596-672  abpoa_add_subgraph_alignment (match / aligned-node reuse / new node)
+//   edges             src/abpoa_graph.c:418-484  abpoa_add_graph_edge (existing edge: weight += w; n_read of the tail node += 1)
+//   aligned nodes     src/abpoa_graph.c:377-401
+//   remaining length  src/abpoa_graph.c:233-274  (1 + remaining length of the HEAVIEST out-edge's target, first maximum wins)
+// What is deliberately NOT the reference's: the row ORDER.  The reference re-runs a Kahn walk over the whole graph before
+// every read (abpoa_graph.c:186-231); here the order is maintained incrementally -- every new node is inserted right
+// after its predecessor on the alignment path, which keeps the order topological (an alignment path is monotone in row
+// order, so no new edge points backwards).  In global mode nothing the DP, the backtrack or the fusion computes depends on
+// which topological order is used (predecessor lists keep their in_id order, band and remaining length are functions of
+// the graph), and the batch driver's tests check the consensus of every set against the host driver, which keeps the
+// reference's order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include "poa_device.h"
+#include "../../include/abpoa_hip.h"
+
+namespace abpoa_hip {
+
+namespace {
+
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+// loads of data that OTHER lanes of this wave stored earlier in the same kernel: agent scope = not served from this CU's L1
+__device__ __forceinline__ int ld_fresh(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int shfl(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+template <int CTRL> __device__ __forceinline__ int dpp_(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false); }
+// inclusive prefix sum / max over the 64 lanes
+__device__ __forceinline__ int wave_scan_add(int x) {
+    x += dpp_<0x111>(0, x); x += dpp_<0x112>(0, x); x += dpp_<0x114>(0, x); x += dpp_<0x118>(0, x);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+__device__ __forceinline__ int wave_scan_max(int x) {
+    x = imax_(x, dpp_<0x111>(x, x)); x = imax_(x, dpp_<0x112>(x, x)); x = imax_(x, dpp_<0x114>(x, x)); x = imax_(x, dpp_<0x118>(x, x));
+    x = imax_(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));
+    x = imax_(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
+    return x;
+}
+// value of lane-1, lane 0 receives `lane0`
+__device__ __forceinline__ int shr1(int lane0, int v) { return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xF, 0xF, false); }
+
+// reference src/simd_abpoa_align.c:1672-1683 (same arithmetic as abpoa_hip_score_bits in engine.cpp)
+__device__ __forceinline__ int score_bits(const PoaDev &p, int n_rows, int qlen, int *inf_min) {
+    const int oe1 = p.o1 + p.e1, oe2 = p.o2 + p.e2;
+    const int len = qlen > n_rows ? qlen : n_rows;
+    const int max_score = imax_(qlen * p.max_mat, len * p.e1 + p.o1);
+    int bits, lo;
+    if (max_score <= INT16_MAX - p.min_mis - oe1 - oe2) { bits = 16; lo = INT16_MIN; } else { bits = 32; lo = INT32_MIN; }
+    *inf_min = imax_(imax_(lo + p.min_mis, lo + oe1), lo + oe2) + 31 * imax_(p.e1, p.e2);
+    return bits;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// round 0: the first read of every set becomes the backbone chain (reference abpoa_add_graph_sequence, :486-502)
+__global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    PoaState *st = p.state + s;
+    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; }
+    if (S.n_reads <= 0) { if (lane == 0) { st->n_nodes = 2; st->status = POA_ST_OK; } return; }
+    const int L = p.read_len[S.read0];
+    const uint8_t *seq = p.reads + p.read_off[S.read0];
+    const int n = L + 2;
+    if (n > S.node_cap) { if (lane == 0) { st->n_nodes = 2; st->status = POA_ST_FALLBACK; st->pad = 1; } return; }
+    const int64_t N0 = S.node0;
+    for (int u = lane; u < n; u += 64) {
+        // node ids: 0 = source, 1 = sink, 2 + i = base i of the read
+        const int i = u - 2;
+        p.nd_base[N0 + u] = u >= 2 ? seq[i] : 0;
+        p.nd_naln[N0 + u] = 0;
+        int nin = 0, nout = 0, in0 = 0, out0 = 0;
+        if (u == 0) { nout = 1; out0 = 2; }
+        else if (u == 1) { nin = 1; in0 = L + 1; }
+        else { nin = 1; in0 = i == 0 ? 0 : u - 1; nout = 1; out0 = i == L - 1 ? 1 : u + 1; }
+        p.nd_nin[N0 + u] = (uint8_t)nin; p.nd_nout[N0 + u] = (uint8_t)nout;
+        p.nd_in[(N0 + u) * POA_IN_CAP] = in0; p.nd_out[(N0 + u) * POA_OUT_CAP] = out0; p.nd_outw[(N0 + u) * POA_OUT_CAP] = 1;
+        p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
+        // row order: source, the chain, sink
+        const int row = u == 0 ? 0 : (u == 1 ? n - 1 : u - 1);
+        p.nd_row[N0 + u] = row; p.row_node[0][N0 + row] = u;
+    }
+    if (lane == 0) { st->n_nodes = n; st->status = POA_ST_OK; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// before the DP of round k: remaining length, rows in order with their predecessor CSR, alignment descriptor
+__global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    PoaState *st = p.state + s;
+    AlnDesc *ad = p.aln + s;
+    const int k = p.round;
+    const int status = st->status, n = st->n_nodes;
+    if (status != POA_ST_OK || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it
+        if (lane == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
+        return;
+    }
+    const int64_t N0 = S.node0;
+    const int32_t *order = p.row_node[st->order_buf] + N0;
+    int32_t *nxt = p.scratch + S.scratch0;                 // [n] row of the heaviest successor
+    int32_t *remain = p.row_remain + N0;
+    // (1) heaviest out-edge per row (first maximum wins, reference :262-268)
+    for (int r = lane; r < n; r += 64) {
+        const int u = order[r];
+        const int no = p.nd_nout[N0 + u];
+        int best_w = -1, best = -1;
+        for (int t = 0; t < no; ++t) { const int w = p.nd_outw[(N0 + u) * POA_OUT_CAP + t]; if (w > best_w) { best_w = w; best = p.nd_out[(N0 + u) * POA_OUT_CAP + t]; } }
+        nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
+        p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
+    }
+    __syncthreads();
+    // (2) remaining length by a reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping
+    for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
+        const int r = t0 + lane;
+        int tgt = r < n ? ld_fresh(nxt + r) : -1, dist = 1, val = 0; bool done = r >= n;
+        if (!done && tgt < 0) { val = -1; done = true; }                         // the sink (reference :247)
+        if (!done && tgt >= t0 + 64) { val = ld_fresh(remain + tgt) + 1; done = true; }
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int src = (!done) ? tgt - t0 : lane;
+            const int t_tgt = shfl(tgt, src), t_dist = shfl(dist, src), t_val = shfl(val, src), t_done = shfl((int)done, src);
+            if (!done) {
+                if (t_done) { val = t_val + dist; done = true; }
+                else { tgt = t_tgt; dist += t_dist; }
+            }
+        }
+        if (r < n) remain[r] = val;
+        __syncthreads();
+    }
+    // (3) predecessor CSR in row order (in_id order kept, reference pre_index[][] :519-530)
+    int carry = 0; bool overflow = false;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int r = t0 + lane;
+        const int u = r < n ? order[r] : 0;
+        const int np = (r < n && r > 0) ? (int)p.nd_nin[N0 + u] : 0;
+        const int incl = wave_scan_add(np);
+        const int off = carry + incl - np;
+        if (r < n) p.pred_off[N0 + r] = off;
+        if (off + np > S.pred_cap) overflow = true;
+        else for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + p.nd_in[(N0 + u) * POA_IN_CAP + t]];
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) p.pred_off[N0 + n] = carry;
+    overflow = __any(overflow);
+    // (4) alignment descriptor of this round
+    if (lane == 0) {
+        AlnDesc d; memset(&d, 0, sizeof(d));
+        const int qlen = p.read_len[S.read0 + k];
+        d.n_rows = n; d.qlen = qlen;
+        d.bits = score_bits(p, n, qlen, &d.inf_min);
+        d.w = p.wb + (int)(p.wf * (float)qlen);            // reference :445 (float32 product)
+        d.cigar_cap = S.cigar_cap; d.flags = ALN_FAST_OK; d.pad0 = 0;
+        d.query_off = p.read_off[S.read0 + k]; d.row0 = N0; d.poff0 = N0; d.pred0 = S.pred0; d.out0 = 0;
+        d.plane_off = S.plane_off; d.plane_cap = S.plane_cap / (d.bits / 8); d.cigar_off = S.cigar_off;
+        if (overflow || n + qlen + 8 > S.cigar_cap) { st->status = POA_ST_FALLBACK; st->pad = overflow ? 2 : 3; d.flags = 0; d.n_rows = 3; }
+        p.aln[s] = d;
+        p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// after the backtrack of round k: fuse the graph cigar of read k into the graph and extend the row order
+__global__ void __launch_bounds__(64) poa_fuse_kernel(const PoaDev p) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    PoaState *st = p.state + s;
+    const int k = p.round;
+    if (st->status != POA_ST_OK || k >= S.n_reads) return;
+    const AlnOut res = p.out[s];
+    if (res.status != 0) { if (lane == 0) { st->status = POA_ST_FALLBACK; st->pad = 1000 + res.status; } return; }
+    const int64_t N0 = S.node0;
+    const int n_old = st->n_nodes, qlen = p.read_len[S.read0 + k], n_cigar = res.n_cigar;
+    const uint8_t *seq = p.reads + p.read_off[S.read0 + k];
+    const uint64_t *cg = p.cigar + S.cigar_off;
+    const int cur = st->order_buf;
+    const int32_t *order_old = p.row_node[cur] + N0; int32_t *order_new = p.row_node[cur ^ 1] + N0;
+    int32_t *cand = p.scratch + S.scratch0, *n_anchor = cand + p.max_qlen, *n_j = n_anchor + p.max_qlen, *addcnt = n_j + p.max_qlen;
+    if (n_cigar == 0) return;                                                   // reference :614-616
+    // F0/F1: node every query base is aligned to (-1: inserted base)
+    for (int q = lane; q < qlen; q += 64) cand[q] = -1;
+    for (int r = lane; r < n_old; r += 64) addcnt[r] = 0;
+    __syncthreads();
+    for (int i = lane; i < n_cigar; i += 64) {
+        const uint64_t w = cg[i];
+        if ((int)(w & 0xf) == ABPOA_HIP_CMATCH) cand[(int)((w >> 4) & 0x3fffffff)] = (int)((w >> 34) & 0x3fffffff);
+    }
+    __syncthreads();
+    // F2: walk the query in chunks of 64 positions
+    int n_nodes = n_old, prev_c = 0 /* source */, prev_new_c = 0, carry_ar = 0 /* row of the source */, carry_sq = -1;
+    bool fail = false;
+    // adds edge from -> to (both lane-private; `from_new` / `to_new`: the node was created by this read, its lists are still empty
+    // apart from what this very walk put there, which is known without a load)
+    auto add_edge = [&](bool act, int from, bool from_new, int to, bool to_new) {
+        if (!act) return;
+        const int64_t F = N0 + from, T = N0 + to;
+        int no = from_new ? 0 : (int)p.nd_nout[F];
+        int hit = -1;
+        if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (p.nd_out[F * POA_OUT_CAP + t] == to) { hit = t; break; }
+        if (hit >= 0) p.nd_outw[F * POA_OUT_CAP + hit] += 1;
+        else {
+            const int ni = to_new ? 0 : (int)p.nd_nin[T];
+            if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; return; }
+            p.nd_out[F * POA_OUT_CAP + no] = to; p.nd_outw[F * POA_OUT_CAP + no] = 1; p.nd_nout[F] = (uint8_t)(no + 1);
+            p.nd_in[T * POA_IN_CAP + ni] = from; p.nd_nin[T] = (uint8_t)(ni + 1);
+        }
+        p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
+    };
+    for (int q0 = 0; q0 < qlen; q0 += 64) {
+        const int q = q0 + lane; const bool act = q < qlen;
+        const int c = act ? ld_fresh(cand + q) : -1;
+        const int b = act ? (int)seq[q] : 0;
+        int node = -1; bool isnew = act;
+        if (act && c >= 0) {
+            if ((int)p.nd_base[N0 + c] == b) { node = c; isnew = false; }
+            else {                                                              // reference abpoa_get_aligned_id :377-386
+                const int na = p.nd_naln[N0 + c];
+                for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + c) * POA_ALN_CAP + t]; if ((int)p.nd_base[N0 + a] == b) { node = a; isnew = false; break; } }
+            }
+        }
+        // group-end row of the aligned group that places this position in the row order (see the bookkeeping below); read before
+        // the group is extended
+        int gv = -1;
+        if (act && c >= 0) {
+            const int ref = isnew ? c : node;
+            gv = p.nd_row[N0 + ref];
+            const int na = p.nd_naln[N0 + ref];
+            for (int t = 0; t < na; ++t) gv = imax_(gv, p.nd_row[N0 + p.nd_aln[(N0 + ref) * POA_ALN_CAP + t]]);
+        }
+        const unsigned long long newmask = __ballot(isnew);
+        const int rank = __builtin_popcountll(newmask & ((1ull << lane) - 1));
+        if (isnew) node = n_nodes + rank;
+        const int n_new = __builtin_popcountll(newmask);
+        if (n_nodes + n_new > S.node_cap) { fail = true; break; }
+        if (isnew) {
+            const int64_t Y = N0 + node;
+            p.nd_base[Y] = (uint8_t)b; p.nd_nin[Y] = 0; p.nd_nout[Y] = 0; p.nd_naln[Y] = 0; p.nd_nread[Y] = 0;
+            if (c >= 0) {                                                       // mismatch: new node joins c's aligned group, reference :393-401
+                const int na = p.nd_naln[N0 + c];
+                if (na + 1 > POA_ALN_CAP) fail = true;
+                else {
+                    for (int t = 0; t < na; ++t) {
+                        const int other = p.nd_aln[(N0 + c) * POA_ALN_CAP + t];
+                        const int no_ = p.nd_naln[N0 + other];                   // == na for every member of the group
+                        p.nd_aln[(N0 + other) * POA_ALN_CAP + no_] = node; p.nd_naln[N0 + other] = (uint8_t)(no_ + 1);
+                        p.nd_aln[Y * POA_ALN_CAP + t] = other;
+                    }
+                    p.nd_aln[(N0 + c) * POA_ALN_CAP + na] = node; p.nd_naln[N0 + c] = (uint8_t)(na + 1);
+                    p.nd_aln[Y * POA_ALN_CAP + na] = c; p.nd_naln[Y] = (uint8_t)(na + 1);
+                }
+            }
+        }
+        // predecessor on the path: lane - 1 (lane 0: last node of the previous chunk)
+        const int prev = shr1(prev_c, node), prev_new = shr1(prev_new_c, (int)isnew);
+        add_edge(act, prev, prev_new != 0, node, isnew);
+        // row-order bookkeeping.  Invariant (the reference's Kahn walk keeps it too, abpoa_graph.c:213-224): the members of an
+        // aligned group are contiguous in the row order.  A new node is therefore spliced in right after the END of a group:
+        // the group of the node it mismatches (which it joins), or the group of the nearest old node before it on the path,
+        // whichever comes later -- i.e. after row AR = running maximum along the path of "group-end row" (old nodes: their own
+        // group; mismatch nodes: the group they join; inserted bases: none).  New nodes with the same AR form a run in path order.
+        const int AR = imax_(wave_scan_max(gv), carry_ar);
+        const int prevAR = shr1(carry_ar, AR);
+        const bool start = isnew && (prev_new == 0 || prevAR != AR);
+        const int sq = imax_(wave_scan_max(start ? q : -1), carry_sq);
+        if (isnew) { n_anchor[node - n_old] = AR; n_j[node - n_old] = q - sq + 1; atomicAdd(addcnt + AR, 1); }
+        // carries into the next chunk (from the last active lane)
+        const int last_lane = imin_(63, qlen - 1 - q0);
+        prev_c = __builtin_amdgcn_readlane(node, last_lane); prev_new_c = __builtin_amdgcn_readlane((int)isnew, last_lane);
+        carry_ar = __builtin_amdgcn_readlane(AR, last_lane); carry_sq = __builtin_amdgcn_readlane(sq, last_lane);
+        n_nodes += n_new;
+    }
+    // F3: last node -> sink (reference :667)
+    if (!__any(fail)) add_edge(lane == 0, prev_c, prev_new_c != 0, 1, false);
+    if (__any(fail)) { if (lane == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }
+    __syncthreads();
+    // F4: new row order = old order with every run of new nodes spliced in after its anchor
+    int carry = 0;
+    for (int t0 = 0; t0 < n_old; t0 += 64) {
+        const int r = t0 + lane;
+        const int cnt = r < n_old ? ld_fresh(addcnt + r) : 0;
+        const int incl = wave_scan_add(cnt);
+        const int shift = carry + incl - cnt;                    // new nodes anchored at earlier rows
+        if (r < n_old) { const int u = order_old[r]; order_new[r + shift] = u; p.nd_row[N0 + u] = r + shift; addcnt[r] = shift; }
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    __syncthreads();
+    for (int i = lane; i < n_nodes - n_old; i += 64) {
+        const int ar = ld_fresh(n_anchor + i), j = ld_fresh(n_j + i);
+        const int nr = ar + ld_fresh(addcnt + ar) + j;
+        order_new[nr] = n_old + i; p.nd_row[N0 + n_old + i] = nr;
+    }
+    if (lane == 0) {
+        st->n_nodes = n_nodes; st->order_buf = cur ^ 1; st->n_cells += res.n_cells;
+        st->algo_bytes += res.n_cells * (p.aln[s].bits / 8) * (p.gap_mode == ABPOA_HIP_AFFINE_GAP ? 5 : 8);
+    }
+}
+
+static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(p.n_sets), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_poa_init(const PoaDev &p, hipStream_t s) { return launch_k(poa_init_kernel, p, s); }
+hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) { return launch_k(poa_prepare_kernel, p, s); }
+hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) { return launch_k(poa_fuse_kernel, p, s); }
+
+}  // namespace abpoa_hip

@@ -26,6 +26,18 @@ void PoaGraph::reset(int tot_reads, bool use_read_ids) {
     sorted_ = false; n_edges_ = 0;
 }
 
+void PoaGraph::import_nodes(int n, const uint8_t *base, const uint8_t *nin, const uint8_t *nout, const uint8_t *naln, const int32_t *in_id, int in_cap,
+                            const int32_t *out_id, const int32_t *out_w, int out_cap, const int32_t *aligned, int aln_cap, const int32_t *n_read) {
+    nodes_.clear(); nodes_.resize(n); read_ids_.clear(); use_read_ids_ = false; words_ = 0; n_edges_ = 0; sorted_ = false;
+    for (int u = 0; u < n; ++u) {
+        PoaNode &nd = nodes_[u];
+        nd.base = base[u]; nd.n_read = n_read[u];
+        for (int t = 0; t < nin[u]; ++t) nd.in_id.push_back(in_id[(size_t)u * in_cap + t]);
+        for (int t = 0; t < nout[u]; ++t) { nd.out_id.push_back(out_id[(size_t)u * out_cap + t]); nd.out_w.push_back(out_w[(size_t)u * out_cap + t]); ++n_edges_; }
+        for (int t = 0; t < naln[u]; ++t) nd.aligned.push_back(aligned[(size_t)u * aln_cap + t]);
+    }
+}
+
 int PoaGraph::add_node(uint8_t base) {                        // reference abpoa_graph.c:409-416
     nodes_.emplace_back(); nodes_.back().base = base;
     if (use_read_ids_) read_ids_.emplace_back();

@@ -85,6 +85,9 @@ class PoaGraph {
     void flatten_into(bool with_remain, uint8_t *row_base, int32_t *row_node_id, int32_t *row_remain, int32_t *pred_off,
                       int32_t *pred_row, int32_t *out_off, int32_t *out_row) const;
     int n_edges() const { return n_edges_; }
+    // Rebuild the node table from flat fixed-capacity arrays (the device-resident graph of poa_device.h); read ids are not carried.
+    void import_nodes(int n, const uint8_t *base, const uint8_t *nin, const uint8_t *nout, const uint8_t *naln, const int32_t *in_id, int in_cap,
+                      const int32_t *out_id, const int32_t *out_w, int out_cap, const int32_t *aligned, int aln_cap, const int32_t *n_read);
 
     // Single heaviest-bundling consensus: node ids of the path, bases and per-base coverage.
     void consensus(std::vector<int> *node_ids, std::vector<uint8_t> *bases, std::vector<int> *cov) const;

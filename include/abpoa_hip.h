@@ -130,6 +130,8 @@ typedef struct abpoa_hip_stats_t {
     double  kernel_ms;           /* sum of DP kernel durations measured with hipEvents on the
                                     engine's own stream                                               */
     double  h2d_ms, d2h_ms;      /* copy durations (same events)                                      */
+    double  tail_ms;             /* fast path only: global-best + backtrack kernel (dp_fast_tail_kernel), timed apart
+                                    from the row-loop kernel that kernel_ms then covers alone                          */
 } abpoa_hip_stats_t;
 
 /* ---- engine life cycle ------------------------------------------------------------------------ */
