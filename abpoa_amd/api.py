@@ -61,7 +61,27 @@ class Params:
 
 
 class SetResult:
-    __slots__ = ("status", "cons_seq", "cons_cov", "cons_len", "msa_seq", "msa_len", "n_cells")
+    """Result of one read-set.  The arrays come back from the library as residue codes; strings / lists are built on first
+    access (building 1000 Python strings and coverage lists eagerly costs more than the whole GPU job of a batch)."""
+    __slots__ = ("status", "cons_len", "msa_len", "n_cells", "_m", "_cons_codes", "_cons_cov", "_msa_codes", "_cons_seq", "_cov_list", "_msa_seq")
+
+    @property
+    def cons_seq(self):
+        if self._cons_seq is None:
+            self._cons_seq = seqio.decode(self._cons_codes, self._m) if self.cons_len > 0 else ""
+        return self._cons_seq
+
+    @property
+    def cons_cov(self):
+        if self._cov_list is None:
+            self._cov_list = self._cons_cov.tolist() if self.cons_len > 0 else []
+        return self._cov_list
+
+    @property
+    def msa_seq(self):
+        if self._msa_seq is None:
+            self._msa_seq = [seqio.decode(row, self._m) for row in self._msa_codes] if self.msa_len > 0 else []
+        return self._msa_seq
 
 
 def _bind_msa(lib):
@@ -103,15 +123,11 @@ def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=
     res = []
     for i in range(enc.n):
         o, r = out[i], SetResult()
-        r.status, r.n_cells = o.status, o.n_cells
-        r.cons_len = o.cons_len
-        r.cons_seq = seqio.decode(np.ctypeslib.as_array(o.cons_base, (o.cons_len,)), params.m) if o.cons_len > 0 else ""
-        r.cons_cov = np.ctypeslib.as_array(o.cons_cov, (o.cons_len,)).tolist() if o.cons_len > 0 else []
-        r.msa_len = o.msa_len
-        r.msa_seq = []
-        if o.msa_len > 0:
-            mb = np.ctypeslib.as_array(o.msa_base, (o.msa_rows, o.msa_len))
-            r.msa_seq = [seqio.decode(row, params.m) for row in mb]
+        r.status, r.n_cells, r.cons_len, r.msa_len, r._m = o.status, o.n_cells, o.cons_len, o.msa_len, params.m
+        r._cons_seq = r._cov_list = r._msa_seq = None
+        r._cons_codes = np.ctypeslib.as_array(o.cons_base, (o.cons_len,)).copy() if o.cons_len > 0 else None
+        r._cons_cov = np.ctypeslib.as_array(o.cons_cov, (o.cons_len,)).copy() if o.cons_len > 0 else None
+        r._msa_codes = np.ctypeslib.as_array(o.msa_base, (o.msa_rows, o.msa_len)).copy() if o.msa_len > 0 else None
         lib.abpoa_hip_free_msa(C.byref(out[i]))
         res.append(r)
     return res

@@ -5,6 +5,8 @@
 #include "batch_stream.h"
 #include "msa_batch.h"
 #include "msa_device.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -50,6 +52,8 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
             memset(&g_timing, 0, sizeof(g_timing));
             g_timing.engine_s = ds.device_s; g_timing.cons_s = ds.cons_s; g_timing.total_s = ds.total_s; g_timing.n_rounds = ds.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = 1;
             g_timing.host_sort_s = ds.prepare_ms / 1e3; g_timing.host_fuse_s = ds.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver: %d sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, consensus %.1f ms, total %.1f ms; %zu sets fall back to the host driver\n",
+                                                     n_sets, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
             if (fb.empty()) return ABPOA_HIP_OK;
             std::vector<abpoa_hip_readset_t> sub(fb.size()); std::vector<abpoa_hip_msa_t> sub_out(fb.size());
             for (size_t i = 0; i < fb.size(); ++i) sub[i] = sets[fb[i]];

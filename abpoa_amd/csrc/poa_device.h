@@ -13,8 +13,8 @@
 
 namespace abpoa_hip {
 
-constexpr int POA_IN_CAP = 8;      // in-edges per node kept on the device (more -> the set falls back to the host driver)
-constexpr int POA_OUT_CAP = 8;     // out-edges per node
+constexpr int POA_IN_CAP = 16;     // in-edges per node kept on the device (more -> the set falls back to the host driver)
+constexpr int POA_OUT_CAP = 16;    // out-edges per node
 constexpr int POA_ALN_CAP = 4;     // aligned (mismatch-alternative) nodes per node: enough for nucleotides (m = 5)
 
 #define POA_ST_OK        0
