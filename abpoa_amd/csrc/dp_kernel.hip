@@ -828,6 +828,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
     // refilled cooperatively; only lane 0 writes cigar words.
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
+    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0;
     if (status == 0 && b.ret_cigar) {
         BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
         T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
@@ -837,7 +838,9 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
         const int cap = d.cigar_cap;
         uint64_t last_word = 0;
+        long long win_ticks = 0; int n_windows = 0;
         auto load_window = [&](int hi) __attribute__((always_inline)) {
+            const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             __syncthreads();
             int lo = imax(0, hi - BTR + 1);
             const int r = lo + lane;
@@ -865,9 +868,16 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             if (ncell == 0) { bt_hi = bt_lo - 1; }
             // 16-byte coalesced copy (arena offsets are multiples of PN cells = 32 bytes)
             const int4 *src = (const int4 *)(planes + bt_c0); int4 *dst = (int4 *)bt;
-            const long long n16 = ncell * (long long)sizeof(T) / 16;
-            for (long long i = lane; i < n16; i += 64) dst[i] = src[i];
+            const int n16 = (int)(ncell * (long long)sizeof(T) / 16);
+            for (int i0 = 0; i0 < n16; i0 += 64 * 8) {                            // 8 loads in flight per lane, then 8 LDS stores
+                int4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; v[u] = idx < n16 ? src[idx] : make_int4(0, 0, 0, 0); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
+            }
             __syncthreads();
+            win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
         auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
             uint64_t L = (uint64_t)(int64_t)len;
@@ -903,7 +913,80 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
 
         int i = best_i, j = best_j, start_i = best_i, start_j = best_j, cur_op = OP_ALL, indel_first = 1;
         if (best_j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
-        while (i > 0 && j > 0 && status == 0) {
+        // ---- lane-parallel step (cell-record arenas, i.e. the fast path): one LDS round trip each for (a) the row's own record,
+        //      (b) its predecessor list, (c) the predecessors' geometry, (d) every score the decision can need -- lane k holds
+        //      predecessor k -- then the reference's priority order (:109-429) is evaluated on ballot masks.  Falls through to
+        //      the one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
+        do {      // fast steps; one slow step whenever a fast one cannot be taken; back to fast steps
+        while (CW > 0 && i > 0 && j > 0 && status == 0) {
+            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
+            if (i < bt_lo || i > bt_hi) break;                                   // row does not fit the window: slow walk
+            const int ti = i - bt_lo;
+            const int ps = B.poff[ti], np = B.poff[ti + 1] - ps, id = B.nid[ti], bs_ = B.base[ti];
+            const int pbi = B.bsn[ti] * PN, Wi = (B.esn[ti] - B.bsn[ti] + 1) * PN; const long long offi = B.coff[ti] - bt_c0;
+            if (np > 64 || ps - bt_pbase + np > BTP) break;
+            const int pk = lane < np ? B.pred[ps - bt_pbase + lane] : bt_lo;
+            if (__any(lane < np && (pk < bt_lo || pk > bt_hi))) { if (i != bt_hi) { load_window(i); continue; } break; }
+            const int tk = pk - bt_lo;
+            const int pbk = B.bsn[tk] * PN, Wk = (B.esn[tk] - B.bsn[tk] + 1) * PN; const long long offk = B.coff[tk] - bt_c0;
+            const int qc = qcode(j - 1);
+            const int sc_ = s_mat[m * bs_ + qc];
+            // scores: own row at j and j-1, predecessor k at j-1 (H) and j (H, E1[, E2])
+            const int xi = j - pbi;
+            const T *ri = bt + offi + (long long)xi * CW;
+            const int Hij = (int)ri[0];
+            const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
+            const int xk = j - pbk;
+            const bool act = lane < np, in_j = act && (unsigned)xk < (unsigned)Wk, in_jm1 = act && (unsigned)(xk - 1) < (unsigned)Wk;
+            const T *rk = bt + offk + (long long)(in_j ? xk : 0) * CW, *rkm1 = bt + offk + (long long)(in_jm1 ? xk - 1 : 0) * CW;
+            const int Hk_j = (int)rk[0], E1k_j = (int)rk[PL_E1], E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
+            start_i = i; start_j = j; ++bt_steps;
+            const unsigned long long mA = __ballot(in_jm1 && Hk_jm1 + sc_ == Hij);
+            int hit = 0;
+            auto do_match = [&](int set_indel) __attribute__((always_inline)) {
+                if (!mA) return;
+                const int k = __builtin_ctzll(mA);
+                cur_op = OP_ALL; hit = 1;
+                push(ABPOA_HIP_CMATCH, 1, id, j - 1);
+                i = __builtin_amdgcn_readlane(pk, k); --j; ++n_aln; n_match += (bs_ == qc);
+                if (set_indel) indel_first = 0;
+            };
+            if ((cur_op & OP_M) && indel_first == 0) do_match(0);
+            if (!hit && (cur_op & OP_E)) {
+                const int E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0;
+                const bool viaM = cur_op & OP_M;
+                unsigned long long m1 = 0, m2 = 0;
+                if (cur_op & OP_E1) m1 = __ballot(in_j && (viaM ? Hij == E1k_j : E1ij == E1k_j - (int)e1));
+                if (GAP == 2 && (cur_op & OP_E2)) m2 = __ballot(in_j && (viaM ? Hij == E2k_j : E2ij == E2k_j - (int)e2));
+                if (m1 | m2) {                                                   // first predecessor in list order, E1 before E2 for the same one
+                    const int k1 = m1 ? __builtin_ctzll(m1) : 64, k2 = m2 ? __builtin_ctzll(m2) : 64;
+                    const bool use1 = k1 <= k2; const int k = use1 ? k1 : k2;
+                    const unsigned long long mD = __ballot(in_j && (use1 ? Hk_j - (int)oe1 == E1k_j : Hk_j - (int)oe2 == E2k_j));
+                    cur_op = ((mD >> k) & 1) ? (OP_M | OP_F) : (use1 ? OP_E1 : OP_E2);
+                    hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); i = __builtin_amdgcn_readlane(pk, k);
+                }
+            }
+            if (!hit && (cur_op & OP_F)) {
+                for (int x = 1; x <= (GAP == 2 ? 2 : 1) && !hit; ++x) {
+                    const int bit = x == 1 ? OP_F1 : OP_F2, pl = x == 1 ? PL_F1 : PL_F2;
+                    const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
+                    if (!(cur_op & bit)) continue;
+                    const int Fij = (int)ri[pl];
+                    if (!(cur_op & OP_M) || Hij == Fij) {
+                        if (st_jm1) {
+                            if ((int)ri[-CW] - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
+                            else if ((int)ri[-CW + pl] - ex == Fij) { cur_op = bit; hit = 1; }
+                        }
+                    }
+                }
+                if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
+            }
+            if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
+            if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
+        }
+        int slow_budget = CW > 0 ? 1 : INT_MAX;
+        while (i > 0 && j > 0 && status == 0 && slow_budget-- > 0) {
+            ++bt_slow_steps;
             if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
             const Geo gi = geo_of(i);
             const int Hij = cell(gi, 0, j);
@@ -982,6 +1065,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             }
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
         }
+        } while (CW > 0 && i > 0 && j > 0 && status == 0);
+        bt_win_ticks = win_ticks; bt_n_windows = n_windows;
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
             __syncthreads();
@@ -997,6 +1082,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = CW;      // pad = arena cell stride (0: plane-major)
         o.n_cells = n_cells; o.cells_used = cursor;
         for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
+        o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000;      // backtrack: ticks spent staging arena windows, number of windows
         o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }
