@@ -1,0 +1,68 @@
+"""GPU (-m gpu): the device-resident read-set driver (graph, fusion, row order, remaining length on the GPU;
+abpoa_amd/csrc/poa_device.hip) must give exactly what the host driver gives (which keeps the reference's graph code
+and row order, and is itself pinned to the reference's outputs in test_gpu_msa.py / test_host_msa.py):
+consensus, per-base coverage and DP cell counts of every set; and, with ABPOA_HIP_DEVSYNC=1, the device graph must
+equal the host graph node for node after every read (the library checks that itself and reports on stderr)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _both(sets, params, n_threads=8):
+    from abpoa_amd import api
+    os.environ["ABPOA_HIP_HOSTGRAPH"] = "1"
+    try:
+        host = api.msa_batch(sets, params, n_threads=n_threads)
+    finally:
+        os.environ["ABPOA_HIP_HOSTGRAPH"] = "0"
+    dev = api.msa_batch(sets, params, n_threads=n_threads)
+    tm = api.msa_timing()
+    return host, dev, tm
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from abpoa_amd import ffi
+    lib = ffi.lib()
+    assert lib.abpoa_hip_device_count() >= 1
+    ffi.check(lib.abpoa_hip_init(0))
+    return lib
+
+
+@pytest.mark.parametrize("name,kw,shape", [
+    ("affine_5pct", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (48, 16, 400, 0.05)),
+    ("affine_15pct", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (24, 20, 300, 0.15)),
+    ("convex_default", dict(), (24, 12, 500, 0.10)),
+    ("ragged_tiny", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (16, 5, 40, 0.05)),
+])
+def test_device_driver_equals_host_driver(engine, name, kw, shape):
+    from abpoa_amd import api, synth
+    n_sets, n_reads, ln, err = shape
+    sets = [synth.make_read_set(11, i, n_reads if i % 5 else max(2, n_reads // 2), ln, err) for i in range(n_sets)]
+    host, dev, tm = _both(sets, api.Params(**kw))
+    assert tm["n_groups"] == 1 and tm["pad"] == 0, f"device driver not used for every set: {tm}"
+    for i, (a, b) in enumerate(zip(dev, host)):
+        assert a.status == 0 and b.status == 0
+        assert a.cons_seq == b.cons_seq, f"{name}: consensus of set {i} differs"
+        assert a.cons_cov == b.cons_cov, f"{name}: coverage of set {i} differs"
+        assert a.n_cells == b.n_cells, f"{name}: DP cell count of set {i} differs"
+
+
+def test_device_graph_equals_host_graph_after_every_read(engine):
+    """Runs in a child process because the check mode is chosen by an environment variable at call time and prints to stderr."""
+    code = ("import os,sys; sys.path.insert(0, %r)\n"
+            "from abpoa_amd import api, ffi, synth\n"
+            "lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
+            "sets = [synth.make_read_set(3, i, 10, 250, 0.08) for i in range(6)]\n"
+            "r = api.msa_batch(sets, api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), n_threads=4)\n"
+            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['pad'])\n" % ROOT)
+    env = dict(os.environ, ABPOA_HIP_DEVSYNC="1", ABPOA_HIP_HOSTGRAPH="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "OK True 0" in p.stdout
+    assert "graph check ok" in p.stderr and "FAILED" not in p.stderr, p.stderr[-3000:]
