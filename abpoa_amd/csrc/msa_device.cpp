@@ -49,6 +49,7 @@ struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
     size_t o_sets, o_roff, o_rlen, o_reads, o_mat, in_bytes;
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
+    size_t o_cnode, o_ccov, o_cbase;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
     size_t o_aln_desc, o_out_rec, o_rbase, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
@@ -110,7 +111,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         for (int r = 0; r < sets[s].n_reads; ++r) { max_qlen = std::max(max_qlen, sets[s].lens[r]); tot_bases += sets[s].lens[r]; }
     }
     std::vector<PoaSet> ps(n_sets);
-    int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0; int max_node_cap = 0;
+    int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
     for (int s = 0; s < n_sets; ++s) {
         PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
@@ -123,6 +124,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         S.pred0 = pred_tot; pred_tot += S.pred_cap;
         S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += S.cigar_cap;
         S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + cap + 1;
+        S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
         // arena: the widest score type the set can reach decides the cell size; columns per row as the band estimate of engine.cpp
         int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((mx + pn) / pn) * pn;
@@ -143,10 +145,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     L.o_mat = take(4 * sc->m * sc->m); L.in_bytes = o;
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
-    // downloaded part first (consensus needs it), contiguous
+    // downloaded part first, contiguous: per-set state and the consensus results
+    L.o_cnode = take(4 * cons_tot); L.o_ccov = take(4 * cons_tot); L.o_cbase = take(cons_tot);
+    const size_t dl_bytes = o;
     L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
     L.o_out = take(4 * node_tot * POA_OUT_CAP); L.o_outw = take(4 * node_tot * POA_OUT_CAP); L.o_nread = take(4 * node_tot);
-    const size_t dl_bytes = o;
     L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_IN_CAP); L.o_aln = take(4 * node_tot * POA_ALN_CAP); L.o_row = take(4 * node_tot);
     L.graph_bytes = o;
     o = 0;
@@ -188,6 +191,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
     p.row_base = dr + L.o_rbase; p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
     p.pred_off = (int32_t *)(dr + L.o_poff); p.pred_row = (int32_t *)(dr + L.o_pred); p.cigar = (uint64_t *)(dr + L.o_cigar);
+    p.cons_node = (int32_t *)(dg + L.o_cnode); p.cons_cov = (int32_t *)(dg + L.o_ccov); p.cons_base = dg + L.o_cbase;
 
     DevBatch b; memset(&b, 0, sizeof(b));
     b.n = n_sets; b.m = sc->m;
@@ -279,7 +283,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         dbg_check(k);
         HIP_OK(hipEventRecord(e[3], st), ABPOA_HIP_ELAUNCH);
     }
-    // ---- results: per-set state + the node arrays the consensus reads
+    // ---- consensus on the device, then one small download: per-set state + consensus (node ids, bases, coverage)
+    HIP_OK(launch_poa_consensus(p, st), ABPOA_HIP_ELAUNCH);
+    if (stage("consensus", max_reads)) return ABPOA_HIP_ELAUNCH;
     uint8_t *hg = C.graph.host;
     HIP_OK(hipMemcpyAsync(hg, dg, dl_bytes, hipMemcpyDeviceToHost, st), ABPOA_HIP_ELAUNCH);
     HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
@@ -298,32 +304,35 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         stats->n_rounds = max_reads > 0 ? max_reads - 1 : 0; stats->device_s = t_done - t_queue;
     }
 
-    // ---- consensus on host threads
+    // ---- results
     const PoaState *hs = (const PoaState *)(hg + L.o_state);
-    const int32_t *h_order[2] = {(const int32_t *)(hg + L.o_order0), (const int32_t *)(hg + L.o_order1)};
-    const uint8_t *h_base = hg + L.o_base, *h_nout = hg + L.o_nout;
-    const int32_t *h_out = (const int32_t *)(hg + L.o_out), *h_outw = (const int32_t *)(hg + L.o_outw), *h_nread = (const int32_t *)(hg + L.o_nread);
-    if (n_threads < 1) n_threads = 1;
-    std::atomic<int> next{0};
+    const int32_t *h_cnode = (const int32_t *)(hg + L.o_cnode), *h_ccov = (const int32_t *)(hg + L.o_ccov); const uint8_t *h_cbase = hg + L.o_cbase;
     std::vector<char> need_fb(n_sets, 0);
-    auto worker = [&]() {
-        std::vector<int> ids, cov, score, mo; std::vector<uint8_t> bases;
-        for (int s; (s = next.fetch_add(1)) < n_sets;) {
-            abpoa_hip_msa_t &o_ = out[s];
-            memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
-            if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
-            const int64_t N0 = ps[s].node0;
-            consensus_flat(hs[s].n_nodes, h_order[hs[s].order_buf] + N0, h_base + N0, h_nout + N0, h_out + N0 * POA_OUT_CAP, h_outw + N0 * POA_OUT_CAP, h_nread + N0,
-                           &ids, &bases, &cov, score, mo);
-            o_.n_cells = hs[s].n_cells; o_.cons_len = (int)ids.size();
-            o_.cons_base = (uint8_t *)malloc(ids.size() + 1); o_.cons_cov = (int32_t *)malloc(4 * (ids.size() + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (ids.size() + 1));
-            memcpy(o_.cons_base, bases.data(), bases.size()); memcpy(o_.cons_cov, cov.data(), 4 * cov.size()); memcpy(o_.cons_node_id, ids.data(), 4 * ids.size());
+    (void)n_threads;
+    for (int s = 0; s < n_sets; ++s) {
+        abpoa_hip_msa_t &o_ = out[s];
+        memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
+        if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
+        const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
+        o_.n_cells = hs[s].n_cells; o_.cons_len = len;
+        o_.cons_base = (uint8_t *)malloc(len + 1); o_.cons_cov = (int32_t *)malloc(4 * (len + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (len + 1));
+        memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len); memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
+    }
+    if (dbg_sync) {      // cross-check the device consensus of the first sets against the host routine on the downloaded graph
+        for (int s = 0; s < std::min(n_sets, 4); ++s) {
+            if (hs[s].status != POA_ST_OK) continue;
+            const PoaSet &S = ps[s]; const int n = hs[s].n_nodes;
+            std::vector<uint8_t> base(n), nout(n); std::vector<int32_t> outv((size_t)n * POA_OUT_CAP), outw((size_t)n * POA_OUT_CAP), nread(n), order(n);
+            auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
+            dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl(outv.data(), p.nd_out, 4, POA_OUT_CAP); dl(outw.data(), p.nd_outw, 4, POA_OUT_CAP);
+            dl(nread.data(), p.nd_nread, 4, 1); dl(order.data(), p.row_node[hs[s].order_buf], 4, 1);
+            std::vector<int> ids, cov, sc_, mo; std::vector<uint8_t> bases;
+            consensus_flat(n, order.data(), base.data(), nout.data(), outv.data(), outw.data(), nread.data(), &ids, &bases, &cov, sc_, mo);
+            bool same = (int)ids.size() == out[s].cons_len;
+            for (size_t i = 0; same && i < ids.size(); ++i) same = ids[i] == out[s].cons_node_id[i] && bases[i] == out[s].cons_base[i] && cov[i] == out[s].cons_cov[i];
+            fprintf(stderr, "[poa-device]   set %d: consensus check %s (device %d, host %zu bases)\n", s, same ? "ok" : "FAILED", out[s].cons_len, ids.size());
         }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
+    }
     for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(s);
     if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -28,11 +28,13 @@ struct PoaSet {                    // immutable per read-set
     int64_t pred0;                 // first slot in pred_row
     int64_t plane_off, plane_cap;  // arena: byte offset, capacity in bytes
     int64_t cigar_off; int32_t cigar_cap, pad2;
-    int64_t scratch0;              // first slot of this set's int32 scratch (2 * max_qlen + node_cap entries)
+    int64_t scratch0;              // first slot of this set's int32 scratch (3 * max_qlen + node_cap + 1 entries)
+    int64_t cons0; int32_t cons_cap, pad3;     // this set's slice of the consensus result pools
 };
 
 struct PoaState {                  // mutable per read-set
-    int32_t n_nodes, status, order_buf, pad;     // order_buf: which row_node buffer is current
+    int32_t n_nodes, status, order_buf, pad;     // order_buf: which row_node buffer is current; pad: fall-back reason
+    int32_t cons_len, pad1;        // heaviest-bundling consensus length (poa_consensus_kernel)
     int64_t n_cells;               // DP cells over all alignments so far
     int64_t algo_bytes;            // cells * algorithmic bytes per cell (affine 5S, convex 8S; S = 2 | 4)
 };
@@ -54,10 +56,13 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     AlnDesc *aln; AlnOut *out;
     uint8_t *row_base; int32_t *row_node_id, *row_remain, *pred_off, *pred_row;
     uint64_t *cigar;
+    // consensus results (poa_consensus_kernel), indexed cons0 + position
+    int32_t *cons_node, *cons_cov; uint8_t *cons_base;
 };
 
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s);
+hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s);
 
 }  // namespace abpoa_hip

@@ -306,6 +306,84 @@ __global__ void __launch_bounds__(64) poa_fuse_kernel(const PoaDev p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// after the last round: heaviest-bundling consensus, reference src/abpoa_output.c:361-415 (scores) and :343-356 (path).
+// score[u] = w* + score[t*] where w* is the largest out-edge weight and t* the target with the best score among the
+// edges of weight w* (ties: the LAST such edge; for the source: best weight, then best score, ties: the FIRST).  The
+// reference fills these in a reverse Kahn walk; they are functions of the successors only, so any reverse topological
+// order gives the same values.  Here: 64-row blocks from the sink upwards, lane = row; inside a block a lane fires as soon
+// as the in-block targets among its heaviest edges are done (their scores travel through LDS), everything above the block
+// is final in HBM.  Then the path is walked from the source, block by block through LDS.
+__global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    PoaState *st = p.state + s;
+    if (st->status != POA_ST_OK) return;
+    const int n = st->n_nodes;
+    if (n <= 2) { if (lane == 0) st->cons_len = 0; return; }
+    const int64_t N0 = S.node0;
+    const int32_t *order = p.row_node[st->order_buf] + N0;
+    int32_t *score = p.row_remain + N0;          // per ROW (pools of the DP inputs, free after the last round)
+    int32_t *nextrow = p.row_node_id + N0;       // per row: row of the chosen successor (-1: none)
+    __shared__ int sh_score[64], sh_next[64], sh_node[64];
+    for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
+        const int r = t0 + lane; const bool valid = r < n;
+        const int u = valid ? order[r] : 1;
+        const int no = valid ? (int)p.nd_nout[N0 + u] : 0;
+        // heaviest weight and the rows of the candidate targets (edges with that weight), as a dependency mask inside the block
+        int wmax = INT_MIN;
+        for (int t = 0; t < no; ++t) wmax = imax_(wmax, p.nd_outw[(N0 + u) * POA_OUT_CAP + t]);
+        unsigned long long dep = 0;
+        for (int t = 0; t < no; ++t) if (p.nd_outw[(N0 + u) * POA_OUT_CAP + t] == wmax) {
+            const int tr = p.nd_row[N0 + p.nd_out[(N0 + u) * POA_OUT_CAP + t]];
+            if (tr < t0 + 64) dep |= 1ull << (tr - t0);
+        }
+        bool done = !valid; int my_score = 0, my_next = -1;
+        if (valid && no == 0) { done = true; }                                  // the sink: score 0, no successor
+        unsigned long long done_mask = __ballot(done);
+        sh_score[lane] = 0; sh_next[lane] = -1;
+        __syncthreads();
+        for (int it = 0; it < 64 && done_mask != ~0ull; ++it) {
+            const bool fire = !done && (dep & ~done_mask) == 0;
+            if (fire) {
+                int best_sc = INT_MIN, best_row = -1; const bool is_src = u == 0;
+                for (int t = 0; t < no; ++t) if (p.nd_outw[(N0 + u) * POA_OUT_CAP + t] == wmax) {
+                    const int tr = p.nd_row[N0 + p.nd_out[(N0 + u) * POA_OUT_CAP + t]];
+                    const int sc_ = tr < t0 + 64 ? sh_score[tr - t0] : ld_fresh(score + tr);
+                    if (best_row < 0 || (is_src ? sc_ > best_sc : sc_ >= best_sc)) { best_sc = sc_; best_row = tr; }
+                }
+                my_score = wmax + best_sc; my_next = best_row; done = true;
+                sh_score[lane] = my_score;
+            }
+            __syncthreads();
+            done_mask |= __ballot(fire);
+        }
+        if (valid) { score[r] = my_score; nextrow[r] = my_next; }
+        __syncthreads();
+    }
+    // ---- path: rows from the source's choice to the sink
+    int cur = ld_fresh(nextrow + 0), len = 0; bool overflow = false;
+    const int sink_row = n - 1;                   // the sink is always the last row
+    while (cur >= 0 && cur < sink_row) {
+        const int t0 = cur & ~63;
+        const int r = t0 + lane;
+        sh_next[lane] = r < n ? ld_fresh(nextrow + r) : -1;
+        sh_node[lane] = r < n ? order[r] : 0;
+        __syncthreads();
+        while (cur >= t0 && cur < t0 + 64 && cur < sink_row) {
+            const int u = sh_node[cur - t0];
+            if (len < S.cons_cap) { if (lane == 0) { p.cons_node[S.cons0 + len] = u; p.cons_base[S.cons0 + len] = p.nd_base[N0 + u]; p.cons_cov[S.cons0 + len] = p.nd_nread[N0 + u]; } }
+            else overflow = true;
+            ++len;
+            cur = sh_next[cur - t0];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { st->cons_len = len; if (overflow) { st->status = POA_ST_FALLBACK; st->pad = 5; } }
+}
+
 static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.n_sets), dim3(64), 0, s, p);
@@ -314,5 +392,6 @@ static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStrea
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s) { return launch_k(poa_init_kernel, p, s); }
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) { return launch_k(poa_prepare_kernel, p, s); }
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) { return launch_k(poa_fuse_kernel, p, s); }
+hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
 
 }  // namespace abpoa_hip

@@ -65,4 +65,4 @@ def test_device_graph_equals_host_graph_after_every_read(engine):
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "OK True 0" in p.stdout
-    assert "graph check ok" in p.stderr and "FAILED" not in p.stderr, p.stderr[-3000:]
+    assert "graph check ok" in p.stderr and "consensus check ok" in p.stderr and "FAILED" not in p.stderr, p.stderr[-3000:]
