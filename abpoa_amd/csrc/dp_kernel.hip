@@ -58,6 +58,10 @@ struct BtLds {              // fixed part of the backtrack-phase LDS image
     long long coff[BTR + 1];
     int32_t bsn[BTR], esn[BTR], poff[BTR + 1], nid[BTR], pred[BTP];
     uint8_t base[BTR];
+    // lane-parallel walk (cell-record arenas): one record per window row and per predecessor edge, so that a step is two LDS
+    // round trips.  rinfo = {first column | columns << 16, arena offset (values, relative to the window), edge index | n_pred << 16 |
+    // base << 24, node id}; edge = {predecessor row, its rinfo.x, its rinfo.y, inside the window?}; edge2 = {its rinfo.z, its rinfo.w}
+    int4 rinfo[BTR]; int4 edge[BTP]; int2 edge2[BTP];
 };
 int lds_fixed_bytes_dp() { return (int)((sizeof(DpLds) + 15) & ~15u); }
 int lds_fixed_bytes_bt() { return (int)((sizeof(BtLds) + 15) & ~15u); }
@@ -125,19 +129,24 @@ __device__ __forceinline__ unsigned wave_max_u32_b(unsigned x) {
 
 
 // inclusive prefix max over the 64 lanes (Hillis-Steele inside each 16-lane DPP row, then row_bcast:15 / row_bcast:31).
-// Written as asm: hipcc does not fold update_dpp(old = x, src = x) into the max and emits 4 instructions per step.
-// s_nop 1 = the two wait states a DPP read needs after a VALU write of the same VGPR.
-#define DPP_SCAN6(OP)                                                                                                    \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                        \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-__device__ __forceinline__ int wave_scan_max_i32(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return x; }
-// wave-wide unsigned max, result valid in lane 63 only (the same six steps), returned as a wave-uniform value
-__device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) { asm(DPP_SCAN6("v_max_u32_dpp") : "+v"(x)); return (unsigned)__builtin_amdgcn_readlane((int)x, 63); }
-__device__ __forceinline__ int wave_max_i32_s(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return __builtin_amdgcn_readlane(x, 63); }
+// `old` = the identity of the operation: hipcc then folds every step into ONE v_max_*_dpp (with old = x it emits
+// mov + mov_dpp + max), and, unlike an asm block, it may fill the two DPP wait states with independent instructions.
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_id(int ident, int src) { return __builtin_amdgcn_update_dpp(ident, src, CTRL, RM, 0xF, false); }
+__device__ __forceinline__ int wave_scan_max_i32(int x) {
+    x = imax(x, dpp_id<0x111, 0xF>(INT_MIN, x)); x = imax(x, dpp_id<0x112, 0xF>(INT_MIN, x));
+    x = imax(x, dpp_id<0x114, 0xF>(INT_MIN, x)); x = imax(x, dpp_id<0x118, 0xF>(INT_MIN, x));
+    x = imax(x, dpp_id<0x142, 0xA>(INT_MIN, x)); x = imax(x, dpp_id<0x143, 0xC>(INT_MIN, x));
+    return x;
+}
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+// wave-wide max (the same six steps; the result is complete in lane 63), returned as a wave-uniform value
+__device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) {
+    x = umax_(x, (unsigned)dpp_id<0x111, 0xF>(0, (int)x)); x = umax_(x, (unsigned)dpp_id<0x112, 0xF>(0, (int)x));
+    x = umax_(x, (unsigned)dpp_id<0x114, 0xF>(0, (int)x)); x = umax_(x, (unsigned)dpp_id<0x118, 0xF>(0, (int)x));
+    x = umax_(x, (unsigned)dpp_id<0x142, 0xA>(0, (int)x)); x = umax_(x, (unsigned)dpp_id<0x143, 0xC>(0, (int)x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ int wave_max_i32_s(int x) { return __builtin_amdgcn_readlane(wave_scan_max_i32(x), 63); }
 // keeps a wave-uniform value in an SGPR and hides it from pattern matching (hipcc otherwise turns scalar min/max chains
 // into VALU v_min3/v_max3 + v_readfirstlane)
 __device__ __forceinline__ int sgpr(int x) { x = __builtin_amdgcn_readfirstlane(x); asm("" : "+s"(x)); return x; }
@@ -877,6 +886,21 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
             }
             __syncthreads();
+            if (CW > 0 && bt_hi >= bt_lo) {
+                const int nrow = bt_hi - bt_lo + 1;
+                if (lane < nrow) {
+                    const int np_ = B.poff[lane + 1] - B.poff[lane];
+                    B.rinfo[lane] = make_int4((B.bsn[lane] * PN) | (((B.esn[lane] - B.bsn[lane] + 1) * PN) << 16), (int)(B.coff[lane] - bt_c0),
+                                              ((B.poff[lane] - bt_pbase) & 0xffff) | (imin(np_, 255) << 16) | ((int)B.base[lane] << 24), B.nid[lane]);
+                }
+                __syncthreads();
+                for (int e = lane; e < pn_t; e += 64) {
+                    const int pr_ = B.pred[e]; const bool ok = pr_ >= bt_lo && pr_ <= bt_hi;
+                    const int4 ri_ = B.rinfo[ok ? pr_ - bt_lo : 0];
+                    B.edge[e] = make_int4(pr_, ri_.x, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int2(ri_.z, ri_.w);
+                }
+                __syncthreads();
+            }
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
         auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
@@ -918,64 +942,71 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         //      predecessor k -- then the reference's priority order (:109-429) is evaluated on ballot masks.  Falls through to
         //      the one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
         do {      // fast steps; one slow step whenever a fast one cannot be taken; back to fast steps
+        // ---- lane-parallel step (cell-record arenas, i.e. the fast path).  The current row's record is carried in SGPRs; round
+        //      trip 1 fetches its predecessor edge records (lane k = predecessor k), its own cells and the query code, round trip 2
+        //      the predecessors' cells and the substitution score; the reference's priority order (:109-429) is then evaluated on
+        //      ballot masks and the chosen predecessor's record becomes the current one.  Falls through to ONE step of the
+        //      one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
+        int4 cr = make_int4(0, 0, 0, 0); int cr_row = -1;                        // rinfo of row cr_row
         while (CW > 0 && i > 0 && j > 0 && status == 0) {
-            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
+            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) { load_window(i); cr_row = -1; }
             if (i < bt_lo || i > bt_hi) break;                                   // row does not fit the window: slow walk
-            const int ti = i - bt_lo;
-            const int ps = B.poff[ti], np = B.poff[ti + 1] - ps, id = B.nid[ti], bs_ = B.base[ti];
-            const int pbi = B.bsn[ti] * PN, Wi = (B.esn[ti] - B.bsn[ti] + 1) * PN; const long long offi = B.coff[ti] - bt_c0;
-            if (np > 64 || ps - bt_pbase + np > BTP) break;
-            const int pk = lane < np ? B.pred[ps - bt_pbase + lane] : bt_lo;
-            if (__any(lane < np && (pk < bt_lo || pk > bt_hi))) { if (i != bt_hi) { load_window(i); continue; } break; }
-            const int tk = pk - bt_lo;
-            const int pbk = B.bsn[tk] * PN, Wk = (B.esn[tk] - B.bsn[tk] + 1) * PN; const long long offk = B.coff[tk] - bt_c0;
-            const int qc = qcode(j - 1);
-            const int sc_ = s_mat[m * bs_ + qc];
-            // scores: own row at j and j-1, predecessor k at j-1 (H) and j (H, E1[, E2])
+            if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr_row = i; }
+            const int pbi = cr.x & 0xffff, Wi = (int)((unsigned)cr.x >> 16), offi = cr.y;
+            const int eb = cr.z & 0xffff, np = (cr.z >> 16) & 0xff, bs_ = (int)((unsigned)cr.z >> 24), id = cr.w;
+            if (np > 64 || eb + np > BTP) break;
+            // round trip 1
+            const int4 er = B.edge[eb + (lane < np ? lane : 0)]; const int2 er2 = B.edge2[eb + (lane < np ? lane : 0)];
             const int xi = j - pbi;
-            const T *ri = bt + offi + (long long)xi * CW;
-            const int Hij = (int)ri[0];
+            const T *ri = bt + offi + xi * CW;
+            const int Hij = (int)ri[0], E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0, F1ij = (int)ri[PL_F1], F2ij = GAP == 2 ? (int)ri[PL_F2] : 0;
             const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
-            const int xk = j - pbk;
-            const bool act = lane < np, in_j = act && (unsigned)xk < (unsigned)Wk, in_jm1 = act && (unsigned)(xk - 1) < (unsigned)Wk;
-            const T *rk = bt + offk + (long long)(in_j ? xk : 0) * CW, *rkm1 = bt + offk + (long long)(in_jm1 ? xk - 1 : 0) * CW;
+            const T *rim1 = bt + offi + (st_jm1 ? xi - 1 : xi) * CW;
+            const int Hijm1 = (int)rim1[0], F1ijm1 = (int)rim1[PL_F1], F2ijm1 = GAP == 2 ? (int)rim1[PL_F2] : 0;
+            const int qc = qcode(j - 1);
+            const bool act = lane < np;
+            if (__any(act && er.w == 0)) { if (i != bt_hi) { load_window(i); cr_row = -1; continue; } break; }
+            // round trip 2
+            const int pbk = er.y & 0xffff, Wk = (int)((unsigned)er.y >> 16), xk = j - pbk;
+            const bool in_j = act && (unsigned)xk < (unsigned)Wk, in_jm1 = act && (unsigned)(xk - 1) < (unsigned)Wk;
+            const T *rk = bt + er.z + (in_j ? xk : 0) * CW, *rkm1 = bt + er.z + (in_jm1 ? xk - 1 : 0) * CW;
             const int Hk_j = (int)rk[0], E1k_j = (int)rk[PL_E1], E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
+            const int sc_ = s_mat[m * bs_ + qc];
             start_i = i; start_j = j; ++bt_steps;
             const unsigned long long mA = __ballot(in_jm1 && Hk_jm1 + sc_ == Hij);
-            int hit = 0;
+            int hit = 0, k_sel = -1;
             auto do_match = [&](int set_indel) __attribute__((always_inline)) {
                 if (!mA) return;
-                const int k = __builtin_ctzll(mA);
+                k_sel = __builtin_ctzll(mA);
                 cur_op = OP_ALL; hit = 1;
                 push(ABPOA_HIP_CMATCH, 1, id, j - 1);
-                i = __builtin_amdgcn_readlane(pk, k); --j; ++n_aln; n_match += (bs_ == qc);
+                --j; ++n_aln; n_match += (bs_ == qc);
                 if (set_indel) indel_first = 0;
             };
             if ((cur_op & OP_M) && indel_first == 0) do_match(0);
             if (!hit && (cur_op & OP_E)) {
-                const int E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0;
                 const bool viaM = cur_op & OP_M;
                 unsigned long long m1 = 0, m2 = 0;
                 if (cur_op & OP_E1) m1 = __ballot(in_j && (viaM ? Hij == E1k_j : E1ij == E1k_j - (int)e1));
                 if (GAP == 2 && (cur_op & OP_E2)) m2 = __ballot(in_j && (viaM ? Hij == E2k_j : E2ij == E2k_j - (int)e2));
                 if (m1 | m2) {                                                   // first predecessor in list order, E1 before E2 for the same one
                     const int k1 = m1 ? __builtin_ctzll(m1) : 64, k2 = m2 ? __builtin_ctzll(m2) : 64;
-                    const bool use1 = k1 <= k2; const int k = use1 ? k1 : k2;
+                    const bool use1 = k1 <= k2; k_sel = use1 ? k1 : k2;
                     const unsigned long long mD = __ballot(in_j && (use1 ? Hk_j - (int)oe1 == E1k_j : Hk_j - (int)oe2 == E2k_j));
-                    cur_op = ((mD >> k) & 1) ? (OP_M | OP_F) : (use1 ? OP_E1 : OP_E2);
-                    hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); i = __builtin_amdgcn_readlane(pk, k);
+                    cur_op = ((mD >> k_sel) & 1) ? (OP_M | OP_F) : (use1 ? OP_E1 : OP_E2);
+                    hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1);
                 }
             }
             if (!hit && (cur_op & OP_F)) {
                 for (int x = 1; x <= (GAP == 2 ? 2 : 1) && !hit; ++x) {
-                    const int bit = x == 1 ? OP_F1 : OP_F2, pl = x == 1 ? PL_F1 : PL_F2;
+                    const int bit = x == 1 ? OP_F1 : OP_F2;
                     const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
                     if (!(cur_op & bit)) continue;
-                    const int Fij = (int)ri[pl];
+                    const int Fij = x == 1 ? F1ij : F2ij;
                     if (!(cur_op & OP_M) || Hij == Fij) {
                         if (st_jm1) {
-                            if ((int)ri[-CW] - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
-                            else if ((int)ri[-CW + pl] - ex == Fij) { cur_op = bit; hit = 1; }
+                            if (Hijm1 - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
+                            else if ((x == 1 ? F1ijm1 : F2ijm1) - ex == Fij) { cur_op = bit; hit = 1; }
                         }
                     }
                 }
@@ -983,6 +1014,11 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
+            if (k_sel >= 0) {                                                    // move to the chosen predecessor: its record comes along
+                i = __builtin_amdgcn_readlane(er.x, k_sel);
+                cr = make_int4(__builtin_amdgcn_readlane(er.y, k_sel), __builtin_amdgcn_readlane(er.z, k_sel), __builtin_amdgcn_readlane(er2.x, k_sel), __builtin_amdgcn_readlane(er2.y, k_sel));
+                cr_row = i;
+            }
         }
         int slow_budget = CW > 0 ? 1 : INT_MAX;
         while (i > 0 && j > 0 && status == 0 && slow_budget-- > 0) {

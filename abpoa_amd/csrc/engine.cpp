@@ -88,7 +88,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
     const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
     L.bt_off = lds_fixed_bytes_bt();
-    L.bt_bytes = std::max(32 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;      // staged arena window of the backtrack
+    L.bt_bytes = std::max(24 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;      // staged arena window of the backtrack
     // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
     const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
     L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally

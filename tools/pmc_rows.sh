@@ -11,6 +11,6 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"][:60]; acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
 for k, v in acc.items():
-    if "dp_" in k: print(k, {c: round(x / 3) for c, x in v.items()})   # 3 iterations in kernel_bench
+    if "dp_" in k: print(k[:50], {c: round(x / 3 / 1000 / 1400, 1) for c, x in v.items()}, "(per alignment-step, ~1400 steps or rows)")   # 3 iterations in kernel_bench
 PY
 done
