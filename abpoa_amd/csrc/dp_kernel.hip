@@ -1908,9 +1908,9 @@ __global__ void __launch_bounds__(64) dp_fast_tail_kernel(const DevBatch b) {
 }
 
 template <typename K>
-static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream) {
+static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int lds_bytes = -1) {
     dim3 grid(b.n), block(64);
-    const size_t lds = (size_t)b.lds.total;
+    const size_t lds = (size_t)(lds_bytes >= 0 ? lds_bytes : b.lds.total);
     if (lds > 65536) { hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, b);
     return hipGetLastError();
@@ -1922,9 +1922,9 @@ hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent
     if (b.n <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
     if (n_fast > 0) {
-        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) e = launch_one(dp_fast_kernel<1>, b, stream); else e = launch_one(dp_fast_kernel<2>, b, stream);
+        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) e = launch_one(dp_fast_kernel<1>, b, stream, b.lds.total_rows); else e = launch_one(dp_fast_kernel<2>, b, stream, b.lds.total_rows);
         if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
-        if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream) : launch_one(dp_fast_tail_kernel<2>, b, stream);
+        if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream, b.lds.total_tail) : launch_one(dp_fast_tail_kernel<2>, b, stream, b.lds.total_tail);
         if (e != hipSuccess) return e;
     }
     if (n_fast < b.n) {
@@ -1940,9 +1940,9 @@ hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent
 // the two fast-path kernels alone (device-resident driver: every alignment of the batch is fast-eligible or skipped)
 hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows) {
     if (b.n <= 0) return hipSuccess;
-    hipError_t e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_kernel<1>, b, stream) : launch_one(dp_fast_kernel<2>, b, stream);
+    hipError_t e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_kernel<1>, b, stream, b.lds.total_rows) : launch_one(dp_fast_kernel<2>, b, stream, b.lds.total_rows);
     if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
-    if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream) : launch_one(dp_fast_tail_kernel<2>, b, stream);
+    if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream, b.lds.total_tail) : launch_one(dp_fast_tail_kernel<2>, b, stream, b.lds.total_tail);
     return e;
 }
 

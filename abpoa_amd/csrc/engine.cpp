@@ -88,7 +88,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     if ((int64_t)L.ring_rows * npr * L.ring_cols * cell > 40 * 1024) L.ring_cols = 0;     // rows too wide: HBM path only
     const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
     L.bt_off = lds_fixed_bytes_bt();
-    L.bt_bytes = std::max(24 * 1024, L.ring_off + ring_bytes - L.bt_off) & ~15;      // staged arena window of the backtrack
+    // staged arena window of the backtrack: 24 KB, less when a long query already takes much of the 40 KB a workgroup may use
+    L.bt_bytes = std::max(std::max(8 * 1024, std::min(24 * 1024, 38 * 1024 - L.phase_off - L.bt_off)), L.ring_off + ring_bytes - L.bt_off) & ~15;
     // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
     const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
     L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally
@@ -99,6 +100,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
     const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
     L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
+    L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes;
 }
 
 int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *sh, unsigned flags) {

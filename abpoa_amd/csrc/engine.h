@@ -57,7 +57,8 @@ struct LdsPlan {
     // --- fast row loop (dp_kernel.hip rows_fast): packed H|E score ring [fr_rows][words][fr_cols + 4] dwords at phase_off + fr_off
     int32_t fr_off, fr_rows, fr_cols;   // fr_rows: power of two <= 64; fr_cols: multiple of 64, 0 = fast loop disabled
     int32_t mx_off;               // int32 [m*(m+1)]: score matrix with an extra all-zero query column (code m = "no query base")
-    int32_t total;                // dynamic LDS bytes to request
+    int32_t total;                // dynamic LDS bytes to request (general kernel: union of every phase)
+    int32_t total_rows, total_tail;   // the two fast-path kernels request only what their phase needs (4+ workgroups per CU must fit)
 };
 
 // Everything one launch needs; passed by value as the kernel argument.

@@ -92,7 +92,7 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
 }
 
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats) {
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor) {
     std::lock_guard<std::mutex> lk(g_mu);
     Cache &C = g_c;
     const int device = engine_device();
@@ -117,7 +117,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
         int64_t sum = 0; int mx = 0;
         for (int r = 0; r < sets[s].n_reads; ++r) { sum += sets[s].lens[r]; mx = std::max(mx, sets[s].lens[r]); }
-        const int64_t cap = std::min<int64_t>(2 + sum, 2 + 5LL * mx + 1024);
+        const int64_t cap = std::min<int64_t>(2 + sum, 2 + (int64_t)(node_factor * mx) + 1024);      // graph nodes this set may grow to on the device
         S.n_reads = sets[s].n_reads; S.node_cap = (int)cap; S.pred_cap = (int)(4 * cap);
         S.read0 = read_i; read_i += sets[s].n_reads;
         S.node0 = node_tot; node_tot += cap + 1;

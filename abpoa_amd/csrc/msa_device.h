@@ -18,8 +18,9 @@ struct DeviceRunStats {
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 
 // Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
-// them) and must be redone by the host driver.  ABPOA_HIP_ENOMEM / EINVAL: nothing was computed, use the host driver.
+// them) and must be redone (with a larger node_factor, or by the host driver).  node_factor: node slots per set = factor x
+// longest read.  ABPOA_HIP_ENOMEM: the job does not fit the device (split it); EINVAL: not a job for the device driver.
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats);
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor);
 
 }  // namespace abpoa_hip
