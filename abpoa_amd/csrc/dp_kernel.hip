@@ -129,24 +129,20 @@ __device__ __forceinline__ unsigned wave_max_u32_b(unsigned x) {
 
 
 // inclusive prefix max over the 64 lanes (Hillis-Steele inside each 16-lane DPP row, then row_bcast:15 / row_bcast:31).
-// `old` = the identity of the operation: hipcc then folds every step into ONE v_max_*_dpp (with old = x it emits
-// mov + mov_dpp + max), and, unlike an asm block, it may fill the two DPP wait states with independent instructions.
-template <int CTRL, int RM> __device__ __forceinline__ int dpp_id(int ident, int src) { return __builtin_amdgcn_update_dpp(ident, src, CTRL, RM, 0xF, false); }
-__device__ __forceinline__ int wave_scan_max_i32(int x) {
-    x = imax(x, dpp_id<0x111, 0xF>(INT_MIN, x)); x = imax(x, dpp_id<0x112, 0xF>(INT_MIN, x));
-    x = imax(x, dpp_id<0x114, 0xF>(INT_MIN, x)); x = imax(x, dpp_id<0x118, 0xF>(INT_MIN, x));
-    x = imax(x, dpp_id<0x142, 0xA>(INT_MIN, x)); x = imax(x, dpp_id<0x143, 0xC>(INT_MIN, x));
-    return x;
-}
-__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
-// wave-wide max (the same six steps; the result is complete in lane 63), returned as a wave-uniform value
-__device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) {
-    x = umax_(x, (unsigned)dpp_id<0x111, 0xF>(0, (int)x)); x = umax_(x, (unsigned)dpp_id<0x112, 0xF>(0, (int)x));
-    x = umax_(x, (unsigned)dpp_id<0x114, 0xF>(0, (int)x)); x = umax_(x, (unsigned)dpp_id<0x118, 0xF>(0, (int)x));
-    x = umax_(x, (unsigned)dpp_id<0x142, 0xA>(0, (int)x)); x = umax_(x, (unsigned)dpp_id<0x143, 0xC>(0, (int)x));
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-}
-__device__ __forceinline__ int wave_max_i32_s(int x) { return __builtin_amdgcn_readlane(wave_scan_max_i32(x), 63); }
+// Written as asm: with update_dpp(old = x, src = x) hipcc emits mov + mov_dpp + max per step; with old = identity it folds
+// to one v_max_*_dpp but schedules the surrounding code worse (measured 2 % slower rows).  s_nop 1 = the two wait states a
+// DPP read needs after a VALU write of the same VGPR.
+#define DPP_SCAN6(OP)                                                                                                    \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                        \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+__device__ __forceinline__ int wave_scan_max_i32(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return x; }
+// wave-wide max (the same six steps; complete in lane 63), returned as a wave-uniform value
+__device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) { asm(DPP_SCAN6("v_max_u32_dpp") : "+v"(x)); return (unsigned)__builtin_amdgcn_readlane((int)x, 63); }
+__device__ __forceinline__ int wave_max_i32_s(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return __builtin_amdgcn_readlane(x, 63); }
 // keeps a wave-uniform value in an SGPR and hides it from pattern matching (hipcc otherwise turns scalar min/max chains
 // into VALU v_min3/v_max3 + v_readfirstlane)
 __device__ __forceinline__ int sgpr(int x) { x = __builtin_amdgcn_readfirstlane(x); asm("" : "+s"(x)); return x; }
