@@ -206,8 +206,15 @@ def main():
         # rate while kernels are resident is ~n_groups x the per-launch figure (reported as achieved_device).
         ach = st["algo_bytes"] / (st["kernel_ms"] / 1e3) / 1e9 if st["kernel_ms"] > 0 else 0.0
         n_groups = max(1, api.msa_timing()["n_groups"])
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process; the number measured for this very
+        # command by tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)
+        # is kept under profiles/ and reported here when the workload matches.
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r1_v5_pmc_traffic_cfg2.json")
+        if args.workload == "cfg2" and n_sets == 1000 and os.path.exists(tp):
+            traffic = json.load(open(tp))["hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel": "abpoa_hip::dp_fast_kernel (row loop; the global-best + backtrack tail kernel is timed apart: tail_ms_total)",
                            "tail_ms_total": round(st.get("tail_ms", 0.0), 3), "launches": st["n_launches"],
                            "avg_launch_ms": round(st["kernel_ms"] / max(1, st["n_launches"]), 4),
