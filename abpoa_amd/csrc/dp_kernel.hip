@@ -60,8 +60,10 @@ struct BtLds {              // fixed part of the backtrack-phase LDS image
     uint8_t base[BTR];
     // lane-parallel walk (cell-record arenas): one record per window row and per predecessor edge, so that a step is two LDS
     // round trips.  rinfo = {first column | columns << 16, arena offset (values, relative to the window), edge index | n_pred << 16 |
-    // base << 24, node id}; edge = {predecessor row, its rinfo.x, its rinfo.y, inside the window?}; edge2 = {its rinfo.z, its rinfo.w}
-    int4 rinfo[BTR]; int4 edge[BTP]; int2 edge2[BTP];
+    // base << 24, node id}; edge = {predecessor row, its rinfo.x, its rinfo.y, inside the window?}; edge2 = {its rinfo.z, its rinfo.w, its rinfo2, -}
+    int4 rinfo[BTR]; int4 edge[BTP]; int4 edge2[BTP];
+    int32_t rinfo2[BTR];        // staged column range of the row: first staged column | count << 16 (the window holds a column slice, not whole rows)
+    long long srcoff[BTR];      // arena offset (values) of the row's first staged record
 };
 int lds_fixed_bytes_dp() { return (int)((sizeof(DpLds) + 15) & ~15u); }
 int lds_fixed_bytes_bt() { return (int)((sizeof(BtLds) + 15) & ~15u); }
@@ -108,6 +110,12 @@ __device__ __forceinline__ long long gld_i64(GLOBAL_AS const int64_t *p) { long 
 __device__ __forceinline__ int gld_cell(GLOBAL_AS const int16_t *p) { int v; asm volatile("global_load_sshort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
 __device__ __forceinline__ int gld_cell(GLOBAL_AS const int32_t *p) { return gld_i32(p); }
 
+// Loads whose completion the CALLER waits for (s_waitcnt vmcnt(0) via gld_wait): used to keep many loads in flight where hipcc
+// would pair every load with its own wait.
+__device__ __forceinline__ void gld_async(int4 &v, const int4 *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int4 *)p) : "memory"); }
+__device__ __forceinline__ void gld_async(int2 &v, const int2 *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int2 *)p) : "memory"); }
+__device__ __forceinline__ void gld_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Moves a wave-uniform pointer into a VGPR pair and hides its uniformity from the compiler.  The kernel keeps ~20
 // per-alignment base pointers; left in SGPRs they (with the per-row uniforms) overflow the 102-SGPR budget and the hot
 // loop drowns in v_readlane/v_writelane spill traffic.  VGPRs are plentiful here (one wave per SIMD).
@@ -143,6 +151,13 @@ __device__ __forceinline__ int wave_scan_max_i32(int x) { asm(DPP_SCAN6("v_max_i
 // wave-wide max (the same six steps; complete in lane 63), returned as a wave-uniform value
 __device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) { asm(DPP_SCAN6("v_max_u32_dpp") : "+v"(x)); return (unsigned)__builtin_amdgcn_readlane((int)x, 63); }
 __device__ __forceinline__ int wave_max_i32_s(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return __builtin_amdgcn_readlane(x, 63); }
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_scan_add_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
 // keeps a wave-uniform value in an SGPR and hides it from pattern matching (hipcc otherwise turns scalar min/max chains
 // into VALU v_min3/v_max3 + v_readfirstlane)
 __device__ __forceinline__ int sgpr(int x) { x = __builtin_amdgcn_readfirstlane(x); asm("" : "+s"(x)); return x; }
@@ -833,7 +848,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
     // refilled cooperatively; only lane 0 writes cigar words.
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
-    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0;
+    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0, bt_wa = 0, bt_wb = 0, bt_wc = 0;
     if (status == 0 && b.ret_cigar) {
         BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
         T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
@@ -843,7 +858,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
         const int cap = d.cigar_cap;
         uint64_t last_word = 0;
-        long long win_ticks = 0; int n_windows = 0;
+        long long win_ticks = 0, win_a = 0, win_b = 0, win_c = 0; int n_windows = 0;
         auto load_window = [&](int hi) __attribute__((always_inline)) {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             __syncthreads();
@@ -882,21 +897,88 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
             }
             __syncthreads();
-            if (CW > 0 && bt_hi >= bt_lo) {
-                const int nrow = bt_hi - bt_lo + 1;
-                if (lane < nrow) {
-                    const int np_ = B.poff[lane + 1] - B.poff[lane];
-                    B.rinfo[lane] = make_int4((B.bsn[lane] * PN) | (((B.esn[lane] - B.bsn[lane] + 1) * PN) << 16), (int)(B.coff[lane] - bt_c0),
-                                              ((B.poff[lane] - bt_pbase) & 0xffff) | (imin(np_, 255) << 16) | ((int)B.base[lane] << 24), B.nid[lane]);
-                }
-                __syncthreads();
-                for (int e = lane; e < pn_t; e += 64) {
-                    const int pr_ = B.pred[e]; const bool ok = pr_ >= bt_lo && pr_ <= bt_hi;
-                    const int4 ri_ = B.rinfo[ok ? pr_ - bt_lo : 0];
-                    B.edge[e] = make_int4(pr_, ri_.x, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int2(ri_.z, ri_.w);
-                }
-                __syncthreads();
+            win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
+        };
+        // ---- window of the lane-parallel walk (cell-record arenas): rows [hi - R + 1, hi] x columns [jtop - WC + 1, jtop].  The walk
+        //      moves up-left (each step: a predecessor row and / or one column back), so a column SLICE of every row is enough;
+        //      with 10 kb reads a whole row is 4-8 KB and whole-row staging would hold 3-6 rows.  Leaving the slice (a long
+        //      insertion run) simply reloads the window at the current cell.
+        int win_i = -1, win_j = -1;                               // cell the current window was loaded for
+        bool win_narrow = false;                                  // the window holds whole rows (every cell of a window row is staged)
+        auto load_window_cols = [&](int hi, int jtop) __attribute__((always_inline)) {
+            const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
+            __syncthreads();
+            const int max_rec = (int)(bt_cells / CW);
+            const int WC = max_rec >= 2048 ? 64 : 48;
+            const int R = imin(BTR, imax(4, max_rec / WC));
+            const int lo = imax(0, hi - R + 1), nrow = hi - lo + 1;
+            const int r = lo + lane; const bool rv = lane < nrow;
+            int b_ = -1, e_ = -1, po = 0, po1 = 0, nid_ = 0, bs_ = 0; long long c_ = 0;
+            if (rv) { b_ = g_bsn[r]; e_ = g_esn[r]; c_ = g_coff[r]; po = pred_off[r]; po1 = pred_off[r + 1]; nid_ = row_node_id[r]; bs_ = row_base[r]; }
+            const int pbc = b_ >= 0 ? b_ * PN : 0, W = b_ >= 0 ? (e_ - b_ + 1) * PN : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long tw1 = (long long)__builtin_amdgcn_s_memtime(); win_a += tw1 - tw0;
+            const bool narrow = !__any(rv && W > WC);                   // every row fits whole: stage whole rows (they are adjacent in the arena)
+            const int sl = narrow ? pbc : imax(pbc, jtop - WC + 1), sh = narrow ? pbc + W : imin(pbc + W, jtop + 1), ns = rv ? imax(0, sh - sl) : 0;
+            const int incl = wave_scan_add_i32(ns);
+            const int off_rec = incl - ns;
+            const int pbase = __builtin_amdgcn_readfirstlane(po);
+            const int pn_t = imin(BTP, __builtin_amdgcn_readlane(po1, nrow - 1) - pbase);
+            if (rv) {
+                B.rinfo[lane] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (imin(po1 - po, 255) << 16) | (bs_ << 24), nid_);
+                B.rinfo2[lane] = sl | (ns << 16);
+                B.srcoff[lane] = c_ + (long long)(sl - pbc) * CW;
             }
+            __syncthreads();
+            const long long tw1b = (long long)__builtin_amdgcn_s_memtime(); win_a += tw1b - tw1;       // (debug split: scan + LDS tables)
+            // staged records: 8 rows per batch, lane = column inside the slice
+            typedef typename std::conditional<(CW * sizeof(T) == 8), int2, int4>::type RecT;       // 8-byte or 16-byte pieces (CW * sizeof(T) = 8, 16 or 32)
+            constexpr int PIECES = (int)(CW * sizeof(T) / sizeof(RecT));
+            // narrow bands: every slice is a whole row, and the rows are adjacent in the arena -> one contiguous 16-byte-wide copy
+            if (narrow) {
+                const long long c_lo = __builtin_amdgcn_readfirstlane((int)(c_ & 0xffffffffll)) | ((long long)__builtin_amdgcn_readfirstlane((int)(c_ >> 32)) << 32);
+                const int n16 = (int)((long long)__builtin_amdgcn_readlane(incl, 63) * CW * (int)sizeof(T) / 16);
+                const int4 *src = (const int4 *)(planes + c_lo); int4 *dst = (int4 *)bt;
+                for (int i0 = 0; i0 < n16; i0 += 64 * 8) {
+                    int4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; gld_async(v[u], src + (idx < n16 ? idx : 0)); }
+                    gld_wait();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
+                }
+            } else {
+                // slices: lane = column inside the slice, 16 rows per batch; the per-row constants travel by v_readlane, not through LDS
+                const int offv = off_rec * CW; const long long srcv = c_ + (long long)(sl - pbc) * CW;
+                const int src_lo = (int)(srcv & 0xffffffffll), src_hi = (int)(srcv >> 32);
+                for (int r0 = 0; r0 < nrow; r0 += 16) {
+                    RecT v[16][PIECES]; int nn[16], oo[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int rr = imin(r0 + u, nrow - 1);
+                        nn[u] = (r0 + u < nrow) ? __builtin_amdgcn_readlane(ns, rr) : 0; oo[u] = __builtin_amdgcn_readlane(offv, rr);
+                        const long long so = (long long)(unsigned)__builtin_amdgcn_readlane(src_lo, rr) | ((long long)__builtin_amdgcn_readlane(src_hi, rr) << 32);
+                        const RecT *src = (const RecT *)(planes + so) + (long long)(lane < nn[u] ? lane : 0) * PIECES;      // unconditional loads (a
+#pragma unroll                                                                                                           // conditional one is waited for at once)
+                        for (int q_ = 0; q_ < PIECES; ++q_) gld_async(v[u][q_], src + q_);
+                    }
+                    gld_wait();                             // all 16 loads in flight, one wait (hipcc pairs load / wait / store otherwise)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        RecT *dst = (RecT *)(bt + oo[u]) + lane * PIECES;
+#pragma unroll
+                        for (int q_ = 0; q_ < PIECES; ++q_) if (lane < nn[u]) dst[q_] = v[u][q_];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long tw2 = (long long)__builtin_amdgcn_s_memtime(); win_b += tw2 - tw1b;
+            for (int e = lane; e < pn_t; e += 64) {
+                const int pr_ = pred_row[pbase + e]; const bool ok = pr_ >= lo && pr_ <= hi;
+                const int4 ri_ = B.rinfo[ok ? pr_ - lo : 0];
+                B.edge[e] = make_int4(pr_, ri_.x, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int4(ri_.z, ri_.w, B.rinfo2[ok ? pr_ - lo : 0], 0);
+            }
+            __syncthreads();
+            bt_lo = lo; bt_hi = hi; bt_pbase = pbase; win_i = hi; win_j = jtop; win_narrow = narrow;
+            win_c += (long long)__builtin_amdgcn_s_memtime() - tw2;
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
         auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
@@ -914,7 +996,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         struct Geo { int pb, pe; long long off; bool in_tile; };
         auto geo_of = [&](int row_) __attribute__((always_inline)) {
             Geo g;
-            g.in_tile = row_ >= bt_lo && row_ <= bt_hi;
+            g.in_tile = CW == 0 && row_ >= bt_lo && row_ <= bt_hi;      // (cell-record arenas: the LDS window holds column slices for the lane-parallel walk only)
             const int i = g.in_tile ? row_ - bt_lo : 0;
             g.pb = B.bsn[i]; g.pe = B.esn[i]; g.off = B.coff[i] - bt_c0;
             if (!g.in_tile) { g.pb = gld_i32(g_bsn + row_); g.pe = gld_i32(g_esn + row_); g.off = gld_i64(g_coff + row_); }
@@ -937,35 +1019,43 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         //      (b) its predecessor list, (c) the predecessors' geometry, (d) every score the decision can need -- lane k holds
         //      predecessor k -- then the reference's priority order (:109-429) is evaluated on ballot masks.  Falls through to
         //      the one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
+        bool bt_walk_narrow = true;                                // false once a window had to be staged as column slices
         do {      // fast steps; one slow step whenever a fast one cannot be taken; back to fast steps
         // ---- lane-parallel step (cell-record arenas, i.e. the fast path).  The current row's record is carried in SGPRs; round
         //      trip 1 fetches its predecessor edge records (lane k = predecessor k), its own cells and the query code, round trip 2
         //      the predecessors' cells and the substitution score; the reference's priority order (:109-429) is then evaluated on
         //      ballot masks and the chosen predecessor's record becomes the current one.  Falls through to ONE step of the
         //      one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
-        int4 cr = make_int4(0, 0, 0, 0); int cr_row = -1;                        // rinfo of row cr_row
-        while (CW > 0 && i > 0 && j > 0 && status == 0) {
-            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) { load_window(i); cr_row = -1; }
-            if (i < bt_lo || i > bt_hi) break;                                   // row does not fit the window: slow walk
+        int4 cr = make_int4(0, 0, 0, 0); int cr2 = 0, cr_row = -1;               // rinfo / rinfo2 of row cr_row
+        // two copies of the step loop: whole-row windows (narrow bands: no slice bookkeeping at all) and column-slice windows
+        while (CW > 0 && i > 0 && j > 0 && status == 0 && bt_walk_narrow) {
+            if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; if (!win_narrow) { bt_walk_narrow = false; break; } }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr_row = i; }
             const int pbi = cr.x & 0xffff, Wi = (int)((unsigned)cr.x >> 16), offi = cr.y;
             const int eb = cr.z & 0xffff, np = (cr.z >> 16) & 0xff, bs_ = (int)((unsigned)cr.z >> 24), id = cr.w;
+            const int sli = pbi, nsi = Wi;                                      // whole rows are staged
             if (np > 64 || eb + np > BTP) break;
-            // round trip 1
-            const int4 er = B.edge[eb + (lane < np ? lane : 0)]; const int2 er2 = B.edge2[eb + (lane < np ? lane : 0)];
-            const int xi = j - pbi;
-            const T *ri = bt + offi + xi * CW;
-            const int Hij = (int)ri[0], E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0, F1ij = (int)ri[PL_F1], F2ij = GAP == 2 ? (int)ri[PL_F2] : 0;
+            // round trip 1: predecessor edge records, own cells, query code
+            const int4 er = B.edge[eb + (lane < np ? lane : 0)]; const int4 er2 = B.edge2[eb + (lane < np ? lane : 0)];
+            const int xi = j - pbi, si = j - sli;
             const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
-            const T *rim1 = bt + offi + (st_jm1 ? xi - 1 : xi) * CW;
+            bool need = false;
+            const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
+            const int Hij = (int)ri[0], E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0, F1ij = (int)ri[PL_F1], F2ij = GAP == 2 ? (int)ri[PL_F2] : 0;
+            const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
             const int Hijm1 = (int)rim1[0], F1ijm1 = (int)rim1[PL_F1], F2ijm1 = GAP == 2 ? (int)rim1[PL_F2] : 0;
             const int qc = qcode(j - 1);
             const bool act = lane < np;
-            if (__any(act && er.w == 0)) { if (i != bt_hi) { load_window(i); cr_row = -1; continue; } break; }
-            // round trip 2
+            // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
             const int pbk = er.y & 0xffff, Wk = (int)((unsigned)er.y >> 16), xk = j - pbk;
+            const int sk = xk, nsk = Wk;
             const bool in_j = act && (unsigned)xk < (unsigned)Wk, in_jm1 = act && (unsigned)(xk - 1) < (unsigned)Wk;
-            const T *rk = bt + er.z + (in_j ? xk : 0) * CW, *rkm1 = bt + er.z + (in_jm1 ? xk - 1 : 0) * CW;
+            need = __any(act && er.w == 0);
+            if (need) {                                                          // something this step reads is not staged: re-centre the window on (i, j) once
+                if (win_i == i && win_j == j) break;
+                load_window_cols(i, j); cr_row = -1; if (!win_narrow) { bt_walk_narrow = false; break; } continue;
+            }
+            const T *rk = bt + er.z + (in_j ? sk : 0) * CW, *rkm1 = bt + er.z + (in_jm1 ? sk - 1 : 0) * CW;
             const int Hk_j = (int)rk[0], E1k_j = (int)rk[PL_E1], E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
             const int sc_ = s_mat[m * bs_ + qc];
             start_i = i; start_j = j; ++bt_steps;
@@ -1016,10 +1106,89 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 cr_row = i;
             }
         }
+        while (CW > 0 && i > 0 && j > 0 && status == 0 && true) {
+            if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; }
+            if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }
+            const int pbi = cr.x & 0xffff, Wi = (int)((unsigned)cr.x >> 16), offi = cr.y;
+            const int eb = cr.z & 0xffff, np = (cr.z >> 16) & 0xff, bs_ = (int)((unsigned)cr.z >> 24), id = cr.w;
+            const int sli = cr2 & 0xffff, nsi = (int)((unsigned)cr2 >> 16);
+            if (np > 64 || eb + np > BTP) break;
+            // round trip 1: predecessor edge records, own cells, query code
+            const int4 er = B.edge[eb + (lane < np ? lane : 0)]; const int4 er2 = B.edge2[eb + (lane < np ? lane : 0)];
+            const int xi = j - pbi, si = j - sli;
+            const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
+            bool need = !win_narrow && ((unsigned)si >= (unsigned)nsi || (st_jm1 && si - 1 < 0));     // a cell of the own row outside the staged slice
+            const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
+            const int Hij = (int)ri[0], E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0, F1ij = (int)ri[PL_F1], F2ij = GAP == 2 ? (int)ri[PL_F2] : 0;
+            const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
+            const int Hijm1 = (int)rim1[0], F1ijm1 = (int)rim1[PL_F1], F2ijm1 = GAP == 2 ? (int)rim1[PL_F2] : 0;
+            const int qc = qcode(j - 1);
+            const bool act = lane < np;
+            // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
+            const int pbk = er.y & 0xffff, Wk = (int)((unsigned)er.y >> 16), xk = j - pbk;
+            const int slk = er2.z & 0xffff, nsk = (int)((unsigned)er2.z >> 16), sk = j - slk;
+            const bool in_j = act && (unsigned)xk < (unsigned)Wk, in_jm1 = act && (unsigned)(xk - 1) < (unsigned)Wk;
+            const bool stg_j = (unsigned)sk < (unsigned)nsk, stg_jm1 = (unsigned)(sk - 1) < (unsigned)nsk;
+            need = need || (win_narrow ? __any(act && er.w == 0) : __any(act && (er.w == 0 || (in_j && !stg_j) || (in_jm1 && !stg_jm1))));
+            if (need) {                                                          // something this step reads is not staged: re-centre the window on (i, j) once
+                if (win_i == i && win_j == j) break;
+                load_window_cols(i, j); cr_row = -1; continue;
+            }
+            const T *rk = bt + er.z + (in_j ? sk : 0) * CW, *rkm1 = bt + er.z + (in_jm1 ? sk - 1 : 0) * CW;
+            const int Hk_j = (int)rk[0], E1k_j = (int)rk[PL_E1], E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
+            const int sc_ = s_mat[m * bs_ + qc];
+            start_i = i; start_j = j; ++bt_steps;
+            const unsigned long long mA = __ballot(in_jm1 && Hk_jm1 + sc_ == Hij);
+            int hit = 0, k_sel = -1;
+            auto do_match = [&](int set_indel) __attribute__((always_inline)) {
+                if (!mA) return;
+                k_sel = __builtin_ctzll(mA);
+                cur_op = OP_ALL; hit = 1;
+                push(ABPOA_HIP_CMATCH, 1, id, j - 1);
+                --j; ++n_aln; n_match += (bs_ == qc);
+                if (set_indel) indel_first = 0;
+            };
+            if ((cur_op & OP_M) && indel_first == 0) do_match(0);
+            if (!hit && (cur_op & OP_E)) {
+                const bool viaM = cur_op & OP_M;
+                unsigned long long m1 = 0, m2 = 0;
+                if (cur_op & OP_E1) m1 = __ballot(in_j && (viaM ? Hij == E1k_j : E1ij == E1k_j - (int)e1));
+                if (GAP == 2 && (cur_op & OP_E2)) m2 = __ballot(in_j && (viaM ? Hij == E2k_j : E2ij == E2k_j - (int)e2));
+                if (m1 | m2) {                                                   // first predecessor in list order, E1 before E2 for the same one
+                    const int k1 = m1 ? __builtin_ctzll(m1) : 64, k2 = m2 ? __builtin_ctzll(m2) : 64;
+                    const bool use1 = k1 <= k2; k_sel = use1 ? k1 : k2;
+                    const unsigned long long mD = __ballot(in_j && (use1 ? Hk_j - (int)oe1 == E1k_j : Hk_j - (int)oe2 == E2k_j));
+                    cur_op = ((mD >> k_sel) & 1) ? (OP_M | OP_F) : (use1 ? OP_E1 : OP_E2);
+                    hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1);
+                }
+            }
+            if (!hit && (cur_op & OP_F)) {
+                for (int x = 1; x <= (GAP == 2 ? 2 : 1) && !hit; ++x) {
+                    const int bit = x == 1 ? OP_F1 : OP_F2;
+                    const int ex = x == 1 ? (int)e1 : (int)e2, oex = x == 1 ? (int)oe1 : (int)oe2;
+                    if (!(cur_op & bit)) continue;
+                    const int Fij = x == 1 ? F1ij : F2ij;
+                    if (!(cur_op & OP_M) || Hij == Fij) {
+                        if (st_jm1) {
+                            if (Hijm1 - oex == Fij) { cur_op = OP_M | OP_E; hit = 1; }
+                            else if ((x == 1 ? F1ijm1 : F2ijm1) - ex == Fij) { cur_op = bit; hit = 1; }
+                        }
+                    }
+                }
+                if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
+            }
+            if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
+            if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
+            if (k_sel >= 0) {                                                    // move to the chosen predecessor: its record comes along
+                i = __builtin_amdgcn_readlane(er.x, k_sel);
+                cr = make_int4(__builtin_amdgcn_readlane(er.y, k_sel), __builtin_amdgcn_readlane(er.z, k_sel), __builtin_amdgcn_readlane(er2.x, k_sel), __builtin_amdgcn_readlane(er2.y, k_sel));
+                cr2 = __builtin_amdgcn_readlane(er2.z, k_sel); cr_row = i;
+            }
+        }
         int slow_budget = CW > 0 ? 1 : INT_MAX;
         while (i > 0 && j > 0 && status == 0 && slow_budget-- > 0) {
             ++bt_slow_steps;
-            if ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo) load_window(i);
+            if (CW == 0 && ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo)) load_window(i);
             const Geo gi = geo_of(i);
             const int Hij = cell(gi, 0, j);
             if (local && Hij == 0) break;
@@ -1098,7 +1267,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
         }
         } while (CW > 0 && i > 0 && j > 0 && status == 0);
-        bt_win_ticks = win_ticks; bt_n_windows = n_windows;
+        bt_win_ticks = win_ticks; bt_n_windows = n_windows; bt_wa = win_a; bt_wb = win_b; bt_wc = win_c;
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
             __syncthreads();
@@ -1114,7 +1283,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = CW;      // pad = arena cell stride (0: plane-major)
         o.n_cells = n_cells; o.cells_used = cursor;
         for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
-        o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000;      // backtrack: ticks spent staging arena windows, number of windows
+        o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_wc;      // backtrack: ticks spent staging arena windows, number of windows
         o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }
