@@ -336,8 +336,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(s);
     if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s : *fallback) { const int r = hs[s].pad; hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : 6)]++; }
-        fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, fuse caps (edge slots / aligned slots / nodes) %d, DP status %d, other %d\n", hist[1], hist[2], hist[3], hist[4], hist[5], hist[6] + hist[0]);
+        for (int s : *fallback) { const int r = hs[s].pad; hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++; }
+        fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, fuse caps (edge slots / aligned slots / nodes) %d, DP status %d, projected node growth (early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], hist[5], hist[7], hist[6] + hist[0]);
     }
     if (stats) {
         stats->cons_s = now_s() - t_done; stats->total_s = now_s() - t_begin;

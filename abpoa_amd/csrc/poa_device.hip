@@ -102,7 +102,16 @@ __global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
     AlnDesc *ad = p.aln + s;
     const int k = p.round;
     const int status = st->status, n = st->n_nodes;
-    if (status != POA_ST_OK || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it
+    // Early exit for sets that will outgrow their node slots: new nodes per read stay close to constant over the first reads
+    // (most errors are novel), so ten reads predict the final size well; failing at once saves the rest of a doomed pass.
+    bool doomed = false;
+    if (status == POA_ST_OK && k == 10 && S.n_reads > 20) {
+        const int n0 = p.read_len[S.read0] + 2;
+        const long long projected = (long long)n + (long long)(n - n0) * (S.n_reads - k) * 8 / (10 * k);
+        doomed = projected > S.node_cap;
+        if (doomed && lane == 0) { st->status = POA_ST_FALLBACK; st->pad = 6; }
+    }
+    if (status != POA_ST_OK || doomed || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it
         if (lane == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
         return;
     }
