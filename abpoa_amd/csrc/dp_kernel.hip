@@ -910,23 +910,30 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             __syncthreads();
             const int max_rec = (int)(bt_cells / CW);
             const int WC = max_rec >= 2048 ? 64 : 48;
-            const int R = imin(BTR, imax(4, max_rec / WC));
-            const int lo = imax(0, hi - R + 1), nrow = hi - lo + 1;
-            const int r = lo + lane; const bool rv = lane < nrow;
+            // candidate rows: the 64 rows ending at hi (lane = row - lo64); how many of them are staged is decided below
+            const int lo64 = imax(0, hi - BTR + 1), n64 = hi - lo64 + 1;
+            const int r = lo64 + lane; const bool rv64 = lane < n64;
             int b_ = -1, e_ = -1, po = 0, po1 = 0, nid_ = 0, bs_ = 0; long long c_ = 0;
-            if (rv) { b_ = g_bsn[r]; e_ = g_esn[r]; c_ = g_coff[r]; po = pred_off[r]; po1 = pred_off[r + 1]; nid_ = row_node_id[r]; bs_ = row_base[r]; }
+            if (rv64) { b_ = g_bsn[r]; e_ = g_esn[r]; c_ = g_coff[r]; po = pred_off[r]; po1 = pred_off[r + 1]; nid_ = row_node_id[r]; bs_ = row_base[r]; }
             const int pbc = b_ >= 0 ? b_ * PN : 0, W = b_ >= 0 ? (e_ - b_ + 1) * PN : 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long tw1 = (long long)__builtin_amdgcn_s_memtime(); win_a += tw1 - tw0;
-            const bool narrow = !__any(rv && W > WC);                   // every row fits whole: stage whole rows (they are adjacent in the arena)
+            // whole rows if at least 16 of them fit (narrow bands; rows are adjacent in the arena -> one contiguous copy), else slices
+            const int Wrev = __builtin_amdgcn_ds_bpermute((n64 - 1 - lane) << 2, rv64 ? W : 0x100000);      // lane l <- row hi - l
+            const int cum = wave_scan_add_i32(lane < n64 ? Wrev : 0x100000);
+            const int r_full = __builtin_popcountll(__ballot(cum <= max_rec));
+            const bool narrow = r_full >= imin(16, n64);
+            const int R = narrow ? r_full : imin(n64, imax(4, max_rec / WC));
+            const int lo = hi - R + 1, nrow = R, li = lane - (lo - lo64);           // li: index of this lane's row inside the window
+            const bool rv = rv64 && li >= 0;
             const int sl = narrow ? pbc : imax(pbc, jtop - WC + 1), sh = narrow ? pbc + W : imin(pbc + W, jtop + 1), ns = rv ? imax(0, sh - sl) : 0;
             const int incl = wave_scan_add_i32(ns);
             const int off_rec = incl - ns;
-            const int pbase = __builtin_amdgcn_readfirstlane(po);
-            const int pn_t = imin(BTP, __builtin_amdgcn_readlane(po1, nrow - 1) - pbase);
+            const int pbase = __builtin_amdgcn_readlane(po, lo - lo64);
+            const int pn_t = imin(BTP, __builtin_amdgcn_readlane(po1, n64 - 1) - pbase);
             if (rv) {
-                B.rinfo[lane] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (imin(po1 - po, 255) << 16) | (bs_ << 24), nid_);
-                B.rinfo2[lane] = sl | (ns << 16);
-                B.srcoff[lane] = c_ + (long long)(sl - pbc) * CW;
+                B.rinfo[li] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (imin(po1 - po, 255) << 16) | (bs_ << 24), nid_);
+                B.rinfo2[li] = sl | (ns << 16);
+                B.srcoff[li] = c_ + (long long)(sl - pbc) * CW;
             }
             __syncthreads();
             const long long tw1b = (long long)__builtin_amdgcn_s_memtime(); win_a += tw1b - tw1;       // (debug split: scan + LDS tables)
@@ -935,7 +942,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             constexpr int PIECES = (int)(CW * sizeof(T) / sizeof(RecT));
             // narrow bands: every slice is a whole row, and the rows are adjacent in the arena -> one contiguous 16-byte-wide copy
             if (narrow) {
-                const long long c_lo = __builtin_amdgcn_readfirstlane((int)(c_ & 0xffffffffll)) | ((long long)__builtin_amdgcn_readfirstlane((int)(c_ >> 32)) << 32);
+                const int l0 = lo - lo64;
+                const long long c_lo = (long long)(unsigned)__builtin_amdgcn_readlane((int)(c_ & 0xffffffffll), l0) | ((long long)__builtin_amdgcn_readlane((int)(c_ >> 32), l0) << 32);
                 const int n16 = (int)((long long)__builtin_amdgcn_readlane(incl, 63) * CW * (int)sizeof(T) / 16);
                 const int4 *src = (const int4 *)(planes + c_lo); int4 *dst = (int4 *)bt;
                 for (int i0 = 0; i0 < n16; i0 += 64 * 8) {
@@ -954,7 +962,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                     RecT v[16][PIECES]; int nn[16], oo[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        const int rr = imin(r0 + u, nrow - 1);
+                        const int rr = imin(r0 + u, nrow - 1) + (lo - lo64);
                         nn[u] = (r0 + u < nrow) ? __builtin_amdgcn_readlane(ns, rr) : 0; oo[u] = __builtin_amdgcn_readlane(offv, rr);
                         const long long so = (long long)(unsigned)__builtin_amdgcn_readlane(src_lo, rr) | ((long long)__builtin_amdgcn_readlane(src_hi, rr) << 32);
                         const RecT *src = (const RecT *)(planes + so) + (long long)(lane < nn[u] ? lane : 0) * PIECES;      // unconditional loads (a
