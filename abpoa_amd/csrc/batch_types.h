@@ -35,4 +35,7 @@ class GroupAligner {
 };
 typedef GroupAligner *(*AlignerFactory)(void);
 
+// Host cores this process may really use: min(online CPUs, cgroup CPU quota) -- a GPU box shows 256 logical CPUs and grants 16.
+int effective_host_cores();
+
 }  // namespace abpoa_hip

@@ -4,7 +4,9 @@
 // inside a group all sets advance one read per round so that one engine launch carries one alignment of every set
 // of the group, and the groups run out of phase on their own streams so that host graph work (fusion, row ordering,
 // flattening straight into pinned staging memory) of one group overlaps the DP kernel of another.
+#include <algorithm>
 #include <atomic>
+#include <stdio.h>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -18,6 +20,16 @@
 #include "poa_graph.h"
 
 namespace abpoa_hip {
+
+int effective_host_cores() {
+    int n = (int)std::thread::hardware_concurrency(); if (n < 1) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long quota = atol(q); if (quota > 0) n = std::min<long>(n, (quota + period - 1) / period); }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
 
 namespace {
 // Minimal persistent fork-join pool: run(n, fn) executes fn(i) for i in [0,n) on all workers + caller.
@@ -126,7 +138,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     if (tm) memset(tm, 0, sizeof(*tm));
     for (int s = 0; s < n_sets; ++s) memset(&out[s], 0, sizeof(out[s]));
     if (n_sets == 0) return ABPOA_HIP_OK;
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = effective_host_cores();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_sets) n_threads = n_sets;
     if (n_groups <= 0) { const char *e_ = getenv("ABPOA_HIP_GROUPS"); if (e_) n_groups = atoi(e_); }

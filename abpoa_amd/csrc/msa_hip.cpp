@@ -43,7 +43,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
     if (engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
     if (n_sets > 0 && sc && sets && out && msa_device_eligible(sc, flags)) {
         // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
-        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads <= 0) n_threads = effective_host_cores();
         for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL; }
         // Pass 1 gives every set 3x its longest read in graph-node slots (5 %-error reads need ~2.5x), pass 2 retries the sets that
         // outgrew that with 6x, whatever is left goes to the host driver.  A pass that does not fit the device memory is split in halves.

@@ -156,10 +156,15 @@ int  abpoa_hip_score_bits(const abpoa_hip_scoring_t *sc, int n_rows, int qlen, i
 
 /* ---- (3) read-set batch API -------------------------------------------------------------------- */
 /* Progressive POA of N independent read-sets in lock-step rounds: round k aligns read k of every
- * set to that set's graph (one engine launch for all sets), then fuses the cigars on host threads.
+ * set to that set's graph (one launch for all sets) and fuses the cigars into the graphs.
  * Per set this is the reference's abpoa_msa() (src/abpoa_align.c:373-437) with plain abpoa_poa()
- * (:302-344): no seeding / guide tree, unit weights, no reverse-complement retry.  Graph fusion,
- * row ordering and the consensus / MSA calls follow the reference so that outputs are identical.   */
+ * (:302-344): no seeding / guide tree, unit weights, no reverse-complement retry.  Graph fusion and
+ * the consensus / MSA calls follow the reference so that outputs are identical.
+ * Two drivers, same results: the DEVICE-RESIDENT driver (global mode, adaptive band, affine / convex
+ * gaps, consensus output, nucleotides) keeps every graph in HBM and runs fusion, row order, band
+ * inputs, DP, backtrack and the consensus as kernels with no host work in between; everything else --
+ * and any set that outgrows a device capacity -- takes the HOST driver (host graph, one H2D / launch /
+ * D2H per round).                                                                                   */
 typedef struct abpoa_hip_readset_t {
     int32_t n_reads;
     const uint8_t *const *seqs;   /* [n_reads] residue codes 0..m-1                                  */
