@@ -94,8 +94,10 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // before the DP of round k: remaining length, rows in order with their predecessor CSR, alignment descriptor
-__global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
-    const int s = blockIdx.x, lane = threadIdx.x;
+// Four wavefronts per read-set: the row-parallel parts (heaviest edge, CSR) are latency-bound gathers, and four waves per SIMD hide
+// most of that latency; the reverse sweep of the remaining length is sequential over 64-row blocks and runs on wavefront 0.
+__global__ void __launch_bounds__(256) poa_prepare_kernel(const PoaDev p) {
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
@@ -109,10 +111,10 @@ __global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
         const int n0 = p.read_len[S.read0] + 2;
         const long long projected = (long long)n + (long long)(n - n0) * (S.n_reads - k) * 8 / (10 * k);
         doomed = projected > S.node_cap;
-        if (doomed && lane == 0) { st->status = POA_ST_FALLBACK; st->pad = 6; }
+        if (doomed && tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 6; }
     }
     if (status != POA_ST_OK || doomed || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it
-        if (lane == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
+        if (tid == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
         return;
     }
     const int64_t N0 = S.node0;
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
     int32_t *nxt = p.scratch + S.scratch0;                 // [n] row of the heaviest successor
     int32_t *remain = p.row_remain + N0;
     // (1) heaviest out-edge per row (first maximum wins, reference :262-268)
-    for (int r = lane; r < n; r += 64) {
+    for (int r = tid; r < n; r += 256) {
         const int u = order[r];
         const int no = p.nd_nout[N0 + u];
         int best_w = -1, best = -1;
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
     }
     __syncthreads();
     // (2) remaining length by a reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping
-    for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
+    if (wave == 0) for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
         const int r = t0 + lane;
         int tgt = r < n ? ld_fresh(nxt + r) : -1, dist = 1, val = 0; bool done = r >= n;
         if (!done && tgt < 0) { val = -1; done = true; }                         // the sink (reference :247)
@@ -145,25 +147,30 @@ __global__ void __launch_bounds__(64) poa_prepare_kernel(const PoaDev p) {
             }
         }
         if (r < n) remain[r] = val;
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores are write-through: once acknowledged, later blocks read them from L2 (ld_fresh)
     }
     // (3) predecessor CSR in row order (in_id order kept, reference pre_index[][] :519-530)
+    __shared__ int wtot[4];
     int carry = 0; bool overflow = false;
-    for (int t0 = 0; t0 < n; t0 += 64) {
-        const int r = t0 + lane;
+    for (int t0 = 0; t0 < n; t0 += 256) {
+        const int r = t0 + tid;
         const int u = r < n ? order[r] : 0;
         const int np = (r < n && r > 0) ? (int)p.nd_nin[N0 + u] : 0;
         const int incl = wave_scan_add(np);
-        const int off = carry + incl - np;
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        const int w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
+        const int off = carry + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0) + incl - np;
         if (r < n) p.pred_off[N0 + r] = off;
         if (off + np > S.pred_cap) overflow = true;
         else for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + p.nd_in[(N0 + u) * POA_IN_CAP + t]];
-        carry += __builtin_amdgcn_readlane(incl, 63);
+        carry += w0 + w1 + w2 + w3;
+        __syncthreads();
     }
-    if (lane == 0) p.pred_off[N0 + n] = carry;
-    overflow = __any(overflow);
+    if (tid == 0) p.pred_off[N0 + n] = carry;
+    overflow = __syncthreads_or(overflow);
     // (4) alignment descriptor of this round
-    if (lane == 0) {
+    if (tid == 0) {
         AlnDesc d; memset(&d, 0, sizeof(d));
         const int qlen = p.read_len[S.read0 + k];
         d.n_rows = n; d.qlen = qlen;
@@ -399,7 +406,11 @@ static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStrea
     return hipGetLastError();
 }
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s) { return launch_k(poa_init_kernel, p, s); }
-hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) { return launch_k(poa_prepare_kernel, p, s); }
+hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(poa_prepare_kernel, dim3(p.n_sets), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) { return launch_k(poa_fuse_kernel, p, s); }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
 
