@@ -187,15 +187,18 @@ __global__ void __launch_bounds__(256) poa_prepare_kernel(const PoaDev p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // after the backtrack of round k: fuse the graph cigar of read k into the graph and extend the row order
-__global__ void __launch_bounds__(64) poa_fuse_kernel(const PoaDev p) {
-    const int s = blockIdx.x, lane = threadIdx.x;
+// Four wavefronts per read-set for the row-parallel parts (clearing, cigar scan, splicing the row order); the walk over the query
+// (F2/F3) is sequential over 64-position chunks and runs on wavefront 0.
+__global__ void __launch_bounds__(256) poa_fuse_kernel(const PoaDev p) {
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int sh_fail, sh_nodes, wtot[4];
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
     const int k = p.round;
     if (st->status != POA_ST_OK || k >= S.n_reads) return;
     const AlnOut res = p.out[s];
-    if (res.status != 0) { if (lane == 0) { st->status = POA_ST_FALLBACK; st->pad = 1000 + res.status; } return; }
+    if (res.status != 0) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 1000 + res.status; } return; }
     const int64_t N0 = S.node0;
     const int n_old = st->n_nodes, qlen = p.read_len[S.read0 + k], n_cigar = res.n_cigar;
     const uint8_t *seq = p.reads + p.read_off[S.read0 + k];
@@ -205,10 +208,10 @@ __global__ void __launch_bounds__(64) poa_fuse_kernel(const PoaDev p) {
     int32_t *cand = p.scratch + S.scratch0, *n_anchor = cand + p.max_qlen, *n_j = n_anchor + p.max_qlen, *addcnt = n_j + p.max_qlen;
     if (n_cigar == 0) return;                                                   // reference :614-616
     // F0/F1: node every query base is aligned to (-1: inserted base)
-    for (int q = lane; q < qlen; q += 64) cand[q] = -1;
-    for (int r = lane; r < n_old; r += 64) addcnt[r] = 0;
+    for (int q = tid; q < qlen; q += 256) cand[q] = -1;
+    for (int r = tid; r < n_old; r += 256) addcnt[r] = 0;
     __syncthreads();
-    for (int i = lane; i < n_cigar; i += 64) {
+    for (int i = tid; i < n_cigar; i += 256) {
         const uint64_t w = cg[i];
         if ((int)(w & 0xf) == ABPOA_HIP_CMATCH) cand[(int)((w >> 4) & 0x3fffffff)] = (int)((w >> 34) & 0x3fffffff);
     }
@@ -233,6 +236,7 @@ __global__ void __launch_bounds__(64) poa_fuse_kernel(const PoaDev p) {
         }
         p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
     };
+    if (wave == 0) {
     for (int q0 = 0; q0 < qlen; q0 += 64) {
         const int q = q0 + lane; const bool act = q < qlen;
         const int c = act ? ld_fresh(cand + q) : -1;
@@ -298,25 +302,33 @@ __global__ void __launch_bounds__(64) poa_fuse_kernel(const PoaDev p) {
     }
     // F3: last node -> sink (reference :667)
     if (!__any(fail)) add_edge(lane == 0, prev_c, prev_new_c != 0, 1, false);
-    if (__any(fail)) { if (lane == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }
-    __syncthreads();
-    // F4: new row order = old order with every run of new nodes spliced in after its anchor
-    int carry = 0;
-    for (int t0 = 0; t0 < n_old; t0 += 64) {
-        const int r = t0 + lane;
-        const int cnt = r < n_old ? ld_fresh(addcnt + r) : 0;
-        const int incl = wave_scan_add(cnt);
-        const int shift = carry + incl - cnt;                    // new nodes anchored at earlier rows
-        if (r < n_old) { const int u = order_old[r]; order_new[r + shift] = u; p.nd_row[N0 + u] = r + shift; addcnt[r] = shift; }
-        carry += __builtin_amdgcn_readlane(incl, 63);
+    const bool any_fail = __any(fail);
+    if (lane == 0) { sh_fail = any_fail ? 1 : 0; sh_nodes = n_nodes; }
     }
     __syncthreads();
-    for (int i = lane; i < n_nodes - n_old; i += 64) {
+    if (sh_fail) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }
+    n_nodes = sh_nodes;
+    // F4: new row order = old order with every run of new nodes spliced in after its anchor
+    int carry = 0;
+    for (int t0 = 0; t0 < n_old; t0 += 256) {
+        const int r = t0 + tid;
+        const int cnt = r < n_old ? ld_fresh(addcnt + r) : 0;
+        const int incl = wave_scan_add(cnt);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        const int w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
+        const int shift = carry + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0) + incl - cnt;      // new nodes anchored at earlier rows
+        if (r < n_old) { const int u = order_old[r]; order_new[r + shift] = u; p.nd_row[N0 + u] = r + shift; addcnt[r] = shift; }
+        carry += w0 + w1 + w2 + w3;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = tid; i < n_nodes - n_old; i += 256) {
         const int ar = ld_fresh(n_anchor + i), j = ld_fresh(n_j + i);
         const int nr = ar + ld_fresh(addcnt + ar) + j;
         order_new[nr] = n_old + i; p.nd_row[N0 + n_old + i] = nr;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         st->n_nodes = n_nodes; st->order_buf = cur ^ 1; st->n_cells += res.n_cells;
         st->algo_bytes += res.n_cells * (p.aln[s].bits / 8) * (p.gap_mode == ABPOA_HIP_AFFINE_GAP ? 5 : 8);
     }
@@ -411,7 +423,11 @@ hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) {
     hipLaunchKernelGGL(poa_prepare_kernel, dim3(p.n_sets), dim3(256), 0, s, p);
     return hipGetLastError();
 }
-hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) { return launch_k(poa_fuse_kernel, p, s); }
+hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(poa_fuse_kernel, dim3(p.n_sets), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
 
 }  // namespace abpoa_hip
