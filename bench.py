@@ -210,7 +210,7 @@ def main():
         # command by tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)
         # is kept under profiles/ and reported here when the workload matches.
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r1_v5_pmc_traffic_cfg2.json")
+        tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic_cfg2.json")
         if args.workload == "cfg2" and n_sets == 1000 and os.path.exists(tp):
             traffic = json.load(open(tp))["hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
