@@ -2044,14 +2044,15 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     if (lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
 }
 
-template <int GAP>
+// One kernel per score width: the row loop of one width is ~40 KB of code, and a CU pair's 64 KB instruction cache has to hold
+// what its 8 or so resident wavefronts execute; an alignment of the other width is left to the other kernel.
+template <int GAP, int BITS>
 __global__ void __launch_bounds__(64) dp_fast_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (!takes_fast(b, d)) return;           // dp_kernel's
-    if (d.bits == 16) align_fast_rows<int16_t, GAP>(b, d, b.out + a);
-    else align_fast_rows<int32_t, GAP>(b, d, b.out + a);
+    if (!takes_fast(b, d) || d.bits != BITS) return;           // dp_kernel's, or the other width's
+    align_fast_rows<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP>(b, d, b.out + a);
 }
 
 template <typename T, int GAP>
@@ -2070,14 +2071,13 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
 }
 
-template <int GAP>
+template <int GAP, int BITS>
 __global__ void __launch_bounds__(64) dp_fast_tail_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (!takes_fast(b, d)) return;
-    if (d.bits == 16) align_fast_tail<int16_t, GAP>(b, d, b.out + a);
-    else align_fast_tail<int32_t, GAP>(b, d, b.out + a);
+    if (!takes_fast(b, d) || d.bits != BITS) return;
+    align_fast_tail<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP>(b, d, b.out + a);
 }
 
 template <typename K>
@@ -2089,15 +2089,25 @@ static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int 
     return hipGetLastError();
 }
 
+template <int GAP>
+static hipError_t launch_fast_pair(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows) {
+    const int mask = b.bits_mask ? b.bits_mask : 3;
+    hipError_t e = hipSuccess;
+    if (mask & 1) e = launch_one(dp_fast_kernel<GAP, 16>, b, stream, b.lds.total_rows);
+    if (e == hipSuccess && (mask & 2)) e = launch_one(dp_fast_kernel<GAP, 32>, b, stream, b.lds.total_rows);
+    if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
+    if (e == hipSuccess && (mask & 1)) e = launch_one(dp_fast_tail_kernel<GAP, 16>, b, stream, b.lds.total_tail);
+    if (e == hipSuccess && (mask & 2)) e = launch_one(dp_fast_tail_kernel<GAP, 32>, b, stream, b.lds.total_tail);
+    return e;
+}
+
 // n_fast: how many alignments of the batch take the fast row loop (engine.cpp applies takes_fast() on the host); a kernel
 // with nothing to do is not launched.
 hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent_t after_rows) {
     if (b.n <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
     if (n_fast > 0) {
-        if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) e = launch_one(dp_fast_kernel<1>, b, stream, b.lds.total_rows); else e = launch_one(dp_fast_kernel<2>, b, stream, b.lds.total_rows);
-        if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
-        if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream, b.lds.total_tail) : launch_one(dp_fast_tail_kernel<2>, b, stream, b.lds.total_tail);
+        e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_fast_pair<1>(b, stream, after_rows) : launch_fast_pair<2>(b, stream, after_rows);
         if (e != hipSuccess) return e;
     }
     if (n_fast < b.n) {
@@ -2110,13 +2120,10 @@ hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent
     return e;
 }
 
-// the two fast-path kernels alone (device-resident driver: every alignment of the batch is fast-eligible or skipped)
+// the fast-path kernels alone (device-resident driver: every alignment of the batch is fast-eligible or skipped)
 hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows) {
     if (b.n <= 0) return hipSuccess;
-    hipError_t e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_kernel<1>, b, stream, b.lds.total_rows) : launch_one(dp_fast_kernel<2>, b, stream, b.lds.total_rows);
-    if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
-    if (e == hipSuccess) e = b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_fast_tail_kernel<1>, b, stream, b.lds.total_tail) : launch_one(dp_fast_tail_kernel<2>, b, stream, b.lds.total_tail);
-    return e;
+    return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_fast_pair<1>(b, stream, after_rows) : launch_fast_pair<2>(b, stream, after_rows);
 }
 
 }  // namespace abpoa_hip

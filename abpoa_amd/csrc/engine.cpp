@@ -201,6 +201,7 @@ int BatchStream::run() {
                 est_cols = std::max<int64_t>(est_cols, banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width);
             }
             make_lds_plan(sc, max_qlen, max_bits, est_cols, &b.lds);
+            for (const AlnDesc &d : pass) b.bits_mask |= d.bits == 16 ? 1 : 2;
         }
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;

@@ -71,6 +71,7 @@ struct DevBatch {
     int32_t dbg;                 // ablation switches for timing experiments (env ABPOA_HIP_DBG); 0 in production
     int32_t fresh_band;          // max_pos_left/right start as (n_rows, 0): initialise them on the device
     int32_t want_lr;             // the caller reads max_pos_left/right back (the fast row loop derives them in a post-pass)
+    int32_t bits_mask;           // score widths that may occur among the fast alignments: 1 = int16, 2 = int32, 3 = both (one kernel per width)
     LdsPlan lds;
     const int32_t *mat;          // [m*m]
     const AlnDesc *aln;          // [n]

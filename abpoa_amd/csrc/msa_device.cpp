@@ -199,6 +199,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
         make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(width, 2LL * w_max + 3 * pn + 32), &b.lds);
+        // score widths the rounds can meet (the width grows with graph and read size): launch only the kernels that can have work
+        int min_qlen = max_qlen;
+        for (int s = 0; s < n_sets; ++s) for (int r = 1; r < sets[s].n_reads; ++r) min_qlen = std::min(min_qlen, sets[s].lens[r]);
+        const int min_bits = abpoa_hip_score_bits(sc, 3, min_qlen, &inf_dummy);
+        b.bits_mask = (min_bits == 16 ? 1 : 0) | (max_bits == 32 ? 2 : 0);
     }
     if (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
@@ -277,6 +282,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         HIP_OK(hipEventRecord(e[0], st), ABPOA_HIP_ELAUNCH);
         HIP_OK(launch_dp_fast(b, st, e[1]), ABPOA_HIP_ELAUNCH);
         if (stage("dp rows + tail", k)) return ABPOA_HIP_ELAUNCH;
+        if (dbg_sync && getenv("ABPOA_HIP_IMBAL")) {      // load balance of the round: ticks of the mean and of the slowest alignment
+            std::vector<AlnOut> ho(n_sets); (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
+            double sd = 0, sb = 0; long long md = 0, mb = 0, ms_ = 0; for (const AlnOut &o_ : ho) { sd += o_.clk_dp; sb += o_.clk_bt; md = std::max<long long>(md, o_.clk_dp); mb = std::max<long long>(mb, o_.clk_bt); ms_ = std::max<long long>(ms_, o_.clk_dp + o_.clk_bt); }
+            fprintf(stderr, "[poa-device] round %d balance: rows mean %.0f max %lld | tail mean %.0f max %lld | rows+tail mean %.0f max %lld\n", k, sd / n_sets, md, sb / n_sets, mb, (sd + sb) / n_sets, ms_);
+        }
         HIP_OK(hipEventRecord(e[2], st), ABPOA_HIP_ELAUNCH);
         HIP_OK(launch_poa_fuse(p, st), ABPOA_HIP_ELAUNCH);
         if (stage("fuse", k)) return ABPOA_HIP_ELAUNCH;
