@@ -571,6 +571,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (I16) { const int w0 = src[0], w1 = src[1]; Mv = (int)(short)w0; E1v = w1 >> 16; if (GAP == 2) E2v = src[RCS + 1]; }
             else { Mv = src[0]; E1v = src[RCS + 1]; if (GAP == 2) E2v = src[2 * RCS + 1]; }
         }
+        const int Mv_first = Mv;                                   // (match flag below: which predecessor supplies the diagonal)
         if (NPC == 2) {
             const int pb1 = g1 & 0xfff, Wp = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
             const int x = colrel - pb1 * PN;
@@ -603,10 +604,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         T *H = io.planes + (long long)off_pn * PN;
         const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
-        if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = F1; *(int2 *)(H + lane * CW) = rec; }
-        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = 0; *(int4 *)(H + lane * CW) = rec; }
-        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = 0; *(int4 *)(H + lane * CW) = rec; }
-        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = 0; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + lane * CW); dst[0] = r0; dst[1] = r1; }
+        // match flag for the backtrack (spare slot of the record, finish_alignment PL_FLAG): 1 + index of the first predecessor k (list order) with
+        // H[k][col-1] + q == H[col], 0 = none.  Only a predecessor that supplies the maximum Mv can satisfy it, and only when H == Mv + q.
+        // (A predecessor value read from outside its band is `inf`: the backtrack re-checks the column range before it trusts the flag.)
+        const int mflag = (h == Hout) ? ((NPC == 2 && Mv != Mv_first) ? 2 : 1) : 0;
+        if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
+        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
+        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
+        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + lane * CW); dst[0] = r0; dst[1] = r1; }
         {
             int *qd = fr + (row & (RR - 1)) * (NPW * RCS) + 2 + lane;
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
@@ -811,6 +816,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     constexpr int PN = Width<T>::PN;
     constexpr int P = CW > 0 ? CW : (GAP == 0 ? 1 : (GAP == 1 ? 3 : 5));      // values per column in the arena
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
+    constexpr int PL_FLAG = GAP == 1 ? 3 : (sizeof(T) == 2 ? 6 : 5);      // cell records only: the row loop's match flag (0 = not known)
     const int lane = threadIdx.x & 63;
     const int gn = d.n_rows, qlen = d.qlen, m = b.m;
     const bool local = b.align_mode == ABPOA_HIP_LOCAL_MODE;
@@ -848,7 +854,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
     // refilled cooperatively; only lane 0 writes cigar words.
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
-    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0, bt_wa = 0, bt_wb = 0, bt_wc = 0;
+    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0, bt_wa = 0, bt_wb = 0, bt_wc = 0, bt_flag_steps = 0;
     if (status == 0 && b.ret_cigar) {
         BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
         T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
@@ -989,17 +995,27 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             win_c += (long long)__builtin_amdgcn_s_memtime() - tw2;
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
+        // cigar words are collected 64 at a time in a VGPR pair (lane = word index & 63) and written out as one coalesced store per 64
+        // words: a store per step would sit in the memory pipeline when the next step's LDS reads are issued, and the compiler's
+        // s_waitcnt vmcnt(0) in front of those reads then costs a full HBM write round trip per step
+        int cgw_lo = 0, cgw_hi = 0;
+        auto flush_cigar = [&](int base, int n) __attribute__((always_inline)) {
+            if (lane < n) cg[base + lane] = ((uint64_t)(unsigned)cgw_hi << 32) | (uint64_t)(unsigned)cgw_lo;
+        };
         auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
             uint64_t L = (uint64_t)(int64_t)len;
             if (n_cigar == 0 || op != ABPOA_HIP_CINS || op != (int)(last_word & 0xf)) {
                 if (n_cigar >= cap) { status = ABPOA_HIP_EBACKTRACK; return; }
+                if (n_cigar > 0 && (n_cigar & 63) == 0) flush_cigar(n_cigar - 64, 64);      // the previous 64 words are final now
                 uint64_t n_id = (uint64_t)(int64_t)node_id, q_id = (uint64_t)(int64_t)query_id, wv;
                 if (op == ABPOA_HIP_CMATCH) wv = n_id << 34 | q_id << 4 | (uint64_t)op;
                 else if (op == ABPOA_HIP_CINS) wv = q_id << 34 | L << 4 | (uint64_t)op;
                 else wv = n_id << 34 | L << 4 | (uint64_t)op;
                 last_word = wv; ++n_cigar;
             } else last_word += L << 4;
-            if (lane == 0) cg[n_cigar - 1] = last_word;      // the newest word lives in a register; memory is write-only here
+            const int w_lo = sgpr((int)(last_word & 0xffffffffull)), w_hi = sgpr((int)(last_word >> 32)), w_idx = sgpr((n_cigar - 1) & 63);
+            asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                         : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx) : "m0");
         };
         struct Geo { int pb, pe; long long off; bool in_tile; };
         auto geo_of = [&](int row_) __attribute__((always_inline)) {
@@ -1028,6 +1044,16 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         //      predecessor k -- then the reference's priority order (:109-429) is evaluated on ballot masks.  Falls through to
         //      the one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
         bool bt_walk_narrow = true;                                // false once a window had to be staged as column slices
+        // the walk's state is the same in every lane; values that came out of vector loads (best cell, the one-read-at-a-time step) are
+        // moved to SGPRs so that the step loops below run on scalar branches
+        auto uniformize = [&]() __attribute__((always_inline)) {
+            i = sgpr(i); j = sgpr(j); cur_op = sgpr(cur_op); indel_first = sgpr(indel_first); status = sgpr(status); n_cigar = sgpr(n_cigar);
+            n_aln = sgpr(n_aln); n_match = sgpr(n_match); start_i = sgpr(start_i); start_j = sgpr(start_j); bt_steps = sgpr(bt_steps);
+            bt_lo = sgpr(bt_lo); bt_hi = sgpr(bt_hi); bt_pbase = sgpr(bt_pbase); win_i = sgpr(win_i); win_j = sgpr(win_j);
+            last_word = (uint64_t)(unsigned)sgpr((int)(last_word & 0xffffffffull)) | ((uint64_t)(unsigned)sgpr((int)(last_word >> 32)) << 32);
+        };
+        uniformize();
+        const long long t_walk0 = (long long)__builtin_amdgcn_s_memtime();
         do {      // fast steps; one slow step whenever a fast one cannot be taken; back to fast steps
         // ---- lane-parallel step (cell-record arenas, i.e. the fast path).  The current row's record is carried in SGPRs; round
         //      trip 1 fetches its predecessor edge records (lane k = predecessor k), its own cells and the query code, round trip 2
@@ -1039,6 +1065,41 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         while (CW > 0 && i > 0 && j > 0 && status == 0 && bt_walk_narrow) {
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; if (!win_narrow) { bt_walk_narrow = false; break; } }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr_row = i; }
+            // ---- match run.  The row loop left "1 + index of the first predecessor whose diagonal cell gives H" in every cell record it
+            //      wrote on its straight-line path (0 = not known).  While a match is what the reference tries first (:130-160 with M allowed
+            //      and indel_first == 0) and the flag is set, a step is ONE LDS round trip (flag, query code, the row's edge records) and a
+            //      handful of scalar instructions; anything else leaves the loop for the full step below.
+            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds) {
+                int mi_ = i, mj = j, pi_ = i, pj_ = j, moved = 0, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr;
+                for (;;) {
+                    const int pbi_ = mc.x & 0xffff, Wi_ = (int)((unsigned)mc.x >> 16), eb_ = mc.z & 0xffff, np_ = (mc.z >> 16) & 0xff, bs_m = (int)((unsigned)mc.z >> 24);
+                    const int si_ = mj - pbi_;
+                    const bool own_ok = (unsigned)si_ < (unsigned)Wi_ && np_ <= 64 && eb_ + np_ <= BTP && n_cigar < cap;
+                    const int fl_v = (int)bt[mc.y + (own_ok ? si_ : 0) * CW + PL_FLAG];
+                    const int qc_v = (int)s_query[mj - 1];
+                    const int e_idx = own_ok ? eb_ + (lane < np_ ? lane : 0) : 0;
+                    const int4 er = B.edge[e_idx]; const int4 er2 = B.edge2[e_idx];
+                    const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+                    if (!own_ok || fl <= 0 || fl > np_) break;
+                    const int ks = fl - 1, ery = __builtin_amdgcn_readlane(er.y, ks), erw = __builtin_amdgcn_readlane(er.w, ks);
+                    if (erw == 0 || (unsigned)(mj - 1 - (ery & 0xffff)) >= ((unsigned)ery >> 16)) break;      // not staged / column j-1 outside that predecessor's band
+                    if (n_cigar > 0 && (n_cigar & 63) == 0) flush_cigar(n_cigar - 64, 64);
+                    w_lo = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH); w_hi = sgpr(mc.w << 2);                  // node id << 34 | query index << 4 | op
+                    { const int w_idx = sgpr(n_cigar & 63);
+                      asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx) : "m0"); }
+                    ++n_cigar; nm_v += (qc_v == bs_m) ? 1 : 0;
+                    pi_ = mi_; pj_ = mj; ++moved; --mj;
+                    mi_ = __builtin_amdgcn_readlane(er.x, ks);
+                    mc = make_int4(ery, __builtin_amdgcn_readlane(er.z, ks), __builtin_amdgcn_readlane(er2.x, ks), __builtin_amdgcn_readlane(er2.y, ks));
+                    if (mi_ <= 0 || mj <= 0) break;
+                }
+                if (moved) {
+                    start_i = pi_; start_j = pj_; bt_steps += moved; bt_flag_steps += moved; n_aln += moved; n_match += __builtin_amdgcn_readfirstlane(nm_v);
+                    last_word = ((uint64_t)(unsigned)w_hi << 32) | (uint64_t)(unsigned)w_lo; cur_op = OP_ALL;
+                    i = mi_; j = mj; cr = mc; cr_row = i;
+                    if (i <= 0 || j <= 0) continue;
+                }
+            }
             const int pbi = cr.x & 0xffff, Wi = (int)((unsigned)cr.x >> 16), offi = cr.y;
             const int eb = cr.z & 0xffff, np = (cr.z >> 16) & 0xff, bs_ = (int)((unsigned)cr.z >> 24), id = cr.w;
             const int sli = pbi, nsi = Wi;                                      // whole rows are staged
@@ -1049,10 +1110,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
             bool need = false;
             const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
-            const int Hij = (int)ri[0], E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0, F1ij = (int)ri[PL_F1], F2ij = GAP == 2 ? (int)ri[PL_F2] : 0;
+            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
-            const int Hijm1 = (int)rim1[0], F1ijm1 = (int)rim1[PL_F1], F2ijm1 = GAP == 2 ? (int)rim1[PL_F2] : 0;
-            const int qc = qcode(j - 1);
+            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
+            const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
             // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
             const int pbk = er.y & 0xffff, Wk = (int)((unsigned)er.y >> 16), xk = j - pbk;
@@ -1127,10 +1188,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
             bool need = !win_narrow && ((unsigned)si >= (unsigned)nsi || (st_jm1 && si - 1 < 0));     // a cell of the own row outside the staged slice
             const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
-            const int Hij = (int)ri[0], E1ij = (int)ri[PL_E1], E2ij = GAP == 2 ? (int)ri[PL_E2] : 0, F1ij = (int)ri[PL_F1], F2ij = GAP == 2 ? (int)ri[PL_F2] : 0;
+            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
-            const int Hijm1 = (int)rim1[0], F1ijm1 = (int)rim1[PL_F1], F2ijm1 = GAP == 2 ? (int)rim1[PL_F2] : 0;
-            const int qc = qcode(j - 1);
+            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
+            const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
             // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
             const int pbk = er.y & 0xffff, Wk = (int)((unsigned)er.y >> 16), xk = j - pbk;
@@ -1274,10 +1335,12 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             }
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
         }
+        if (CW > 0) uniformize();
         } while (CW > 0 && i > 0 && j > 0 && status == 0);
-        bt_win_ticks = win_ticks; bt_n_windows = n_windows; bt_wa = win_a; bt_wb = win_b; bt_wc = win_c;
+        bt_win_ticks = win_ticks; bt_n_windows = n_windows; bt_wa = win_a; bt_wb = (long long)__builtin_amdgcn_s_memtime() - t_walk0; bt_wc = win_c;
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
+            if (n_cigar > 0) { const int base_ = ((n_cigar - 1) >> 6) << 6; flush_cigar(base_, n_cigar - base_); }
             __syncthreads();
             if (!b.rev_cigar) for (int k = lane; k < n_cigar >> 1; k += 64) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
             node_e = row_node_id[best_i]; query_e = best_j - 1;
@@ -1291,7 +1354,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = CW;      // pad = arena cell stride (0: plane-major)
         o.n_cells = n_cells; o.cells_used = cursor;
         for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
-        o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_wc;      // backtrack: ticks spent staging arena windows, number of windows
+        o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_flag_steps * 1000;      // backtrack: ticks spent staging arena windows, number of windows
         o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }
