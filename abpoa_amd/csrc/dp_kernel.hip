@@ -443,21 +443,23 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
     };
     // one predecessor's contribution from the score ring (k == 0: unmasked, see the header comment)
-    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v) __attribute__((always_inline)) {
+    // kb: 1 + list index of the first predecessor that supplies the maximum of H[.][col-1] (kidx = this one's 1 + list index): the match flag
+    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v, int &kb, int kidx) __attribute__((always_inline)) {
         const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
         const int x = col - pb * PN;
         const int *src = fr + (p & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
         int hm1, ev1, ev2 = inf;
         if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
         else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
-        if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; }
+        if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; kb = kidx; }
         else {
             const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
+            kb = (inH && hm1 > Mv) ? kidx : kb;
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         }
     };
     // everything of a chunk after the predecessor gather: F, H, E, stores, ring, arg-max candidate (reference :854-883 / :972-1008)
-    auto chunk_tail = [&](int c, int nch, int Wr, int Mv, int E1v, int E2v, int q, int &first, int &first2, T *H, int my_slot) __attribute__((always_inline)) {
+    auto chunk_tail = [&](int c, int nch, int Wr, int Mv, int E1v, int E2v, int q, int kb, int &first, int &first2, T *H, int my_slot) __attribute__((always_inline)) {
         const int rel = c * 64 + lane, col = beg_sn * PN + rel, vb = beg_sn + c * NV, v = vb + vvl;
         const bool in_band = rel < Wr;
         const int h = wr(Mv + q);
@@ -496,11 +498,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // one record store per lane, all 64 lanes (lanes past the band write into cells the NEXT row overwrites: same wave,
         // program order; the arena carries 64 records of slack at its end)
         const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));      // int16: also the score-ring word
+        // match flag for the backtrack (see turbo_body): compared without wrapping, as the reference's backtrack does (:130-160)
+        const int mflag = (Mv + q == Hout && kb <= 64) ? kb : 0;
         if (ABL(1)) {}
-        else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = F1 & 0xffff; *(int2 *)(H + (long long)rel * CW) = rec; }
-        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = 0; *(int4 *)(H + (long long)rel * CW) = rec; }
-        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = 0; *(int4 *)(H + (long long)rel * CW) = rec; }
-        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = 0; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + (long long)rel * CW); dst[0] = r0; dst[1] = r1; }
+        else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + (long long)rel * CW) = rec; }
+        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)(H + (long long)rel * CW) = rec; }
+        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + (long long)rel * CW) = rec; }
+        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + (long long)rel * CW); dst[0] = r0; dst[1] = r1; }
         if (to_ring && !ABL(2)) {
             int *qd = fr + my_slot + 2 + rel;
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
@@ -668,12 +672,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int qc = c == 0 ? qoff0 : qoff1;
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
             const int q = mrow[qc];
-            int Mv = lane, E1v = inf, E2v = inf;
-            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v);
-            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v);
-            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v); }
+            int Mv = lane, E1v = inf, E2v = inf, kb = 0;
+            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v, kb, 1);
+            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v, kb, 2);
+            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v, kb, 3); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v, kb, 4); }
             FSTAMP(1)
-            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, first, first2, H, my_slot);
+            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot);
         }
         pad_ring(nch, my_slot);
         return 1;
@@ -706,11 +710,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int qc = c == 0 ? qoff0 : qoff1;
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
             const int q = mrow[qc];
-            int Mv = inf, E1v = inf, E2v = inf;
+            int Mv = inf, E1v = inf, E2v = inf, kb = 0;
             for (int k = 0; k < np; ++k) {
                 int g_, mi_, off_; const int p = __builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)); geo_of(p, row, g_, mi_, off_);
                 if ((g_ & GEO_RING) && row - p < RR) {
-                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v); else from_ring(1, p, g_, col, Mv, E1v, E2v);
+                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1);
                 } else {
                     const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
                     const int x = col - pb * PN;
@@ -719,11 +723,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     int hval = inf, ev1 = inf, ev2 = inf;
                     if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CW));
                     if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E2)); }
-                    if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; }
-                    else { Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
+                    if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; kb = 1; }
+                    else { kb = (inH && hval > Mv) ? k + 1 : kb; Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
                 }
             }
-            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, first, first2, H, my_slot);
+            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot);
         }
         if (to_ring) pad_ring(nch, my_slot);
         return 1;
