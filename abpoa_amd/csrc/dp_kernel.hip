@@ -867,6 +867,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         long long bt_c0 = 0;                                     // arena cell of B.coff[0]
         GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
         const int cap = d.cigar_cap;
+        const bool cap_safe = cap >= gn + qlen + 2;               // a walk emits at most one word per row or column it leaves: no per-step capacity check needed
         uint64_t last_word = 0;
         long long win_ticks = 0, win_a = 0, win_b = 0, win_c = 0; int n_windows = 0;
         auto load_window = [&](int hi) __attribute__((always_inline)) {
@@ -941,7 +942,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int pbase = __builtin_amdgcn_readlane(po, lo - lo64);
             const int pn_t = imin(BTP, __builtin_amdgcn_readlane(po1, n64 - 1) - pbase);
             if (rv) {
-                B.rinfo[li] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (imin(po1 - po, 255) << 16) | (bs_ << 24), nid_);
+                B.rinfo[li] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (((po1 - po > 64 || po1 - pbase > BTP) ? 255 : po1 - po) << 16) | (bs_ << 24), nid_);      // n_pred 255: not for the lane-parallel steps
                 B.rinfo2[li] = sl | (ns << 16);
                 B.srcoff[li] = c_ + (long long)(sl - pbc) * CW;
             }
@@ -992,7 +993,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             for (int e = lane; e < pn_t; e += 64) {
                 const int pr_ = pred_row[pbase + e]; const bool ok = pr_ >= lo && pr_ <= hi;
                 const int4 ri_ = B.rinfo[ok ? pr_ - lo : 0];
-                B.edge[e] = make_int4(pr_, ri_.x, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int4(ri_.z, ri_.w, B.rinfo2[ok ? pr_ - lo : 0], 0);
+                B.edge[e] = make_int4(pr_, ok ? ri_.x : 0, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int4(ri_.z, ri_.w, B.rinfo2[ok ? pr_ - lo : 0], 0);      // (not staged: empty band)
             }
             __syncthreads();
             bt_lo = lo; bt_hi = hi; bt_pbase = pbase; win_i = hi; win_j = jtop; win_narrow = narrow;
@@ -1073,32 +1074,36 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             //      wrote on its straight-line path (0 = not known).  While a match is what the reference tries first (:130-160 with M allowed
             //      and indel_first == 0) and the flag is set, a step is ONE LDS round trip (flag, query code, the row's edge records) and a
             //      handful of scalar instructions; anything else leaves the loop for the full step below.
-            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds) {
-                int mi_ = i, mj = j, pi_ = i, pj_ = j, moved = 0, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr;
+            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
+                int mi_ = i, mj = j, pi_ = i, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr;
+                const int nc0 = n_cigar;
+                int slots = n_cigar == 0 ? 64 : ((64 - (n_cigar & 63)) & 63);           // words that still fit before the VGPR pair has to be written out
                 for (;;) {
-                    const int pbi_ = mc.x & 0xffff, Wi_ = (int)((unsigned)mc.x >> 16), eb_ = mc.z & 0xffff, np_ = (mc.z >> 16) & 0xff, bs_m = (int)((unsigned)mc.z >> 24);
-                    const int si_ = mj - pbi_;
-                    const bool own_ok = (unsigned)si_ < (unsigned)Wi_ && np_ <= 64 && eb_ + np_ <= BTP && n_cigar < cap;
-                    const int fl_v = (int)bt[mc.y + (own_ok ? si_ : 0) * CW + PL_FLAG];
-                    const int qc_v = (int)s_query[mj - 1];
-                    const int e_idx = own_ok ? eb_ + (lane < np_ ? lane : 0) : 0;
-                    const int4 er = B.edge[e_idx]; const int4 er2 = B.edge2[e_idx];
+                    const int si_ = mj - (mc.x & 0xffff), np_ = (mc.z >> 16) & 0xff;
+                    if ((unsigned)si_ >= ((unsigned)mc.x >> 16)) break;                  // (cannot happen on a sane path: the cell lies in its row's band)
+                    int fl_v = (int)bt[mc.y + si_ * CW + PL_FLAG];
+                    int qc_v = (int)s_query[mj - 1];
+                    const int e_idx = (mc.z & 0xffff) + (lane < np_ ? lane : 0);        // (n_pred 255 = row not eligible: the reads stay inside the LDS image, the result is not used)
+                    int4 er = B.edge[e_idx & (BTP - 1)]; int4 er2 = B.edge2[e_idx & (BTP - 1)];
+                    asm volatile("" : "+v"(fl_v), "+v"(qc_v), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er2.x), "+v"(er2.y));      // every load issued before the one wait
                     const int fl = __builtin_amdgcn_readfirstlane(fl_v);
-                    if (!own_ok || fl <= 0 || fl > np_) break;
-                    const int ks = fl - 1, ery = __builtin_amdgcn_readlane(er.y, ks), erw = __builtin_amdgcn_readlane(er.w, ks);
-                    if (erw == 0 || (unsigned)(mj - 1 - (ery & 0xffff)) >= ((unsigned)ery >> 16)) break;      // not staged / column j-1 outside that predecessor's band
-                    if (n_cigar > 0 && (n_cigar & 63) == 0) flush_cigar(n_cigar - 64, 64);
+                    const int ks = (fl - 1) & 63, ery = __builtin_amdgcn_readlane(er.y, ks);
+                    // flag known and in range, row eligible, column j-1 inside that predecessor's band (empty when it is not staged)
+                    if (!((unsigned)(fl - 1) < (unsigned)np_ && np_ != 255 && (unsigned)(mj - 1 - (ery & 0xffff)) < ((unsigned)ery >> 16))) break;
+                    if (slots == 0) { flush_cigar(n_cigar - 64, 64); slots = 64; }
+                    --slots;
                     w_lo = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH); w_hi = sgpr(mc.w << 2);                  // node id << 34 | query index << 4 | op
                     { const int w_idx = sgpr(n_cigar & 63);
                       asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx) : "m0"); }
-                    ++n_cigar; nm_v += (qc_v == bs_m) ? 1 : 0;
-                    pi_ = mi_; pj_ = mj; ++moved; --mj;
+                    ++n_cigar; nm_v += (qc_v == (int)((unsigned)mc.z >> 24)) ? 1 : 0;
+                    pi_ = mi_; --mj;
                     mi_ = __builtin_amdgcn_readlane(er.x, ks);
                     mc = make_int4(ery, __builtin_amdgcn_readlane(er.z, ks), __builtin_amdgcn_readlane(er2.x, ks), __builtin_amdgcn_readlane(er2.y, ks));
-                    if (mi_ <= 0 || mj <= 0) break;
+                    if (imin(mi_, mj) <= 0) break;
                 }
+                const int moved = n_cigar - nc0;
                 if (moved) {
-                    start_i = pi_; start_j = pj_; bt_steps += moved; bt_flag_steps += moved; n_aln += moved; n_match += __builtin_amdgcn_readfirstlane(nm_v);
+                    start_i = pi_; start_j = mj + 1; bt_steps += moved; bt_flag_steps += moved; n_aln += moved; n_match += __builtin_amdgcn_readfirstlane(nm_v);
                     last_word = ((uint64_t)(unsigned)w_hi << 32) | (uint64_t)(unsigned)w_lo; cur_op = OP_ALL;
                     i = mi_; j = mj; cr = mc; cr_row = i;
                     if (i <= 0 || j <= 0) continue;

@@ -25,6 +25,17 @@ namespace {
         set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return code; } } while (0)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// [0, n) split into contiguous ranges, one per worker (the calling thread takes the last range)
+template <typename F>
+void parallel_ranges(int n_threads, int n, F fn) {
+    const int T = std::max(1, std::min(n_threads, n / 64));
+    if (T <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th; th.reserve(T - 1);
+    for (int t = 0; t < T - 1; ++t) th.emplace_back(fn, (int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T));
+    fn((int)((int64_t)n * (T - 1) / T), n);
+    for (auto &x : th) x.join();
+}
 size_t up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Arena {                 // grow-only device / pinned-host buffers kept across calls (one job at a time, see g_mu)
@@ -169,8 +180,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     memcpy(hi + L.o_sets, ps.data(), sizeof(PoaSet) * n_sets);
     {
         int64_t *roff = (int64_t *)(hi + L.o_roff); int32_t *rlen = (int32_t *)(hi + L.o_rlen); uint8_t *rd = hi + L.o_reads; int64_t at = 0, ri = 0;
-        for (int s = 0; s < n_sets; ++s) for (int r = 0; r < sets[s].n_reads; ++r) { roff[ri] = at; rlen[ri] = sets[s].lens[r]; memcpy(rd + at, sets[s].seqs[r], sets[s].lens[r]); at += sets[s].lens[r]; ++ri; }
+        for (int s = 0; s < n_sets; ++s) for (int r = 0; r < sets[s].n_reads; ++r) { roff[ri] = at; rlen[ri] = sets[s].lens[r]; at += sets[s].lens[r]; ++ri; }
         roff[ri] = at;
+        parallel_ranges(std::min(n_threads, 16), n_sets, [&](int lo, int hi_) {      // 50 MB of residue codes into the pinned blob for config 2
+            for (int s = lo; s < hi_; ++s) { const int64_t r0 = ps[s].read0; for (int r = 0; r < sets[s].n_reads; ++r) memcpy(rd + roff[r0 + r], sets[s].seqs[r], sets[s].lens[r]); }
+        });
     }
     memcpy(hi + L.o_mat, sc->mat, 4 * sc->m * sc->m);
     hipStream_t st = C.stream;
@@ -320,16 +334,17 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     const PoaState *hs = (const PoaState *)(hg + L.o_state);
     const int32_t *h_cnode = (const int32_t *)(hg + L.o_cnode), *h_ccov = (const int32_t *)(hg + L.o_ccov); const uint8_t *h_cbase = hg + L.o_cbase;
     std::vector<char> need_fb(n_sets, 0);
-    (void)n_threads;
-    for (int s = 0; s < n_sets; ++s) {
-        abpoa_hip_msa_t &o_ = out[s];
-        memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
-        if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
-        const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
-        o_.n_cells = hs[s].n_cells; o_.cons_len = len;
-        o_.cons_base = (uint8_t *)malloc(len + 1); o_.cons_cov = (int32_t *)malloc(4 * (len + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (len + 1));
-        memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len); memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
-    }
+    parallel_ranges(std::min(n_threads, 8), n_sets, [&](int lo, int hi_) {
+        for (int s = lo; s < hi_; ++s) {
+            abpoa_hip_msa_t &o_ = out[s];
+            memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
+            if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
+            const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
+            o_.n_cells = hs[s].n_cells; o_.cons_len = len;
+            o_.cons_base = (uint8_t *)malloc(len + 1); o_.cons_cov = (int32_t *)malloc(4 * (len + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (len + 1));
+            memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len); memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
+        }
+    });
     if (dbg_sync) {      // cross-check the device consensus of the first sets against the host routine on the downloaded graph
         for (int s = 0; s < std::min(n_sets, 4); ++s) {
             if (hs[s].status != POA_ST_OK) continue;
