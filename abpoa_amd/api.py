@@ -121,14 +121,17 @@ def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=
     if rc != 0:
         raise ffi.EngineError(f"abpoa_hip_msa_batch failed ({rc}): {lib.abpoa_hip_last_error().decode() if hasattr(lib, 'abpoa_hip_last_error') else ''}")
     res = []
+    m, string_at, free_msa, frombuffer = params.m, C.string_at, lib.abpoa_hip_free_msa, np.frombuffer
     for i in range(enc.n):
         o, r = out[i], SetResult()
-        r.status, r.n_cells, r.cons_len, r.msa_len, r._m = o.status, o.n_cells, o.cons_len, o.msa_len, params.m
+        n = o.cons_len
+        r.status, r.n_cells, r.cons_len, r.msa_len, r._m = o.status, o.n_cells, n, o.msa_len, m
         r._cons_seq = r._cov_list = r._msa_seq = None
-        r._cons_codes = np.ctypeslib.as_array(o.cons_base, (o.cons_len,)).copy() if o.cons_len > 0 else None
-        r._cons_cov = np.ctypeslib.as_array(o.cons_cov, (o.cons_len,)).copy() if o.cons_len > 0 else None
-        r._msa_codes = np.ctypeslib.as_array(o.msa_base, (o.msa_rows, o.msa_len)).copy() if o.msa_len > 0 else None
-        lib.abpoa_hip_free_msa(C.byref(out[i]))
+        # one bytes copy per array (np.ctypeslib.as_array costs several microseconds per call: more than the GPU job's share of a set)
+        r._cons_codes = frombuffer(string_at(o.cons_base, n), dtype=np.uint8) if n > 0 else None
+        r._cons_cov = frombuffer(string_at(o.cons_cov, 4 * n), dtype=np.int32) if n > 0 else None
+        r._msa_codes = frombuffer(string_at(o.msa_base, o.msa_rows * o.msa_len), dtype=np.uint8).reshape(o.msa_rows, o.msa_len) if o.msa_len > 0 else None
+        free_msa(C.byref(o))
         res.append(r)
     return res
 

@@ -43,7 +43,7 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     int32_t n_sets, m;
     int32_t max_mat, min_mis, o1, e1, o2, e2, wb; float wf;
     int32_t gap_mode, round;       // round k: read k of every set is aligned / fused
-    int32_t max_qlen, pad;
+    int32_t max_qlen, pad;         // pad: node capacity of the prepare kernel's LDS jump records (4 bytes each; 0 = use the global-memory sweep)
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
     // graph, indexed node0 + node id

@@ -44,7 +44,6 @@ __device__ __forceinline__ int wave_scan_max(int x) {
     return x;
 }
 // value of lane-1, lane 0 receives `lane0`
-__device__ __forceinline__ int shr1(int lane0, int v) { return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xF, 0xF, false); }
 
 // reference src/simd_abpoa_align.c:1672-1683 (same arithmetic as abpoa_hip_score_bits in engine.cpp)
 __device__ __forceinline__ int score_bits(const PoaDev &p, int n_rows, int qlen, int *inf_min) {
@@ -96,7 +95,10 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
 // before the DP of round k: remaining length, rows in order with their predecessor CSR, alignment descriptor
 // Four wavefronts per read-set: the row-parallel parts (heaviest edge, CSR) are latency-bound gathers, and four waves per SIMD hide
 // most of that latency; the reverse sweep of the remaining length is sequential over 64-row blocks and runs on wavefront 0.
-__global__ void __launch_bounds__(256) poa_prepare_kernel(const PoaDev p) {
+// workgroup size of the row-parallel graph kernels: 4 wavefronts per read-set (8 measured slower: the serial parts on wavefront 0 and the barriers dominate)
+constexpr int GT = 256, GW = GT / 64;
+
+__global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
@@ -122,16 +124,33 @@ __global__ void __launch_bounds__(256) poa_prepare_kernel(const PoaDev p) {
     int32_t *nxt = p.scratch + S.scratch0;                 // [n] row of the heaviest successor
     int32_t *remain = p.row_remain + N0;
     // (1) heaviest out-edge per row (first maximum wins, reference :262-268)
-    for (int r = tid; r < n; r += 256) {
+    extern __shared__ unsigned jump_lds[];                 // [n] remaining-length jump records (see (2)), when the launch provides them
+    const bool in_lds = p.pad > 0 && n <= p.pad;
+    for (int r = tid; r < n; r += GT) {
         const int u = order[r];
         const int no = p.nd_nout[N0 + u];
         int best_w = -1, best = -1;
         for (int t = 0; t < no; ++t) { const int w = p.nd_outw[(N0 + u) * POA_OUT_CAP + t]; if (w > best_w) { best_w = w; best = p.nd_out[(N0 + u) * POA_OUT_CAP + t]; } }
-        nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
+        const int nx = best >= 0 ? p.nd_row[N0 + best] : -1;
+        if (in_lds) jump_lds[r] = nx >= 0 ? ((unsigned)nx << 16) | 1u : ((unsigned)r << 16);
+        else nxt[r] = nx;
         p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
     }
     __syncthreads();
-    // (2) remaining length by a reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping
+    // (2) remaining length = (edges to the sink along heaviest successors) - 1, reference :233-274.
+    if (in_lds) {
+        // Pointer jumping over all rows at once in LDS.  A record "row of a later node on the chain << 16 | edges up to it" is one
+        // 32-bit word, so a row may read a neighbour's record while that neighbour is being advanced: either version is a valid jump.
+        for (int span = 1; span < n; span <<= 1) {
+            for (int r = tid; r < n; r += GT) {
+                const unsigned w = jump_lds[r]; const int t = (int)(w >> 16);
+                if (t != r) { const unsigned wt = jump_lds[t]; jump_lds[r] = (wt & 0xffff0000u) | ((w & 0xffffu) + (wt & 0xffffu)); }
+            }
+            __syncthreads();
+        }
+        for (int r = tid; r < n; r += GT) remain[r] = (int)(jump_lds[r] & 0xffffu) - 1;
+    } else
+    // (graphs too large for the LDS records) reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping
     if (wave == 0) for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
         const int r = t0 + lane;
         int tgt = r < n ? ld_fresh(nxt + r) : -1, dist = 1, val = 0; bool done = r >= n;
@@ -150,21 +169,23 @@ __global__ void __launch_bounds__(256) poa_prepare_kernel(const PoaDev p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores are write-through: once acknowledged, later blocks read them from L2 (ld_fresh)
     }
     // (3) predecessor CSR in row order (in_id order kept, reference pre_index[][] :519-530)
-    __shared__ int wtot[4];
+    __shared__ int wtot[GW];
     int carry = 0; bool overflow = false;
-    for (int t0 = 0; t0 < n; t0 += 256) {
+    for (int t0 = 0; t0 < n; t0 += GT) {
         const int r = t0 + tid;
         const int u = r < n ? order[r] : 0;
         const int np = (r < n && r > 0) ? (int)p.nd_nin[N0 + u] : 0;
         const int incl = wave_scan_add(np);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        const int w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
-        const int off = carry + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0) + incl - np;
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < GW; ++w_) { const int x_ = wtot[w_]; all += x_; before += w_ < wave ? x_ : 0; }
+        const int off = carry + before + incl - np;
         if (r < n) p.pred_off[N0 + r] = off;
         if (off + np > S.pred_cap) overflow = true;
         else for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + p.nd_in[(N0 + u) * POA_IN_CAP + t]];
-        carry += w0 + w1 + w2 + w3;
+        carry += all;
         __syncthreads();
     }
     if (tid == 0) p.pred_off[N0 + n] = carry;
@@ -187,11 +208,10 @@ __global__ void __launch_bounds__(256) poa_prepare_kernel(const PoaDev p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // after the backtrack of round k: fuse the graph cigar of read k into the graph and extend the row order
-// Four wavefronts per read-set for the row-parallel parts (clearing, cigar scan, splicing the row order); the walk over the query
-// (F2/F3) is sequential over 64-position chunks and runs on wavefront 0.
-__global__ void __launch_bounds__(256) poa_fuse_kernel(const PoaDev p) {
+// Four wavefronts per read-set; the walk over the query (F2) takes GT positions per pass.
+__global__ void __launch_bounds__(GT) poa_fuse_kernel(const PoaDev p) {
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_fail, sh_nodes, wtot[4];
+    __shared__ int sh_fail, sh_nodes, wtot[GW];
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
@@ -208,10 +228,10 @@ __global__ void __launch_bounds__(256) poa_fuse_kernel(const PoaDev p) {
     int32_t *cand = p.scratch + S.scratch0, *n_anchor = cand + p.max_qlen, *n_j = n_anchor + p.max_qlen, *addcnt = n_j + p.max_qlen;
     if (n_cigar == 0) return;                                                   // reference :614-616
     // F0/F1: node every query base is aligned to (-1: inserted base)
-    for (int q = tid; q < qlen; q += 256) cand[q] = -1;
-    for (int r = tid; r < n_old; r += 256) addcnt[r] = 0;
+    for (int q = tid; q < qlen; q += GT) cand[q] = -1;
+    for (int r = tid; r < n_old; r += GT) addcnt[r] = 0;
     __syncthreads();
-    for (int i = tid; i < n_cigar; i += 256) {
+    for (int i = tid; i < n_cigar; i += GT) {
         const uint64_t w = cg[i];
         if ((int)(w & 0xf) == ABPOA_HIP_CMATCH) cand[(int)((w >> 4) & 0x3fffffff)] = (int)((w >> 34) & 0x3fffffff);
     }
@@ -236,9 +256,11 @@ __global__ void __launch_bounds__(256) poa_fuse_kernel(const PoaDev p) {
         }
         p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
     };
-    if (wave == 0) {
-    for (int q0 = 0; q0 < qlen; q0 += 64) {
-        const int q = q0 + lane; const bool act = q < qlen;
+    // all wavefronts walk the query together, GT positions per pass: per-position work (node lookup, new node, edge) is private to
+    // its thread; what flows along the path (new-node ids, previous node, the running maxima AR / sq) crosses wavefronts through LDS
+    __shared__ int sCnt[GW], sMax[GW], sSqm[GW], sNode[GT], sIsNew[GT], sAR[GT], sSq[GT];
+    for (int q0 = 0; q0 < qlen; q0 += GT) {
+        const int q = q0 + tid; const bool act = q < qlen;
         const int c = act ? ld_fresh(cand + q) : -1;
         const int b = act ? (int)seq[q] : 0;
         int node = -1; bool isnew = act;
@@ -258,11 +280,17 @@ __global__ void __launch_bounds__(256) poa_fuse_kernel(const PoaDev p) {
             const int na = p.nd_naln[N0 + ref];
             for (int t = 0; t < na; ++t) gv = imax_(gv, p.nd_row[N0 + p.nd_aln[(N0 + ref) * POA_ALN_CAP + t]]);
         }
+        // exchange 1: ids of the new nodes (path order) and the running maximum AR
         const unsigned long long newmask = __ballot(isnew);
         const int rank = __builtin_popcountll(newmask & ((1ull << lane) - 1));
-        if (isnew) node = n_nodes + rank;
-        const int n_new = __builtin_popcountll(newmask);
-        if (n_nodes + n_new > S.node_cap) { fail = true; break; }
+        const int gmax_w = wave_scan_max(gv);
+        if (lane == 63) { sCnt[wave] = __builtin_popcountll(newmask); sMax[wave] = gmax_w; }
+        __syncthreads();
+        int before_cnt = 0, n_new = 0, before_max = carry_ar;
+#pragma unroll
+        for (int w_ = 0; w_ < GW; ++w_) { const int x_ = sCnt[w_]; n_new += x_; if (w_ < wave) { before_cnt += x_; before_max = imax_(before_max, sMax[w_]); } }
+        if (n_nodes + n_new > S.node_cap) { fail = true; break; }                // (the same in every thread)
+        if (isnew) node = n_nodes + before_cnt + rank;
         if (isnew) {
             const int64_t Y = N0 + node;
             p.nd_base[Y] = (uint8_t)b; p.nd_nin[Y] = 0; p.nd_nout[Y] = 0; p.nd_naln[Y] = 0; p.nd_nread[Y] = 0;
@@ -281,49 +309,58 @@ __global__ void __launch_bounds__(256) poa_fuse_kernel(const PoaDev p) {
                 }
             }
         }
-        // predecessor on the path: lane - 1 (lane 0: last node of the previous chunk)
-        const int prev = shr1(prev_c, node), prev_new = shr1(prev_new_c, (int)isnew);
-        add_edge(act, prev, prev_new != 0, node, isnew);
         // row-order bookkeeping.  Invariant (the reference's Kahn walk keeps it too, abpoa_graph.c:213-224): the members of an
         // aligned group are contiguous in the row order.  A new node is therefore spliced in right after the END of a group:
         // the group of the node it mismatches (which it joins), or the group of the nearest old node before it on the path,
         // whichever comes later -- i.e. after row AR = running maximum along the path of "group-end row" (old nodes: their own
         // group; mismatch nodes: the group they join; inserted bases: none).  New nodes with the same AR form a run in path order.
-        const int AR = imax_(wave_scan_max(gv), carry_ar);
-        const int prevAR = shr1(carry_ar, AR);
+        const int AR = imax_(gmax_w, before_max);
+        // exchange 2: the previous position on the path (thread - 1; thread 0: last position of the previous pass).  The barrier also
+        // orders the new nodes' initialisation above before the edge updates below.
+        sNode[tid] = node; sIsNew[tid] = (int)isnew; sAR[tid] = AR;
+        __syncthreads();
+        const int prev = tid > 0 ? sNode[tid - 1] : prev_c, prev_new = tid > 0 ? sIsNew[tid - 1] : prev_new_c, prevAR = tid > 0 ? sAR[tid - 1] : carry_ar;
+        add_edge(act, prev, prev_new != 0, node, isnew);
         const bool start = isnew && (prev_new == 0 || prevAR != AR);
-        const int sq = imax_(wave_scan_max(start ? q : -1), carry_sq);
+        const int sq_w = wave_scan_max(start ? q : -1);
+        if (lane == 63) sSqm[wave] = sq_w;
+        __syncthreads();
+        int sq = imax_(sq_w, carry_sq);
+#pragma unroll
+        for (int w_ = 0; w_ < GW; ++w_) if (w_ < wave) sq = imax_(sq, sSqm[w_]);
         if (isnew) { n_anchor[node - n_old] = AR; n_j[node - n_old] = q - sq + 1; atomicAdd(addcnt + AR, 1); }
-        // carries into the next chunk (from the last active lane)
-        const int last_lane = imin_(63, qlen - 1 - q0);
-        prev_c = __builtin_amdgcn_readlane(node, last_lane); prev_new_c = __builtin_amdgcn_readlane((int)isnew, last_lane);
-        carry_ar = __builtin_amdgcn_readlane(AR, last_lane); carry_sq = __builtin_amdgcn_readlane(sq, last_lane);
+        sSq[tid] = sq;
+        __syncthreads();
+        // carries into the next pass (from the last active position)
+        const int lt = imin_(GT - 1, qlen - 1 - q0);
+        prev_c = sNode[lt]; prev_new_c = sIsNew[lt]; carry_ar = sAR[lt]; carry_sq = sSq[lt];
         n_nodes += n_new;
     }
     // F3: last node -> sink (reference :667)
-    if (!__any(fail)) add_edge(lane == 0, prev_c, prev_new_c != 0, 1, false);
-    const bool any_fail = __any(fail);
-    if (lane == 0) { sh_fail = any_fail ? 1 : 0; sh_nodes = n_nodes; }
-    }
+    bool any_fail = __syncthreads_or(fail);
+    if (!any_fail) { add_edge(tid == 0, prev_c, prev_new_c != 0, 1, false); any_fail = __syncthreads_or(fail); }
+    if (tid == 0) { sh_fail = any_fail ? 1 : 0; sh_nodes = n_nodes; }
     __syncthreads();
     if (sh_fail) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }
     n_nodes = sh_nodes;
     // F4: new row order = old order with every run of new nodes spliced in after its anchor
     int carry = 0;
-    for (int t0 = 0; t0 < n_old; t0 += 256) {
+    for (int t0 = 0; t0 < n_old; t0 += GT) {
         const int r = t0 + tid;
         const int cnt = r < n_old ? ld_fresh(addcnt + r) : 0;
         const int incl = wave_scan_add(cnt);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        const int w0 = wtot[0], w1 = wtot[1], w2 = wtot[2], w3 = wtot[3];
-        const int shift = carry + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0) + incl - cnt;      // new nodes anchored at earlier rows
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < GW; ++w_) { const int x_ = wtot[w_]; all += x_; before += w_ < wave ? x_ : 0; }
+        const int shift = carry + before + incl - cnt;      // new nodes anchored at earlier rows
         if (r < n_old) { const int u = order_old[r]; order_new[r + shift] = u; p.nd_row[N0 + u] = r + shift; addcnt[r] = shift; }
-        carry += w0 + w1 + w2 + w3;
+        carry += all;
         __syncthreads();
     }
     __syncthreads();
-    for (int i = tid; i < n_nodes - n_old; i += 256) {
+    for (int i = tid; i < n_nodes - n_old; i += GT) {
         const int ar = ld_fresh(n_anchor + i), j = ld_fresh(n_j + i);
         const int nr = ar + ld_fresh(addcnt + ar) + j;
         order_new[nr] = n_old + i; p.nd_row[N0 + n_old + i] = nr;
@@ -420,12 +457,12 @@ static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStrea
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s) { return launch_k(poa_init_kernel, p, s); }
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
-    hipLaunchKernelGGL(poa_prepare_kernel, dim3(p.n_sets), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(poa_prepare_kernel, dim3(p.n_sets), dim3(GT), (size_t)4 * (size_t)(p.pad > 0 ? p.pad : 0), s, p);      // p.pad: rows the LDS jump records hold (0: none)
     return hipGetLastError();
 }
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
-    hipLaunchKernelGGL(poa_fuse_kernel, dim3(p.n_sets), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(poa_fuse_kernel, dim3(p.n_sets), dim3(GT), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
