@@ -195,7 +195,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     PoaDev p; memset(&p, 0, sizeof(p));
     p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2; p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
-    p.pad = max_node_cap <= 9000 ? max_node_cap : 0;      // remaining-length records in LDS (36 KB at most: four workgroups per CU still fit)
+    p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;      // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
     p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
     p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;
     p.nd_base = dg + L.o_base; p.nd_nin = dg + L.o_nin; p.nd_nout = dg + L.o_nout; p.nd_naln = dg + L.o_naln;

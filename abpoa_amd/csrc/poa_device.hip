@@ -126,14 +126,49 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
     // (1) heaviest out-edge per row (first maximum wins, reference :262-268)
     extern __shared__ unsigned jump_lds[];                 // [n] remaining-length jump records (see (2)), when the launch provides them
     const bool in_lds = p.pad > 0 && n <= p.pad;
+    uint8_t *np_lds = (uint8_t *)(jump_lds + p.pad);       // [n] in-degree per row (row 0: none), for (3)
+    if (in_lds) {
+        // four rows per thread and pass, every load level issued for all four before the next one: the chain order -> node -> edge
+        // slots -> row of the successor is four dependent HBM/L2 round trips, and a thread owns ~10 rows
+        for (int r0 = tid; r0 < n; r0 += 4 * GT) {
+            int u[4], no[4], ni[4], bs[4], best[4], nx[4]; int4 w4[4], o4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; u[j] = order[r < n ? r : 0]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t X = N0 + u[j];
+                no[j] = p.nd_nout[X]; ni[j] = p.nd_nin[X]; bs[j] = p.nd_base[X];
+                w4[j] = *(const int4 *)(p.nd_outw + X * POA_OUT_CAP); o4[j] = *(const int4 *)(p.nd_out + X * POA_OUT_CAP);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int bw = -1, bb = -1;
+                if (no[j] > 0 && w4[j].x > bw) { bw = w4[j].x; bb = o4[j].x; }
+                if (no[j] > 1 && w4[j].y > bw) { bw = w4[j].y; bb = o4[j].y; }
+                if (no[j] > 2 && w4[j].z > bw) { bw = w4[j].z; bb = o4[j].z; }
+                if (no[j] > 3 && w4[j].w > bw) { bw = w4[j].w; bb = o4[j].w; }
+                for (int t = 4; t < no[j]; ++t) { const int w = p.nd_outw[(N0 + u[j]) * POA_OUT_CAP + t]; if (w > bw) { bw = w; bb = p.nd_out[(N0 + u[j]) * POA_OUT_CAP + t]; } }
+                best[j] = bb;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nx[j] = best[j] >= 0 ? p.nd_row[N0 + best[j]] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + j * GT;
+                if (r < n) {
+                    jump_lds[r] = nx[j] >= 0 ? ((unsigned)nx[j] << 16) | 1u : ((unsigned)r << 16);
+                    np_lds[r] = (uint8_t)(r > 0 ? ni[j] : 0);
+                    p.row_base[N0 + r] = (uint8_t)bs[j]; p.row_node_id[N0 + r] = u[j];
+                }
+            }
+        }
+    } else
     for (int r = tid; r < n; r += GT) {
         const int u = order[r];
         const int no = p.nd_nout[N0 + u];
         int best_w = -1, best = -1;
         for (int t = 0; t < no; ++t) { const int w = p.nd_outw[(N0 + u) * POA_OUT_CAP + t]; if (w > best_w) { best_w = w; best = p.nd_out[(N0 + u) * POA_OUT_CAP + t]; } }
-        const int nx = best >= 0 ? p.nd_row[N0 + best] : -1;
-        if (in_lds) jump_lds[r] = nx >= 0 ? ((unsigned)nx << 16) | 1u : ((unsigned)r << 16);
-        else nxt[r] = nx;
+        nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
         p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
     }
     __syncthreads();
@@ -173,8 +208,8 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
     int carry = 0; bool overflow = false;
     for (int t0 = 0; t0 < n; t0 += GT) {
         const int r = t0 + tid;
-        const int u = r < n ? order[r] : 0;
-        const int np = (r < n && r > 0) ? (int)p.nd_nin[N0 + u] : 0;
+        const int u = (r < n && !in_lds) ? order[r] : 0;
+        const int np = r < n ? (in_lds ? (int)np_lds[r] : (r > 0 ? (int)p.nd_nin[N0 + u] : 0)) : 0;
         const int incl = wave_scan_add(np);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
@@ -184,9 +219,31 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
         const int off = carry + before + incl - np;
         if (r < n) p.pred_off[N0 + r] = off;
         if (off + np > S.pred_cap) overflow = true;
-        else for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + p.nd_in[(N0 + u) * POA_IN_CAP + t]];
+        else if (!in_lds) for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + p.nd_in[(N0 + u) * POA_IN_CAP + t]];
         carry += all;
         __syncthreads();
+    }
+    if (in_lds) {      // the lists themselves, four rows per thread and pass (see (1)); pred_off is read back by the thread that wrote it
+        for (int r0 = tid; r0 < n; r0 += 4 * GT) {
+            int u[4], np[4], off[4]; int4 i4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; const bool ok = r < n; u[j] = order[ok ? r : 0]; np[j] = ok ? (int)np_lds[r] : 0; off[j] = p.pred_off[N0 + (ok ? r : 0)]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (off[j] + np[j] > S.pred_cap) np[j] = 0; i4[j] = *(const int4 *)(p.nd_in + (N0 + u[j]) * POA_IN_CAP); }
+            int pr[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pr[j][0] = np[j] > 0 ? p.nd_row[N0 + i4[j].x] : 0; pr[j][1] = np[j] > 1 ? p.nd_row[N0 + i4[j].y] : 0;
+                pr[j][2] = np[j] > 2 ? p.nd_row[N0 + i4[j].z] : 0; pr[j][3] = np[j] > 3 ? p.nd_row[N0 + i4[j].w] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int32_t *dst = p.pred_row + S.pred0 + off[j];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < np[j]) dst[t] = pr[j][t];
+                for (int t = 4; t < np[j]; ++t) dst[t] = p.nd_row[N0 + p.nd_in[(N0 + u[j]) * POA_IN_CAP + t]];
+            }
+        }
     }
     if (tid == 0) p.pred_off[N0 + n] = carry;
     overflow = __syncthreads_or(overflow);
@@ -457,7 +514,7 @@ static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStrea
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s) { return launch_k(poa_init_kernel, p, s); }
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
-    hipLaunchKernelGGL(poa_prepare_kernel, dim3(p.n_sets), dim3(GT), (size_t)4 * (size_t)(p.pad > 0 ? p.pad : 0), s, p);      // p.pad: rows the LDS jump records hold (0: none)
+    hipLaunchKernelGGL(poa_prepare_kernel, dim3(p.n_sets), dim3(GT), (size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), s, p);      // p.pad: rows the LDS records hold (4 + 1 bytes each; 0: none)
     return hipGetLastError();
 }
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
