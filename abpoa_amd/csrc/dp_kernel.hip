@@ -114,6 +114,7 @@ __device__ __forceinline__ int gld_cell(GLOBAL_AS const int32_t *p) { return gld
 // would pair every load with its own wait.
 __device__ __forceinline__ void gld_async(int4 &v, const int4 *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int4 *)p) : "memory"); }
 __device__ __forceinline__ void gld_async(int2 &v, const int2 *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int2 *)p) : "memory"); }
+__device__ __forceinline__ void gld_async(int &v, const int32_t *p) { asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int32_t *)p) : "memory"); }
 __device__ __forceinline__ void gld_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Moves a wave-uniform pointer into a VGPR pair and hides its uniformity from the compiler.  The kernel keeps ~20
@@ -948,6 +949,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             }
             __syncthreads();
             const long long tw1b = (long long)__builtin_amdgcn_s_memtime(); win_a += tw1b - tw1;       // (debug split: scan + LDS tables)
+            // the window's predecessor rows travel with the cell copy below (issued here, waited for with the first batch of cells)
+            int prv[BTP / 64];
+#pragma unroll
+            for (int k_ = 0; k_ < BTP / 64; ++k_) { const int e_ = k_ * 64 + lane; gld_async(prv[k_], (const int32_t *)pred_row + pbase + (e_ < pn_t ? e_ : 0)); }
             // staged records: 8 rows per batch, lane = column inside the slice
             typedef typename std::conditional<(CW * sizeof(T) == 8), int2, int4>::type RecT;       // 8-byte or 16-byte pieces (CW * sizeof(T) = 8, 16 or 32)
             constexpr int PIECES = (int)(CW * sizeof(T) / sizeof(RecT));
@@ -957,13 +962,14 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 const long long c_lo = (long long)(unsigned)__builtin_amdgcn_readlane((int)(c_ & 0xffffffffll), l0) | ((long long)__builtin_amdgcn_readlane((int)(c_ >> 32), l0) << 32);
                 const int n16 = (int)((long long)__builtin_amdgcn_readlane(incl, 63) * CW * (int)sizeof(T) / 16);
                 const int4 *src = (const int4 *)(planes + c_lo); int4 *dst = (int4 *)bt;
-                for (int i0 = 0; i0 < n16; i0 += 64 * 8) {
-                    int4 v[8];
+                constexpr int NB = 24;                       // 24 x 64 lanes x 16 bytes = the whole 24 KB window in one HBM round trip
+                for (int i0 = 0; i0 < n16; i0 += 64 * NB) {
+                    int4 v[NB];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; gld_async(v[u], src + (idx < n16 ? idx : 0)); }
+                    for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; gld_async(v[u], src + (idx < n16 ? idx : 0)); }
                     gld_wait();
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
+                    for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
                 }
             } else {
                 // slices: lane = column inside the slice, 16 rows per batch; the per-row constants travel by v_readlane, not through LDS
@@ -990,8 +996,11 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long tw2 = (long long)__builtin_amdgcn_s_memtime(); win_b += tw2 - tw1b;
-            for (int e = lane; e < pn_t; e += 64) {
-                const int pr_ = pred_row[pbase + e]; const bool ok = pr_ >= lo && pr_ <= hi;
+            gld_wait();                                     // (a window without cells to copy still has predecessor rows in flight)
+#pragma unroll
+            for (int k_ = 0; k_ < BTP / 64; ++k_) {
+                const int e = k_ * 64 + lane; if (e >= pn_t) continue;
+                const int pr_ = prv[k_]; const bool ok = pr_ >= lo && pr_ <= hi;
                 const int4 ri_ = B.rinfo[ok ? pr_ - lo : 0];
                 B.edge[e] = make_int4(pr_, ok ? ri_.x : 0, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int4(ri_.z, ri_.w, B.rinfo2[ok ? pr_ - lo : 0], 0);      // (not staged: empty band)
             }
