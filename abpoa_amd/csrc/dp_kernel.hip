@@ -743,22 +743,34 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         switch_tile(t0);
         const int r_hi = imin(t0 + 64, gn - 1);
-        for (int row = imax(t0, 1); row < r_hi; ++row) {
+        auto commit_row = [&](int ti) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
+            const int geo_new = sgpr(beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
+            asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+                         : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
+        };
+        int row = imax(t0, 1);
+        while (row < r_hi) {
+            // ---- tight loop over consecutive straight-line rows: only these merge at its back edge (in one loop with the other row
+            //      bodies every row paid ~30 register copies for the merge of all paths)
+            for (;;) {
+                const int ti_ = row & 63;
+                const int meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
+                if (!__builtin_expect((meta_ >> 17) & 1, 1)) break;
+                rterm = __builtin_amdgcn_readlane(tv_rterm, ti_);
+                base = meta_ & 0xff; np = (meta_ >> 8) & 0xff;
+                const int ok_ = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, row, ti_) : turbo_body(std::integral_constant<int, 2>{}, row, ti_);
+                if (!__builtin_expect(ok_, 1)) break;
+                commit_row(ti_);
+                last_done = row;
+                if (++row >= r_hi) break;
+            }
+            if (row >= r_hi) break;
             const int ti = row & 63;
             last_done = row;
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
             am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
-            auto commit_row = [&]() __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
-                const int geo_new = sgpr(beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
-                asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
-                             : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
-            };
-            if (__builtin_expect((meta >> 17) & 1, 1)) {
-                if (np == 1) { if (__builtin_expect(turbo_body(std::integral_constant<int, 1>{}, row, ti), 1)) { commit_row(); continue; } }
-                else if (__builtin_expect(turbo_body(std::integral_constant<int, 2>{}, row, ti), 1)) { commit_row(); continue; }
-            }
             int rc = 0;
             {
                 if ((meta >> 16) & 1) {
@@ -786,9 +798,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     }
                 }
             }
-            commit_row();
+            commit_row(ti);
             FSTAMP(4)
+            ++row;
         }
+        if (status != 0) break;
     }
     // ---- geometry of the last (partial) tile
     if (status == 0) {
