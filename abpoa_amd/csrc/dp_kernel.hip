@@ -1210,6 +1210,42 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         while (CW > 0 && i > 0 && j > 0 && status == 0 && true) {
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }
+            // ---- match run, as in the whole-row loop above; here a row's staged cells are the column slice cr2 = first column | count << 16
+            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
+                int mi_ = i, mj = j, pi_ = i, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr; int mc2 = cr2;
+                const int nc0 = n_cigar;
+                int slots = n_cigar == 0 ? 64 : ((64 - (n_cigar & 63)) & 63);           // words that still fit before the VGPR pair has to be written out
+                for (;;) {
+                    const int si_ = mj - (mc2 & 0xffff), np_ = (mc.z >> 16) & 0xff;
+                    if ((unsigned)si_ >= ((unsigned)mc2 >> 16)) break;                   // the cell is outside the staged slice of its row: the full step re-centres the window
+                    int fl_v = (int)bt[mc.y + si_ * CW + PL_FLAG];
+                    int qc_v = (int)s_query[mj - 1];
+                    const int e_idx = (mc.z & 0xffff) + (lane < np_ ? lane : 0);        // (n_pred 255 = row not eligible: the reads stay inside the LDS image, the result is not used)
+                    int4 er = B.edge[e_idx & (BTP - 1)]; int4 er2 = B.edge2[e_idx & (BTP - 1)];
+                    asm volatile("" : "+v"(fl_v), "+v"(qc_v), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er2.x), "+v"(er2.y), "+v"(er2.z));      // every load issued before the one wait
+                    const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+                    const int ks = (fl - 1) & 63, ery = __builtin_amdgcn_readlane(er.y, ks);
+                    // flag known and in range, row eligible, column j-1 inside that predecessor's band (empty when it is not staged)
+                    if (!((unsigned)(fl - 1) < (unsigned)np_ && np_ != 255 && (unsigned)(mj - 1 - (ery & 0xffff)) < ((unsigned)ery >> 16))) break;
+                    if (slots == 0) { flush_cigar(n_cigar - 64, 64); slots = 64; }
+                    --slots;
+                    w_lo = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH); w_hi = sgpr(mc.w << 2);                  // node id << 34 | query index << 4 | op
+                    { const int w_idx = sgpr(n_cigar & 63);
+                      asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx) : "m0"); }
+                    ++n_cigar; nm_v += (qc_v == (int)((unsigned)mc.z >> 24)) ? 1 : 0;
+                    pi_ = mi_; --mj;
+                    mi_ = __builtin_amdgcn_readlane(er.x, ks);
+                    mc = make_int4(ery, __builtin_amdgcn_readlane(er.z, ks), __builtin_amdgcn_readlane(er2.x, ks), __builtin_amdgcn_readlane(er2.y, ks)); mc2 = __builtin_amdgcn_readlane(er2.z, ks);
+                    if (imin(mi_, mj) <= 0) break;
+                }
+                const int moved = n_cigar - nc0;
+                if (moved) {
+                    start_i = pi_; start_j = mj + 1; bt_steps += moved; bt_flag_steps += moved; n_aln += moved; n_match += __builtin_amdgcn_readfirstlane(nm_v);
+                    last_word = ((uint64_t)(unsigned)w_hi << 32) | (uint64_t)(unsigned)w_lo; cur_op = OP_ALL;
+                    i = mi_; j = mj; cr = mc; cr2 = mc2; cr_row = i;
+                    if (i <= 0 || j <= 0) continue;
+                }
+            }
             const int pbi = cr.x & 0xffff, Wi = (int)((unsigned)cr.x >> 16), offi = cr.y;
             const int eb = cr.z & 0xffff, np = (cr.z >> 16) & 0xff, bs_ = (int)((unsigned)cr.z >> 24), id = cr.w;
             const int sli = cr2 & 0xffff, nsi = (int)((unsigned)cr2 >> 16);
