@@ -359,7 +359,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else { q[0] = H; q[RCS] = E1; if (GAP == 2) q[2 * RCS] = E2; }
     };
 
-    int cur = 0, n_vec = 0, rows_done = 0;          // arena cursor and cell count in units of PN cells (one reference SIMD vector)
+    int cur = 0, n_vec_lane = 0;                    // arena cursor in units of PN cells (one reference SIMD vector); cell count: per-lane sums of the flushed rows' vectors
     const int cap_pn = (int)(d.plane_cap / PN > 0x7fffffffLL ? 0x7fffffffLL : d.plane_cap / PN);
     const int remain_end = __builtin_amdgcn_readfirstlane(io.row_remain[gn - 1]);
     // ------------------------------------------------------------------ row 0, reference :553-662
@@ -531,7 +531,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto reserve = [&]() __attribute__((always_inline)) {
         const int nvr = end_sn - beg_sn + 1;
         if (cur + nvr * CW > cap_pn) return false;
-        off_pn = cur; cur += nvr * CW; n_vec += nvr; ++rows_done;
+        off_pn = cur; cur += nvr * CW;
         return true;
     };
 
@@ -592,7 +592,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         int lowest = imin(h, E1v); if (GAP == 2) lowest = imin(lowest, E2v);
         if (__builtin_expect(__any(in_band && lowest < fast_lo), 0)) return 0;
         // ---- from here on the row is committed
-        off_pn = cur; cur += nvr * CW; n_vec += nvr; ++rows_done; to_ring = true;
+        off_pn = cur; cur += nvr * CW;
         int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
         const int first = __builtin_amdgcn_readlane(h, 0);
         const int g1s = hs + le1;
@@ -740,11 +740,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     for (int t0 = 0; t0 < gn - 1 && status == 0; t0 += 64) {
         if (t0 > 0) {       // geometry of the finished tile goes to HBM in one coalesced burst (older predecessors, backtrack, trace)
             const int rb = t0 - 64 + lane; io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi;
+            if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1;
         }
         switch_tile(t0);
         const int r_hi = imin(t0 + 64, gn - 1);
-        auto commit_row = [&](int ti) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
-            const int geo_new = sgpr(beg_sn | (end_sn << 12) | (to_ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
+        auto commit_row = [&](int ti, bool ring) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
+            const int geo_new = sgpr(beg_sn | (end_sn << 12) | (ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
             asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
                          : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
         };
@@ -752,19 +753,21 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         while (row < r_hi) {
             // ---- tight loop over consecutive straight-line rows: only these merge at its back edge (in one loop with the other row
             //      bodies every row paid ~30 register copies for the merge of all paths)
+            int ok_ = 0;
             for (;;) {
                 const int ti_ = row & 63;
                 const int meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
                 if (!__builtin_expect((meta_ >> 17) & 1, 1)) break;
                 rterm = __builtin_amdgcn_readlane(tv_rterm, ti_);
                 base = meta_ & 0xff; np = (meta_ >> 8) & 0xff;
-                const int ok_ = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, row, ti_) : turbo_body(std::integral_constant<int, 2>{}, row, ti_);
-                if (!__builtin_expect(ok_, 1)) break;
-                commit_row(ti_);
-                last_done = row;
+                ok_ = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, row, ti_) : turbo_body(std::integral_constant<int, 2>{}, row, ti_);
+                if (__builtin_expect(ok_ != 1, 0)) break;
+                commit_row(ti_, true);
                 if (++row >= r_hi) break;
             }
+            last_done = row - 1;
             if (row >= r_hi) break;
+            if (ok_ == 2) { refresh_qc(); continue; }                // (the band of `row` is set: refresh_qc reads beg_sn) then the same row again
             const int ti = row & 63;
             last_done = row;
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
@@ -798,7 +801,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     }
                 }
             }
-            commit_row(ti);
+            commit_row(ti, to_ring);
             FSTAMP(4)
             ++row;
         }
@@ -807,7 +810,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // ---- geometry of the last (partial) tile
     if (status == 0) {
         const int tb = last_done & ~63, rb = tb + lane;
-        if (rb <= last_done) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
+        if (rb <= last_done) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi;
+                               if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1; }
     }
     __syncthreads();
     // ---- max_pos_left/right as the reference leaves them (only when the caller reads them back)
@@ -822,7 +826,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             io.g_left[r] = lf; io.g_right[r] = rt;
         }
     }
-    cursor_out = (long long)cur * PN; n_cells_out = (long long)n_vec * PN; rows_done_out = rows_done;
+    cursor_out = (long long)cur * PN; n_cells_out = (long long)__builtin_amdgcn_readlane(wave_scan_add_i32(n_vec_lane), 63) * PN; rows_done_out = last_done;
 }
 
 // Everything after the row loop: global best (reference :1028-1041), backtrack (:109-429) and the result record.  Shared by the
