@@ -335,6 +335,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
     const int RR = b.lds.fr_rows, RC = b.lds.fr_cols, RCS = RC + 4;
     int *fr = (int *)(lds_raw + b.lds.phase_off + b.lds.fr_off);
+    // LDS byte address of ring row (r & (RR - 1)), column 0, held by lane r & 63: RR divides 64, so one lane-constant VGPR serves
+    // every row -- a v_readlane replaces the and / mul / shift / add chain per predecessor and for the row's own slot
+    typedef __attribute__((address_space(3))) int lds_int_t;
+    const int vslot = (int)(unsigned)(size_t)(lds_int_t *)fr + 4 * ((threadIdx.x & 63 & (RR - 1)) * (NPW * RCS) + 2);
+    auto ring_at = [&](int slot_addr, int col_idx) __attribute__((always_inline)) { return (const int *)(lds_int_t *)(size_t)(unsigned)(slot_addr + 4 * col_idx); };
     int *s_mx = (int *)(lds_raw + b.lds.mx_off);
     const int infw = I16 ? (int)(((unsigned)inf & 0xffffu) | ((unsigned)inf << 16)) : inf;
     const int qlen_sn = qlen / PN;
@@ -572,7 +577,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         int Mv, E1v, E2v = inf;
         {
             const int x = colrel - pb0 * PN;
-            const int *src = fr + (p0 & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+            const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p0), med3i(x - 1, -2, RC));
             if (I16) { const int w0 = src[0], w1 = src[1]; Mv = (int)(short)w0; E1v = w1 >> 16; if (GAP == 2) E2v = src[RCS + 1]; }
             else { Mv = src[0]; E1v = src[RCS + 1]; if (GAP == 2) E2v = src[2 * RCS + 1]; }
         }
@@ -580,7 +585,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (NPC == 2) {
             const int pb1 = g1 & 0xfff, Wp = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
             const int x = colrel - pb1 * PN;
-            const int *src = fr + (p1 & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+            const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p1), med3i(x - 1, -2, RC));
             int hm1, ev1, ev2 = inf;
             if (I16) { int w0 = src[0], w1 = src[1]; asm volatile("" : "+v"(w0), "+v"(w1)); hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) { ev2 = src[RCS + 1]; asm volatile("" : "+v"(ev2)); } }
             else { hm1 = src[0]; ev1 = src[RCS + 1]; asm volatile("" : "+v"(hm1), "+v"(ev1)); if (GAP == 2) { ev2 = src[2 * RCS + 1]; asm volatile("" : "+v"(ev2)); } }      // (loads stay unconditional)
@@ -618,7 +623,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + lane * CW); dst[0] = r0; dst[1] = r1; }
         {
-            int *qd = fr + (row & (RR - 1)) * (NPW * RCS) + 2 + lane;
+            int *qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti), lane);
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
             else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
             qd[64] = infw; if (NPW > 1) qd[RCS + 64] = inf; if (NPW > 2) qd[2 * RCS + 64] = inf;
