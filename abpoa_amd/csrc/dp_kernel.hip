@@ -882,7 +882,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     // The walk is executed redundantly (uniformly) by all lanes so that the LDS window of the arena can be
     // refilled cooperatively; only lane 0 writes cigar words.
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
-    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0, bt_wa = 0, bt_wb = 0, bt_wc = 0, bt_flag_steps = 0;
+    long long bt_win_ticks = 0, bt_n_windows = 0, bt_slow_steps = 0, bt_wa = 0, bt_wb = 0, bt_flag_steps = 0;
     if (status == 0 && b.ret_cigar) {
         BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
         T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
@@ -893,7 +893,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         const int cap = d.cigar_cap;
         const bool cap_safe = cap >= gn + qlen + 2;               // a walk emits at most one word per row or column it leaves: no per-step capacity check needed
         uint64_t last_word = 0;
-        long long win_ticks = 0, win_a = 0, win_b = 0, win_c = 0; int n_windows = 0;
+        long long win_ticks = 0, win_a = 0; int n_windows = 0;
         auto load_window = [&](int hi) __attribute__((always_inline)) {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             __syncthreads();
@@ -943,7 +943,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         auto load_window_cols = [&](int hi, int jtop) __attribute__((always_inline)) {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             __syncthreads();
-            const int max_rec = (int)(bt_cells / CW);
+            const int max_rec = (int)(bt_cells / (CW > 0 ? CW : 1));
             const int WC = max_rec >= 2048 ? 64 : 48;
             // candidate rows: the 64 rows ending at hi (lane = row - lo64); how many of them are staged is decided below
             const int lo64 = imax(0, hi - BTR + 1), n64 = hi - lo64 + 1;
@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long tw2 = (long long)__builtin_amdgcn_s_memtime(); win_b += tw2 - tw1b;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             gld_wait();                                     // (a window without cells to copy still has predecessor rows in flight)
 #pragma unroll
             for (int k_ = 0; k_ < BTP / 64; ++k_) {
@@ -1029,7 +1029,6 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             }
             __syncthreads();
             bt_lo = lo; bt_hi = hi; bt_pbase = pbase; win_i = hi; win_j = jtop; win_narrow = narrow;
-            win_c += (long long)__builtin_amdgcn_s_memtime() - tw2;
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
         // cigar words are collected 64 at a time in a VGPR pair (lane = word index & 63) and written out as one coalesced store per 64
@@ -1414,7 +1413,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         }
         if (CW > 0) uniformize();
         } while (CW > 0 && i > 0 && j > 0 && status == 0);
-        bt_win_ticks = win_ticks; bt_n_windows = n_windows; bt_wa = win_a; bt_wb = (long long)__builtin_amdgcn_s_memtime() - t_walk0; bt_wc = win_c;
+        bt_win_ticks = win_ticks; bt_n_windows = n_windows; bt_wa = win_a; bt_wb = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
             if (n_cigar > 0) { const int base_ = ((n_cigar - 1) >> 6) << 6; flush_cigar(base_, n_cigar - base_); }
