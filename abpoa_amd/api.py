@@ -60,27 +60,59 @@ class Params:
                            float(self.wf), self.zdrop, 1, 0)
 
 
+class _BatchOut:
+    """Owns the result records of one abpoa_hip_msa_batch call; the library's arrays are released when the last SetResult goes."""
+    __slots__ = ("lib", "out", "n")
+
+    def __init__(self, lib, out, n):
+        self.lib, self.out, self.n = lib, out, n
+
+    def __del__(self):
+        try:
+            free_msa, out = self.lib.abpoa_hip_free_msa, self.out
+            for i in range(self.n):
+                free_msa(C.byref(out[i]))
+        except Exception:      # interpreter shutdown: the library may already be gone
+            pass
+
+
 class SetResult:
-    """Result of one read-set.  The arrays come back from the library as residue codes; strings / lists are built on first
-    access (building 1000 Python strings and coverage lists eagerly costs more than the whole GPU job of a batch)."""
-    __slots__ = ("status", "cons_len", "msa_len", "n_cells", "_m", "_cons_codes", "_cons_cov", "_msa_codes", "_cons_seq", "_cov_list", "_msa_seq")
+    """Result of one read-set: a view of the library's record.  Strings / lists are built on first access (building 1000 Python
+    strings and coverage lists eagerly costs more than the whole GPU job of a batch)."""
+    __slots__ = ("_o", "_owner", "_m", "_cons_seq", "_cov_list", "_msa_seq")
+
+    def __init__(self, owner, rec, m):
+        self._owner, self._o, self._m = owner, rec, m
+        self._cons_seq = self._cov_list = self._msa_seq = None
+
+    status = property(lambda self: self._o.status)
+    n_cells = property(lambda self: self._o.n_cells)
+    cons_len = property(lambda self: self._o.cons_len)
+    msa_len = property(lambda self: self._o.msa_len)
 
     @property
     def cons_seq(self):
         if self._cons_seq is None:
-            self._cons_seq = seqio.decode(self._cons_codes, self._m) if self.cons_len > 0 else ""
+            n = self._o.cons_len
+            self._cons_seq = seqio.decode(np.frombuffer(C.string_at(self._o.cons_base, n), dtype=np.uint8), self._m) if n > 0 else ""
         return self._cons_seq
 
     @property
     def cons_cov(self):
         if self._cov_list is None:
-            self._cov_list = self._cons_cov.tolist() if self.cons_len > 0 else []
+            n = self._o.cons_len
+            self._cov_list = np.frombuffer(C.string_at(self._o.cons_cov, 4 * n), dtype=np.int32).tolist() if n > 0 else []
         return self._cov_list
 
     @property
     def msa_seq(self):
         if self._msa_seq is None:
-            self._msa_seq = [seqio.decode(row, self._m) for row in self._msa_codes] if self.msa_len > 0 else []
+            o = self._o
+            if o.msa_len > 0:
+                rows = np.frombuffer(C.string_at(o.msa_base, o.msa_rows * o.msa_len), dtype=np.uint8).reshape(o.msa_rows, o.msa_len)
+                self._msa_seq = [seqio.decode(row, self._m) for row in rows]
+            else:
+                self._msa_seq = []
         return self._msa_seq
 
 
@@ -120,19 +152,8 @@ def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=
     rc = lib.abpoa_hip_msa_batch(C.byref(sc), enc.n, enc.sets, out, flags, n_threads)
     if rc != 0:
         raise ffi.EngineError(f"abpoa_hip_msa_batch failed ({rc}): {lib.abpoa_hip_last_error().decode() if hasattr(lib, 'abpoa_hip_last_error') else ''}")
-    res = []
-    m, string_at, free_msa, frombuffer = params.m, C.string_at, lib.abpoa_hip_free_msa, np.frombuffer
-    for i in range(enc.n):
-        o, r = out[i], SetResult()
-        n = o.cons_len
-        r.status, r.n_cells, r.cons_len, r.msa_len, r._m = o.status, o.n_cells, n, o.msa_len, m
-        r._cons_seq = r._cov_list = r._msa_seq = None
-        # one bytes copy per array (np.ctypeslib.as_array costs several microseconds per call: more than the GPU job's share of a set)
-        r._cons_codes = frombuffer(string_at(o.cons_base, n), dtype=np.uint8) if n > 0 else None
-        r._cons_cov = frombuffer(string_at(o.cons_cov, 4 * n), dtype=np.int32) if n > 0 else None
-        r._msa_codes = frombuffer(string_at(o.msa_base, o.msa_rows * o.msa_len), dtype=np.uint8).reshape(o.msa_rows, o.msa_len) if o.msa_len > 0 else None
-        free_msa(C.byref(o))
-        res.append(r)
+    owner, m = _BatchOut(lib, out, enc.n), params.m
+    res = [SetResult(owner, out[i], m) for i in range(enc.n)]
     return res
 
 
