@@ -301,6 +301,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             std::vector<AlnOut> ho(n_sets); (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
             double sd = 0, sb = 0; long long md = 0, mb = 0, ms_ = 0; for (const AlnOut &o_ : ho) { sd += o_.clk_dp; sb += o_.clk_bt; md = std::max<long long>(md, o_.clk_dp); mb = std::max<long long>(mb, o_.clk_bt); ms_ = std::max<long long>(ms_, o_.clk_dp + o_.clk_bt); }
             fprintf(stderr, "[poa-device] round %d balance: rows mean %.0f max %lld | tail mean %.0f max %lld | rows+tail mean %.0f max %lld\n", k, sd / n_sets, md, sb / n_sets, mb, (sd + sb) / n_sets, ms_);
+            static std::vector<double> tot_set; static double sum_max = 0;      // (debug) what lock-step costs: sum over rounds of the slowest set vs the slowest set's own total
+            if (k == 1) { tot_set.assign(n_sets, 0.0); sum_max = 0; }
+            for (int s_ = 0; s_ < n_sets; ++s_) tot_set[s_] += (double)ho[s_].clk_dp + (double)ho[s_].clk_bt;
+            sum_max += (double)ms_;
+            if (k == max_reads - 1) { double mx_ = 0, mean_ = 0; for (double v_ : tot_set) { mx_ = std::max(mx_, v_); mean_ += v_; } fprintf(stderr, "[poa-device] rows+tail ticks over all rounds: sum of per-round maxima %.0f | slowest set alone %.0f | mean set %.0f\n", sum_max, mx_, mean_ / n_sets); }
             double sg[6] = {0, 0, 0, 0, 0, 0}, st_ = 0; for (const AlnOut &o_ : ho) { for (int q_ = 0; q_ < 6; ++q_) sg[q_] += o_.seg[q_]; st_ += o_.n_bt_steps; }
             fprintf(stderr, "[poa-device] round %d tail means: steps %.0f  flag steps %.0f  slow steps %.0f  windows %.1f  window ticks %.0f (setup %.0f)  walk ticks %.0f\n", k, st_ / n_sets, sg[2] / n_sets / 1000, sg[3] / n_sets / 1000, sg[4] / n_sets / 1000, sg[5] / n_sets, sg[0] / n_sets, sg[1] / n_sets);
         }
