@@ -61,7 +61,7 @@ struct Layout {                // byte offsets inside the three device blobs
     size_t o_sets, o_roff, o_rlen, o_reads, o_mat, in_bytes;
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
     size_t o_cnode, o_ccov, o_cbase;
-    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
+    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
     size_t o_aln_desc, o_out_rec, o_rbase, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
 };
@@ -160,8 +160,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     L.o_cnode = take(4 * cons_tot); L.o_ccov = take(4 * cons_tot); L.o_cbase = take(cons_tot);
     const size_t dl_bytes = o;
     L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
-    L.o_out = take(4 * node_tot * POA_OUT_CAP); L.o_outw = take(4 * node_tot * POA_OUT_CAP); L.o_nread = take(4 * node_tot);
-    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_IN_CAP); L.o_aln = take(4 * node_tot * POA_ALN_CAP); L.o_row = take(4 * node_tot);
+    L.o_out = take(4 * node_tot * POA_HOT); L.o_outw = take(4 * node_tot * POA_HOT); L.o_nread = take(4 * node_tot);
+    L.o_outx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_outwx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_inx = take(4 * node_tot * (POA_IN_CAP - POA_HOT));
+    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * POA_ALN_CAP); L.o_row = take(4 * node_tot);
     L.graph_bytes = o;
     o = 0;
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
@@ -200,6 +201,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;
     p.nd_base = dg + L.o_base; p.nd_nin = dg + L.o_nin; p.nd_nout = dg + L.o_nout; p.nd_naln = dg + L.o_naln;
     p.nd_in = (int32_t *)(dg + L.o_in); p.nd_out = (int32_t *)(dg + L.o_out); p.nd_outw = (int32_t *)(dg + L.o_outw); p.nd_aln = (int32_t *)(dg + L.o_aln);
+    p.nd_inx = (int32_t *)(dg + L.o_inx); p.nd_outx = (int32_t *)(dg + L.o_outx); p.nd_outwx = (int32_t *)(dg + L.o_outwx);
     p.nd_nread = (int32_t *)(dg + L.o_nread); p.nd_row = (int32_t *)(dg + L.o_row);
     p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
     p.scratch = (int32_t *)(dr + L.o_scratch);
@@ -261,7 +263,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln(n * POA_ALN_CAP), nread(n), row(n), order(n);
             auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
             dl(base.data(), p.nd_base, 1, 1); dl(nin.data(), p.nd_nin, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl(naln.data(), p.nd_naln, 1, 1);
-            dl(in.data(), p.nd_in, 4, POA_IN_CAP); dl(outv.data(), p.nd_out, 4, POA_OUT_CAP); dl(outw.data(), p.nd_outw, 4, POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, POA_ALN_CAP);
+            // edge lists come back as hot + cold halves and are merged into [node][CAP] arrays
+            auto dl_list = [&](int32_t *dst, const int32_t *hot, const int32_t *cold, int cap_) {
+                std::vector<int32_t> h_((size_t)n * POA_HOT), c_((size_t)n * (cap_ - POA_HOT));
+                (void)hipMemcpy(h_.data(), hot + (size_t)S.node0 * POA_HOT, h_.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(c_.data(), cold + (size_t)S.node0 * (cap_ - POA_HOT), c_.size() * 4, hipMemcpyDeviceToHost);
+                for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_] : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
+            };
+            dl_list(in.data(), p.nd_in, p.nd_inx, POA_IN_CAP); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx, POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, POA_ALN_CAP);
             dl(nread.data(), p.nd_nread, 4, 1); dl(row.data(), p.nd_row, 4, 1); dl(order.data(), p.row_node[hst.order_buf], 4, 1);
             int bad = 0;
             auto complain = [&](const char *what, int a, int b_) { if (bad++ < 8) fprintf(stderr, "[poa-device]   set %d round %d: %s (%d, %d)\n", s, k, what, a, b_); };
@@ -357,7 +366,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             const PoaSet &S = ps[s]; const int n = hs[s].n_nodes;
             std::vector<uint8_t> base(n), nout(n); std::vector<int32_t> outv((size_t)n * POA_OUT_CAP), outw((size_t)n * POA_OUT_CAP), nread(n), order(n);
             auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
-            dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl(outv.data(), p.nd_out, 4, POA_OUT_CAP); dl(outw.data(), p.nd_outw, 4, POA_OUT_CAP);
+            // edge lists come back as hot + cold halves and are merged into [node][CAP] arrays
+            auto dl_list = [&](int32_t *dst, const int32_t *hot, const int32_t *cold, int cap_) {
+                std::vector<int32_t> h_((size_t)n * POA_HOT), c_((size_t)n * (cap_ - POA_HOT));
+                (void)hipMemcpy(h_.data(), hot + (size_t)S.node0 * POA_HOT, h_.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(c_.data(), cold + (size_t)S.node0 * (cap_ - POA_HOT), c_.size() * 4, hipMemcpyDeviceToHost);
+                for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_] : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
+            };
+            dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx, POA_OUT_CAP);
             dl(nread.data(), p.nd_nread, 4, 1); dl(order.data(), p.row_node[hs[s].order_buf], 4, 1);
             std::vector<int> ids, cov, sc_, mo; std::vector<uint8_t> bases;
             consensus_flat(n, order.data(), base.data(), nout.data(), outv.data(), outw.data(), nread.data(), &ids, &bases, &cov, sc_, mo);

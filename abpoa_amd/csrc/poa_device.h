@@ -15,6 +15,8 @@ namespace abpoa_hip {
 
 constexpr int POA_IN_CAP = 16;     // in-edges per node kept on the device (more -> the set falls back to the host driver)
 constexpr int POA_OUT_CAP = 16;    // out-edges per node
+constexpr int POA_HOT = 4;         // slots of every edge list in the hot arrays (16-byte records: most nodes have 1-2 edges, and the graph
+                                   // kernels stream the whole graph every round); the other slots live in the cold arrays
 constexpr int POA_ALN_CAP = 4;     // aligned (mismatch-alternative) nodes per node: enough for nucleotides (m = 5)
 
 #define POA_ST_OK        0
@@ -48,7 +50,9 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
     // graph, indexed node0 + node id
     uint8_t *nd_base, *nd_nin, *nd_nout, *nd_naln;
-    int32_t *nd_in, *nd_out, *nd_outw, *nd_aln;     // [node][CAP]
+    int32_t *nd_in, *nd_out, *nd_outw;              // hot slots  [node][POA_HOT]: in ids, out ids, out weights
+    int32_t *nd_inx, *nd_outx, *nd_outwx;           // cold slots [node][CAP - POA_HOT]
+    int32_t *nd_aln;                                // [node][POA_ALN_CAP]
     int32_t *nd_nread, *nd_row;
     int32_t *row_node[2];          // row order (double buffered), indexed node0 + row
     int32_t *scratch;

@@ -27,6 +27,10 @@ __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 // loads of data that OTHER lanes of this wave stored earlier in the same kernel: agent scope = not served from this CU's L1
 __device__ __forceinline__ int ld_fresh(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// slot t of a node's edge lists (X = node0 + node id): the first POA_HOT slots are in the hot arrays
+__device__ __forceinline__ int32_t &in_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_in[X * POA_HOT + t] : p.nd_inx[X * (POA_IN_CAP - POA_HOT) + t - POA_HOT]; }
+__device__ __forceinline__ int32_t &out_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_out[X * POA_HOT + t] : p.nd_outx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT]; }
+__device__ __forceinline__ int32_t &outw_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_outw[X * POA_HOT + t] : p.nd_outwx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT]; }
 __device__ __forceinline__ int shfl(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
 template <int CTRL> __device__ __forceinline__ int dpp_(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false); }
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
         else if (u == 1) { nin = 1; in0 = L + 1; }
         else { nin = 1; in0 = i == 0 ? 0 : u - 1; nout = 1; out0 = i == L - 1 ? 1 : u + 1; }
         p.nd_nin[N0 + u] = (uint8_t)nin; p.nd_nout[N0 + u] = (uint8_t)nout;
-        p.nd_in[(N0 + u) * POA_IN_CAP] = in0; p.nd_out[(N0 + u) * POA_OUT_CAP] = out0; p.nd_outw[(N0 + u) * POA_OUT_CAP] = 1;
+        in_slot(p, N0 + u, 0) = in0; out_slot(p, N0 + u, 0) = out0; outw_slot(p, N0 + u, 0) = 1;
         p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
         // row order: source, the chain, sink
         const int row = u == 0 ? 0 : (u == 1 ? n - 1 : u - 1);
@@ -138,7 +142,7 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
             for (int j = 0; j < 4; ++j) {
                 const int64_t X = N0 + u[j];
                 no[j] = p.nd_nout[X]; ni[j] = p.nd_nin[X]; bs[j] = p.nd_base[X];
-                w4[j] = *(const int4 *)(p.nd_outw + X * POA_OUT_CAP); o4[j] = *(const int4 *)(p.nd_out + X * POA_OUT_CAP);
+                w4[j] = *(const int4 *)(p.nd_outw + X * POA_HOT); o4[j] = *(const int4 *)(p.nd_out + X * POA_HOT);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
                 if (no[j] > 1 && w4[j].y > bw) { bw = w4[j].y; bb = o4[j].y; }
                 if (no[j] > 2 && w4[j].z > bw) { bw = w4[j].z; bb = o4[j].z; }
                 if (no[j] > 3 && w4[j].w > bw) { bw = w4[j].w; bb = o4[j].w; }
-                for (int t = 4; t < no[j]; ++t) { const int w = p.nd_outw[(N0 + u[j]) * POA_OUT_CAP + t]; if (w > bw) { bw = w; bb = p.nd_out[(N0 + u[j]) * POA_OUT_CAP + t]; } }
+                for (int t = POA_HOT; t < no[j]; ++t) { const int w = outw_slot(p, N0 + u[j], t); if (w > bw) { bw = w; bb = out_slot(p, N0 + u[j], t); } }
                 best[j] = bb;
             }
 #pragma unroll
@@ -167,7 +171,7 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
         const int u = order[r];
         const int no = p.nd_nout[N0 + u];
         int best_w = -1, best = -1;
-        for (int t = 0; t < no; ++t) { const int w = p.nd_outw[(N0 + u) * POA_OUT_CAP + t]; if (w > best_w) { best_w = w; best = p.nd_out[(N0 + u) * POA_OUT_CAP + t]; } }
+        for (int t = 0; t < no; ++t) { const int w = outw_slot(p, N0 + u, t); if (w > best_w) { best_w = w; best = out_slot(p, N0 + u, t); } }
         nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
         p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
     }
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
         const int off = carry + before + incl - np;
         if (r < n) p.pred_off[N0 + r] = off;
         if (off + np > S.pred_cap) overflow = true;
-        else if (!in_lds) for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + p.nd_in[(N0 + u) * POA_IN_CAP + t]];
+        else if (!in_lds) for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + in_slot(p, N0 + u, t)];
         carry += all;
         __syncthreads();
     }
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; const bool ok = r < n; u[j] = order[ok ? r : 0]; np[j] = ok ? (int)np_lds[r] : 0; off[j] = p.pred_off[N0 + (ok ? r : 0)]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { if (off[j] + np[j] > S.pred_cap) np[j] = 0; i4[j] = *(const int4 *)(p.nd_in + (N0 + u[j]) * POA_IN_CAP); }
+            for (int j = 0; j < 4; ++j) { if (off[j] + np[j] > S.pred_cap) np[j] = 0; i4[j] = *(const int4 *)(p.nd_in + (N0 + u[j]) * POA_HOT); }
             int pr[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
                 int32_t *dst = p.pred_row + S.pred0 + off[j];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) if (t < np[j]) dst[t] = pr[j][t];
-                for (int t = 4; t < np[j]; ++t) dst[t] = p.nd_row[N0 + p.nd_in[(N0 + u[j]) * POA_IN_CAP + t]];
+                for (int t = POA_HOT; t < np[j]; ++t) dst[t] = p.nd_row[N0 + in_slot(p, N0 + u[j], t)];
             }
         }
     }
@@ -303,13 +307,13 @@ __global__ void __launch_bounds__(GT) poa_fuse_kernel(const PoaDev p) {
         const int64_t F = N0 + from, T = N0 + to;
         int no = from_new ? 0 : (int)p.nd_nout[F];
         int hit = -1;
-        if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (p.nd_out[F * POA_OUT_CAP + t] == to) { hit = t; break; }
-        if (hit >= 0) p.nd_outw[F * POA_OUT_CAP + hit] += 1;
+        if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (out_slot(p, F, t) == to) { hit = t; break; }
+        if (hit >= 0) outw_slot(p, F, hit) += 1;
         else {
             const int ni = to_new ? 0 : (int)p.nd_nin[T];
             if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; return; }
-            p.nd_out[F * POA_OUT_CAP + no] = to; p.nd_outw[F * POA_OUT_CAP + no] = 1; p.nd_nout[F] = (uint8_t)(no + 1);
-            p.nd_in[T * POA_IN_CAP + ni] = from; p.nd_nin[T] = (uint8_t)(ni + 1);
+            out_slot(p, F, no) = to; outw_slot(p, F, no) = 1; p.nd_nout[F] = (uint8_t)(no + 1);
+            in_slot(p, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
         }
         p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
     };
@@ -456,10 +460,10 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
         const int no = valid ? (int)p.nd_nout[N0 + u] : 0;
         // heaviest weight and the rows of the candidate targets (edges with that weight), as a dependency mask inside the block
         int wmax = INT_MIN;
-        for (int t = 0; t < no; ++t) wmax = imax_(wmax, p.nd_outw[(N0 + u) * POA_OUT_CAP + t]);
+        for (int t = 0; t < no; ++t) wmax = imax_(wmax, outw_slot(p, N0 + u, t));
         unsigned long long dep = 0;
-        for (int t = 0; t < no; ++t) if (p.nd_outw[(N0 + u) * POA_OUT_CAP + t] == wmax) {
-            const int tr = p.nd_row[N0 + p.nd_out[(N0 + u) * POA_OUT_CAP + t]];
+        for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
+            const int tr = p.nd_row[N0 + out_slot(p, N0 + u, t)];
             if (tr < t0 + 64) dep |= 1ull << (tr - t0);
         }
         bool done = !valid; int my_score = 0, my_next = -1;
@@ -471,8 +475,8 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
             const bool fire = !done && (dep & ~done_mask) == 0;
             if (fire) {
                 int best_sc = INT_MIN, best_row = -1; const bool is_src = u == 0;
-                for (int t = 0; t < no; ++t) if (p.nd_outw[(N0 + u) * POA_OUT_CAP + t] == wmax) {
-                    const int tr = p.nd_row[N0 + p.nd_out[(N0 + u) * POA_OUT_CAP + t]];
+                for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
+                    const int tr = p.nd_row[N0 + out_slot(p, N0 + u, t)];
                     const int sc_ = tr < t0 + 64 ? sh_score[tr - t0] : ld_fresh(score + tr);
                     if (best_row < 0 || (is_src ? sc_ > best_sc : sc_ >= best_sc)) { best_sc = sc_; best_row = tr; }
                 }
