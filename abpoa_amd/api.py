@@ -3,6 +3,7 @@
 `Params` mirrors abpoa_para_t (ref src/abpoa.h:62-81) with the defaults of abpoa_init_para
 (src/abpoa_align.c:93-141) and the derived fields of abpoa_post_set_para (:143-168)."""
 import ctypes as C
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -116,6 +117,28 @@ class SetResult:
         return self._msa_seq
 
 
+class BatchResults(Sequence):
+    """The results of one batch call as a read-only sequence of SetResult; the objects are made on first access (1000 of them cost
+    more Python time than the call's own host work)."""
+    __slots__ = ("_owner", "_m", "_items")
+
+    def __init__(self, owner, m):
+        self._owner, self._m, self._items = owner, m, [None] * owner.n
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self._items)))]
+        r = self._items[i]
+        if r is None:
+            if i < 0:
+                i += len(self._items)
+            r = self._items[i] = SetResult(self._owner, self._owner.out[i], self._m)
+        return r
+
+
 def _bind_msa(lib):
     if not getattr(lib, "_msa_bound", False):
         lib.abpoa_hip_msa_batch.argtypes = [C.POINTER(ffi.Scoring), C.c_int, C.POINTER(ReadSet), C.POINTER(Msa), C.c_uint, C.c_int]
@@ -152,8 +175,7 @@ def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=
     rc = lib.abpoa_hip_msa_batch(C.byref(sc), enc.n, enc.sets, out, flags, n_threads)
     if rc != 0:
         raise ffi.EngineError(f"abpoa_hip_msa_batch failed ({rc}): {lib.abpoa_hip_last_error().decode() if hasattr(lib, 'abpoa_hip_last_error') else ''}")
-    owner, m = _BatchOut(lib, out, enc.n), params.m
-    res = [SetResult(owner, out[i], m) for i in range(enc.n)]
+    res = BatchResults(_BatchOut(lib, out, enc.n), params.m)
     return res
 
 
