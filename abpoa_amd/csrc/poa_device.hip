@@ -461,10 +461,18 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
         // heaviest weight and the rows of the candidate targets (edges with that weight), as a dependency mask inside the block
         int wmax = INT_MIN;
         for (int t = 0; t < no; ++t) wmax = imax_(wmax, outw_slot(p, N0 + u, t));
-        unsigned long long dep = 0;
+        // candidates = targets of the heaviest edges, in edge order: their rows (and, for targets in later blocks, their final scores)
+        // are fetched once, so that a row's turn in the loop below costs LDS reads only; a row with more than NCAND candidates re-reads
+        constexpr int NCAND = 4;
+        unsigned long long dep = 0; int ctr[NCAND], csc[NCAND], ncand = 0;
+#pragma unroll
+        for (int c_ = 0; c_ < NCAND; ++c_) { ctr[c_] = -1; csc[c_] = 0; }
         for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
             const int tr = p.nd_row[N0 + out_slot(p, N0 + u, t)];
             if (tr < t0 + 64) dep |= 1ull << (tr - t0);
+#pragma unroll
+            for (int c_ = 0; c_ < NCAND; ++c_) if (c_ == ncand) { ctr[c_] = tr; csc[c_] = tr >= t0 + 64 ? ld_fresh(score + tr) : 0; }
+            ++ncand;
         }
         bool done = !valid; int my_score = 0, my_next = -1;
         if (valid && no == 0) { done = true; }                                  // the sink: score 0, no successor
@@ -475,7 +483,14 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
             const bool fire = !done && (dep & ~done_mask) == 0;
             if (fire) {
                 int best_sc = INT_MIN, best_row = -1; const bool is_src = u == 0;
-                for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
+                if (ncand <= NCAND) {
+#pragma unroll
+                    for (int c_ = 0; c_ < NCAND; ++c_) if (c_ < ncand) {
+                        const int tr = ctr[c_];
+                        const int sc_ = tr < t0 + 64 ? sh_score[tr - t0] : csc[c_];
+                        if (best_row < 0 || (is_src ? sc_ > best_sc : sc_ >= best_sc)) { best_sc = sc_; best_row = tr; }
+                    }
+                } else for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
                     const int tr = p.nd_row[N0 + out_slot(p, N0 + u, t)];
                     const int sc_ = tr < t0 + 64 ? sh_score[tr - t0] : ld_fresh(score + tr);
                     if (best_row < 0 || (is_src ? sc_ > best_sc : sc_ >= best_sc)) { best_sc = sc_; best_row = tr; }
