@@ -366,6 +366,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 
     int cur = 0, n_vec_lane = 0;                    // arena cursor in units of PN cells (one reference SIMD vector); cell count: per-lane sums of the flushed rows' vectors
     const int cap_pn = (int)(d.plane_cap / PN > 0x7fffffffLL ? 0x7fffffffLL : d.plane_cap / PN);
+    const int cap_turbo = cap_pn - NV * CW;       // arena room test of the straight-line rows (at most NV vectors)
     const int remain_end = __builtin_amdgcn_readfirstlane(io.row_remain[gn - 1]);
     // ------------------------------------------------------------------ row 0, reference :553-662
     int vg_geo = 0, vg_mi = 0, vg_off = 0;          // lane = row & 63: beg_sn | end_sn << 12 | in-ring << 24, arg-max column, arena offset / PN
@@ -436,7 +437,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // band of the row from (min, max) predecessor arg-max and predecessor geometry, reference :710-720
     auto set_band = [&](auto pin, int mn_mi, int mx_mi, int min_pb) __attribute__((always_inline)) {
         auto S = [](int x) __attribute__((always_inline)) { if constexpr (decltype(pin)::value) return sgpr(x); else return x; };
-        const int left = S(imin(gn, mn_mi + 1)), right = S(imax(0, mx_mi + 1));
+        const int left = S(imin(gn, mn_mi + 1)), right = S(decltype(pin)::value ? mx_mi + 1 : imax(0, mx_mi + 1));      // (row arg-max >= -1)
         const int lo = S(imin(left, rterm) - w), hi = S(imax(right, rterm) + w);
         const int beg = S(imax(0, lo)), end = S(imin(qlen, hi));
         beg_sn = imax((int)((unsigned)beg / PN), min_pb); end_sn = (int)((unsigned)end / PN);
@@ -547,7 +548,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     //      Returns 1 = done (mi set), 0 = not applicable.
     int mi = -1;
     const int lane4 = lane * 4;
-    const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (unsigned)(NV - 1 - vvl)), kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | 8u);     // arg-max key constants: normal / end_sn vector
+    // arg-max key constants (normal / end_sn vector): lane residue, vector priority, and -- never decisive, it only saves the decoding -- the lane
+    const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)(NV - 1 - vvl) << 8) | (unsigned)lane), kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (8u << 8) | (unsigned)lane);
     auto turbo_body = [&](auto npc, int row, int ti) __attribute__((always_inline)) -> int {
         constexpr int NPC = decltype(npc)::value;
         const int tb = __builtin_amdgcn_readlane(tv_tb, ti);
@@ -564,8 +566,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         set_band(std::true_type{}, mn, mx, min_pb);
         const int nvr = end_sn - beg_sn + 1;
         // all conditions as sign bits: (x <= y) <=> (x - y - 1) < 0
-        const int okbits = (nvr - NV - 1) & (end_sn - max_pe - 1) & (cur + nvr * CW - cap_pn - 1) & (ring << 7);      // GEO_RING (bit 24) -> bit 31
-        if (__builtin_expect(okbits >= 0 || end_sn == qlen_sn, 0)) return 0;
+        // (arena room: checked for a full-width row, cap_turbo = cap_pn - NV * CW; the last query vector: end_sn <= qlen_sn always)
+        const int okbits = (nvr - NV - 1) & (end_sn - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7) & (end_sn - qlen_sn);      // GEO_RING (bit 24) -> bit 31
+        if (__builtin_expect(okbits >= 0, 0)) return 0;
         const int Wr = nvr * PN;
         if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
             qc_beg_sn = beg_sn;
@@ -633,8 +636,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (I16) {
             const unsigned key = ((unsigned)Hout << 16) + (unsigned)((vvl == nvr - 1) ? kE : kN);
             const unsigned kb = wave_max_u32_s(in_band ? key : 0u);
-            const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
-            mi = ((int)(kb >> 16) - 32768 > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
+            mi = ((int)(kb >> 16) - 32768 > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
         } else {
             const int vmax = wave_max_i32_s(in_band ? Hout : INT_MIN);
             const unsigned key = (in_band && Hout == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
