@@ -53,7 +53,7 @@ struct Arena {                 // grow-only device / pinned-host buffers kept ac
         HIP_OK(hipHostMalloc((void **)&host, n, hipHostMallocDefault), ABPOA_HIP_ENOMEM); host_cap = n; return 0;
     }
 };
-struct Cache { Arena in, graph, rows, planes, out; hipStream_t stream = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
+struct Cache { Arena in, graph, rows, planes, out; hipStream_t stream = nullptr, copy_stream = nullptr; hipEvent_t ev_copy = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
 Cache g_c; std::mutex g_mu;
 
 struct Layout {                // byte offsets inside the three device blobs
@@ -152,8 +152,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     }
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
-    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_reads = take(tot_bases + 64);
-    L.o_mat = take(4 * sc->m * sc->m); L.in_bytes = o;
+    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m);
+    L.o_reads = take(tot_bases + 64); L.in_bytes = o;      // reads last: they go up in two parts
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
     // downloaded part first, contiguous: per-set state and the consensus results
@@ -179,17 +179,30 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     // ---- upload: set table, reads (already residue codes), score matrix
     uint8_t *hi = C.in.host;
     memcpy(hi + L.o_sets, ps.data(), sizeof(PoaSet) * n_sets);
+    // Reads are laid out round by round (read k of every set, then read k + 1 ...): the first two rounds go up at once, the rest is staged
+    // and copied while the GPU already works on round 1 (config 2: 50 MB of residue codes, ~1 ms of staging + ~1 ms of PCIe)
+    int64_t *roff = (int64_t *)(hi + L.o_roff); int32_t *rlen = (int32_t *)(hi + L.o_rlen); uint8_t *rd = hi + L.o_reads;
+    int64_t split_at = 0;
     {
-        int64_t *roff = (int64_t *)(hi + L.o_roff); int32_t *rlen = (int32_t *)(hi + L.o_rlen); uint8_t *rd = hi + L.o_reads; int64_t at = 0, ri = 0;
-        for (int s = 0; s < n_sets; ++s) for (int r = 0; r < sets[s].n_reads; ++r) { roff[ri] = at; rlen[ri] = sets[s].lens[r]; at += sets[s].lens[r]; ++ri; }
-        roff[ri] = at;
-        parallel_ranges(std::min(n_threads, 16), n_sets, [&](int lo, int hi_) {      // 50 MB of residue codes into the pinned blob for config 2
-            for (int s = lo; s < hi_; ++s) { const int64_t r0 = ps[s].read0; for (int r = 0; r < sets[s].n_reads; ++r) memcpy(rd + roff[r0 + r], sets[s].seqs[r], sets[s].lens[r]); }
-        });
+        int64_t at = 0;
+        for (int k = 0; k < max_reads; ++k) {
+            if (k == 2) split_at = at;
+            for (int s = 0; s < n_sets; ++s) if (k < sets[s].n_reads) { const int64_t ri = ps[s].read0 + k; roff[ri] = at; rlen[ri] = sets[s].lens[k]; at += sets[s].lens[k]; }
+        }
+        if (max_reads <= 2) split_at = at;
+        roff[tot_reads] = at;
     }
+    auto stage_reads = [&](int k_lo, int k_hi) {
+        parallel_ranges(std::min(n_threads, 16), n_sets, [&](int lo, int hi_) {
+            for (int s = lo; s < hi_; ++s) { const int64_t r0 = ps[s].read0; const int ke = std::min(k_hi, sets[s].n_reads); for (int r = k_lo; r < ke; ++r) memcpy(rd + roff[r0 + r], sets[s].seqs[r], sets[s].lens[r]); }
+        });
+    };
+    stage_reads(0, 2);
     memcpy(hi + L.o_mat, sc->mat, 4 * sc->m * sc->m);
     hipStream_t st = C.stream;
-    HIP_OK(hipMemcpyAsync(C.in.dev, hi, L.in_bytes, hipMemcpyHostToDevice, st), ABPOA_HIP_ELAUNCH);
+    if (!C.copy_stream) { HIP_OK(hipStreamCreateWithFlags(&C.copy_stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV); HIP_OK(hipEventCreateWithFlags(&C.ev_copy, hipEventDisableTiming), ABPOA_HIP_ENODEV); }
+    HIP_OK(hipMemcpyAsync(C.in.dev, hi, L.o_reads + (size_t)split_at, hipMemcpyHostToDevice, st), ABPOA_HIP_ELAUNCH);
+    bool rest_up = split_at >= roff[tot_reads];      // nothing left for the second part
 
     // ---- kernel arguments
     uint8_t *di = C.in.dev, *dg = C.graph.dev, *dr = C.rows.dev;
@@ -299,6 +312,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     dbg_check(0);
     HIP_OK(hipEventRecord(C.ev[1], st), ABPOA_HIP_ELAUNCH);
     for (int k = 1; k < max_reads; ++k) {
+        if (k == 2 && !rest_up) {      // round 1 is queued: stage and send the reads of the later rounds behind it
+            stage_reads(2, max_reads);
+            HIP_OK(hipMemcpyAsync(C.in.dev + L.o_reads + (size_t)split_at, hi + L.o_reads + (size_t)split_at, (size_t)(roff[tot_reads] - split_at), hipMemcpyHostToDevice, C.copy_stream), ABPOA_HIP_ELAUNCH);
+            HIP_OK(hipEventRecord(C.ev_copy, C.copy_stream), ABPOA_HIP_ELAUNCH);
+            HIP_OK(hipStreamWaitEvent(st, C.ev_copy, 0), ABPOA_HIP_ELAUNCH);
+            rest_up = true;
+        }
         p.round = k;
         hipEvent_t *e = C.ev.data() + 4 * k;
         HIP_OK(launch_poa_prepare(p, st), ABPOA_HIP_ELAUNCH);
