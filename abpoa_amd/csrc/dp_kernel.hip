@@ -598,14 +598,17 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int h = Mv + q;                                      // no wrap possible once the check below passes
         const bool in_band = lane < Wr;
         int lowest = imin(h, E1v); if (GAP == 2) lowest = imin(lowest, E2v);
-        if (__builtin_expect(__any(in_band && lowest < fast_lo), 0)) return 0;
+        const bool near_wrap = __any(in_band && lowest < fast_lo);      // decided here, acted on after the scan below: the compare runs beside it, the
+                                                                        // branch is off the row's dependent chain (nothing is stored before it)
+        int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
+        // lane 0's scan input is first - e (first = H of the band's first column before any E / F merge = h of lane 0): the shift leaves lane 0's
+        // own h - e in place, no trip through an SGPR
+        const int g1s = hs + le1;
+        int F1 = imax(wave_scan_max_i32(wave_shr1(h - e1, g1s)) - cf1, inj1), F2 = inf;
+        if (GAP == 2) { const int g2s = hs + le2; F2 = imax(wave_scan_max_i32(wave_shr1(h - e2, g2s)) - cf2, inj2); }
+        if (__builtin_expect(near_wrap, 0)) return 0;
         // ---- from here on the row is committed
         off_pn = cur; cur += nvr * CW;
-        int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
-        const int first = __builtin_amdgcn_readlane(h, 0);
-        const int g1s = hs + le1;
-        int F1 = imax(wave_scan_max_i32(wave_shr1(first - e1, g1s)) - cf1, inj1), F2 = inf;
-        if (GAP == 2) { const int g2s = hs + le2; F2 = imax(wave_scan_max_i32(wave_shr1(first - e2, g2s)) - cf2, inj2); }
         int Hout, E1out, E2out = inf;
         if (GAP == 1) {
             const int tmp = imax(h, E1v);
