@@ -577,13 +577,22 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         const int q = *(const int *)((const char *)s_mx + (tb >> 16) + qoff0 * 4);
         const int colrel = beg_sn * PN + lane;                     // this lane's column
-        int Mv, E1v, E2v = inf;
+        int Mv, E1v, E2v = inf, raw0, raw1, raw2 = inf;            // the first predecessor's words as loaded (decoded after the block below)
         {
             const int x = colrel - pb0 * PN;
             const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p0), med3i(x - 1, -2, RC));
-            if (I16) { const int w0 = src[0], w1 = src[1]; Mv = (int)(short)w0; E1v = w1 >> 16; if (GAP == 2) E2v = src[RCS + 1]; }
-            else { Mv = src[0]; E1v = src[RCS + 1]; if (GAP == 2) E2v = src[2 * RCS + 1]; }
+            if (I16) { raw0 = src[0]; raw1 = src[1]; if (GAP == 2) raw2 = src[RCS + 1]; }
+            else { raw0 = src[0]; raw1 = src[RCS + 1]; if (GAP == 2) raw2 = src[2 * RCS + 1]; }
         }
+        // work that does not depend on the loaded scores, placed here so that it runs while the LDS reads are in flight (the scheduling
+        // barrier keeps the compiler from sinking it behind the wait): band mask, arg-max key constant, ring and arena addresses
+        const bool in_band = lane < Wr;
+        const int key_c = (vvl == nvr - 1) ? kE : kN;
+        const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * lane;                                       // LDS byte address of this lane's ring cell
+        const unsigned rec_off = (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));            // arena byte offset of this lane's record (cur = the row's offset once committed)
+        asm volatile("" :: "v"(key_c), "v"(qd_addr), "v"(rec_off));      // (materialised here, not sunk to their uses)
+        __builtin_amdgcn_sched_barrier(0);
+        if (I16) { Mv = (int)(short)raw0; E1v = raw1 >> 16; E2v = raw2; } else { Mv = raw0; E1v = raw1; E2v = raw2; }
         const int Mv_first = Mv;                                   // (match flag below: which predecessor supplies the diagonal)
         if (NPC == 2) {
             const int pb1 = g1 & 0xfff, Wp = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
@@ -596,7 +605,6 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         }
         const int h = Mv + q;                                      // no wrap possible once the check below passes
-        const bool in_band = lane < Wr;
         int lowest = imin(h, E1v); if (GAP == 2) lowest = imin(lowest, E2v);
         const bool near_wrap = __any(in_band && lowest < fast_lo);      // decided here, acted on after the scan below: the compare runs beside it, the
                                                                         // branch is off the row's dependent chain (nothing is stored before it)
@@ -619,7 +627,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             E1out = imax(E1v - e1, Hout - oe1); E2out = imax(E2v - e2, Hout - oe2);
         }
         // record address = arena base + a 32-bit byte offset (an arena is far below 4 GB): one VALU add, no 64-bit pointer arithmetic per row
-        T *H = (T *)((char *)io.planes + (size_t)(unsigned)(off_pn * (int)(PN * sizeof(T))));
+        T *const H = (T *)((char *)io.planes + (size_t)rec_off) - lane * CW;
         const int he = I16 ? (int)__builtin_amdgcn_perm((unsigned)E1out, (unsigned)Hout, 0x05040100u) : 0;      // H | E1 << 16 (int16: also the score-ring word)
         // match flag for the backtrack (spare slot of the record, finish_alignment PL_FLAG): 1 + index of the first predecessor k (list order) with
         // H[k][col-1] + q == H[col], 0 = none.  Only a predecessor that supplies the maximum Mv can satisfy it, and only when H == Mv + q.
@@ -630,14 +638,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + lane * CW); dst[0] = r0; dst[1] = r1; }
         {
-            int *qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti), lane);
+            int *qd = (int *)ring_at(qd_addr, 0);
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
             else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
             qd[64] = infw; if (NPW > 1) qd[RCS + 64] = inf; if (NPW > 2) qd[2 * RCS + 64] = inf;      // (RC <= 128 for these rows: tv_meta bit 17)
         }
         // ---- arg-max, reference :1043-1057: value, then lowest lane residue, then the end_sn vector, then the lowest vector
         if (I16) {
-            const unsigned key = ((unsigned)Hout << 16) + (unsigned)((vvl == nvr - 1) ? kE : kN);
+            const unsigned key = ((unsigned)Hout << 16) + (unsigned)key_c;
             const unsigned kb = wave_max_u32_s(in_band ? key : 0u);
             mi = ((int)(kb >> 16) - 32768 > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
         } else {
