@@ -105,8 +105,8 @@ def cpu_baseline(wl, sets, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--sets", type=int, default=0, help="read-sets per GPU (default: 1000 for cfg2, 32 for the 10 kb configs)")
     ap.add_argument("--threads", type=int, default=0, help="host threads per rank (default: online cores / ranks per node)")
