@@ -1246,6 +1246,9 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                     int qc_v = (int)s_query[mj - 1];
                     const int e_idx = (mc.z & 0xffff) + (lane < np_ ? lane : 0);        // (n_pred 255 = row not eligible: the reads stay inside the LDS image, the result is not used)
                     int4 er = B.edge[e_idx & (BTP - 1)]; int4 er2 = B.edge2[e_idx & (BTP - 1)];
+                    const int w_lo_n = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH), w_hi_n = sgpr(mc.w << 2), w_idx_n = sgpr(n_cigar & 63), bs_n = sgpr((int)((unsigned)mc.z >> 24));      // (as in the whole-row loop)
+                    asm volatile("" :: "s"(w_lo_n), "s"(w_hi_n), "s"(w_idx_n), "s"(bs_n));
+                    __builtin_amdgcn_sched_barrier(0);
                     asm volatile("" : "+v"(fl_v), "+v"(qc_v), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er2.x), "+v"(er2.y), "+v"(er2.z));      // every load issued before the one wait
                     const int fl = __builtin_amdgcn_readfirstlane(fl_v);
                     const int ks = (fl - 1) & 63, ery = __builtin_amdgcn_readlane(er.y, ks);
@@ -1253,10 +1256,9 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                     if (!((unsigned)(fl - 1) < (unsigned)np_ && np_ != 255 && (unsigned)(mj - 1 - (ery & 0xffff)) < ((unsigned)ery >> 16))) break;
                     if (slots == 0) { flush_cigar(n_cigar - 64, 64); slots = 64; }
                     --slots;
-                    w_lo = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH); w_hi = sgpr(mc.w << 2);                  // node id << 34 | query index << 4 | op
-                    { const int w_idx = sgpr(n_cigar & 63);
-                      asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx) : "m0"); }
-                    ++n_cigar; nm_v += (qc_v == (int)((unsigned)mc.z >> 24)) ? 1 : 0;
+                    w_lo = w_lo_n; w_hi = w_hi_n;                                                                 // node id << 34 | query index << 4 | op
+                    asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx_n) : "m0");
+                    ++n_cigar; nm_v += (qc_v == bs_n) ? 1 : 0;
                     pi_ = mi_; --mj;
                     mi_ = __builtin_amdgcn_readlane(er.x, ks);
                     mc = make_int4(ery, __builtin_amdgcn_readlane(er.z, ks), __builtin_amdgcn_readlane(er2.x, ks), __builtin_amdgcn_readlane(er2.y, ks)); mc2 = __builtin_amdgcn_readlane(er2.z, ks);
