@@ -785,7 +785,6 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             last_done = row - 1;
             if (row >= r_hi) break;
-            if (ok_ == 2) { refresh_qc(); continue; }                // (the band of `row` is set: refresh_qc reads beg_sn) then the same row again
             const int ti = row & 63;
             last_done = row;
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
