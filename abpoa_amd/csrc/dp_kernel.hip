@@ -566,8 +566,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         set_band(std::true_type{}, mn, mx, min_pb);
         const int nvr = end_sn - beg_sn + 1;
         // all conditions as sign bits: (x <= y) <=> (x - y - 1) < 0
-        // (arena room: checked for a full-width row, cap_turbo = cap_pn - NV * CW; the last query vector: end_sn <= qlen_sn always)
-        const int okbits = (nvr - NV - 1) & (end_sn - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7) & (end_sn - qlen_sn);      // GEO_RING (bit 24) -> bit 31
+        // (arena room: checked for a full-width row, cap_turbo = cap_pn - NV * CW)
+        const int okbits = (nvr - NV - 1) & (end_sn - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7);      // GEO_RING (bit 24) -> bit 31
         if (__builtin_expect(okbits >= 0, 0)) return 0;
         const int Wr = nvr * PN;
         if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
@@ -646,11 +646,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // ---- arg-max, reference :1043-1057: value, then lowest lane residue, then the end_sn vector, then the lowest vector
         if (I16) {
             const unsigned key = ((unsigned)Hout << 16) + (unsigned)key_c;
-            const unsigned kb = wave_max_u32_s(in_band ? key : 0u);
+            // columns past the query end exist in the last query vector only: computed and stored like the others, never the row's arg-max (ref :1049-1056)
+            const unsigned kb = wave_max_u32_s((in_band && colrel <= qlen) ? key : 0u);
             mi = ((int)(kb >> 16) - 32768 > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
         } else {
-            const int vmax = wave_max_i32_s(in_band ? Hout : INT_MIN);
-            const unsigned key = (in_band && Hout == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
+            const bool am_ok = in_band && colrel <= qlen;
+            const int vmax = wave_max_i32_s(am_ok ? Hout : INT_MIN);
+            const unsigned key = (am_ok && Hout == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
             const unsigned kb = wave_max_u32_s(key);
             const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
             mi = (vmax > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
