@@ -584,6 +584,15 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (I16) { raw0 = src[0]; raw1 = src[1]; if (GAP == 2) raw2 = src[RCS + 1]; }
             else { raw0 = src[0]; raw1 = src[RCS + 1]; if (GAP == 2) raw2 = src[2 * RCS + 1]; }
         }
+        // the second predecessor's words go out with the first one's: both LDS reads are in flight together
+        int rb0 = 0, rb1 = 0, rb2 = inf, x1 = 0, Wp1 = 0;
+        if (NPC == 2) {
+            const int pb1 = g1 & 0xfff; Wp1 = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
+            x1 = colrel - pb1 * PN;
+            const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p1), med3i(x1 - 1, -2, RC));
+            if (I16) { rb0 = src[0]; rb1 = src[1]; if (GAP == 2) rb2 = src[RCS + 1]; }
+            else { rb0 = src[0]; rb1 = src[RCS + 1]; if (GAP == 2) rb2 = src[2 * RCS + 1]; }
+        }
         // work that does not depend on the loaded scores, placed here so that it runs while the LDS reads are in flight (the scheduling
         // barrier keeps the compiler from sinking it behind the wait): band mask, arg-max key constant, ring and arena addresses
         const bool in_band = lane < Wr;
@@ -595,13 +604,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (I16) { Mv = (int)(short)raw0; E1v = raw1 >> 16; E2v = raw2; } else { Mv = raw0; E1v = raw1; E2v = raw2; }
         const int Mv_first = Mv;                                   // (match flag below: which predecessor supplies the diagonal)
         if (NPC == 2) {
-            const int pb1 = g1 & 0xfff, Wp = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
-            const int x = colrel - pb1 * PN;
-            const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p1), med3i(x - 1, -2, RC));
+            asm volatile("" : "+v"(rb0), "+v"(rb1));               // (the loads above stay unconditional)
+            if (GAP == 2) asm volatile("" : "+v"(rb2));
             int hm1, ev1, ev2 = inf;
-            if (I16) { int w0 = src[0], w1 = src[1]; asm volatile("" : "+v"(w0), "+v"(w1)); hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) { ev2 = src[RCS + 1]; asm volatile("" : "+v"(ev2)); } }
-            else { hm1 = src[0]; ev1 = src[RCS + 1]; asm volatile("" : "+v"(hm1), "+v"(ev1)); if (GAP == 2) { ev2 = src[2 * RCS + 1]; asm volatile("" : "+v"(ev2)); } }      // (loads stay unconditional)
-            const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
+            if (I16) { hm1 = (int)(short)rb0; ev1 = rb1 >> 16; ev2 = rb2; } else { hm1 = rb0; ev1 = rb1; ev2 = rb2; }
+            const bool inH = (unsigned)x1 < (unsigned)(Wp1 + PN), inE = (unsigned)x1 < (unsigned)Wp1;
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         }
         const int h = Mv + q;                                      // no wrap possible once the check below passes
