@@ -454,7 +454,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v, int &kb, int kidx) __attribute__((always_inline)) {
         const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
         const int x = col - pb * PN;
-        const int *src = fr + (p & (RR - 1)) * (NPW * RCS) + med3i(x - 1, -2, RC) + 2;
+        const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p), med3i(x - 1, -2, RC));
         int hm1, ev1, ev2 = inf;
         if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
         else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
