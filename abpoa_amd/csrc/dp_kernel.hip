@@ -415,7 +415,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         bool fastrow = np >= 1 && np <= 4 && myrow < gn - 1 && myrow >= 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int dk = myrow - b1.p[k]; fastrow = fastrow && dk >= 1 && dk < RR; }
-        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0) | ((fastrow && np <= 2 && RC <= 128) ? (1 << 17) : 0);      // bit 17: straight-line body (pads 128 ring columns)
+        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0) | ((fastrow && np <= 2 && RC <= 128) ? (1 << 17) : 0) | ((fastrow && np >= 3 && RC <= 128) ? (1 << 18) : 0);      // bit 17: straight-line body (pads 128 ring columns)
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
         tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
@@ -557,11 +557,18 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int g0 = __builtin_amdgcn_readlane(vg_geo, p0 & 63), m0 = __builtin_amdgcn_readlane(vg_mi, p0 & 63);
         const int pb0 = g0 & 0xfff, pe0 = (g0 >> 12) & 0xfff;
         int mn = m0, mx = m0, min_pb = pb0, ring = g0; max_pe = pe0;
-        int p1 = p0, g1 = g0;
-        if (NPC == 2) {
+        int p1 = p0, g1 = g0, p2 = p0, g2 = g0, p3 = p0, g3 = g0;
+        if (NPC >= 2) {
             p1 = row - ((tb >> 8) & 0xff);
             g1 = __builtin_amdgcn_readlane(vg_geo, p1 & 63); const int m1_ = __builtin_amdgcn_readlane(vg_mi, p1 & 63);
             mn = sgpr(imin(m0, m1_)); mx = sgpr(imax(m0, m1_)); min_pb = imin(pb0, g1 & 0xfff); max_pe = imax(pe0, (g1 >> 12) & 0xfff); ring &= g1;
+        }
+        if (NPC == 4) {      // three or four predecessors (np at run time); a missing fourth repeats the third
+            p2 = __builtin_amdgcn_readlane(tv_p2, ti); p3 = np > 3 ? __builtin_amdgcn_readlane(tv_p3, ti) : p2;
+            g2 = __builtin_amdgcn_readlane(vg_geo, p2 & 63); g3 = __builtin_amdgcn_readlane(vg_geo, p3 & 63);
+            const int m2_ = __builtin_amdgcn_readlane(vg_mi, p2 & 63), m3_ = __builtin_amdgcn_readlane(vg_mi, p3 & 63);
+            mn = sgpr(imin(mn, imin(m2_, m3_))); mx = sgpr(imax(mx, imax(m2_, m3_)));
+            min_pb = imin(min_pb, imin(g2 & 0xfff, g3 & 0xfff)); max_pe = imax(max_pe, imax((g2 >> 12) & 0xfff, (g3 >> 12) & 0xfff)); ring &= g2 & g3;
         }
         set_band(std::true_type{}, mn, mx, min_pb);
         const int nvr = end_sn - beg_sn + 1;
@@ -586,7 +593,15 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         // the second predecessor's words go out with the first one's: both LDS reads are in flight together
         int rb0 = 0, rb1 = 0, rb2 = inf, x1 = 0, Wp1 = 0;
-        if (NPC == 2) {
+        int rc0 = 0, rc1 = 0, rc2 = inf, x2 = 0, Wp2 = 0, rd0 = 0, rd1 = 0, rd2 = inf, x3 = 0, Wp3 = 0;
+        if (NPC == 4) {
+            const int pb2 = g2 & 0xfff, pb3 = g3 & 0xfff; Wp2 = (((g2 >> 12) & 0xfff) - pb2 + 1) * PN; Wp3 = (((g3 >> 12) & 0xfff) - pb3 + 1) * PN;
+            x2 = colrel - pb2 * PN; x3 = colrel - pb3 * PN;
+            const int *s2 = ring_at(__builtin_amdgcn_readlane(vslot, p2), med3i(x2 - 1, -2, RC)), *s3 = ring_at(__builtin_amdgcn_readlane(vslot, p3), med3i(x3 - 1, -2, RC));
+            if (I16) { rc0 = s2[0]; rc1 = s2[1]; rd0 = s3[0]; rd1 = s3[1]; if (GAP == 2) { rc2 = s2[RCS + 1]; rd2 = s3[RCS + 1]; } }
+            else { rc0 = s2[0]; rc1 = s2[RCS + 1]; rd0 = s3[0]; rd1 = s3[RCS + 1]; if (GAP == 2) { rc2 = s2[2 * RCS + 1]; rd2 = s3[2 * RCS + 1]; } }
+        }
+        if (NPC >= 2) {
             const int pb1 = g1 & 0xfff; Wp1 = (((g1 >> 12) & 0xfff) - pb1 + 1) * PN;
             x1 = colrel - pb1 * PN;
             const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p1), med3i(x1 - 1, -2, RC));
@@ -603,13 +618,24 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         __builtin_amdgcn_sched_barrier(0);
         if (I16) { Mv = (int)(short)raw0; E1v = raw1 >> 16; E2v = raw2; } else { Mv = raw0; E1v = raw1; E2v = raw2; }
         const int Mv_first = Mv;                                   // (match flag below: which predecessor supplies the diagonal)
-        if (NPC == 2) {
+        int kfirst = 1;                                            // 1 + index of the first predecessor that reaches the running maximum of H[.][col-1]
+        auto merge_pred = [&](int r0_, int r1_, int r2_, int x_, int Wp_, int kidx) __attribute__((always_inline)) {
+            int hm1, ev1, ev2 = inf;
+            if (I16) { hm1 = (int)(short)r0_; ev1 = r1_ >> 16; ev2 = r2_; } else { hm1 = r0_; ev1 = r1_; ev2 = r2_; }
+            const bool inH = (unsigned)x_ < (unsigned)(Wp_ + PN), inE = (unsigned)x_ < (unsigned)Wp_;
+            if (NPC == 4) kfirst = (inH && hm1 > Mv) ? kidx : kfirst;
+            Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
+        };
+        if (NPC >= 2) {
             asm volatile("" : "+v"(rb0), "+v"(rb1));               // (the loads above stay unconditional)
             if (GAP == 2) asm volatile("" : "+v"(rb2));
-            int hm1, ev1, ev2 = inf;
-            if (I16) { hm1 = (int)(short)rb0; ev1 = rb1 >> 16; ev2 = rb2; } else { hm1 = rb0; ev1 = rb1; ev2 = rb2; }
-            const bool inH = (unsigned)x1 < (unsigned)(Wp1 + PN), inE = (unsigned)x1 < (unsigned)Wp1;
-            Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
+            merge_pred(rb0, rb1, rb2, x1, Wp1, 2);
+        }
+        if (NPC == 4) {
+            asm volatile("" : "+v"(rc0), "+v"(rc1), "+v"(rd0), "+v"(rd1));
+            if (GAP == 2) asm volatile("" : "+v"(rc2), "+v"(rd2));
+            merge_pred(rc0, rc1, rc2, x2, Wp2, 3);
+            merge_pred(rd0, rd1, rd2, x3, Wp3, 4);                 // (np == 3: the third predecessor again -- no change, kfirst keeps 3 or less)
         }
         const int h = Mv + q;                                      // no wrap possible once the check below passes
         int lowest = imin(h, E1v); if (GAP == 2) lowest = imin(lowest, E2v);
@@ -639,7 +665,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // match flag for the backtrack (spare slot of the record, finish_alignment PL_FLAG): 1 + index of the first predecessor k (list order) with
         // H[k][col-1] + q == H[col], 0 = none.  Only a predecessor that supplies the maximum Mv can satisfy it, and only when H == Mv + q.
         // (A predecessor value read from outside its band is `inf`: the backtrack re-checks the column range before it trusts the flag.)
-        const int mflag = (h == Hout) ? ((NPC == 2 && Mv != Mv_first) ? 2 : 1) : 0;
+        const int mflag = (h == Hout) ? (NPC == 4 ? kfirst : ((NPC == 2 && Mv != Mv_first) ? 2 : 1)) : 0;
         if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
@@ -799,6 +825,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
+            if ((meta >> 18) & 1) {                                   // three or four predecessors: the straight-line body, outside the tight loop
+                if (turbo_body(std::integral_constant<int, 4>{}, row, ti)) { commit_row(ti, true); ++row; continue; }
+            }
             am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
             int rc = 0;
             {
