@@ -604,7 +604,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = CW;      // pad = arena cell stride (0: plane-major)
         o.n_cells = n_cells; o.cells_used = cursor;
         for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
-        o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_flag_steps * 1000;      // backtrack: ticks spent staging arena windows, number of windows
+        if (!(b.dbg & 128)) { o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_flag_steps * 1000; }      // (dbg bit 7: keep the row loop's counters) backtrack: ticks spent staging arena windows, number of windows
         o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }

@@ -62,7 +62,7 @@ class BatchStream {
 };
 
 void set_err(const char *fmt, ...);
-void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, LdsPlan *L);
+void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, int n_aln, LdsPlan *L);
 int engine_device();            // device the process is bound to, or -1
 void add_global_stats(const StreamStats &s);
 

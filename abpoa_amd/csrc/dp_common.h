@@ -151,6 +151,48 @@ __device__ __forceinline__ int wave_scan_max_i32(int x) { asm(DPP_SCAN6("v_max_i
 // wave-wide max (the same six steps; complete in lane 63), returned as a wave-uniform value
 __device__ __forceinline__ unsigned wave_max_u32_s(unsigned x) { asm(DPP_SCAN6("v_max_u32_dpp") : "+v"(x)); return (unsigned)__builtin_amdgcn_readlane((int)x, 63); }
 __device__ __forceinline__ int wave_max_i32_s(int x) { asm(DPP_SCAN6("v_max_i32_dpp") : "+v"(x)); return __builtin_amdgcn_readlane(x, 63); }
+// Two / three independent 64-lane reductions of the DPP_SCAN6 shape with their steps interleaved: the partners' instructions are
+// the wait states a DPP read needs after a VALU write of the same VGPR (two chains: one s_nop 0 per step; three: none).
+#define DPP_ROW2(OPA, OPB, CTRL) OPA " %0, %0, %0 " CTRL "\n\t" OPB " %1, %1, %1 " CTRL "\n\t"
+#define DPP_ROW3(OPA, OPB, OPC, CTRL) OPA " %0, %0, %0 " CTRL "\n\t" OPB " %1, %1, %1 " CTRL "\n\t" OPC " %2, %2, %2 " CTRL "\n\t"
+#define DPP_SCAN6_2(OPA, OPB)                                                           \
+    "s_nop 1\n\t" DPP_ROW2(OPA, OPB, "row_shr:1 row_mask:0xf bank_mask:0xf")            \
+    "s_nop 0\n\t" DPP_ROW2(OPA, OPB, "row_shr:2 row_mask:0xf bank_mask:0xf")            \
+    "s_nop 0\n\t" DPP_ROW2(OPA, OPB, "row_shr:4 row_mask:0xf bank_mask:0xf")            \
+    "s_nop 0\n\t" DPP_ROW2(OPA, OPB, "row_shr:8 row_mask:0xf bank_mask:0xf")            \
+    "s_nop 0\n\t" DPP_ROW2(OPA, OPB, "row_bcast:15 row_mask:0xa bank_mask:0xf")         \
+    "s_nop 0\n\t" DPP_ROW2(OPA, OPB, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+#define DPP_SCAN6_3(OPA, OPB, OPC)                                                      \
+    "s_nop 1\n\t" DPP_ROW3(OPA, OPB, OPC, "row_shr:1 row_mask:0xf bank_mask:0xf")       \
+    DPP_ROW3(OPA, OPB, OPC, "row_shr:2 row_mask:0xf bank_mask:0xf")                     \
+    DPP_ROW3(OPA, OPB, OPC, "row_shr:4 row_mask:0xf bank_mask:0xf")                     \
+    DPP_ROW3(OPA, OPB, OPC, "row_shr:8 row_mask:0xf bank_mask:0xf")                     \
+    DPP_ROW3(OPA, OPB, OPC, "row_bcast:15 row_mask:0xa bank_mask:0xf")                  \
+    DPP_ROW3(OPA, OPB, OPC, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+// (signed scan, unsigned reduction) / (signed, signed) / (signed, signed, unsigned) / (signed, signed, signed): prefix max in every
+// lane, wave maximum in lane 63
+__device__ __forceinline__ void wave_scan2_iu(int &a, unsigned &k) { asm(DPP_SCAN6_2("v_max_i32_dpp", "v_max_u32_dpp") : "+v"(a), "+v"(k)); }
+__device__ __forceinline__ void wave_scan2_ii(int &a, int &c) { asm(DPP_SCAN6_2("v_max_i32_dpp", "v_max_i32_dpp") : "+v"(a), "+v"(c)); }
+__device__ __forceinline__ void wave_scan3_iiu(int &a, int &c, unsigned &k) { asm(DPP_SCAN6_3("v_max_i32_dpp", "v_max_i32_dpp", "v_max_u32_dpp") : "+v"(a), "+v"(c), "+v"(k)); }
+__device__ __forceinline__ void wave_scan3_iii(int &a, int &c, int &k) { asm(DPP_SCAN6_3("v_max_i32_dpp", "v_max_i32_dpp", "v_max_i32_dpp") : "+v"(a), "+v"(c), "+v"(k)); }
+__device__ __forceinline__ unsigned wave_max_u32_v(unsigned x) { asm(DPP_SCAN6("v_max_u32_dpp") : "+v"(x)); return x; }      // (complete in lane 63, stays in the VGPR)
+// maximum over aligned groups of G = 2 / 4 / 8 lanes, left in every lane of the group
+template <int G> __device__ __forceinline__ int group_allmax_i32(int x) {
+    x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));                   // quad_perm [1,0,3,2]
+    if (G >= 4) x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));       // quad_perm [2,3,0,1]
+    if (G >= 8) x = imax(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));      // row_half_mirror
+    return x;
+}
+template <int G> __device__ __forceinline__ unsigned group_allmax_u32(unsigned x) {
+    auto umax = [](unsigned p, unsigned q) { return p > q ? p : q; };
+    x = umax(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false));
+    if (G >= 4) x = umax(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false));
+    if (G >= 8) x = umax(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false));
+    return x;
+}
+// workgroup barrier for LDS hand-overs only: waits for this wave's LDS operations, NOT for its outstanding global stores
+// (__syncthreads() would add s_waitcnt vmcnt(0), i.e. the HBM round trip of the score-plane stores, to every row)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ int wave_scan_add_i32(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
@@ -251,6 +293,11 @@ __device__ __forceinline__ bool takes_fast(const DevBatch &b, const AlnDesc &d) 
            d.qlen <= b.lds.q_cap && !(b.dbg & 64);
 }
 
+// ... and among those, the ones whose rows are wide enough for NW wavefronts per alignment (dp_wide_rows.hip); the rest keep one wavefront
+__device__ __forceinline__ bool takes_wide(const DevBatch &b, const AlnDesc &d) {
+    return b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi;
+}
+
 // kernel launch helper shared by the translation units (block = NT threads)
 template <typename K>
 static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int lds_bytes, int block_threads = 64) {
@@ -263,6 +310,7 @@ static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int 
 
 // per-TU launchers (one translation unit per kernel family: parallel builds, one row loop per file)
 hipError_t launch_fast_rows(const DevBatch &b, hipStream_t stream);       // dp_fast_rows.hip
+hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream);       // dp_wide_rows.hip
 hipError_t launch_fast_tail(const DevBatch &b, hipStream_t stream);       // dp_fast_tail.hip
 hipError_t launch_general(const DevBatch &b, hipStream_t stream);         // dp_general.hip
 

@@ -1,0 +1,42 @@
+// Row-loop kernels for WIDE bands (10 kb reads: 240-300 columns = 4-5 chunks of 64 per row).  Production: one wavefront per alignment with
+// every chunk of a row in registers at once (rows_fast.h, ilp_chunks).  Experimental (-DABPOA_HIP_MULTIWAVE): WIDE_NW wavefronts per
+// alignment, wavefront c owns chunk c (wide_body); rows the wide bodies cannot take are done with the single-chunk bodies.
+#include <stdio.h>
+#include <stdlib.h>
+#include "rows_fast.h"
+
+namespace abpoa_hip {
+
+template <int GAP, int BITS, int NW>
+__global__ void __launch_bounds__(NW * 64) dp_wide_kernel(const DevBatch b) {      // NW = 1: one wavefront, every chunk of a row in registers (rows_fast.h, ilp_chunks)
+    const int a = blockIdx.x;
+    if (a >= b.n) return;
+    const AlnDesc d = b.aln[a];
+    if (!takes_fast(b, d) || d.bits != BITS || !takes_wide(b, d)) return;
+    align_fast_rows<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP, NW, NW == 1>(b, d, b.out + a);
+}
+
+template <int GAP, int NW>
+static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
+    const int mask = b.bits_mask ? b.bits_mask : 3;
+    hipError_t e = hipSuccess;
+    static bool told = false;
+    if (!told && getenv("ABPOA_HIP_VERBOSE")) {      // residency of the wide kernels on one CU
+        told = true; int nb16 = 0, nb32 = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, dp_wide_kernel<GAP, 16, NW>, NW * 64, (size_t)b.lds.total_wide);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, dp_wide_kernel<GAP, 32, NW>, NW * 64, (size_t)b.lds.total_wide);
+        fprintf(stderr, "[abpoa-hip] wide row loop: %d wavefronts per alignment, %d B of LDS per workgroup, ring %d rows x %d columns, workgroups per CU: %d (int16) %d (int32)\n", NW, b.lds.total_wide, b.lds.wfr_rows, b.lds.wfr_cols, nb16, nb32);
+    }
+    if (mask & 1) e = launch_one(dp_wide_kernel<GAP, 16, NW>, b, stream, b.lds.total_wide, NW * 64);
+    if (e == hipSuccess && (mask & 2)) e = launch_one(dp_wide_kernel<GAP, 32, NW>, b, stream, b.lds.total_wide, NW * 64);
+    return e;
+}
+hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream) {
+    if (b.lds.wide_nw == 1) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, 1>(b, stream) : launch_wide_gap<2, 1>(b, stream);
+#ifdef ABPOA_HIP_MULTIWAVE      // experimental build: WIDE_NW wavefronts per alignment, one chunk each
+    if (b.lds.wide_nw == WIDE_NW) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, WIDE_NW>(b, stream) : launch_wide_gap<2, WIDE_NW>(b, stream);
+#endif
+    return hipSuccess;
+}
+
+}  // namespace abpoa_hip

@@ -76,7 +76,7 @@ void BatchStream::close() {
 
 // LDS carve-up of one wavefront (engine.h LdsPlan) for a launch whose largest query is max_qlen, widest score type max_bits
 // and widest expected band est_cols columns.
-void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, LdsPlan *Lp) {
+void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, int n_aln, LdsPlan *Lp) {
     LdsPlan &L = *Lp;
     const int P = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
     const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
@@ -101,6 +101,26 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
     L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
     L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes;
+    // wide row loop (dp_wide_rows.hip): alignments whose band half-width w is in [wide_w_lo, wide_w_hi] -- rows of 2..5 chunks of 64 columns --
+    // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (320 columns; depth by what fits:
+    // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
+    // the depth, ABPOA_HIP_WIDE_MW=1 selects the experimental multi-wavefront variant in builds that have it.
+    L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0;
+    { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_WIDE_MW");
+      if (L.fr_cols && L.q_cap && !(nw_ && atoi(nw_))) {
+          L.wide_nw = (mw_ && atoi(mw_)) ? WIDE_NW : 1; L.wfr_cols = 5 * 64; L.wfr_rows = 16;
+          L.wide_w_lo = 40; L.wide_w_hi = (L.wfr_cols - 2 * 8 - 1) / 2;
+          { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
+          const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");
+          if (rr_env_ && atoi(rr_env_) >= 4) L.wfr_rows = atoi(rr_env_) >= 16 ? 16 : (atoi(rr_env_) >= 8 ? 8 : 4); else rr_env_ = nullptr;
+          const int budget = 64 * 1024 - L.phase_off - 512;
+          while ((int64_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4 > budget && L.wfr_rows > 4) L.wfr_rows /= 2;
+          // one wavefront per alignment: LDS is what limits how many alignments a CU holds (160 KB, 256 CUs) -- a shallower ring when the
+          // launch has more alignments than fit (rows with an older predecessor take the HBM gather: 1 % of rows at depth 8 on 5 % reads)
+          if (!(rr_env_)) while (L.wfr_rows > 8 && (int64_t)(160 * 1024 / (L.phase_off + (int64_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4 + 320)) * 256 < n_aln) L.wfr_rows /= 2;
+          L.wx_off = L.fr_off + (int)align_up((size_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4, 16);
+          L.total_wide = L.phase_off + L.wx_off + 16 * 16 + 64;
+      } }
 }
 
 int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *sh, unsigned flags) {
@@ -200,7 +220,7 @@ int BatchStream::run() {
                 const int pn = d.bits == 16 ? 16 : 8; const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
                 est_cols = std::max<int64_t>(est_cols, banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width);
             }
-            make_lds_plan(sc, max_qlen, max_bits, est_cols, &b.lds);
+            make_lds_plan(sc, max_qlen, max_bits, est_cols, (int)pass.size(), &b.lds);
             for (const AlnDesc &d : pass) b.bits_mask |= d.bits == 16 ? 1 : 2;
         }
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;

@@ -41,6 +41,9 @@ struct AlnOut {
 };
 
 #define ALN_FAST_OK 1
+#ifndef WIDE_NW
+#define WIDE_NW 5          // wavefronts per alignment of the wide row loop (5 x 64 = 320 columns: 2 w + 1 + vector rounding + band drift of a 10 kb read)
+#endif
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
 
 // LDS carve-up of one wavefront (= one workgroup), chosen on the host per launch.  Byte offsets from the
@@ -56,6 +59,11 @@ struct LdsPlan {
     int32_t bt_off, bt_bytes;     // arena tile (relative to phase_off)
     // --- fast row loop (dp_kernel.hip rows_fast): packed H|E score ring [fr_rows][words][fr_cols + 4] dwords at phase_off + fr_off
     int32_t fr_off, fr_rows, fr_cols;   // fr_rows: power of two <= 64; fr_cols: multiple of 64, 0 = fast loop disabled
+    // --- wide row loop (NW wavefronts per alignment, rows_fast<.., NW>): its own score ring [wfr_rows][words][wfr_cols + 4] at phase_off + fr_off,
+    //     then the exchange slots (wx_off, relative to phase_off); wide_nw = 0: not used by this launch
+    int32_t wfr_rows, wfr_cols, wx_off, wide_nw;
+    int32_t wide_w_lo, wide_w_hi; // an alignment takes the wide loop iff wide_w_lo <= its band half-width w <= wide_w_hi
+    int32_t total_wide;           // dynamic LDS bytes of the wide row-loop kernel
     int32_t mx_off;               // int32 [m*(m+1)]: score matrix with an extra all-zero query column (code m = "no query base")
     int32_t total;                // dynamic LDS bytes to request (general kernel: union of every phase)
     int32_t total_rows, total_tail;   // the two fast-path kernels request only what their phase needs (4+ workgroups per CU must fit)

@@ -228,7 +228,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     {
         int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
-        make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(width, 2LL * w_max + 3 * pn + 32), &b.lds);
+        make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(width, 2LL * w_max + 3 * pn + 32), n_sets, &b.lds);
         // score widths the rounds can meet (the width grows with graph and read size): launch only the kernels that can have work
         int min_qlen = max_qlen;
         for (int s = 0; s < n_sets; ++s) for (int r = 1; r < sets[s].n_reads; ++r) min_qlen = std::min(min_qlen, sets[s].lens[r]);

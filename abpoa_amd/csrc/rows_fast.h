@@ -69,12 +69,19 @@ __device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pr
 #define FSTAMP(I)
 #endif
 // Timing-only ablation switches (tools/kernel_bench.py with ABPOA_HIP_DBG=bits on the "prof" build): results are wrong on purpose.
+// Diagnostic builds (-DABPOA_HIP_WIDE_COUNTERS, with ABPOA_HIP_DBG=128 so that the tail keeps them): rows per path of the wide loop in AlnOut.seg --
+// 0 wide body, 1 not eligible (predecessor count / distance), 2 ring / geometry, 3 wider than NW chunks, 4 slow vectors span two wavefronts, 5 wrap guard
+#ifdef ABPOA_HIP_WIDE_COUNTERS
+#define WCOUNT(I) { fseg[I] += 1; }
+#else
+#define WCOUNT(I) {}
+#endif
 #ifdef ABPOA_HIP_ABLATE
 #define ABL(BIT) (b.dbg & (BIT))
 #else
 #define ABL(BIT) false
 #endif
-template <typename T, int GAP>
+template <typename T, int GAP, int NW = 1, bool WIDEB = false>
 __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, const FastIO<T> &io, const uint8_t *s_query,
                                           long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done, long long *fseg) {
 #ifdef ABPOA_HIP_PROFILE
@@ -87,11 +94,18 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
     constexpr int GEO_RING = 1 << 24;
     const int lane = threadIdx.x & 63, l = lane % PN, vvl = lane / PN;
+    const int wid = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // wavefront of the workgroup = 64-column chunk of a wide row
+    const int tid = NW > 1 ? (int)threadIdx.x : lane;
+    constexpr int NT = NW * 64;
     const int gn = d.n_rows, qlen = d.qlen, m = b.m, m1 = b.m + 1, w = d.w;
     const int inf = d.inf_min;
     const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
-    const int RR = b.lds.fr_rows, RC = b.lds.fr_cols, RCS = RC + 4;
+    constexpr bool WPLAN = NW > 1 || WIDEB;          // the wide kernels have their own score ring (LdsPlan wfr_*)
+    const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WPLAN ? b.lds.wfr_cols : b.lds.fr_cols, RCS = RC + 4;
     int *fr = (int *)(lds_raw + b.lds.phase_off + b.lds.fr_off);
+    // wide rows: exchange slots (two parities x 8 entries of 16 bytes) and the hand-over record of a row done by wavefront 0 alone
+    int4 *xch = (int4 *)(lds_raw + b.lds.phase_off + b.lds.wx_off);
+    int *bcast = (int *)(xch + 16);
     // LDS byte address of ring row (r & (RR - 1)), column 0, held by lane r & 63: RR divides 64, so one lane-constant VGPR serves
     // every row -- a v_readlane replaces the and / mul / shift / add chain per predecessor and for the row's own slot
     typedef __attribute__((address_space(3))) int lds_int_t;
@@ -112,8 +126,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int kconst = I16 ? (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (unsigned)(2047 - vvl)) : 0;
 
     // ---- LDS: extended score matrix (column m = 0) and the score ring, everything "inf"
-    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < m * m1; i += 64) { const int bb = i / m1, qc = i - bb * m1; s_mx[i] = qc < m ? g_mat[bb * m + qc] : 0; } }
-    for (int i = lane; i < RR * NPW * RCS; i += 64) { const int pl = (i / RCS) % NPW; fr[i] = (I16 && pl == 0) ? infw : inf; }
+    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = tid; i < m * m1; i += NT) { const int bb = i / m1, qc = i - bb * m1; s_mx[i] = qc < m ? g_mat[bb * m + qc] : 0; } }
+    for (int i = tid; i < RR * NPW * RCS; i += NT) { const int pl = (i / RCS) % NPW; fr[i] = (I16 && pl == 0) ? infw : inf; }
+    if (NW > 1 && tid < 16) xch[tid] = make_int4(INT_MIN, INT_MIN, I16 ? 0 : INT_MIN, 0);      // entries of absent wavefronts stay neutral
     __syncthreads();
     auto ring_put = [&](int slot, int x, int H, int E1, int E2) __attribute__((always_inline)) {
         int *q = fr + slot * (NPW * RCS) + 2 + x;
@@ -134,7 +149,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if ((long long)W0 * CW > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
         const bool ring0 = W0 <= RC;
         T *H = io.planes;
-        for (int i = lane; i < W0; i += 64) {
+        for (int i = tid; i < W0; i += NT) {
             int h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
             if (GAP == 1) { const int g = wr(-o1 - e1 * i); h = i == 0 ? 0 : g; x1 = i == 0 ? wr(-oe1) : inf; f1 = i == 0 ? inf : g; }
             else {
@@ -148,11 +163,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         cur = (end_sn0 + 1) * CW;
         if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = 0; }     // source: successors get left = right = 1 (:556-561)
+        if (NW > 1) __syncthreads();               // ring row 0 was written by every wavefront
     }
 
     // ------------------------------------------------------------------ static metadata, two tiles ahead
     struct MetaA { int ps, pe, base, rem; };
-    struct MetaB { int p[4]; };
+    constexpr int NPM = 8;                          // predecessors kept in registers per row (wide rows: up to 8 take the common path)
+    struct MetaB { int p[NPM]; };
     auto load_a = [&](int t0) __attribute__((always_inline)) {
         MetaA a; const int r = imin(t0 + lane, gn - 1);
         a.ps = io.pred_off[r]; a.pe = io.pred_off[r + 1]; a.base = io.row_base[r]; a.rem = io.row_remain[r];
@@ -161,21 +178,30 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto load_b = [&](const MetaA &a) __attribute__((always_inline)) {
         MetaB q; const int np = a.pe - a.ps;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q.p[k] = io.pred_row[a.ps + imin(k, imax(np - 1, 0))];
+        for (int k = 0; k < NPM; ++k) q.p[k] = io.pred_row[a.ps + imin(k, imax(np - 1, 0))];
         return q;
     };
     MetaA a1 = load_a(0); MetaB b1 = load_b(a1); MetaA a2 = load_a(64);
     int tv_meta = 0, tv_rterm = 0, tv_ps = 0, tv_p0 = 0, tv_p1 = 0, tv_p2 = 0, tv_p3 = 0;
+    int tv_p4 = 0, tv_p5 = 0, tv_p6 = 0, tv_p7 = 0;      // (wide rows only)
     int tv_tb = 0;          // turbo rows: dist(pred 0) | dist(pred 1) << 8 | (base * (m + 1) * 4) << 16
     auto switch_tile = [&](int t0) __attribute__((always_inline)) {
         const int myrow = t0 + lane, np = a1.pe - a1.ps;
         bool fastrow = np >= 1 && np <= 4 && myrow < gn - 1 && myrow >= 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int dk = myrow - b1.p[k]; fastrow = fastrow && dk >= 1 && dk < RR; }
-        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0) | ((fastrow && np <= 2 && RC <= 128) ? (1 << 17) : 0) | ((fastrow && np >= 3 && RC <= 128) ? (1 << 18) : 0);      // bit 17: straight-line body (pads 128 ring columns)
+        tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0);
+        if (!WPLAN) tv_meta |= ((fastrow && np <= 2 && RC <= 128) ? (1 << 17) : 0) | ((fastrow && np >= 3 && RC <= 128) ? (1 << 18) : 0);      // bit 17: straight-line body (pads 128 ring columns)
+        else {                                       // bit 19: the row may take the wide body (1..8 predecessors, all inside the score ring)
+            bool widerow = np >= 1 && np <= 8 && myrow < gn - 1 && myrow >= 1;
+#pragma unroll
+            for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < RR; }
+            tv_meta |= widerow ? (1 << 19) : 0;
+        }
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
         tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
+        tv_p4 = b1.p[4]; tv_p5 = b1.p[5]; tv_p6 = b1.p[6]; tv_p7 = b1.p[7];
         a1 = a2; b1 = load_b(a1); a2 = load_a(t0 + 128);
     };
     int qc_beg_sn = -1, qoff0 = 0, qoff1 = 0;        // cached query code of this lane's column for chunks 0/1 of band start qc_beg_sn
@@ -450,6 +476,359 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         return 1;
     };
 
+    // ---- WIDE body (NW wavefronts per alignment): wavefront c owns columns [64 c, 64 c + 64) of the row's band, every wavefront computes
+    //      the same band scalars from its own copy of the per-row registers.  One exchange through LDS carries, per wavefront, the
+    //      total of its local F scan(s) and its arg-max candidate; the arg-max never depends on F (an F term is some H of the same row
+    //      minus at least o + e, reference :870-874 / :990-997), so candidates are taken from max(M + q, E) before the scans finish.
+    //      Returns 0 = not applicable (nothing touched), 1 = done, 2 = arena overflow.
+    constexpr int NWP = NW <= 2 ? 2 : (NW <= 4 ? 4 : 8);
+    const int relw = wid * 64 + lane;                               // this lane's column inside a wide row
+    const int le1w = relw * e1, le2w = relw * e2, cf1w = oe1 - e1 + le1w, cf2w = oe2 - e2 + le2w;
+    int qcw_beg_sn = -1, qoffw = 0;                                 // cached query code of column beg_sn * PN + relw
+    auto wide_body = [&](int row, int ti) __attribute__((always_inline)) -> int {
+        int mn_mi, mx_mi, min_pb, allring;
+        {
+            const int p = __builtin_amdgcn_readlane(tv_p0, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
+            mn_mi = mx_mi = __builtin_amdgcn_readlane(vg_mi, p & 63); min_pb = g_ & 0xfff; max_pe = (g_ >> 12) & 0xfff; allring = g_;
+        }
+        auto more = [&](int tvp) __attribute__((always_inline)) {
+            const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63), mi_ = __builtin_amdgcn_readlane(vg_mi, p & 63);
+            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff); allring &= g_;
+        };
+        if (np > 1) { more(tv_p1); if (np > 2) { more(tv_p2); if (np > 3) { more(tv_p3); if (np > 4) { more(tv_p4); if (np > 5) { more(tv_p5); if (np > 6) { more(tv_p6); if (np > 7) more(tv_p7); } } } } } }
+        set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
+        const int nvr = end_sn - beg_sn + 1, Wr = nvr * PN, nch = (Wr + 63) >> 6;
+        // vectors beyond every predecessor's band take the literal masked scan after the exchange: they must sit in ONE wavefront
+        bool ok = (allring & GEO_RING) && nch <= NW && max_pe >= beg_sn;
+        if (!ok) { WCOUNT(nch > NW ? 3 : 2); return 0; }
+        if (end_sn > max_pe) ok = ok && ((max_pe + 1 - beg_sn) / NV == (end_sn - beg_sn) / NV);
+        if (!ok) { WCOUNT(4); return 0; }
+        if (cur + nvr * CW > cap_pn) return 2;
+        const int c = wid, vb = beg_sn + c * NV, col = beg_sn * PN + relw;
+        const bool active = c < nch, in_band = relw < Wr;
+        const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * relw;      // LDS byte address of this lane's cell in the row's ring slot
+        int Mv = inf, E1v = inf, E2v = inf, kb = 0, q = 0;
+        if (active) {
+            if (beg_sn != qcw_beg_sn) { qcw_beg_sn = beg_sn; qoffw = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m; }
+            q = s_mx[base * m1 + qoffw];
+            auto pred = [&](int k, int tvp) __attribute__((always_inline)) {
+                const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
+                if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1);
+            };
+            pred(0, tv_p0);
+            if (np > 1) { pred(1, tv_p1); if (np > 2) { pred(2, tv_p2); if (np > 3) { pred(3, tv_p3); if (np > 4) { pred(4, tv_p4); if (np > 5) { pred(5, tv_p5); if (np > 6) { pred(6, tv_p6); if (np > 7) pred(7, tv_p7); } } } } } }
+        }
+        const int h = wr(Mv + q);
+        int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
+        const int hsE = GAP == 1 ? imax(h, E1v) : hs;
+        const int nvec = imin(NV, end_sn - vb + 1);                 // <= 0: this wavefront holds no vector of the row
+        int nfast = imin(nvec, max_pe - vb + 1); if (nfast < 0) nfast = 0;
+        const bool wrap = __any(vvl < nfast && h < fast_lo);        // closed-form F not provably wrap-free: the row is redone by wavefront 0
+        // ---- local exclusive prefix maxima of g = hs + column * e (wavefront 0: seeded with `first - e` of the row, as chunk_tail)
+        const int g1 = hs + le1w, g2 = hs + le2w;
+        int s1 = wave_shr1(wid == 0 ? h - e1 : INT_MIN, g1), s2 = INT_MIN;
+        if (GAP == 2) s2 = wave_shr1(wid == 0 ? h - e2 : INT_MIN, g2);
+        // ---- arg-max candidate, reference :1043-1057 (same keys as chunk_tail / the row epilogue)
+        const int v = vb + vvl; const bool is_end = v == end_sn;
+        int cand = hsE; if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
+        unsigned key = 0; int aval = INT_MIN;
+        if (I16) {
+            key = in_band ? ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u) : 0u;
+            if (GAP == 2) wave_scan3_iiu(s1, s2, key); else wave_scan2_iu(s1, key);
+        } else {
+            aval = in_band ? cand : INT_MIN;
+            if (GAP == 2) wave_scan3_iii(s1, s2, aval); else wave_scan2_ii(s1, aval);
+            const int vmaxw = __builtin_amdgcn_readlane(aval, 63);
+            key = (in_band && cand == vmaxw) ? (((unsigned)(PN - 1 - l) << 27) | ((unsigned)is_end << 26) | (0x3FFFFFFu - (unsigned)v)) : 0u;
+            key = wave_max_u32_v(key);
+        }
+        // ---- exchange: lane 63 holds the wave totals
+        int4 *xs = xch + (row & 1) * 8;
+        if (lane == 63) xs[wid] = make_int4(imax(s1, g1), imax(s2, g2), wrap ? INT_MAX : aval, wrap ? (int)0xFFFFFFFFu : (int)key);
+        lds_barrier();
+        const int4 en = xs[lane & (NWP - 1)];
+        const bool before = (lane & (NWP - 1)) < wid;
+        const int carry1 = group_allmax_i32<NWP>(before ? en.x : INT_MIN), carry2 = GAP == 2 ? group_allmax_i32<NWP>(before ? en.y : INT_MIN) : INT_MIN;
+        unsigned kmax; int vmax = 0;
+        if (I16) {
+            kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)group_allmax_u32<NWP>((unsigned)en.w));
+            if (kmax == 0xFFFFFFFFu) { WCOUNT(5); return 0; }
+            vmax = (int)(kmax >> 16) - 32768;
+        } else {
+            const int vm = group_allmax_i32<NWP>(en.z);
+            vmax = __builtin_amdgcn_readfirstlane(vm);
+            if (vmax == INT_MAX) { WCOUNT(5); return 0; }
+            kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)group_allmax_u32<NWP>(en.z == vm ? (unsigned)en.w : 0u));
+        }
+        // ---- from here on the row is committed
+        off_pn = cur; cur += nvr * CW;
+        int Hout = inf, E1out = inf, E2out = inf;
+        if (active) {
+            const int S1 = imax(s1, carry1), S2 = imax(s2, carry2);
+            int F1 = imax(S1 - cf1w, inj1), F2 = inf;
+            if (GAP == 2) F2 = imax(S2 - cf2w, inj2);
+            if (nfast < nvec) {
+                int first, first2 = 0;
+                if (nfast > 0) {
+                    const int lastl = nfast * PN - 1;
+                    first = __builtin_amdgcn_readlane(imax(S1, g1), lastl) - (c * 64 + lastl) * e1;
+                    if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(S2, g2), lastl) - (c * 64 + lastl) * e2;
+                } else {                                            // the slow vectors open this wavefront's chunk (c > 0: max_pe >= beg_sn)
+                    first = __builtin_amdgcn_readfirstlane(carry1) - (c * 64 - 1) * e1;
+                    if (GAP == 2) first2 = __builtin_amdgcn_readfirstlane(carry2) - (c * 64 - 1) * e2;
+                }
+                T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
+                slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
+                F1 = (int)f1t; F2 = (int)f2t;
+            }
+            if (GAP == 1) {
+                const int tmp = imax(h, E1v);
+                Hout = imax(tmp, F1);
+                const int en_ = imax(wr(E1v - e1), wr(Hout - oe1));
+                E1out = (Hout == tmp) ? en_ : inf;
+            } else {
+                Hout = imax(hs, imax(F1, F2));
+                E1out = imax(wr(E1v - e1), wr(Hout - oe1));
+                E2out = imax(wr(E2v - e2), wr(Hout - oe2));
+            }
+            const int mflag = (Mv + q == Hout && kb <= 64) ? kb : 0;
+            // one record store per IN-BAND lane (another wavefront owns the cells behind the row's end: no stores past it)
+            if (in_band) {
+                T *H = io.planes + (long long)off_pn * PN + (long long)relw * CW;
+                const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
+                if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)H = rec; }
+                else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
+                else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)H = rec; }
+                else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
+            }
+        }
+        {   // ring slot of the row: every wavefront writes its 64 columns ("inf" outside the band)
+            int *qd = (int *)ring_at(qd_addr, 0);
+            if (I16) { qd[0] = in_band ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16)) : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
+            else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
+        }
+        mi = -1;
+        if (vmax > inf) {
+            if (I16) mi = (2047 - (int)(kmax & 0x7ff)) * PN + (PN - 1 - (int)((kmax >> 12) & 0xf));
+            else mi = (int)(0x3FFFFFFu - (kmax & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kmax >> 27));
+            if (mi > qlen) mi = -1;
+        }
+        return 1;
+    };
+
+    // ---- MULTI-CHUNK body for wide bands (10 kb reads: 240-300 columns = 4-5 chunks of 64): every chunk of the row is in registers at once.
+    //      The lane owns column (64 c + lane) of each chunk c, so the chunks are independent instruction streams that the scheduler interleaves
+    //      (LDS reads of all chunks in flight together, DPP scans of all chunks back to back without wait states), and everything that is
+    //      per row -- band, conditions, arg-max reduction, commit -- is paid once for ~250 columns instead of once per 64.
+    //      F: per-chunk UNSEEDED prefix maxima of g = hs + lane * e, then a scalar carry chain over the chunk totals:
+    //      seed[0] = first - e, seed[c+1] = max(total[c], seed[c]) - 64 e, F = max(S, seed) - cf  (chunk_tail's closed form, carried in H units).
+    //      The arg-max is taken from max(M + q, E): an F term is some H of the same row minus at least o + e (reference :870-874 / :990-997).
+    //      ilp_band: 0 = not applicable, -2 = arena overflow, else the number of chunks; ilp_chunks: 0 = not applicable (nothing touched), 1 = done.
+    constexpr int NCHX = 5;
+    int qcx_beg_sn = -1, qoffx[NCHX] = {0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk, for band start qcx_beg_sn
+    auto ilp_band = [&](int row, int ti) __attribute__((always_inline)) -> int {
+        int mn_mi, mx_mi, min_pb, allring;
+        {
+            const int p = __builtin_amdgcn_readlane(tv_p0, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
+            mn_mi = mx_mi = __builtin_amdgcn_readlane(vg_mi, p & 63); min_pb = g_ & 0xfff; max_pe = (g_ >> 12) & 0xfff; allring = g_;
+        }
+        auto more = [&](int tvp) __attribute__((always_inline)) {
+            const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63), mi_ = __builtin_amdgcn_readlane(vg_mi, p & 63);
+            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff); allring &= g_;
+        };
+        if (np > 1) { more(tv_p1); if (np > 2) { more(tv_p2); if (np > 3) { more(tv_p3); if (np > 4) { more(tv_p4); if (np > 5) { more(tv_p5); if (np > 6) { more(tv_p6); if (np > 7) more(tv_p7); } } } } } }
+        set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
+        const int nvr = end_sn - beg_sn + 1, Wr = nvr * PN, nch = (Wr + 63) >> 6;
+        bool ok = (allring & GEO_RING) && nch <= NCHX && Wr <= RC && max_pe >= beg_sn;
+        // vectors beyond every predecessor's band (literal masked scan) must all sit in the row's last chunk
+        if (end_sn > max_pe) ok = ok && ((max_pe + 1 - beg_sn) / NV == nch - 1);
+        if (!ok) return 0;
+        if (cur + nvr * CW > cap_pn) return -2;
+        return nch;
+    };
+    auto ilp_chunks = [&](auto nchc, int nch, int row, int ti) __attribute__((always_inline)) -> int {
+        constexpr int NCH = decltype(nchc)::value;
+        const int Wr = (end_sn - beg_sn + 1) * PN;
+        const int colb = beg_sn * PN + lane;                        // this lane's column in chunk 0
+        if (__builtin_expect(beg_sn != qcx_beg_sn, 0)) {
+            qcx_beg_sn = beg_sn;
+#pragma unroll
+            for (int c = 0; c < NCHX; ++c) { const int col = colb + 64 * c; qoffx[c] = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m; }
+        }
+        FSTAMP(0)
+        const int *mrow = s_mx + base * m1;
+        int q[NCH], Mv[NCH], E1v[NCH], E2v[NCH], kb[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) q[c] = mrow[qoffx[c]];
+        // ---- predecessor gather: the first one unmasked (guard cells and padding of the ring row yield what the reference reads), the others
+        //      with one unsigned range compare per plane; the first two predecessors' reads go out together
+        auto ring_read = [&](int p, int g_, int c, int &hm1, int &ev1, int &ev2) __attribute__((always_inline)) {
+            const int x = colb + 64 * c - (g_ & 0xfff) * PN;
+            const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p), med3i(x - 1, -2, RC));
+            ev2 = inf;
+            if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
+            else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
+        };
+        auto merge = [&](int g_, int c, int hm1, int ev1, int ev2, int kidx) __attribute__((always_inline)) {
+            const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN, x = colb + 64 * c - pb * PN;
+            const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
+            kb[c] = (inH && hm1 > Mv[c]) ? kidx : kb[c];
+            Mv[c] = inH ? imax(Mv[c], hm1) : Mv[c]; E1v[c] = inE ? imax(E1v[c], ev1) : E1v[c]; if (GAP == 2) E2v[c] = inE ? imax(E2v[c], ev2) : E2v[c];
+        };
+        {
+            const int p0 = __builtin_amdgcn_readlane(tv_p0, ti), g0 = __builtin_amdgcn_readlane(vg_geo, p0 & 63);
+            if (np == 1) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; }
+            } else {
+                const int p1 = __builtin_amdgcn_readlane(tv_p1, ti), g1_ = __builtin_amdgcn_readlane(vg_geo, p1 & 63);
+                int hb[NCH], eb1[NCH], eb2[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; ring_read(p1, g1_, c, hb[c], eb1[c], eb2[c]); }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) merge(g1_, c, hb[c], eb1[c], eb2[c], 2);
+                auto further = [&](int tvp, int kidx) __attribute__((always_inline)) {
+                    const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
+                    int hc[NCH], ec1[NCH], ec2[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) ring_read(p, g_, c, hc[c], ec1[c], ec2[c]);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) merge(g_, c, hc[c], ec1[c], ec2[c], kidx);
+                };
+                if (np > 2) { further(tv_p2, 3); if (np > 3) { further(tv_p3, 4); if (np > 4) { further(tv_p4, 5); if (np > 5) { further(tv_p5, 6); if (np > 6) { further(tv_p6, 7); if (np > 7) further(tv_p7, 8); } } } } }
+            }
+        }
+        FSTAMP(1)
+        // ---- H before F, wrap guard of the closed form (lanes of vectors <= max_pre_end_sn, as chunk_tail)
+        const int lim = imin(end_sn, max_pe) - beg_sn;              // last vector (relative to the band start) that takes the closed form
+        int h[NCH], hs[NCH], hsE[NCH], lowest = INT_MAX;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            h[c] = wr(Mv[c] + q[c]);
+            hs[c] = h[c]; if (GAP == 2) hs[c] = imax(imax(h[c], E1v[c]), E2v[c]);
+            hsE[c] = GAP == 1 ? imax(h[c], E1v[c]) : hs[c];
+            lowest = imin(lowest, (c * NV + vvl <= lim) ? h[c] : INT_MAX);
+        }
+        if (__builtin_expect(__any(lowest < fast_lo), 0)) return 0;
+        // ---- unseeded prefix maxima per chunk, all chains interleaved
+        int g1[NCH], g2[NCH], s1[NCH], s2[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { g1[c] = hs[c] + le1; s1[c] = wave_shr1(INT_MIN, g1[c]); if (GAP == 2) { g2[c] = hs[c] + le2; s2[c] = wave_shr1(INT_MIN, g2[c]); } }
+        // ---- arg-max candidates per lane over the chunks (reference :1043-1057; keys as in chunk_tail / the row epilogue)
+        unsigned amk = 0; int amv = INT_MIN, amc = 0;                // int16: packed key; int32: best value of the lane and its chunk | is_end << 8
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int rel = c * 64 + lane, vb = beg_sn + c * NV;
+            const bool in_band = rel < Wr, is_end = (vb + vvl == end_sn);
+            int cand = hsE[c]; if (end_sn == qlen_sn) cand = (is_end && colb + 64 * c > qlen) ? inf : cand;
+            if (I16) {
+                const unsigned key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
+                amk = (in_band && key > amk) ? key : amk;
+            } else {
+                const bool take = in_band && (c == 0 || (is_end ? cand >= amv : cand > amv));
+                amv = take ? cand : amv; amc = take ? (c | (is_end ? 256 : 0)) : amc;
+            }
+        }
+        if (!I16) amv = (lane < Wr) ? amv : INT_MIN;                 // (chunk 0 was taken unconditionally)
+        // interleaved DPP chains: F scans of every chunk (+ the arg-max value / key chain)
+        {
+            auto step = [&](auto ctrl, auto rmask) __attribute__((always_inline)) {
+                constexpr int CT = decltype(ctrl)::value, RM = decltype(rmask)::value;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    s1[c] = imax(s1[c], __builtin_amdgcn_update_dpp(INT_MIN, s1[c], CT, RM, 0xF, false));
+                    if (GAP == 2) s2[c] = imax(s2[c], __builtin_amdgcn_update_dpp(INT_MIN, s2[c], CT, RM, 0xF, false));
+                }
+                if (I16) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)amk, CT, RM, 0xF, false); amk = t > amk ? t : amk; }
+                else amv = imax(amv, __builtin_amdgcn_update_dpp(INT_MIN, amv, CT, RM, 0xF, false));
+            };
+            // (amv is reduced on a copy below for int32: the per-lane value is needed again for the tie-break)
+            const int amv_lane = amv;
+            step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{});
+            step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{});
+            step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{});
+            step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{});
+            step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
+            step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
+            if (!I16) {
+                const int vmax_ = __builtin_amdgcn_readlane(amv, 63);
+                const int cbest = amc & 0xff, v_ = beg_sn + cbest * NV + vvl;
+                amk = (amv_lane == vmax_ && lane + 64 * cbest < Wr) ? (((unsigned)(PN - 1 - l) << 27) | ((unsigned)(amc >> 8) << 26) | (0x3FFFFFFu - (unsigned)v_)) : 0u;
+                amv = vmax_;
+            }
+        }
+        FSTAMP(2)
+        // ---- carry chain over the chunk totals (scalar), then F of every chunk
+        int seed1[NCH], seed2[NCH];
+        seed1[0] = __builtin_amdgcn_readlane(h[0], 0) - e1; if (GAP == 2) seed2[0] = seed1[0] + e1 - e2;
+#pragma unroll
+        for (int c = 0; c + 1 < NCH; ++c) {
+            seed1[c + 1] = imax(__builtin_amdgcn_readlane(imax(s1[c], g1[c]), 63), seed1[c]) - 64 * e1;
+            if (GAP == 2) seed2[c + 1] = imax(__builtin_amdgcn_readlane(imax(s2[c], g2[c]), 63), seed2[c]) - 64 * e2;
+        }
+        FSTAMP(3)
+        // ---- from here on the row is committed
+        off_pn = cur; cur += (end_sn - beg_sn + 1) * CW;
+        T *const Hrow = io.planes + (long long)off_pn * PN + (long long)lane * CW;
+        int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * lane, 0);
+        const int cs = nch - 1;                                      // the only chunk that may hold slow vectors
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int rel = c * 64 + lane, vb = beg_sn + c * NV;
+            const bool in_band = rel < Wr;
+            const int S1 = imax(s1[c], seed1[c]);
+            int F1 = imax(S1 - cf1, inj1), F2 = inf, S2 = 0;
+            if (GAP == 2) { S2 = imax(s2[c], seed2[c]); F2 = imax(S2 - cf2, inj2); }
+            if (__builtin_expect(c == cs && end_sn > max_pe, 0)) {
+                const int nvec = imin(NV, end_sn - vb + 1), nfast = imax(0, imin(nvec, max_pe - vb + 1));
+                int first, first2 = 0;
+                if (nfast > 0) {
+                    const int lastl = nfast * PN - 1;
+                    first = __builtin_amdgcn_readlane(imax(S1, g1[c]), lastl) - lastl * e1;
+                    if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(S2, g2[c]), lastl) - lastl * e2;
+                } else { first = seed1[c] + e1; if (GAP == 2) first2 = seed2[c] + e2; }
+                T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
+                slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs[c], (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
+                F1 = (int)f1t; F2 = (int)f2t;
+            }
+            int Hout, E1out, E2out = inf;
+            if (GAP == 1) {
+                Hout = imax(hsE[c], F1);
+                const int en_ = imax(wr(E1v[c] - e1), wr(Hout - oe1));
+                E1out = (Hout == hsE[c]) ? en_ : inf;
+            } else {
+                Hout = imax(hs[c], imax(F1, F2));
+                E1out = imax(wr(E1v[c] - e1), wr(Hout - oe1));
+                E2out = imax(wr(E2v[c] - e2), wr(Hout - oe2));
+            }
+            const int mflag = (Mv[c] + q[c] == Hout && kb[c] <= 64) ? kb[c] : 0;
+            const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
+            if (c < nch) {      // one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
+                T *H = Hrow + c * 64 * CW;
+                if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)H = rec; }
+                else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
+                else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)H = rec; }
+                else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
+            }
+            if (I16) { qd[c * 64] = in_band ? he : infw; if (GAP == 2) qd[RCS + c * 64] = in_band ? E2out : inf; }
+            else { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS + c * 64] = in_band ? E2out : inf; }
+        }
+        for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; }      // "inf" up to the ring width
+        FSTAMP(4)
+        // ---- row arg-max
+        mi = -1;
+        if (I16) {
+            const unsigned kbst = (unsigned)__builtin_amdgcn_readlane((int)amk, 63);
+            const int vmax = (int)(kbst >> 16) - 32768;
+            if (vmax > inf) { mi = (2047 - (int)(kbst & 0x7ff)) * PN + (PN - 1 - (int)((kbst >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+        } else if (amv > inf) {
+            const unsigned kbst = wave_max_u32_s(amk);
+            mi = (int)(0x3FFFFFFu - (kbst & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kbst >> 27));
+            if (mi > qlen) mi = -1;
+        }
+        return 1;
+    };
+
     // ---- FAST body: NP (1, 2, or up to 4 with run-time count) predecessors, all in the 64-row geometry ring and the score ring.
     //      Returns 0 = not applicable (nothing touched), 1 = done, 2 = arena overflow.
     auto fast_body = [&](auto npc, int row, int ti) __attribute__((always_inline)) -> int {
@@ -549,7 +928,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #endif
     for (int t0 = 0; t0 < gn - 1 && status == 0; t0 += 64) {
         if (t0 > 0) {       // geometry of the finished tile goes to HBM in one coalesced burst (older predecessors, backtrack, trace)
-            const int rb = t0 - 64 + lane; io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi;
+            const int rb = t0 - 64 + lane; if (wid == 0) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
             if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1;
         }
         switch_tile(t0);
@@ -561,10 +940,60 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         };
         int row = imax(t0, 1);
         while (row < r_hi) {
+            if constexpr (NW > 1) {
+                // ---- NW wavefronts per alignment: the wide body, else wavefront 0 alone with the single-wave bodies below
+                const int ti = row & 63;
+                last_done = row;
+                const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
+                rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
+                base = meta & 0xff; np = (meta >> 8) & 0xff;
+                int rc = 0;
+                if ((meta >> 19) & 1) rc = wide_body(row, ti); else WCOUNT(1);
+                if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                if (rc == 1) { WCOUNT(0); commit_row(ti, true); lds_barrier(); ++row; continue; }      // (barrier: the ring slot is complete before any wavefront reads it)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the HBM gathers of the general body read cells other wavefronts stored
+                lds_barrier();
+                if (wid == 0) {
+                    am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
+                    if ((meta >> 16) & 1) {
+                        if (np == 1) rc = fast_body(std::integral_constant<int, 1>{}, row, ti);
+                        else if (np == 2) rc = fast_body(std::integral_constant<int, 2>{}, row, ti);
+                        else rc = fast_body(std::integral_constant<int, 4>{}, row, ti);
+                    }
+                    if (rc == 0) rc = general_body(row, ti);
+                    mi = -1;
+                    if (rc == 1) {
+                        if (I16) {
+                            const unsigned kb = wave_max_u32_s(am_key);
+                            const int vmax = (int)(kb >> 16) - 32768;
+                            if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+                        } else {
+                            const int vmax = wave_max_i32_s(am_any ? am_val : INT_MIN);
+                            if (vmax > inf) {
+                                unsigned key = 0;
+                                if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
+                                const unsigned kb = wave_max_u32_s(key);
+                                mi = (int)(0x3FFFFFFu - (kb & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kb >> 27));
+                                if (mi > qlen) mi = -1;
+                            }
+                        }
+                    }
+                    if (lane == 0) { bcast[0] = rc; bcast[1] = beg_sn; bcast[2] = end_sn; bcast[3] = off_pn; bcast[4] = mi; bcast[5] = to_ring ? 1 : 0; bcast[6] = cur; }
+                }
+                lds_barrier();
+                rc = __builtin_amdgcn_readfirstlane(bcast[0]); beg_sn = __builtin_amdgcn_readfirstlane(bcast[1]); end_sn = __builtin_amdgcn_readfirstlane(bcast[2]);
+                off_pn = __builtin_amdgcn_readfirstlane(bcast[3]); mi = __builtin_amdgcn_readfirstlane(bcast[4]); to_ring = __builtin_amdgcn_readfirstlane(bcast[5]) != 0;
+                cur = __builtin_amdgcn_readfirstlane(bcast[6]);
+                if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                commit_row(ti, to_ring);
+                lds_barrier();                                         // (bcast is free again)
+                ++row;
+                continue;
+            }
             // ---- tight loop over consecutive straight-line rows: only these merge at its back edge (in one loop with the other row
             //      bodies every row paid ~30 register copies for the merge of all paths)
             int ok_ = 0;
-            for (;;) {
+            if constexpr (!WPLAN) for (;;) {
                 const int ti_ = row & 63;
                 const int meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
                 if (!__builtin_expect((meta_ >> 17) & 1, 1)) break;
@@ -582,8 +1011,16 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
-            if ((meta >> 18) & 1) {                                   // three or four predecessors: the straight-line body, outside the tight loop
+            if (!WPLAN && ((meta >> 18) & 1)) {                       // three or four predecessors: the straight-line body, outside the tight loop
                 if (turbo_body(std::integral_constant<int, 4>{}, row, ti)) { commit_row(ti, true); ++row; continue; }
+            }
+            if (WIDEB && ((meta >> 19) & 1)) {                        // wide band: every chunk of the row at once
+                const int nch_ = ilp_band(row, ti);
+                if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                if (nch_ >= 2) {
+                    const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti);
+                    if (ok2 == 1) { commit_row(ti, true); FSTAMP(5) ++row; continue; }
+                }
             }
             am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
             int rc = 0;
@@ -622,12 +1059,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // ---- geometry of the last (partial) tile
     if (status == 0) {
         const int tb = last_done & ~63, rb = tb + lane;
-        if (rb <= last_done) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi;
+        if (rb <= last_done) { if (wid == 0) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
                                if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1; }
     }
     __syncthreads();
     // ---- max_pos_left/right as the reference leaves them (only when the caller reads them back)
-    if (status == 0 && b.want_lr) {
+    if (status == 0 && b.want_lr && wid == 0) {
         for (int r = lane; r < gn; r += 64) {
             int lf = gn, rt = 0;
             if (r == 0) { lf = 0; rt = 0; }
@@ -640,5 +1077,28 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     }
     cursor_out = (long long)cur * PN; n_cells_out = (long long)__builtin_amdgcn_readlane(wave_scan_add_i32(n_vec_lane), 63) * PN; rows_done_out = last_done;
 }
+
+// The fast path is two kernels -- row loop, then global best + backtrack -- so that the row loop's register allocation
+// (its SGPR budget above all) is not shared with the tail; the hand-over is the AlnOut record in HBM.
+template <typename T, int GAP, int NW = 1, bool WIDEB = false>
+__device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
+    const int lane = threadIdx.x & 63;
+    FastIO<T> io;
+    io.row_base = vgpr_ptr(b.row_base + d.row0); io.row_remain = vgpr_ptr(b.row_remain + d.row0);
+    io.pred_off = vgpr_ptr(b.pred_off + d.poff0); io.pred_row = vgpr_ptr(b.pred_row + d.pred0);
+    io.g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0); io.g_esn = vgpr_ptr(b.dp_end_sn + d.row0); io.row_max_i = vgpr_ptr(b.row_max_i + d.row0);
+    io.g_left = vgpr_ptr(b.left + d.row0); io.g_right = vgpr_ptr(b.right + d.row0); io.g_coff = vgpr_ptr(b.row_cell_off + d.row0);
+    io.planes = (T *)(b.planes + d.plane_off);
+    uint8_t *s_query = lds_raw + b.lds.q_off;
+    { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = (NW > 1 ? (int)threadIdx.x : lane); i < d.qlen; i += NW * 64) s_query[i] = g_query[i]; }
+    __syncthreads();
+    long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
+    const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
+    long long fseg[6] = {0, 0, 0, 0, 0, 0};
+    rows_fast<T, GAP, NW, WIDEB>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
+    const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
+}
+
 
 }  // namespace abpoa_hip

@@ -12,14 +12,16 @@ import torch.multiprocessing as mp
 
 import helpers as H
 from abpoa_amd import api, synth
+from abpoa_amd.shard import shard_range, deal_by_cost, set_cost
 
 AG = dict(gap_open1=4, gap_open2=0, gap_ext1=2)
 N_SETS = 6
 
 
-def _shard_sets(rank, world, n_per_rank):
-    """same rule as bench.py: rank r owns set indices [r*n, (r+1)*n)"""
-    return [synth.make_read_set(1, rank * n_per_rank + i, 6, 150, 0.05) for i in range(n_per_rank)]
+def _shard_sets(rank, world, total):
+    """bench.py's own rule (abpoa_amd.shard.shard_range): rank r owns a contiguous slice of the set indices"""
+    first, n = shard_range(total, world, rank)
+    return [synth.make_read_set(1, first + i, 6, 150, 0.05) for i in range(n)]
 
 
 def _digest_int(results):
@@ -33,7 +35,7 @@ def _digest_int(results):
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sets = _shard_sets(rank, world, N_SETS // world)
+    sets = _shard_sets(rank, world, N_SETS)
     res = api.msa_batch(sets, api.Params(**AG), lib=H.cpu_shim_lib(), n_threads=2)
     agg = torch.tensor([_digest_int(res), sum(r.n_cells for r in res)], dtype=torch.int64)
     dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -59,3 +61,17 @@ def test_two_rank_shards_equal_single_process(tmp_path):
     want = _digest_int(single[:N_SETS // 2]) + _digest_int(single[N_SETS // 2:])
     assert int(lines[0][0].split()[0]) == want
     assert int(lines[0][0].split()[1]) == sum(r.n_cells for r in single)
+
+
+def test_shard_rules():
+    for total in (0, 1, 7, 8, 1000, 8000):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(total, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and sum(n for _, n in parts) == total
+            assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+            assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
+    costs = [set_cost([100 * (i % 5 + 1)] * 10) for i in range(23)]
+    q = deal_by_cost(costs, 4)
+    assert sorted(i for part in q for i in part) == list(range(23))
+    loads = [sum(costs[i] for i in part) for part in q]
+    assert max(loads) - min(loads) <= max(costs)
