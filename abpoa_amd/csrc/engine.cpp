@@ -108,7 +108,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0;
     { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_WIDE_MW");
       if (L.fr_cols && L.q_cap && !(nw_ && atoi(nw_))) {
-          L.wide_nw = (mw_ && atoi(mw_)) ? WIDE_NW : 1; L.wfr_cols = 5 * 64; L.wfr_rows = 16;
+          L.wide_nw = (mw_ && atoi(mw_)) ? WIDE_NW : 1; L.wfr_cols = WIDE_RING_COLS; L.wfr_rows = 16;
           L.wide_w_lo = 40; L.wide_w_hi = (L.wfr_cols - 2 * 8 - 1) / 2;
           { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");

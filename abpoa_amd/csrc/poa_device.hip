@@ -113,10 +113,10 @@ __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
     // Early exit for sets that will outgrow their node slots: new nodes per read stay close to constant over the first reads
     // (most errors are novel), so ten reads predict the final size well; failing at once saves the rest of a doomed pass.
     bool doomed = false;
-    if (status == POA_ST_OK && k == 10 && S.n_reads > 20) {
+    if (status == POA_ST_OK && (k == 10 || k == 5) && S.n_reads > 20) {      // (read 5: only a clear miss, 25 % over; read 10: any)
         const int n0 = p.read_len[S.read0] + 2;
         const long long projected = (long long)n + (long long)(n - n0) * (S.n_reads - k) * 8 / (10 * k);
-        doomed = projected > S.node_cap;
+        doomed = k == 10 ? projected > S.node_cap : projected * 4 > (long long)S.node_cap * 5;
         if (doomed && tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 6; }
     }
     if (status != POA_ST_OK || doomed || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it

@@ -101,7 +101,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int inf = d.inf_min;
     const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
     constexpr bool WPLAN = NW > 1 || WIDEB;          // the wide kernels have their own score ring (LdsPlan wfr_*)
-    const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WPLAN ? b.lds.wfr_cols : b.lds.fr_cols, RCS = RC + 4;
+    // (the single-wave wide kernel's ring width is a compile-time constant: address offsets and clamps fold into the instructions)
+    const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WIDEB ? WIDE_RING_COLS : (WPLAN ? b.lds.wfr_cols : b.lds.fr_cols), RCS = RC + 4;
     int *fr = (int *)(lds_raw + b.lds.phase_off + b.lds.fr_off);
     // wide rows: exchange slots (two parities x 8 entries of 16 bytes) and the hand-over record of a row done by wavefront 0 alone
     int4 *xch = (int4 *)(lds_raw + b.lds.phase_off + b.lds.wx_off);
@@ -124,6 +125,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const long long lo_ll = (long long)(I16 ? INT16_MIN : INT32_MIN) + imax(oe1, oe2) + (long long)PN * imax(e1, e2);
     const int fast_lo = (int)lo_ll;
     const int kconst = I16 ? (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (unsigned)(2047 - vvl)) : 0;
+    const int ktie = ((PN - 1 - l) << 7) | (63 - vvl);                                  // int32 wide rows: residue, then (bit 6) the end vector, then the vector order
 
     // ---- LDS: extended score matrix (column m = 0) and the score ring, everything "inf"
     { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = tid; i < m * m1; i += NT) { const int bb = i / m1, qc = i - bb * m1; s_mx[i] = qc < m ? g_mat[bb * m + qc] : 0; } }
@@ -142,6 +144,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int remain_end = __builtin_amdgcn_readfirstlane(io.row_remain[gn - 1]);
     // ------------------------------------------------------------------ row 0, reference :553-662
     int vg_geo = 0, vg_mi = 0, vg_off = 0;          // lane = row & 63: beg_sn | end_sn << 12 | in-ring << 24, arg-max column, arena offset / PN
+    int vg_vm = 0, rowmax = 0;                      // (wide kernel) the row's maximum H: the next rows centre their packed arg-max keys on it
     {
         const int r = __builtin_amdgcn_readfirstlane(io.row_remain[0]) - remain_end - 1;
         const int dp_end0 = imin(qlen, imax(0, qlen - r) + w);
@@ -700,37 +703,38 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         FSTAMP(1)
         // ---- H before F, wrap guard of the closed form (lanes of vectors <= max_pre_end_sn, as chunk_tail)
-        const int lim = imin(end_sn, max_pe) - beg_sn;              // last vector (relative to the band start) that takes the closed form
+        //      (checked over ALL lanes: lanes outside the closed-form vectors hold inf + q, which is above the limit unless the penalties are
+        //       extreme -- then the row simply takes the exact bodies)
         int h[NCH], hs[NCH], hsE[NCH], lowest = INT_MAX;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             h[c] = wr(Mv[c] + q[c]);
             hs[c] = h[c]; if (GAP == 2) hs[c] = imax(imax(h[c], E1v[c]), E2v[c]);
             hsE[c] = GAP == 1 ? imax(h[c], E1v[c]) : hs[c];
-            lowest = imin(lowest, (c * NV + vvl <= lim) ? h[c] : INT_MAX);
+            lowest = imin(lowest, h[c]);
         }
         if (__builtin_expect(__any(lowest < fast_lo), 0)) return 0;
         // ---- unseeded prefix maxima per chunk, all chains interleaved
         int g1[NCH], g2[NCH], s1[NCH], s2[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { g1[c] = hs[c] + le1; s1[c] = wave_shr1(INT_MIN, g1[c]); if (GAP == 2) { g2[c] = hs[c] + le2; s2[c] = wave_shr1(INT_MIN, g2[c]); } }
-        // ---- arg-max candidates per lane over the chunks (reference :1043-1057; keys as in chunk_tail / the row epilogue)
-        unsigned amk = 0; int amv = INT_MIN, amc = 0;                // int16: packed key; int32: best value of the lane and its chunk | is_end << 8
+        // ---- arg-max candidates (reference :1043-1057): one packed key per lane, one reduction.  int16: chunk_tail's key.  int32: the value is
+        //      taken relative to floor = (maximum of the first predecessor's row) - 2^19, 21 bits, above residue / end-vector / vector-order bits;
+        //      a winner outside (0, 2^21 - 1) -- never seen on real scores, consecutive rows differ by a few units -- sends the row to the exact bodies.
+        unsigned amk = 0;
+        const int vfloor = I16 ? 0 : __builtin_amdgcn_readlane(vg_vm, __builtin_amdgcn_readlane(tv_p0, ti) & 63) - (1 << 19);
+        const int relv_end = end_sn - beg_sn;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int rel = c * 64 + lane, vb = beg_sn + c * NV;
-            const bool in_band = rel < Wr, is_end = (vb + vvl == end_sn);
+            const bool in_band = rel < Wr, is_end = (c * NV + vvl == relv_end);
             int cand = hsE[c]; if (end_sn == qlen_sn) cand = (is_end && colb + 64 * c > qlen) ? inf : cand;
-            if (I16) {
-                const unsigned key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
-                amk = (in_band && key > amk) ? key : amk;
-            } else {
-                const bool take = in_band && (c == 0 || (is_end ? cand >= amv : cand > amv));
-                amv = take ? cand : amv; amc = take ? (c | (is_end ? 256 : 0)) : amc;
-            }
+            unsigned key;
+            if (I16) key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
+            else key = ((unsigned)imin(imax(cand, vfloor) - vfloor, 0x1FFFFF) << 11) | (unsigned)(ktie - c * NV) | (is_end ? 64u : 0u);      // (max first: inf - floor must not wrap)
+            amk = (in_band && key > amk) ? key : amk;
         }
-        if (!I16) amv = (lane < Wr) ? amv : INT_MIN;                 // (chunk 0 was taken unconditionally)
-        // interleaved DPP chains: F scans of every chunk (+ the arg-max value / key chain)
+        // interleaved DPP chains: F scans of every chunk + the arg-max key
         {
             auto step = [&](auto ctrl, auto rmask) __attribute__((always_inline)) {
                 constexpr int CT = decltype(ctrl)::value, RM = decltype(rmask)::value;
@@ -739,24 +743,17 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     s1[c] = imax(s1[c], __builtin_amdgcn_update_dpp(INT_MIN, s1[c], CT, RM, 0xF, false));
                     if (GAP == 2) s2[c] = imax(s2[c], __builtin_amdgcn_update_dpp(INT_MIN, s2[c], CT, RM, 0xF, false));
                 }
-                if (I16) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)amk, CT, RM, 0xF, false); amk = t > amk ? t : amk; }
-                else amv = imax(amv, __builtin_amdgcn_update_dpp(INT_MIN, amv, CT, RM, 0xF, false));
+                const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)amk, CT, RM, 0xF, false); amk = t > amk ? t : amk;
             };
-            // (amv is reduced on a copy below for int32: the per-lane value is needed again for the tie-break)
-            const int amv_lane = amv;
             step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{});
             step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{});
             step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{});
             step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{});
             step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
             step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
-            if (!I16) {
-                const int vmax_ = __builtin_amdgcn_readlane(amv, 63);
-                const int cbest = amc & 0xff, v_ = beg_sn + cbest * NV + vvl;
-                amk = (amv_lane == vmax_ && lane + 64 * cbest < Wr) ? (((unsigned)(PN - 1 - l) << 27) | ((unsigned)(amc >> 8) << 26) | (0x3FFFFFFu - (unsigned)v_)) : 0u;
-                amv = vmax_;
-            }
         }
+        const unsigned kbst = (unsigned)__builtin_amdgcn_readlane((int)amk, 63);
+        if (!I16) { const unsigned tv = kbst >> 11; if (__builtin_expect(tv == 0u || tv == 0x1FFFFFu, 0)) return 0; }
         FSTAMP(2)
         // ---- carry chain over the chunk totals (scalar), then F of every chunk
         int seed1[NCH], seed2[NCH];
@@ -818,13 +815,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // ---- row arg-max
         mi = -1;
         if (I16) {
-            const unsigned kbst = (unsigned)__builtin_amdgcn_readlane((int)amk, 63);
-            const int vmax = (int)(kbst >> 16) - 32768;
-            if (vmax > inf) { mi = (2047 - (int)(kbst & 0x7ff)) * PN + (PN - 1 - (int)((kbst >> 12) & 0xf)); if (mi > qlen) mi = -1; }
-        } else if (amv > inf) {
-            const unsigned kbst = wave_max_u32_s(amk);
-            mi = (int)(0x3FFFFFFu - (kbst & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kbst >> 27));
-            if (mi > qlen) mi = -1;
+            rowmax = (int)(kbst >> 16) - 32768;
+            if (rowmax > inf) { mi = (2047 - (int)(kbst & 0x7ff)) * PN + (PN - 1 - (int)((kbst >> 12) & 0xf)); if (mi > qlen) mi = -1; }
+        } else {
+            rowmax = vfloor + (int)(kbst >> 11);
+            if (rowmax > inf) { mi = (beg_sn + 63 - (int)(kbst & 63)) * PN + (PN - 1 - (int)((kbst >> 7) & 0xf)); if (mi > qlen) mi = -1; }
         }
         return 1;
     };
@@ -935,6 +930,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r_hi = imin(t0 + 64, gn - 1);
         auto commit_row = [&](int ti, bool ring) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
             const int geo_new = sgpr(beg_sn | (end_sn << 12) | (ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
+            if constexpr (WIDEB) {
+                const int vm_new = sgpr(rowmax);
+                asm volatile("s_mov_b32 m0, %8\n\ts_nop 3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
+                             : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off), "+v"(vg_vm) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(vm_new), "s"(ti) : "m0");
+            } else
             asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
                          : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
         };
@@ -1038,9 +1038,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 if (I16) {
                     const unsigned kb = wave_max_u32_s(am_key);
                     const int vmax = (int)(kb >> 16) - 32768;
+                    rowmax = vmax;
                     if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
                 } else {
                     const int vmax = wave_max_i32_s(am_any ? am_val : INT_MIN);
+                    rowmax = vmax;
                     if (vmax > inf) {
                         unsigned key = 0;
                         if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
