@@ -430,9 +430,19 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
         // lane 0's scan input is first - e (first = H of the band's first column before any E / F merge = h of lane 0): the shift leaves lane 0's
         // own h - e in place, no trip through an SGPR
-        const int g1s = hs + le1;
-        int F1 = imax(wave_scan_max_i32(wave_shr1(h - e1, g1s)) - cf1, inj1), F2 = inf;
-        if (GAP == 2) { const int g2s = hs + le2; F2 = imax(wave_scan_max_i32(wave_shr1(h - e2, g2s)) - cf2, inj2); }
+        // The row arg-max is taken from max(M + q, E) -- an F term is some H of the same row minus at least o + e (reference :870-874 / :990-997), it
+        // never holds the row maximum -- so its reduction runs beside the F scan(s), steps interleaved, instead of after H (reference :1043-1057:
+        // value, then lowest lane residue, then the end_sn vector, then the lowest vector; columns past the query end never win, :1049-1056)
+        const int hsE_ = GAP == 1 ? imax(h, E1v) : hs;
+        const bool am_ok = in_band && colrel <= qlen;
+        unsigned akey = I16 ? (am_ok ? ((unsigned)hsE_ << 16) + (unsigned)key_c : 0u) : 0u;
+        int aval = am_ok ? hsE_ : INT_MIN;
+        int s1_ = wave_shr1(h - e1, hs + le1), s2_ = 0;
+        if (GAP == 2) s2_ = wave_shr1(h - e2, hs + le2);
+        if (I16) { if (GAP == 2) wave_scan3_iiu(s1_, s2_, akey); else wave_scan2_iu(s1_, akey); }
+        else { if (GAP == 2) wave_scan3_iii(s1_, s2_, aval); else wave_scan2_ii(s1_, aval); }
+        int F1 = imax(s1_ - cf1, inj1), F2 = inf;
+        if (GAP == 2) F2 = imax(s2_ - cf2, inj2);
         if (__builtin_expect(near_wrap, 0)) return 0;
         // ---- from here on the row is committed
         off_pn = cur; cur += nvr * CW;
@@ -462,16 +472,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
             qd[64] = infw; if (NPW > 1) qd[RCS + 64] = inf; if (NPW > 2) qd[2 * RCS + 64] = inf;      // (RC <= 128 for these rows: tv_meta bit 17)
         }
-        // ---- arg-max, reference :1043-1057: value, then lowest lane residue, then the end_sn vector, then the lowest vector
+        // ---- arg-max (keys reduced above)
         if (I16) {
-            const unsigned key = ((unsigned)Hout << 16) + (unsigned)key_c;
-            // columns past the query end exist in the last query vector only: computed and stored like the others, never the row's arg-max (ref :1049-1056)
-            const unsigned kb = wave_max_u32_s((in_band && colrel <= qlen) ? key : 0u);
+            const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)akey, 63);
             mi = ((int)(kb >> 16) - 32768 > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
         } else {
-            const bool am_ok = in_band && colrel <= qlen;
-            const int vmax = wave_max_i32_s(am_ok ? Hout : INT_MIN);
-            const unsigned key = (am_ok && Hout == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
+            const int vmax = __builtin_amdgcn_readlane(aval, 63);
+            const unsigned key = (am_ok && hsE_ == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
             const unsigned kb = wave_max_u32_s(key);
             const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
             mi = (vmax > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
@@ -726,8 +733,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int relv_end = end_sn - beg_sn;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int rel = c * 64 + lane, vb = beg_sn + c * NV;
-            const bool in_band = rel < Wr, is_end = (c * NV + vvl == relv_end);
+            const int vb = beg_sn + c * NV;
+            const bool in_band = c < NCH - 2 ? true : c * 64 + lane < Wr, is_end = c < NCH - 2 ? false : (c * NV + vvl == relv_end);      // (the end vector is in the last chunk)
             int cand = hsE[c]; if (end_sn == qlen_sn) cand = (is_end && colb + 64 * c > qlen) ? inf : cand;
             unsigned key;
             if (I16) key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
@@ -768,44 +775,50 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         off_pn = cur; cur += (end_sn - beg_sn + 1) * CW;
         T *const Hrow = io.planes + (long long)off_pn * PN + (long long)lane * CW;
         int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * lane, 0);
-        const int cs = nch - 1;                                      // the only chunk that may hold slow vectors
+        // (nch is NCH - 1 or NCH: chunks 0 .. NCH - 3 are full, only the last two need band masks, only the last one a store guard)
+        int F1[NCH], F2[NCH], S1[NCH], S2[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int rel = c * 64 + lane, vb = beg_sn + c * NV;
-            const bool in_band = rel < Wr;
-            const int S1 = imax(s1[c], seed1[c]);
-            int F1 = imax(S1 - cf1, inj1), F2 = inf, S2 = 0;
-            if (GAP == 2) { S2 = imax(s2[c], seed2[c]); F2 = imax(S2 - cf2, inj2); }
-            if (__builtin_expect(c == cs && end_sn > max_pe, 0)) {
+            S1[c] = imax(s1[c], seed1[c]); F1[c] = imax(S1[c] - cf1, inj1); F2[c] = inf; S2[c] = 0;
+            if (GAP == 2) { S2[c] = imax(s2[c], seed2[c]); F2[c] = imax(S2[c] - cf2, inj2); }
+        }
+        if (__builtin_expect(end_sn > max_pe, 0)) {                  // vectors beyond every predecessor's band: literal masked scan, last chunk only
+#pragma unroll
+            for (int c = NCH - 2; c < NCH; ++c) if (c == nch - 1) {
+                const int vb = beg_sn + c * NV;
                 const int nvec = imin(NV, end_sn - vb + 1), nfast = imax(0, imin(nvec, max_pe - vb + 1));
                 int first, first2 = 0;
                 if (nfast > 0) {
                     const int lastl = nfast * PN - 1;
-                    first = __builtin_amdgcn_readlane(imax(S1, g1[c]), lastl) - lastl * e1;
-                    if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(S2, g2[c]), lastl) - lastl * e2;
+                    first = __builtin_amdgcn_readlane(imax(S1[c], g1[c]), lastl) - lastl * e1;
+                    if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(S2[c], g2[c]), lastl) - lastl * e2;
                 } else { first = seed1[c] + e1; if (GAP == 2) first2 = seed2[c] + e2; }
-                T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
+                T f1t = (T)F1[c], f2t = (T)F2[c], fi = (T)first, fi2 = (T)first2;
                 slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs[c], (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
-                F1 = (int)f1t; F2 = (int)f2t;
+                F1[c] = (int)f1t; F2[c] = (int)f2t;
             }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool in_band = c < NCH - 2 ? true : c * 64 + lane < Wr;
             int Hout, E1out, E2out = inf;
             if (GAP == 1) {
-                Hout = imax(hsE[c], F1);
+                Hout = imax(hsE[c], F1[c]);
                 const int en_ = imax(wr(E1v[c] - e1), wr(Hout - oe1));
                 E1out = (Hout == hsE[c]) ? en_ : inf;
             } else {
-                Hout = imax(hs[c], imax(F1, F2));
+                Hout = imax(hs[c], imax(F1[c], F2[c]));
                 E1out = imax(wr(E1v[c] - e1), wr(Hout - oe1));
                 E2out = imax(wr(E2v[c] - e2), wr(Hout - oe2));
             }
             const int mflag = (Mv[c] + q[c] == Hout && kb[c] <= 64) ? kb[c] : 0;
             const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
-            if (c < nch) {      // one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
+            if (c < NCH - 1 || nch == NCH) {      // one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
                 T *H = Hrow + c * 64 * CW;
-                if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)H = rec; }
-                else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
-                else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)H = rec; }
-                else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
+                if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1[c], 0x05040100u); *(int2 *)H = rec; }
+                else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1[c] << 16)); rec.z = F2[c] & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
+                else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1[c]; rec.w = mflag; *(int4 *)H = rec; }
+                else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1[c]; r1.x = F2[c]; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
             }
             if (I16) { qd[c * 64] = in_band ? he : infw; if (GAP == 2) qd[RCS + c * 64] = in_band ? E2out : inf; }
             else { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS + c * 64] = in_band ? E2out : inf; }
