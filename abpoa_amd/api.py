@@ -11,17 +11,19 @@ from . import ffi, seqio
 
 GLOBAL, LOCAL, EXTEND = 0, 1, 2
 LINEAR, AFFINE, CONVEX = 0, 1, 2
-OUT_CONS, OUT_MSA = 1, 2
+OUT_CONS, OUT_MSA, AMB_STRAND = 1, 2, 4
 
 
 class ReadSet(C.Structure):          # abpoa_hip_readset_t
-    _fields_ = [("n_reads", C.c_int32), ("seqs", C.POINTER(C.POINTER(C.c_uint8))), ("lens", C.POINTER(C.c_int32))]
+    _fields_ = [("n_reads", C.c_int32), ("seqs", C.POINTER(C.POINTER(C.c_uint8))), ("lens", C.POINTER(C.c_int32)),
+                ("weights", C.POINTER(C.POINTER(C.c_int32)))]
 
 
 class Msa(C.Structure):              # abpoa_hip_msa_t
     _fields_ = [("status", C.c_int32), ("n_reads", C.c_int32), ("cons_len", C.c_int32),
                 ("cons_base", C.POINTER(C.c_uint8)), ("cons_cov", C.POINTER(C.c_int32)), ("cons_node_id", C.POINTER(C.c_int32)),
-                ("msa_len", C.c_int32), ("msa_rows", C.c_int32), ("msa_base", C.POINTER(C.c_uint8)), ("n_cells", C.c_int64)]
+                ("msa_len", C.c_int32), ("msa_rows", C.c_int32), ("msa_base", C.POINTER(C.c_uint8)), ("n_cells", C.c_int64),
+                ("is_rc", C.POINTER(C.c_uint8))]
 
 
 class MsaTiming(C.Structure):        # abpoa_hip_msa_timing_t
@@ -87,6 +89,7 @@ class SetResult:
         self._cons_seq = self._cov_list = self._msa_seq = None
 
     status = property(lambda self: self._o.status)
+    is_rc = property(lambda self: [bool(self._o.is_rc[i]) for i in range(self._o.n_reads)] if self._o.is_rc else [False] * self._o.n_reads)
     n_cells = property(lambda self: self._o.n_cells)
     cons_len = property(lambda self: self._o.cons_len)
     msa_len = property(lambda self: self._o.msa_len)
@@ -151,7 +154,8 @@ def _bind_msa(lib):
 class EncodedSets:
     """Read-sets encoded once into residue codes and laid out for abpoa_hip_msa_batch (kept alive on self)."""
 
-    def __init__(self, read_sets, m=5):
+    def __init__(self, read_sets, m=5, weights=None):
+        """weights: None, or per set a list of per-read integer sequences (the reference's qv weights with -Q: seqio.qv_weights)."""
         self.n = len(read_sets)
         self.codes = [[np.ascontiguousarray(seqio.encode(r, m)) for r in rs] for rs in read_sets]
         self.sets = (ReadSet * self.n)()
@@ -159,19 +163,26 @@ class EncodedSets:
         for i, rs in enumerate(self.codes):
             ptrs = (C.POINTER(C.c_uint8) * len(rs))(*[a.ctypes.data_as(C.POINTER(C.c_uint8)) for a in rs])
             lens = (C.c_int32 * len(rs))(*[len(a) for a in rs])
-            self._keep.append((ptrs, lens))
-            self.sets[i] = ReadSet(len(rs), ptrs, lens)
+            wptrs = None
+            if weights is not None and weights[i] is not None:
+                ws = [np.ascontiguousarray(w, np.int32) for w in weights[i]]
+                assert all(len(w) == len(a) for w, a in zip(ws, rs)), "one weight per base"
+                wptrs = (C.POINTER(C.c_int32) * len(rs))(*[w.ctypes.data_as(C.POINTER(C.c_int32)) for w in ws])
+                self._keep.append(ws)
+            self._keep.append((ptrs, lens, wptrs))
+            self.sets[i] = ReadSet(len(rs), ptrs, lens, wptrs)
 
 
-def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=None, encoded=None):
+def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=None, encoded=None, weights=None, amb_strand=False):
     """Consensus / MSA of many independent read-sets (lists of strings) in one call.
-    Returns a list of SetResult.  `lib` defaults to the HIP engine (tests may pass the CPU shim)."""
+    Returns a list of SetResult.  `lib` defaults to the HIP engine (tests may pass the CPU shim).
+    weights: per set, per read, per base edge weights (the reference's -Q); amb_strand: the reference's -s."""
     lib = lib or ffi.lib()
     _bind_msa(lib)
-    enc = encoded or EncodedSets(read_sets, params.m)
+    enc = encoded or EncodedSets(read_sets, params.m, weights)
     out = (Msa * enc.n)()
     sc = params.scoring()
-    flags = (OUT_CONS if out_cons else 0) | (OUT_MSA if out_msa else 0)
+    flags = (OUT_CONS if out_cons else 0) | (OUT_MSA if out_msa else 0) | (AMB_STRAND if amb_strand else 0)
     rc = lib.abpoa_hip_msa_batch(C.byref(sc), enc.n, enc.sets, out, flags, n_threads)
     if rc != 0:
         raise ffi.EngineError(f"abpoa_hip_msa_batch failed ({rc}): {lib.abpoa_hip_last_error().decode() if hasattr(lib, 'abpoa_hip_last_error') else ''}")
@@ -195,9 +206,10 @@ def format_output(result, names=None, out_cons=True, out_msa=False):
         if result.msa_len <= 0:
             return ""
         n_reads = len(result.msa_seq) - (1 if out_cons else 0)
+        rc = result.is_rc
         for i in range(n_reads):
             nm = names[i] if names and i < len(names) and names[i] else None
-            lines.append(f">{nm}" if nm else f">Seq_{i + 1}")
+            lines.append((f">{nm}" if nm else f">Seq_{i + 1}") + ("_reverse_complement" if rc[i] else ""))      # src/abpoa_output.c:77
             lines.append(result.msa_seq[i])
         if out_cons:
             lines.append(">Consensus_sequence")

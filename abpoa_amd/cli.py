@@ -6,10 +6,11 @@
   -O INT[,INT] gap open (O1,O2)   -E INT[,INT] gap extension (E1,E2)   -b INT / -f FLOAT adaptive band (b < 0: off)
   -c amino-acid input   -l input is a LIST of sequence files (one read-set each)   -o FILE output [stdout]
   -r INT  0 consensus FASTA, 1 MSA (PIR), 2 both
+  -s  ambiguous strand: a read that aligns badly is tried as its reverse complement    -Q  FASTQ qualities as edge weights
 
 With -l every file of the list is one read-set and ALL of them go through ONE abpoa_hip_msa_batch call (the reference
 loops over the files one at a time, src/abpoa.c:128-135); the output is the concatenation the reference prints.
-Options outside the engine (-s -S -p -Q -i -d -g, -r 3/4/5) exit with an error rather than being ignored."""
+Options outside the engine (-S -p -i -d -g, -r 3/4/5) exit with an error rather than being ignored."""
 import argparse
 import sys
 
@@ -36,6 +37,8 @@ def build_parser():
     ap.add_argument("-l", "--in-list", action="store_true")
     ap.add_argument("-o", "--output", default=None)
     ap.add_argument("-r", "--result", type=int, default=0)
+    ap.add_argument("-s", "--amb-strand", action="store_true")
+    ap.add_argument("-Q", "--use-qual-weight", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
     return ap
 
@@ -50,13 +53,15 @@ def main(argv=None, lib=None, out=None):
     params = api.Params(aln_mode=a.aln_mode, is_aa=a.amino_acid, match=a.match, mismatch=a.mismatch, score_matrix=a.matrix,
                         gap_open1=o1, gap_open2=o2, gap_ext1=e1, gap_ext2=e2, extra_b=a.extra_b, extra_f=a.extra_f)
     files = [ln.strip() for ln in open(a.input) if ln.strip()] if a.in_list else [a.input]
-    names, sets = [], []
+    names, sets, weights = [], [], []
     for fn in files:
-        n, s = seqio.read_fasta(fn)
+        n, s, q = seqio.read_fastx(fn)
         names.append(n)
         sets.append(s)
+        weights.append([seqio.qv_weights(x, y) for x, y in zip(s, q)])
     out_cons, out_msa = a.result in (0, 2), a.result in (1, 2)
-    res = api.msa_batch(sets, params, out_cons=out_cons, out_msa=out_msa, n_threads=a.threads, lib=lib)
+    res = api.msa_batch(sets, params, out_cons=out_cons, out_msa=out_msa, n_threads=a.threads, lib=lib,
+                        weights=weights if a.use_qual_weight else None, amb_strand=a.amb_strand)
     sink = out or (open(a.output, "w") if a.output else sys.stdout)
     try:
         for n, r in zip(names, res):

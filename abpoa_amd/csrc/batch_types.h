@@ -30,6 +30,7 @@ class GroupAligner {
     virtual int run() = 0;
     virtual int status(int i) = 0;
     virtual int64_t n_cells(int i) = 0;
+    virtual int best_score(int i) = 0;
     virtual int n_cigar(int i) = 0;
     virtual const uint64_t *cigar(int i) = 0;
 };

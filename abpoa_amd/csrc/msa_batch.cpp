@@ -72,11 +72,12 @@ class Pool {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct GroupTimes { double sort_s = 0, engine_s = 0, fuse_s = 0; int rounds = 0; };
+inline const int32_t *weights_of(const abpoa_hip_readset_t &rs, int r) { return rs.weights ? rs.weights[r] : nullptr; }
 }  // namespace
 
 // One group of read-sets [s0, s1): the whole progressive POA, lock-step over reads.
 static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int s0, int s1,
-                     std::vector<PoaGraph> &graphs, int n_threads, GroupAligner *al, bool with_remain, GroupTimes *gt) {
+                     std::vector<PoaGraph> &graphs, int n_threads, GroupAligner *al, bool with_remain, bool amb_strand, GroupTimes *gt) {
     Pool pool(n_threads);
     int max_reads = 0;
     for (int s = s0; s < s1; ++s) if (sets[s].n_reads > max_reads) max_reads = sets[s].n_reads;
@@ -90,7 +91,7 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
         if (k == 0) {       // first read of every set seeds its graph (reference: abpoa_align_sequence_to_graph returns -1, :186)
             pool.run((int)active.size(), [&](int a) {
                 const int s = active[a];
-                try { graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0); } catch (...) { fail.store(1); }
+                try { graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0, weights_of(sets[s], 0)); } catch (...) { fail.store(1); }
             });
             if (fail.load()) return ABPOA_HIP_EINVAL;
             continue;
@@ -116,13 +117,70 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
         const double t1 = now_s();
         rc = al->run();
         if (rc) return rc;
-        const double t2 = now_s();
+        double t2 = now_s();
+        // ---- ambiguous strand (reference abpoa_poa, src/abpoa_align.c:315-336): reads that score below a third of the best possible are
+        //      aligned again as their reverse complement, on the SAME rows (the reference calls the DP without re-sorting); the strand
+        //      with the strictly better score goes into the graph.  The forward cigars are saved first: the aligner is run again.
+        std::vector<int> retry;
+        std::vector<std::vector<uint64_t>> fwd_cig;
+        std::vector<std::vector<uint8_t>> rc_seq; std::vector<std::vector<int32_t>> rc_w;
+        std::vector<char> use_rc(active.size(), 0);
+        if (amb_strand) {
+            for (size_t a = 0; a < active.size(); ++a) {
+                const int s = active[a];
+                if (al->status((int)a) != 0) continue;
+                const int qlen = sets[s].lens[k], lim = std::min(qlen, graphs[s].n_nodes() - 2);
+                if ((double)al->best_score((int)a) < (double)lim * scoring.max_mat * .3333) retry.push_back((int)a);
+            }
+        }
+        if (!retry.empty()) {
+            fwd_cig.resize(active.size()); rc_seq.resize(active.size()); rc_w.resize(active.size());
+            std::vector<int> fwd_score(active.size(), 0), fwd_st(active.size(), 0); std::vector<int64_t> fwd_cells(active.size(), 0);
+            for (size_t a = 0; a < active.size(); ++a) {
+                fwd_st[a] = al->status((int)a); fwd_score[a] = al->best_score((int)a); fwd_cells[a] = al->n_cells((int)a);
+                fwd_cig[a].assign(al->cigar((int)a), al->cigar((int)a) + al->n_cigar((int)a));
+            }
+            std::vector<BatchShape> sh2(retry.size());
+            for (size_t t = 0; t < retry.size(); ++t) sh2[t] = shapes[retry[t]];
+            rc = al->prepare(&scoring, (int)retry.size(), sh2.data());
+            if (rc) return rc;
+            pool.run((int)retry.size(), [&](int t) {
+                const int a = retry[t], s = active[a], qlen = sets[s].lens[k];
+                try {
+                    const uint8_t *q = sets[s].seqs[k]; const int32_t *wq = weights_of(sets[s], k);
+                    rc_seq[a].resize(qlen); if (wq) rc_w[a].resize(qlen);
+                    for (int j = 0; j < qlen; ++j) { const uint8_t c = q[qlen - j - 1]; rc_seq[a][j] = c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; if (wq) rc_w[a][j] = wq[qlen - j - 1]; }
+                    ProblemSlots sl = al->slots(t);
+                    memcpy(sl.query, rc_seq[a].data(), qlen);
+                    graphs[s].flatten_into(with_remain, sl.row_base, sl.row_node_id, sl.row_remain, sl.pred_off, sl.pred_row, sl.out_off, sl.out_row);
+                } catch (...) { fail.store(1); }
+            });
+            if (fail.load()) return ABPOA_HIP_EINVAL;
+            rc = al->run();
+            if (rc) return rc;
+            t2 = now_s();
+            pool.run((int)active.size(), [&](int a) {
+                const int s = active[a];
+                if (fwd_st[a] != 0) { out[s].status = fwd_st[a]; return; }
+                out[s].n_cells += fwd_cells[a];
+                const uint64_t *cg = fwd_cig[a].data(); int ncg = (int)fwd_cig[a].size();
+                const uint8_t *q = sets[s].seqs[k]; const int32_t *wq = weights_of(sets[s], k);
+                const auto it = std::find(retry.begin(), retry.end(), a);
+                if (it != retry.end()) {
+                    const int t = (int)(it - retry.begin());
+                    if (al->status(t) != 0) { out[s].status = al->status(t); return; }
+                    out[s].n_cells += al->n_cells(t);
+                    if (al->best_score(t) > fwd_score[a]) { cg = al->cigar(t); ncg = al->n_cigar(t); q = rc_seq[a].data(); wq = wq ? rc_w[a].data() : nullptr; if (out[s].is_rc) out[s].is_rc[k] = 1; }
+                }
+                try { graphs[s].add_alignment(q, sets[s].lens[k], cg, ncg, k, wq); } catch (...) { fail.store(1); }
+            });
+        } else
         pool.run((int)active.size(), [&](int a) {
             const int s = active[a];
             const int st = al->status(a);
             if (st != 0) { out[s].status = st; return; }
             out[s].n_cells += al->n_cells(a);
-            try { graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], al->cigar(a), al->n_cigar(a), k); } catch (...) { fail.store(1); }
+            try { graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], al->cigar(a), al->n_cigar(a), k, weights_of(sets[s], k)); } catch (...) { fail.store(1); }
         });
         if (fail.load()) return ABPOA_HIP_EINVAL;
         const double t3 = now_s();
@@ -145,6 +203,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     if (n_groups <= 0) n_groups = n_sets >= 512 ? 4 : (n_sets >= 128 ? 2 : 1);
     if (n_groups > n_threads) n_groups = n_threads;
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
+    const bool amb_strand = (flags & ABPOA_HIP_AMB_STRAND) && sc->m <= 5;      // (nucleotides only: the complement is 3 - code)
     abpoa_hip_scoring_t scoring = *sc;
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE) scoring.wb = -1;        // reference abpoa_post_set_para, abpoa_align.c:150
     scoring.ret_cigar = 1; scoring.rev_cigar = 0;
@@ -153,6 +212,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
         if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL;
         for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL;
         out[s].n_reads = sets[s].n_reads;
+        if (amb_strand) out[s].is_rc = (uint8_t *)calloc((size_t)std::max(1, sets[s].n_reads), 1);
     }
     std::vector<PoaGraph> graphs(n_sets);
     for (int s = 0; s < n_sets; ++s) graphs[s].reset(sets[s].n_reads, want_msa);
@@ -165,7 +225,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     const int per_group_threads = n_threads / n_groups > 0 ? n_threads / n_groups : 1;
     for (int g = 0; g < n_groups; ++g) {
         const int s0 = (int)((int64_t)n_sets * g / n_groups), s1 = (int)((int64_t)n_sets * (g + 1) / n_groups);
-        auto body = [&, g, s0, s1] { rcs[g] = run_group(scoring, sets, out, s0, s1, graphs, per_group_threads, aligners[g].get(), with_remain, &gts[g]); };
+        auto body = [&, g, s0, s1] { rcs[g] = run_group(scoring, sets, out, s0, s1, graphs, per_group_threads, aligners[g].get(), with_remain, amb_strand, &gts[g]); };
         if (g + 1 < n_groups) drivers.emplace_back(body); else body();
     }
     for (auto &t : drivers) t.join();
@@ -214,8 +274,8 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
 extern "C" {
 void abpoa_hip_free_msa(abpoa_hip_msa_t *r) {
     if (!r) return;
-    free(r->cons_base); free(r->cons_cov); free(r->cons_node_id); free(r->msa_base);
-    r->cons_base = nullptr; r->cons_cov = nullptr; r->cons_node_id = nullptr; r->msa_base = nullptr;
+    free(r->cons_base); free(r->cons_cov); free(r->cons_node_id); free(r->msa_base); free(r->is_rc);
+    r->cons_base = nullptr; r->cons_cov = nullptr; r->cons_node_id = nullptr; r->msa_base = nullptr; r->is_rc = nullptr;
     r->cons_len = r->msa_len = r->msa_rows = 0;
 }
 }

@@ -98,7 +98,7 @@ void consensus_flat(int n, const int32_t *order, const uint8_t *base, const uint
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;
-    return sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0 && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && !(flags & ABPOA_HIP_OUT_MSA) &&
+    return sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0 && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && !(flags & (ABPOA_HIP_OUT_MSA | ABPOA_HIP_AMB_STRAND)) &&
            sc->m - 1 <= POA_ALN_CAP && sc->zdrop <= 0;
 }
 

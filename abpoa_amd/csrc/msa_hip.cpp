@@ -22,6 +22,7 @@ class HipGroupAligner : public GroupAligner {
     int run() override { return bs_.run(); }
     int status(int i) override { return bs_.rec(i).status; }
     int64_t n_cells(int i) override { return bs_.rec(i).n_cells; }
+    int best_score(int i) override { return bs_.rec(i).best_score; }
     int n_cigar(int i) override { return bs_.rec(i).n_cigar; }
     const uint64_t *cigar(int i) override { return bs_.cigar(i); }
   private:
@@ -41,7 +42,9 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
                         abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
     using namespace abpoa_hip;
     if (engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
-    if (n_sets > 0 && sc && sets && out && msa_device_eligible(sc, flags)) {
+    bool plain = true;      // per-base weights and the strand retry are host-driver features
+    for (int s = 0; plain && sets && s < n_sets; ++s) plain = sets[s].weights == nullptr;
+    if (n_sets > 0 && sc && sets && out && plain && msa_device_eligible(sc, flags)) {
         // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
         if (n_threads <= 0) n_threads = effective_host_cores();
         for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL; }

@@ -77,13 +77,14 @@ void PoaGraph::add_aligned(int node_id, int new_id) {                  // :393-4
     nodes_[new_id].aligned.push_back(node_id);
 }
 
-void PoaGraph::add_alignment(const uint8_t *seq, int len, const uint64_t *cigar, int n_cigar, int read_id) {
+void PoaGraph::add_alignment(const uint8_t *seq, int len, const uint64_t *cigar, int n_cigar, int read_id, const int32_t *weight) {
     const bool rid = use_read_ids_;
+    auto w = [&](int q) { return weight ? (int)weight[q] : 1; };      // reference: weight[query_id] on every edge INTO the base's node, :486-499 / :634-667
     if (nodes_.size() == 2) {                                          // empty graph: :486-502
         if (len <= 0) throw std::invalid_argument("empty first read");
         int last = SRC;
-        for (int i = 0; i < len; ++i) { int cur = add_node(seq[i]); add_edge(last, cur, false, 1, rid, read_id); last = cur; }
-        add_edge(last, SINK, false, 1, rid, read_id);
+        for (int i = 0; i < len; ++i) { int cur = add_node(seq[i]); add_edge(last, cur, false, w(i), rid, read_id); last = cur; }
+        add_edge(last, SINK, false, w(len - 1), rid, read_id);
         sorted_ = false; return;
     }
     if (n_cigar == 0) return;                                          // :614-616
@@ -95,25 +96,25 @@ void PoaGraph::add_alignment(const uint8_t *seq, int len, const uint64_t *cigar,
             ++query_id;
             if (nodes_[node_id].base != seq[query_id]) {
                 int al = aligned_with_base(node_id, seq[query_id]);
-                if (al != -1) { add_edge(last_id, al, !last_new, 1, rid, read_id); last_id = al; last_new = false; }
+                if (al != -1) { add_edge(last_id, al, !last_new, w(query_id), rid, read_id); last_id = al; last_new = false; }
                 else {
                     int nid = add_node(seq[query_id]);
-                    add_edge(last_id, nid, false, 1, rid, read_id);
+                    add_edge(last_id, nid, false, w(query_id), rid, read_id);
                     last_id = nid; last_new = true;
                     add_aligned(node_id, nid);
                 }
-            } else { add_edge(last_id, node_id, !last_new, 1, rid, read_id); last_id = node_id; last_new = false; }
+            } else { add_edge(last_id, node_id, !last_new, w(query_id), rid, read_id); last_id = node_id; last_new = false; }
         } else if (op == ABPOA_HIP_CINS || op == 4 || op == 5) {       // insertion / clips add nodes
             const int l = (int)((cigar[i] >> 4) & 0x3fffffff);
             query_id += l;
             for (int j = l - 1; j >= 0; --j) {
                 int nid = add_node(seq[query_id - j]);
-                add_edge(last_id, nid, false, 1, rid, read_id);
+                add_edge(last_id, nid, false, w(query_id - j), rid, read_id);
                 last_id = nid; last_new = true;
             }
         }                                                              // deletion: nothing
     }
-    add_edge(last_id, SINK, !last_new, 1, rid, read_id);                // :667
+    add_edge(last_id, SINK, !last_new, w(len - 1), rid, read_id);       // :667
     sorted_ = false;
 }
 

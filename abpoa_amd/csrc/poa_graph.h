@@ -75,7 +75,7 @@ class PoaGraph {
 
     // Fuse an alignment (graph cigar from the DP) of read `read_id` into the graph; with an empty graph
     // the read becomes the backbone chain and the cigar is ignored.
-    void add_alignment(const uint8_t *seq, int len, const uint64_t *cigar, int n_cigar, int read_id);
+    void add_alignment(const uint8_t *seq, int len, const uint64_t *cigar, int n_cigar, int read_id, const int32_t *weight = nullptr);      // weight: per-base edge weights (qv), NULL = 1
 
     // Row order + (if `with_remain`) heaviest-path remaining length.
     void topological_sort(bool with_remain);

@@ -38,9 +38,9 @@ def decode(codes, m=5):
     return "".join(tbl[c] for c in codes)
 
 
-def read_fasta(path):
-    """-> (names, sequences); FASTA or FASTQ, plain text (quality lines are skipped)."""
-    names, seqs, cur, fastq_skip = [], [], None, 0
+def read_fastx(path):
+    """-> (names, sequences, qualities); FASTA or FASTQ, plain text.  qualities[i] is the FASTQ quality string of record i or None."""
+    names, seqs, quals = [], [], []
     with open(path) as f:
         lines = [ln.rstrip("\r\n") for ln in f]
     i = 0
@@ -52,15 +52,31 @@ def read_fasta(path):
         if ln[0] == ">":
             names.append(ln[1:].split()[0] if len(ln) > 1 else "")
             seqs.append([])
+            quals.append(None)
         elif ln[0] == "@" and (i + 2 < len(lines) and lines[i + 2].startswith("+")):
             names.append(ln[1:].split()[0] if len(ln) > 1 else "")
             seqs.append([lines[i + 1]])
+            quals.append(lines[i + 3] if i + 3 < len(lines) else None)
             i += 4
             continue
         elif seqs:
             seqs[-1].append(ln.strip())
         i += 1
-    return names, ["".join(s) for s in seqs]
+    return names, ["".join(s) for s in seqs], quals
+
+
+def read_fasta(path):
+    """-> (names, sequences); FASTA or FASTQ, plain text (quality lines are dropped)."""
+    n, s, _ = read_fastx(path)
+    return n, s
+
+
+def qv_weights(seq, qual):
+    """Per-base edge weights as the reference derives them with -Q (src/abpoa_align.c:464-467): quality character - 32 where the record
+    has a quality string as long as the sequence, 1 otherwise."""
+    if qual is None or len(qual) != len(seq):
+        return np.ones(len(seq), np.int32)
+    return (np.frombuffer(qual.encode(), np.uint8).astype(np.int32) - 32)
 
 
 def simple_matrix(m, match, mismatch):

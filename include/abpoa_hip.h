@@ -169,6 +169,8 @@ typedef struct abpoa_hip_readset_t {
     int32_t n_reads;
     const uint8_t *const *seqs;   /* [n_reads] residue codes 0..m-1                                  */
     const int32_t *lens;          /* [n_reads] each > 0                                               */
+    const int32_t *const *weights;/* NULL, or [n_reads] per-base edge weights (NULL entry = all 1): the reference's
+                                     qv weights, abpoa_msa1 src/abpoa_align.c:462-467 (quality - 32 with -Q)  */
 } abpoa_hip_readset_t;
 
 typedef struct abpoa_hip_msa_t {
@@ -182,10 +184,14 @@ typedef struct abpoa_hip_msa_t {
     int32_t  msa_rows;            /* n_reads (+1 consensus row when both outputs are requested)       */
     uint8_t *msa_base;            /* [msa_rows*msa_len] row-major, gap = m (abpoa_cons_t.msa_base)    */
     int64_t  n_cells;             /* DP cells over all alignments of the set                          */
+    uint8_t *is_rc;               /* NULL unless ABPOA_HIP_AMB_STRAND: [n_reads] 1 where the reverse complement of the read
+                                     went into the graph (abpoa_seq_t.is_rc, src/abpoa_align.c:331)   */
 } abpoa_hip_msa_t;
 
 #define ABPOA_HIP_OUT_CONS 0x1u   /* abpoa_para_t.out_cons */
 #define ABPOA_HIP_OUT_MSA  0x2u   /* abpoa_para_t.out_msa  */
+#define ABPOA_HIP_AMB_STRAND 0x4u /* abpoa_para_t.amb_strand (-s): a read whose best score is below min(qlen, nodes - 2) * max_mat / 3 is aligned
+                                     again as its reverse complement and the better strand goes into the graph (src/abpoa_align.c:315-336) */
 
 /* n_threads <= 0: one host thread per online core.  Every out[i] must be released with
  * abpoa_hip_free_msa.  Fails with ABPOA_HIP_ENODEV when no GPU is usable. */

@@ -13,6 +13,7 @@ import gzip
 import glob
 import os
 import shutil
+import subprocess
 import sys
 import tempfile
 
@@ -58,6 +59,21 @@ def cases(tmp):
     out.append(("out_test_cons_msa", tst, ["-r", "2"], "none", 0, None))
     out.append(("out_heter_cons", het, CG, "none", 0, None))
     out.append(("out_s1k_cons", s1k, AG, "none", 0, None))
+    # -s (ambiguous strand): reads 2, 5, 8 of a seeded set handed over as their reverse complement; -Q: FASTQ with seeded qualities
+    rcfa = os.path.join(tmp, "rc.fa")
+    rs = synth.make_read_set(7, 0, 10, 400, 0.08)
+    comp = str.maketrans("ACGT", "TGCA")
+    synth.write_fasta(rcfa, [r[::-1].translate(comp) if i in (2, 5, 8) else r for i, r in enumerate(rs)])
+    out.append(("out_rc_cons", rcfa, AG + ["-s"], "none", 0, None))
+    out.append(("out_rc_msa", rcfa, ["-s", "-r", "2"], "none", 0, None))
+    qfq = os.path.join(tmp, "qv.fq")
+    rng = synth.SplitMix64(99)
+    with open(qfq, "w") as f:
+        for i, r in enumerate(synth.make_read_set(8, 0, 9, 300, 0.1)):
+            q = "".join(chr(33 + int(x % 41)) for x in rng.block(len(r)))
+            f.write(f"@q{i}\n{r}\n+\n{q}\n")
+    out.append(("out_qv_cons", qfq, AG + ["-Q"], "none", 0, None))
+    out.append(("out_qv_msa", qfq, ["-Q", "-r", "2"], "none", 0, None))
     return out
 
 
@@ -67,7 +83,12 @@ def main():
     tmp = tempfile.mkdtemp()
     for name, fa, opts, reads, planes, sub in cases(tmp):
         d = os.path.join(tmp, name)
-        H.run_ref_dump(fa, d, opts, reads, planes=planes, sub=sub)
+        if name.startswith(("out_rc_", "out_qv_")):      # options the dump harness does not parse: the reference's own command line prints the text
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "output.txt"), "w") as fo:
+                subprocess.run([os.path.join(H.REF_DIR, "abpoa_ref")] + opts + [fa], stdout=fo, check=True)
+        else:
+            H.run_ref_dump(fa, d, opts, reads, planes=planes, sub=sub)
         dst = os.path.join(H.GOLDEN_DIR, name)
         shutil.rmtree(dst, ignore_errors=True)
         os.makedirs(dst)
@@ -78,7 +99,7 @@ def main():
         with open(os.path.join(dst, "cmd.txt"), "w") as f:
             f.write(" ".join(o.replace(REF, "$REF").replace(tmp, "$TMP") for o in opts) + f" | reads={reads} sub={sub} input={os.path.basename(fa)}\n")
         if fa.startswith(tmp):
-            shutil.copy(fa, os.path.join(dst, "input.fa"))
+            shutil.copy(fa, os.path.join(dst, "input.fq" if fa.endswith(".fq") else "input.fa"))
     # the reference's own small inputs and matrices are data fixtures too
     fx = os.path.join(H.GOLDEN_DIR, "data")
     os.makedirs(fx, exist_ok=True)

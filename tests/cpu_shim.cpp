@@ -45,6 +45,7 @@ class OracleGroupAligner : public GroupAligner {
     }
     int status(int i) override { return res_[i].status; }
     int64_t n_cells(int i) override { return res_[i].n_cells; }
+    int best_score(int i) override { return res_[i].best_score; }
     int n_cigar(int i) override { return res_[i].n_cigar; }
     const uint64_t *cigar(int i) override { return res_[i].cigar; }
   private:

@@ -89,3 +89,37 @@ def test_full_size_read_set_vs_reference_binary(tmp_path, cfg, opts, pk):
     r = api.msa_batch([reads], api.Params(**pk))[0]
     assert r.status == 0
     assert api.format_output(r) == exp
+
+
+def _run_fx(path, params, out_cons, out_msa, qv=False, amb=False):
+    names, seqs, quals = seqio.read_fastx(path)
+    w = [[seqio.qv_weights(x, y) for x, y in zip(seqs, quals)]] if qv else None
+    r = api.msa_batch([seqs], params, out_cons=out_cons, out_msa=out_msa, weights=w, amb_strand=amb)[0]
+    assert r.status == 0
+    return api.format_output(r, names, out_cons, out_msa), r
+
+
+def test_ambiguous_strand_and_quality_weights():
+    """reference -s (src/abpoa_align.c:315-336) and -Q (:462-467) through the engine: byte-identical text."""
+    fa = os.path.join(D, "out_rc_cons", "input.fa")
+    txt, r = _run_fx(fa, api.Params(**AG), True, False, amb=True)
+    assert txt == _golden("out_rc_cons") and [i for i, f in enumerate(r.is_rc) if f] == [2, 5, 8]
+    assert _run_fx(fa, api.Params(), True, True, amb=True)[0] == _golden("out_rc_msa")
+    fq = os.path.join(D, "out_qv_cons", "input.fq")
+    assert _run_fx(fq, api.Params(**AG), True, False, qv=True)[0] == _golden("out_qv_cons")
+    assert _run_fx(fq, api.Params(), True, True, qv=True)[0] == _golden("out_qv_msa")
+
+
+@pytest.mark.parametrize("wl,idx", [("cfg2", [0, 1, 2, 3, 999]), ("cfg4", [0, 1]), ("cfg3", [0, 1]), ("cfg5", [0, 1, 2, 3, 999])])
+def test_full_size_sets_against_committed_reference_digests(wl, idx):
+    """Full-size BASELINE read-sets (50 x 1 kb; 50 x 10 kb affine 5 % and convex 15 %; 30 x 500 aa local BLOSUM62 MSA): the output text of
+    each set must hash to what the reference printed for it (tests/golden/bench_digests/, oracle/make_bench_digests.py)."""
+    from abpoa_amd import workloads as W
+    w = W.WORKLOADS[wl]
+    ref = W.load_digests(wl)
+    sets = [synth.make_read_set(1, i, **synth.CONFIGS[w["cfg"]]) for i in idx]
+    res = api.msa_batch(sets, api.Params(**w["params"]), out_cons=not w["out_msa"], out_msa=w["out_msa"])
+    for i, r in zip(idx, res):
+        assert r.status == 0
+        txt = api.format_output(r, [f"r{j}" for j in range(len(sets[0]))], not w["out_msa"], w["out_msa"])
+        assert W.output_sha(txt) == ref[i], f"{wl} set {i}"

@@ -55,6 +55,33 @@ def test_amino_acid_blosum62_local_msa():       # BASELINE.json config 5 shape (
     assert txt == _golden("aa_blosum_loc")
 
 
+def _run_fx(path, params, out_cons, out_msa, qv=False, amb=False, lib=None):
+    names, seqs, quals = seqio.read_fastx(path)
+    w = [[seqio.qv_weights(x, y) for x, y in zip(seqs, quals)]] if qv else None
+    r = api.msa_batch([seqs], params, out_cons=out_cons, out_msa=out_msa, lib=lib or H.cpu_shim_lib(), n_threads=2, weights=w, amb_strand=amb)[0]
+    assert r.status == 0
+    return api.format_output(r, names, out_cons, out_msa), r
+
+
+def test_ambiguous_strand_retry():              # reference -s, src/abpoa_align.c:315-336
+    fa = os.path.join(D, "out_rc_cons", "input.fa")
+    txt, r = _run_fx(fa, api.Params(**AG), True, False, amb=True)
+    assert txt == _golden("out_rc_cons")
+    assert [i for i, f in enumerate(r.is_rc) if f] == [2, 5, 8]
+    txt, _ = _run_fx(fa, api.Params(), True, True, amb=True)
+    assert txt == _golden("out_rc_msa")             # (names carry _reverse_complement, src/abpoa_output.c:77)
+    no_retry, _ = _run_fx(fa, api.Params(**AG), True, False)
+    assert no_retry != _golden("out_rc_cons")       # the retry matters on this input
+
+
+def test_quality_weights():                     # reference -Q, src/abpoa_align.c:462-467, abpoa_graph.c:486-499 / :634-667
+    fq = os.path.join(D, "out_qv_cons", "input.fq")
+    txt, _ = _run_fx(fq, api.Params(**AG), True, False, qv=True)
+    assert txt == _golden("out_qv_cons")
+    txt, _ = _run_fx(fq, api.Params(), True, True, qv=True)
+    assert txt == _golden("out_qv_msa")
+
+
 def test_pyabpoa_readme_example():              # reference python/README.md:28-33 (golden captured via pyabpoa)
     seqs = ["CCGAAGA", "CCGAACTCGA", "CCCGGAAGA", "CCGAAGA"]
     r = api.msa_batch([seqs], api.Params(), out_cons=True, out_msa=True, lib=H.cpu_shim_lib())[0]
