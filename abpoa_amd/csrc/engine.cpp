@@ -18,8 +18,12 @@
 
 namespace abpoa_hip {
 
-static thread_local char g_err[512] = "";
+// Last error of the PROCESS (the batch calls run on worker threads; the caller reads the message from its own thread).  Readers get a
+// per-thread copy taken under the lock.
+static char g_err[512] = ""; static std::mutex g_err_mu;
+static thread_local char g_err_copy[512] = "";
 void set_err(const char *fmt, ...) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 #define HIP_TRY(expr, code)                                                                          \
@@ -368,7 +372,7 @@ void abpoa_hip_shutdown(void) {
     g.ready = false; g.device = -1;
 }
 
-const char *abpoa_hip_last_error(void) { return g_err; }
+const char *abpoa_hip_last_error(void) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err_copy, g_err, sizeof(g_err)); return g_err_copy; }
 void abpoa_hip_get_stats(abpoa_hip_stats_t *out) { std::lock_guard<std::mutex> lk(g.stats_mu); *out = g.stats; }
 void abpoa_hip__debug_clocks(long long *out) { for (int i = 0; i < 10; ++i) { out[i] = g_dbg[i]; g_dbg[i] = 0; } }
 void abpoa_hip_reset_stats(void) { std::lock_guard<std::mutex> lk(g.stats_mu); memset(&g.stats, 0, sizeof(g.stats)); }

@@ -54,7 +54,7 @@ struct Arena {                 // grow-only device / pinned-host buffers kept ac
     }
 };
 struct Cache { Arena in, graph, rows, planes, out; hipStream_t stream = nullptr, copy_stream = nullptr; hipEvent_t ev_copy = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
-Cache g_c; std::mutex g_mu;
+Cache g_cache[MSA_DEVICE_SLOTS]; std::mutex g_cache_mu[MSA_DEVICE_SLOTS];      // one per worker of the multi-device batch call
 
 struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
@@ -103,13 +103,25 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
 }
 
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Cache &C = g_c;
-    const int device = engine_device();
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, int device, int slot) {
+    if (slot < 0 || slot >= MSA_DEVICE_SLOTS) { set_err("bad device slot %d", slot); return ABPOA_HIP_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_cache_mu[slot]);
+    Cache &C = g_cache[slot];
+    if (device < 0) device = engine_device();
     if (device < 0) { set_err("engine not initialised"); return ABPOA_HIP_ENODEV; }
-    HIP_OK(hipSetDevice(device), ABPOA_HIP_ENODEV);
-    if (C.device != device) { if (!C.stream) HIP_OK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV); C.device = device; }
+    HIP_OK(hipSetDevice(device), ABPOA_HIP_ENODEV);          // (the HIP device is per host thread)
+    if (C.device != device) {
+        if (C.device >= 0) {      // the slot served another device before: its pools and stream live there
+            (void)hipSetDevice(C.device);
+            for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
+            if (C.stream) (void)hipStreamDestroy(C.stream); if (C.copy_stream) (void)hipStreamDestroy(C.copy_stream); if (C.ev_copy) (void)hipEventDestroy(C.ev_copy);
+            for (hipEvent_t e : C.ev) (void)hipEventDestroy(e);
+            C = Cache();
+            HIP_OK(hipSetDevice(device), ABPOA_HIP_ENODEV);
+        }
+        if (!C.stream) HIP_OK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV);
+        C.device = device;
+    }
     fallback->clear();
     if (stats) memset(stats, 0, sizeof(*stats));
     const double t_begin = now_s();
@@ -145,11 +157,6 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
         max_node_cap = std::max(max_node_cap, (int)cap);
     }
-    {   // the whole job must fit (the caller splits very large jobs)
-        size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t need = (size_t)plane_tot + (size_t)node_tot * 200 + (size_t)pred_tot * 4 + (size_t)cig_tot * 8 + (size_t)scr_tot * 4 + (size_t)tot_bases;
-        if (need > free_b + C.planes.dev_cap + C.graph.dev_cap + C.rows.dev_cap) { set_err("device-resident job needs %zu bytes, %zu free", need, free_b); return ABPOA_HIP_ENOMEM; }
-    }
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
     L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m);
@@ -170,6 +177,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
     L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot); L.rows_bytes = o;
 
+    {   // the whole job must fit (the caller splits very large jobs): checked on the computed layout, before any cached buffer is given up
+        size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t want[4] = {L.in_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap, C.planes.dev_cap};
+        size_t need = 0, given_back = 0;
+        for (int i = 0; i < 4; ++i) if (want[i] > have[i]) { need += want[i]; given_back += have[i]; }      // a buffer that must grow is freed first
+        if (need > free_b + given_back) { set_err("device-resident job needs %zu more bytes, %zu free", need, free_b + given_back); return ABPOA_HIP_ENOMEM; }
+    }
     int rc;
     if ((rc = C.in.need_dev(L.in_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc = C.graph.need_host(dl_bytes)) ||
         (rc = C.rows.need_dev(L.rows_bytes)) || (rc = C.planes.need_dev((size_t)plane_tot))) return rc;

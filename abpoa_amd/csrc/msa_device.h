@@ -20,7 +20,10 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 // Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
 // them) and must be redone (with a larger node_factor, or by the host driver).  node_factor: node slots per set = factor x
 // longest read.  ABPOA_HIP_ENOMEM: the job does not fit the device (split it); EINVAL: not a job for the device driver.
+// device < 0: the device the engine was initialised on.  slot: which of the per-worker pool caches to use (one worker = one device queue of
+// the multi-GPU batch call; workers may share a device); a slot runs one job at a time.
+constexpr int MSA_DEVICE_SLOTS = 16;
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor);
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, int device = -1, int slot = 0);
 
 }  // namespace abpoa_hip

@@ -1,5 +1,7 @@
 // The product's binding of the read-set driver to the HIP engine: every group gets its own BatchStream.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <memory>
 #include <thread>
 #include <mutex>
@@ -37,6 +39,60 @@ abpoa_hip_msa_timing_t g_timing;
 }  // namespace
 }  // namespace abpoa_hip
 
+namespace abpoa_hip {
+namespace {
+// The device passes over the sets `idx` on ONE device queue (device, slot): pass 1 gives every set 3x its longest read in graph-node
+// slots (5 %-error reads need ~2.5x), pass 2 retries the sets that outgrew that with 6x; whatever is left (listed in `left`) goes to
+// the host driver.  A pass that does not fit the device memory is split in halves.
+struct PassOut { int rc = ABPOA_HIP_OK; bool device_ok = true; DeviceRunStats tot; std::vector<int> left; };
+PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, const std::vector<int> &idx,
+                      int n_threads, int device, int slot) {
+    PassOut R; memset(&R.tot, 0, sizeof(R.tot));
+    std::vector<int> todo = idx, left;
+    const double factors[2] = {3.0, 6.0};
+    for (int pass = 0; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
+        left.clear();
+        size_t chunk = todo.size();
+        for (size_t at = 0; at < todo.size() && R.device_ok;) {
+            const size_t nb = std::min(chunk, todo.size() - at);
+            std::vector<abpoa_hip_readset_t> sub(nb); std::vector<abpoa_hip_msa_t> sub_out(nb);
+            for (size_t i = 0; i < nb; ++i) sub[i] = sets[todo[at + i]];
+            std::vector<int> fb; DeviceRunStats ds;
+            const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], device, slot);
+            if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; continue; }           // split and retry this chunk
+            if (rc != ABPOA_HIP_OK) { if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; } R.device_ok = false; break; }
+            for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
+            for (int f : fb) left.push_back(todo[at + f]);
+            DeviceRunStats &tot = R.tot;
+            tot.prepare_ms += ds.prepare_ms; tot.rows_ms += ds.rows_ms; tot.tail_ms += ds.tail_ms; tot.fuse_ms += ds.fuse_ms; tot.device_s += ds.device_s; tot.cons_s += ds.cons_s;
+            tot.total_s += ds.total_s; tot.n_cells += ds.n_cells; tot.algo_bytes += ds.algo_bytes; tot.n_alignments += ds.n_alignments; tot.n_rounds += ds.n_rounds;
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %.0fx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
+                                                     device, pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
+            at += nb;
+        }
+        if (R.device_ok) todo.swap(left);
+    }
+    R.left = todo;
+    return R;
+}
+
+// ABPOA_GPU_DEVICES: "all", or a comma list of device ordinals (a repeated ordinal = two queues on that
+// device); unset = the device the engine was initialised on.
+std::vector<int> device_list() {
+    std::vector<int> d;
+    const char *e = getenv("ABPOA_GPU_DEVICES");
+    int n = 0; (void)hipGetDeviceCount(&n);
+    if (e && *e) {
+        if (!strcmp(e, "all")) { for (int i = 0; i < n; ++i) d.push_back(i); }
+        else for (const char *q = e; *q;) { char *end; long v = strtol(q, &end, 10); if (end == q) break; if (v >= 0 && v < n) d.push_back((int)v); q = *end == ',' ? end + 1 : end; if (*end && *end != ',') break; }
+    }
+    if (d.empty()) d.push_back(engine_device());
+    if ((int)d.size() > MSA_DEVICE_SLOTS) d.resize(MSA_DEVICE_SLOTS);
+    return d;
+}
+}  // namespace
+}  // namespace abpoa_hip
+
 extern "C" {
 int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
                         abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
@@ -48,39 +104,62 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
         // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
         if (n_threads <= 0) n_threads = effective_host_cores();
         for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL; }
-        // Pass 1 gives every set 3x its longest read in graph-node slots (5 %-error reads need ~2.5x), pass 2 retries the sets that
-        // outgrew that with 6x, whatever is left goes to the host driver.  A pass that does not fit the device memory is split in halves.
         for (int s = 0; s < n_sets; ++s) memset(&out[s], 0, sizeof(out[s]));
-        std::vector<int> todo(n_sets), left; for (int s = 0; s < n_sets; ++s) todo[s] = s;
-        DeviceRunStats tot; memset(&tot, 0, sizeof(tot));
-        bool device_ok = true;
-        const double factors[2] = {3.0, 6.0};
-        for (int pass = 0; pass < 2 && device_ok && !todo.empty(); ++pass) {
-            left.clear();
-            size_t chunk = todo.size();
-            for (size_t at = 0; at < todo.size() && device_ok;) {
-                const size_t nb = std::min(chunk, todo.size() - at);
-                std::vector<abpoa_hip_readset_t> sub(nb); std::vector<abpoa_hip_msa_t> sub_out(nb);
-                for (size_t i = 0; i < nb; ++i) sub[i] = sets[todo[at + i]];
-                std::vector<int> fb; DeviceRunStats ds;
-                const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass]);
-                if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; continue; }           // split and retry this chunk
-                if (rc != ABPOA_HIP_OK) { if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) return rc; device_ok = false; break; }
-                for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
-                for (int f : fb) left.push_back(todo[at + f]);
-                tot.prepare_ms += ds.prepare_ms; tot.rows_ms += ds.rows_ms; tot.tail_ms += ds.tail_ms; tot.fuse_ms += ds.fuse_ms; tot.device_s += ds.device_s; tot.cons_s += ds.cons_s;
-                tot.total_s += ds.total_s; tot.n_cells += ds.n_cells; tot.algo_bytes += ds.algo_bytes; tot.n_alignments += ds.n_alignments; tot.n_rounds += ds.n_rounds;
-                if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (pass %d, node slots %.0fx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
-                                                         pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
-                at += nb;
-            }
-            todo.swap(left);
+        const std::vector<int> devs = device_list();
+        const int n_q = (int)devs.size();
+        // ---- batches: sets sorted by estimated DP cost (sum of read lengths x reads), heaviest first, dealt round-robin so that every batch
+        //      holds the same mix; device queues pull batches from one shared counter (a fast device simply takes more of them)
+        std::vector<std::vector<int>> batches;
+        if (n_q == 1) { batches.emplace_back(n_sets); for (int s = 0; s < n_sets; ++s) batches[0][s] = s; }
+        else {
+            std::vector<int64_t> cost(n_sets);
+            for (int s = 0; s < n_sets; ++s) { int64_t sum = 0; for (int r = 0; r < sets[s].n_reads; ++r) sum += sets[s].lens[r]; cost[s] = sum * std::max(1, sets[s].n_reads); }
+            std::vector<int> order(n_sets); for (int s = 0; s < n_sets; ++s) order[s] = s;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+            int per_q = 2; { const char *e_ = getenv("ABPOA_GPU_BATCHES_PER_DEVICE"); if (e_ && atoi(e_) > 0) per_q = atoi(e_); }
+            int nb = std::max(n_q, std::min(n_q * per_q, n_sets / 256));      // batches below ~256 sets leave a GPU's 1024 SIMDs idle
+            nb = std::max(1, std::min(nb, n_sets));
+            batches.resize(nb);
+            for (int i = 0; i < n_sets; ++i) batches[i % nb].push_back(order[i]);
+            for (auto &b_ : batches) std::sort(b_.begin(), b_.end());        // (caller order inside a batch)
         }
+        std::atomic<int> next{0};
+        std::vector<PassOut> results(batches.size());
+        std::vector<double> q_busy(n_q, 0.0);
+        auto worker = [&](int q) {
+            const int thr = std::max(1, n_threads / n_q);
+            for (int b_; (b_ = next.fetch_add(1)) < (int)batches.size();) {
+                const auto t0 = std::chrono::steady_clock::now();
+                results[b_] = device_passes(sc, sets, out, batches[b_], thr, devs[q], q);
+                q_busy[q] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (results[b_].rc != ABPOA_HIP_OK) break;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int q = 1; q < n_q; ++q) th.emplace_back(worker, q);
+        worker(0);
+        for (auto &t : th) t.join();
+        (void)hipSetDevice(engine_device());
+        DeviceRunStats tot; memset(&tot, 0, sizeof(tot));
+        bool device_ok = true; int rc_dev = ABPOA_HIP_OK;
+        std::vector<int> todo;
+        for (size_t b_ = 0; b_ < batches.size(); ++b_) {
+            const PassOut &R = results[b_];
+            if (R.rc != ABPOA_HIP_OK && rc_dev == ABPOA_HIP_OK) rc_dev = R.rc;
+            if (!R.device_ok) device_ok = false;
+            todo.insert(todo.end(), R.left.begin(), R.left.end());
+            tot.prepare_ms += R.tot.prepare_ms; tot.rows_ms += R.tot.rows_ms; tot.tail_ms += R.tot.tail_ms; tot.fuse_ms += R.tot.fuse_ms; tot.cons_s += R.tot.cons_s;
+            tot.n_cells += R.tot.n_cells; tot.algo_bytes += R.tot.algo_bytes; tot.n_alignments += R.tot.n_alignments; tot.n_rounds += R.tot.n_rounds;
+            tot.device_s += R.tot.device_s; tot.total_s += R.tot.total_s;
+        }
+        if (rc_dev != ABPOA_HIP_OK) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); return rc_dev; }
+        if (n_q > 1) { tot.device_s = tot.total_s = *std::max_element(q_busy.begin(), q_busy.end()); }      // queues ran side by side: the busiest one is the wall time
         if (device_ok) {
+            std::sort(todo.begin(), todo.end());
             StreamStats ss; ss.n_launches = tot.n_rounds; ss.n_alignments = tot.n_alignments; ss.n_cells = tot.n_cells; ss.algo_bytes = tot.algo_bytes;
             ss.kernel_ms = tot.rows_ms; ss.tail_ms = tot.tail_ms; add_global_stats(ss);
             memset(&g_timing, 0, sizeof(g_timing));
-            g_timing.engine_s = tot.device_s; g_timing.cons_s = tot.cons_s; g_timing.total_s = tot.total_s; g_timing.n_rounds = tot.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = 1;
+            g_timing.engine_s = tot.device_s; g_timing.cons_s = tot.cons_s; g_timing.total_s = tot.total_s; g_timing.n_rounds = tot.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = n_q;
             g_timing.host_sort_s = tot.prepare_ms / 1e3; g_timing.host_fuse_s = tot.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
             g_timing.pad = (int32_t)todo.size();             // how many sets take the host driver
             if (todo.empty()) return ABPOA_HIP_OK;

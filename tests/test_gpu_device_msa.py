@@ -66,3 +66,22 @@ def test_device_graph_equals_host_graph_after_every_read(engine):
     assert p.returncode == 0, p.stderr[-2000:]
     assert "OK True 0" in p.stdout
     assert "graph check ok" in p.stderr and "consensus check ok" in p.stderr and "FAILED" not in p.stderr, p.stderr[-3000:]
+
+
+def test_multi_queue_batch_call_matches_single_queue(engine):
+    """abpoa_hip_msa_batch with ABPOA_GPU_DEVICES: cost-sorted batches dealt to per-device queues on worker threads, results in caller
+    order.  One GPU here, so the list names device 0 twice (two queues, two pool caches, two streams): same records as the single queue.
+    The read-sets are ragged (different read counts and lengths) so that the cost sort really permutes them."""
+    from abpoa_amd import api, synth
+    sets = [synth.make_read_set(11, i, 4 + i % 7, 120 + 40 * (i % 5), 0.06) for i in range(600)]
+    p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
+    one = api.msa_batch(sets, p, n_threads=8)
+    os.environ["ABPOA_GPU_DEVICES"] = "0,0"
+    os.environ["ABPOA_GPU_BATCHES_PER_DEVICE"] = "2"
+    try:
+        two = api.msa_batch(sets, p, n_threads=8)
+        assert api.msa_timing()["n_groups"] == 2
+    finally:
+        del os.environ["ABPOA_GPU_DEVICES"], os.environ["ABPOA_GPU_BATCHES_PER_DEVICE"]
+    for a, b in zip(one, two):
+        assert (a.status, a.cons_seq, a.cons_cov, a.n_cells) == (0, b.cons_seq, b.cons_cov, b.n_cells)
