@@ -84,7 +84,10 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     LdsPlan &L = *Lp;
     const int P = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
     const int cell = max_bits / 8, npr = P == 1 ? 1 : (P == 3 ? 2 : 3);
-    L.q_off = 0; L.q_cap = max_qlen + 1 <= 16384 ? (int)align_up(max_qlen + 1, 16) : 0;
+    // query codes in LDS: up to 32000 bases keep the fast row loops (their per-row registers hold band vectors in 12 bits: 4095 x 8 columns);
+    // longer reads take the general kernel.  Above 16 K bases the kernels may use up to 62 KB of LDS per wavefront instead of 36 - 38 KB.
+    const bool longq = max_qlen + 1 > 16384;
+    L.q_off = 0; L.q_cap = max_qlen + 1 <= 32000 ? (int)align_up(max_qlen + 1, 16) : 0;
     L.mat_off = L.q_cap; L.mx_off = L.mat_off + (int)align_up(4 * sc->m * sc->m, 16);
     L.phase_off = L.mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
     L.ring_off = lds_fixed_bytes_dp(); L.ring_rows = 16; L.ring_cols = (int)align_up((size_t)est_cols, 64);
@@ -93,11 +96,11 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     const int ring_bytes = L.ring_rows * npr * L.ring_cols * cell;
     L.bt_off = lds_fixed_bytes_bt();
     // staged arena window of the backtrack: 24 KB, less when a long query already takes much of the 40 KB a workgroup may use
-    L.bt_bytes = std::max(std::max(8 * 1024, std::min(24 * 1024, 38 * 1024 - L.phase_off - L.bt_off)), L.ring_off + ring_bytes - L.bt_off) & ~15;
+    L.bt_bytes = std::max(std::max(8 * 1024, std::min(24 * 1024, (longq ? 62 : 38) * 1024 - L.phase_off - L.bt_off)), L.ring_off + ring_bytes - L.bt_off) & ~15;
     // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
     const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
     L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally
-    const int fr_budget = 36 * 1024 - L.phase_off;
+    const int fr_budget = (longq ? 62 : 36) * 1024 - L.phase_off;
     while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
     if (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget) L.fr_cols = 0;
     if (L.q_cap == 0 || est_cols > 1024) L.fr_cols = 0;

@@ -51,6 +51,9 @@ def cases(tmp):
     out.append(("s1k_cg_gb", s1k, CG, "5", 0, None))
     out.append(("s10k_cg_i32", s10k, CG, "8", 0, None))
     out.append(("s10k_ag_i32", s10k, AG, "8", 0, None))
+    s20k = os.path.join(tmp, "s20k.fa")                 # reads above 16 K bases: query beyond the old LDS limit of the fast row loops, band of ~440 columns
+    synth.write_fasta(s20k, synth.make_read_set(3, 0, 4, 20000, 0.05))
+    out.append(("s20k_ag_i32", s20k, AG, "3", 0, None))
     out.append(("aa_blosum_loc", aa, ["-m", "1", "-c", "-t", os.path.join(REF, "BLOSUM62.mtx"), "-r", "1"], "3,7", 0, None))
     out.append(("aa_blosum_gb", aa, ["-c", "-t", os.path.join(REF, "BLOSUM62.mtx")], "7", 0, None))
     # whole-pipeline text goldens (consensus / MSA) used by the host-layer tests
