@@ -35,6 +35,22 @@ def test_pyabpoa_seq_fa_affine():               # msa_aligne
     assert r2.msa_seq == [] and r2.msa_len == 0 and r2.cons_seq == r.cons_seq
 
 
+def _pyabpoa_cases():
+    import json
+    return json.load(open(os.path.join(D, "pyabpoa", "cases.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _pyabpoa_cases(), ids=lambda c: c["name"])
+def test_pyabpoa_matches_the_reference_module(case):
+    """Fixtures recorded from the reference's own cythonized pyabpoa (oracle/make_pyabpoa_golden.py): every result attribute."""
+    a = pyabpoa.msa_aligner(_lib=H.cpu_shim_lib(), **case["ctor"])
+    r = a.msa(case["seqs"], **case["msa"])
+    e = case["expect"]
+    got = dict(n_seq=r.n_seq, n_cons=r.n_cons, clu_n_seq=r.clu_n_seq, clu_read_ids=r.clu_read_ids, cons_len=r.cons_len, cons_seq=r.cons_seq,
+               cons_cov=r.cons_cov, msa_len=r.msa_len, msa_seq=r.msa_seq)
+    assert got == e
+
+
 def test_pyabpoa_rejects_what_the_engine_does_not_build():
     a = pyabpoa.msa_aligner(_lib=H.cpu_shim_lib())
     with pytest.raises(NotImplementedError):

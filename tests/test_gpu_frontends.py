@@ -42,3 +42,20 @@ def test_pyabpoa_class_on_gpu():
     assert r.msa_seq == ["CC--GAA---GA", "CC--GAACTCGA", "CCCGGAA---GA", "CC--GAA---GA", "CC--GAA---GA"]
     r = pyabpoa.msa_aligner().msa(["CCGAAGA", "CCGAACTCGA", "CCCGGAAGA", "CCGAAGA"], out_cons=True, out_msa=False)   # device-resident driver
     assert r.cons_seq == ["CCGAAGA"] and r.cons_cov == [[4] * 7] and r.msa_seq == []
+
+
+def test_pyabpoa_matches_the_reference_module_on_gpu():
+    """The fixtures recorded from the reference's cythonized pyabpoa (oracle/make_pyabpoa_golden.py), through the engine; plus the CLI's -s / -Q."""
+    import json
+    from abpoa_amd import cli, pyabpoa
+    for case in json.load(open(os.path.join(D, "pyabpoa", "cases.json")))["cases"]:
+        r = pyabpoa.msa_aligner(**case["ctor"]).msa(case["seqs"], **case["msa"])
+        got = dict(n_seq=r.n_seq, n_cons=r.n_cons, clu_n_seq=r.clu_n_seq, clu_read_ids=r.clu_read_ids, cons_len=r.cons_len, cons_seq=r.cons_seq,
+                   cons_cov=r.cons_cov, msa_len=r.msa_len, msa_seq=r.msa_seq)
+        assert got == case["expect"], case["name"]
+    buf = io.StringIO()
+    assert cli.main(["-s", "-r", "2", os.path.join(D, "out_rc_cons", "input.fa")], out=buf) == 0
+    assert buf.getvalue() == _golden("out_rc_msa")
+    buf = io.StringIO()
+    assert cli.main(["-O", "4,0", "-E", "2", "-Q", os.path.join(D, "out_qv_cons", "input.fq")], out=buf) == 0
+    assert buf.getvalue() == _golden("out_qv_cons")
