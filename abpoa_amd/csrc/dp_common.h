@@ -114,6 +114,8 @@ __device__ __forceinline__ int gld_cell(GLOBAL_AS const int32_t *p) { return gld
 __device__ __forceinline__ void gld_async(int4 &v, const int4 *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int4 *)p) : "memory"); }
 __device__ __forceinline__ void gld_async(int2 &v, const int2 *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int2 *)p) : "memory"); }
 __device__ __forceinline__ void gld_async(int &v, const int32_t *p) { asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int32_t *)p) : "memory"); }
+__device__ __forceinline__ void gld_async_cell(int &v, const int32_t *p) { gld_async(v, p); }
+__device__ __forceinline__ void gld_async_cell(int &v, const int16_t *p) { asm volatile("global_load_sshort %0, %1, off" : "=v"(v) : "v"((GLOBAL_AS const int16_t *)p) : "memory"); }
 __device__ __forceinline__ void gld_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Moves a wave-uniform pointer into a VGPR pair and hides its uniformity from the compiler.  The kernel keeps ~20

@@ -120,7 +120,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");
           if (rr_env_ && atoi(rr_env_) >= 4) L.wfr_rows = atoi(rr_env_) >= 16 ? 16 : (atoi(rr_env_) >= 8 ? 8 : 4); else rr_env_ = nullptr;
-          const int budget = 64 * 1024 - L.phase_off - 512;
+          // (up to 96 KB per wavefront: a convex int32 ring of 16 rows is 62 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
+          const int budget = 96 * 1024 - L.phase_off - 512;
           while ((int64_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4 > budget && L.wfr_rows > 4) L.wfr_rows /= 2;
           // one wavefront per alignment: LDS is what limits how many alignments a CU holds (160 KB, 256 CUs) -- a shallower ring when the
           // launch has more alignments than fit (rows with an older predecessor take the HBM gather: 1 % of rows at depth 8 on 5 % reads)

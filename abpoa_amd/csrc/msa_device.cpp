@@ -182,7 +182,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         const size_t want[4] = {L.in_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap, C.planes.dev_cap};
         size_t need = 0, given_back = 0;
         for (int i = 0; i < 4; ++i) if (want[i] > have[i]) { need += want[i]; given_back += have[i]; }      // a buffer that must grow is freed first
-        if (need > free_b + given_back) { set_err("device-resident job needs %zu more bytes, %zu free", need, free_b + given_back); return ABPOA_HIP_ENOMEM; }
+        if (need > free_b + given_back) {
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device %d: %d sets need %.1f GB in growing buffers (arenas %.1f GB), %.1f GB free + %.1f GB given back: splitting\n", device, n_sets, need / 1e9, plane_tot / 1e9, free_b / 1e9, given_back / 1e9);
+            set_err("device-resident job needs %zu more bytes, %zu free", need, free_b + given_back); return ABPOA_HIP_ENOMEM;
+        }
     }
     int rc;
     if ((rc = C.in.need_dev(L.in_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc = C.graph.need_host(dl_bytes)) ||
@@ -253,6 +256,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
     b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
+    { const char *dbg_ = getenv("ABPOA_HIP_DBG"); if (dbg_) b.dbg = atoi(dbg_); }      // (diagnostics: bit 7 keeps the row loop's counters in AlnOut.seg)
     b.mat = (const int32_t *)(di + L.o_mat); b.aln = p.aln; b.out = p.out;
     b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
     b.pred_off = p.pred_off; b.pred_row = p.pred_row; b.out_off = p.pred_off; b.out_row = p.pred_row;
@@ -350,6 +354,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             sum_max += (double)ms_;
             if (k == max_reads - 1) { double mx_ = 0, mean_ = 0; for (double v_ : tot_set) { mx_ = std::max(mx_, v_); mean_ += v_; } fprintf(stderr, "[poa-device] rows+tail ticks over all rounds: sum of per-round maxima %.0f | slowest set alone %.0f | mean set %.0f\n", sum_max, mx_, mean_ / n_sets); }
             double sg[6] = {0, 0, 0, 0, 0, 0}, st_ = 0; for (const AlnOut &o_ : ho) { for (int q_ = 0; q_ < 6; ++q_) sg[q_] += o_.seg[q_]; st_ += o_.n_bt_steps; }
+            if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr, "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible (preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key window / wrap %.0f\n", k, sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);
             fprintf(stderr, "[poa-device] round %d tail means: steps %.0f  flag steps %.0f  slow steps %.0f  windows %.1f  window ticks %.0f (setup %.0f)  walk ticks %.0f\n", k, st_ / n_sets, sg[2] / n_sets / 1000, sg[3] / n_sets / 1000, sg[4] / n_sets / 1000, sg[5] / n_sets, sg[0] / n_sets, sg[1] / n_sets);
         }
         HIP_OK(hipEventRecord(e[2], st), ABPOA_HIP_ELAUNCH);

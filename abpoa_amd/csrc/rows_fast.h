@@ -198,7 +198,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else {                                       // bit 19: the row may take the wide body (1..8 predecessors, all inside the score ring)
             bool widerow = np >= 1 && np <= 8 && myrow < gn - 1 && myrow >= 1;
 #pragma unroll
-            for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < RR; }
+            for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < (WIDEB ? 64 : RR); }      // (single-wave wide loop: older ones come from HBM)
             tv_meta |= widerow ? (1 << 19) : 0;
         }
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
@@ -636,23 +636,27 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     //      ilp_band: 0 = not applicable, -2 = arena overflow, else the number of chunks; ilp_chunks: 0 = not applicable (nothing touched), 1 = done.
     constexpr int NCHX = 5;
     int qcx_beg_sn = -1, qoffx[NCHX] = {0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk, for band start qcx_beg_sn
+    int ilp_far = 0;                                                // bit k: predecessor k of the row is not in the score ring (older than its depth, or a row too wide for it): HBM gather
     auto ilp_band = [&](int row, int ti) __attribute__((always_inline)) -> int {
-        int mn_mi, mx_mi, min_pb, allring;
+        int mn_mi, mx_mi, min_pb;
+        ilp_far = 0;
+        auto is_far = [&](int p, int g_) __attribute__((always_inline)) { return (row - p >= RR || !(g_ & GEO_RING)) ? 1 : 0; };
         {
             const int p = __builtin_amdgcn_readlane(tv_p0, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
-            mn_mi = mx_mi = __builtin_amdgcn_readlane(vg_mi, p & 63); min_pb = g_ & 0xfff; max_pe = (g_ >> 12) & 0xfff; allring = g_;
+            mn_mi = mx_mi = __builtin_amdgcn_readlane(vg_mi, p & 63); min_pb = g_ & 0xfff; max_pe = (g_ >> 12) & 0xfff; ilp_far = is_far(p, g_);
         }
-        auto more = [&](int tvp) __attribute__((always_inline)) {
+        auto more = [&](int tvp, int k) __attribute__((always_inline)) {
             const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63), mi_ = __builtin_amdgcn_readlane(vg_mi, p & 63);
-            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff); allring &= g_;
+            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff); ilp_far |= is_far(p, g_) << k;
         };
-        if (np > 1) { more(tv_p1); if (np > 2) { more(tv_p2); if (np > 3) { more(tv_p3); if (np > 4) { more(tv_p4); if (np > 5) { more(tv_p5); if (np > 6) { more(tv_p6); if (np > 7) more(tv_p7); } } } } } }
+        if (np > 1) { more(tv_p1, 1); if (np > 2) { more(tv_p2, 2); if (np > 3) { more(tv_p3, 3); if (np > 4) { more(tv_p4, 4); if (np > 5) { more(tv_p5, 5); if (np > 6) { more(tv_p6, 6); if (np > 7) more(tv_p7, 7); } } } } } }
         set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
         const int nvr = end_sn - beg_sn + 1, Wr = nvr * PN, nch = (Wr + 63) >> 6;
-        bool ok = (allring & GEO_RING) && nch <= NCHX && Wr <= RC && max_pe >= beg_sn;
+        bool ok = nch <= NCHX && Wr <= RC && max_pe >= beg_sn;
+        if (!ok) { WCOUNT(nch > NCHX ? 3 : 2); return 0; }
         // vectors beyond every predecessor's band (literal masked scan) must all sit in the row's last chunk
         if (end_sn > max_pe) ok = ok && ((max_pe + 1 - beg_sn) / NV == nch - 1);
-        if (!ok) return 0;
+        if (!ok) { WCOUNT(4); return 0; }
         if (cur + nvr * CW > cap_pn) return -2;
         return nch;
     };
@@ -685,27 +689,54 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             kb[c] = (inH && hm1 > Mv[c]) ? kidx : kb[c];
             Mv[c] = inH ? imax(Mv[c], hm1) : Mv[c]; E1v[c] = inE ? imax(E1v[c], ev1) : E1v[c]; if (GAP == 2) E2v[c] = inE ? imax(E2v[c], ev2) : E2v[c];
         };
+        // a predecessor outside the ring: its cells come from the arena in HBM (records this wave stored at least RR rows ago), every
+        // chunk's loads in flight together; outside its band the reference reads / assigns "inf", exactly what the ring's guards and padding give
+        auto hbm_read_all = [&](int p, int g_, int *hc, int *ec1, int *ec2) __attribute__((always_inline)) {
+            const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN;
+            const T *Hp = io.planes + (long long)(uint32_t)__builtin_amdgcn_readlane(vg_off, p & 63) * PN;
+            gld_wait();                                              // (earlier score-plane stores of this wave are complete)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int x = colb + 64 * c - pb * PN, xh = med3i(x - 1, 0, Wp - 1), xe = med3i(x, 0, Wp - 1);
+                gld_async_cell(hc[c], Hp + (long long)xh * CW); gld_async_cell(ec1[c], Hp + (long long)xe * CW + PL_E1);
+                if (GAP == 2) gld_async_cell(ec2[c], Hp + (long long)xe * CW + PL_E2); else ec2[c] = inf;
+            }
+            // (the wait names the loaded registers: a register-only use must not be scheduled above it)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int x = colb + 64 * c - pb * PN;
+                hc[c] = (unsigned)(x - 1) < (unsigned)Wp ? hc[c] : inf; ec1[c] = (unsigned)x < (unsigned)Wp ? ec1[c] : inf; if (GAP == 2) ec2[c] = (unsigned)x < (unsigned)Wp ? ec2[c] : inf;
+            }
+        };
+        auto gather_pred = [&](int k, int tvp) __attribute__((always_inline)) {
+            const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
+            int hc[NCH], ec1[NCH], ec2[NCH];
+            if ((ilp_far >> k) & 1) hbm_read_all(p, g_, hc, ec1, ec2);
+            else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) ring_read(p, g_, c, hc[c], ec1[c], ec2[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { if (k == 0) { Mv[c] = hc[c]; E1v[c] = ec1[c]; E2v[c] = ec2[c]; kb[c] = 1; } else merge(g_, c, hc[c], ec1[c], ec2[c], k + 1); }
+        };
         {
             const int p0 = __builtin_amdgcn_readlane(tv_p0, ti), g0 = __builtin_amdgcn_readlane(vg_geo, p0 & 63);
-            if (np == 1) {
+            if (np == 1 && !ilp_far) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; }
-            } else {
-                const int p1 = __builtin_amdgcn_readlane(tv_p1, ti), g1_ = __builtin_amdgcn_readlane(vg_geo, p1 & 63);
-                int hb[NCH], eb1[NCH], eb2[NCH];
+            } else if (np == 1) gather_pred(0, tv_p0);
+            else {
+                if (!(ilp_far & 3)) {                               // the first two predecessors' ring reads go out together
+                    const int p1 = __builtin_amdgcn_readlane(tv_p1, ti), g1_ = __builtin_amdgcn_readlane(vg_geo, p1 & 63);
+                    int hb[NCH], eb1[NCH], eb2[NCH];
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; ring_read(p1, g1_, c, hb[c], eb1[c], eb2[c]); }
+                    for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; ring_read(p1, g1_, c, hb[c], eb1[c], eb2[c]); }
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) merge(g1_, c, hb[c], eb1[c], eb2[c], 2);
-                auto further = [&](int tvp, int kidx) __attribute__((always_inline)) {
-                    const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
-                    int hc[NCH], ec1[NCH], ec2[NCH];
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) ring_read(p, g_, c, hc[c], ec1[c], ec2[c]);
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) merge(g_, c, hc[c], ec1[c], ec2[c], kidx);
-                };
-                if (np > 2) { further(tv_p2, 3); if (np > 3) { further(tv_p3, 4); if (np > 4) { further(tv_p4, 5); if (np > 5) { further(tv_p5, 6); if (np > 6) { further(tv_p6, 7); if (np > 7) further(tv_p7, 8); } } } } }
+                    for (int c = 0; c < NCH; ++c) merge(g1_, c, hb[c], eb1[c], eb2[c], 2);
+                } else { gather_pred(0, tv_p0); gather_pred(1, tv_p1); }
+                if (np > 2) { gather_pred(2, tv_p2); if (np > 3) { gather_pred(3, tv_p3); if (np > 4) { gather_pred(4, tv_p4); if (np > 5) { gather_pred(5, tv_p5); if (np > 6) { gather_pred(6, tv_p6); if (np > 7) gather_pred(7, tv_p7); } } } } }
             }
         }
         FSTAMP(1)
@@ -1032,9 +1063,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
                 if (nch_ >= 2) {
                     const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti);
-                    if (ok2 == 1) { commit_row(ti, true); FSTAMP(5) ++row; continue; }
+                    if (ok2 == 1) { WCOUNT(0); commit_row(ti, true); FSTAMP(5) ++row; continue; }
+                    WCOUNT(5);
                 }
-            }
+            } else if (WIDEB) WCOUNT(1);
             am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
             int rc = 0;
             {
