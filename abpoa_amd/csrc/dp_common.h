@@ -313,6 +313,7 @@ static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int 
 // per-TU launchers (one translation unit per kernel family: parallel builds, one row loop per file)
 hipError_t launch_fast_rows(const DevBatch &b, hipStream_t stream);       // dp_fast_rows.hip
 hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream);       // dp_wide_rows.hip
+hipError_t launch_team_rows(const DevBatch &b, hipStream_t stream);       // dp_team_rows.hip
 hipError_t launch_fast_tail(const DevBatch &b, hipStream_t stream);       // dp_fast_tail.hip
 hipError_t launch_general(const DevBatch &b, hipStream_t stream);         // dp_general.hip
 

@@ -1,6 +1,6 @@
-// Row-loop kernels for WIDE bands (10 kb reads: 240-300 columns = 4-5 chunks of 64 per row).  Production: one wavefront per alignment with
-// every chunk of a row in registers at once (rows_fast.h, ilp_chunks).  Experimental (-DABPOA_HIP_MULTIWAVE): WIDE_NW wavefronts per
-// alignment, wavefront c owns chunk c (wide_body); rows the wide bodies cannot take are done with the single-chunk bodies.
+// Row-loop kernels for WIDE bands (10 kb reads: 240-300 columns = 4-5 chunks of 64 per row): every chunk of a row in registers at once
+// (rows_fast.h, ilp_chunks).  This file: one wavefront per alignment; dp_team_rows.hip: teams of 2 / 4 wavefronts per alignment that share the
+// chunks of every row (small batches: fewer alignments than SIMDs).  Rows the all-chunk body cannot take are done with the single-chunk bodies.
 #include <stdio.h>
 #include <stdlib.h>
 #include "rows_fast.h"
@@ -8,7 +8,7 @@
 namespace abpoa_hip {
 
 template <int GAP, int BITS, int NW>
-__global__ void __launch_bounds__(NW * 64) dp_wide_kernel(const DevBatch b) {      // NW = 1: one wavefront, every chunk of a row in registers (rows_fast.h, ilp_chunks)
+__global__ void __launch_bounds__(NW * 64) dp_wide_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
@@ -33,10 +33,7 @@ static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
 }
 hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream) {
     if (b.lds.wide_nw == 1) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, 1>(b, stream) : launch_wide_gap<2, 1>(b, stream);
-#ifdef ABPOA_HIP_MULTIWAVE      // experimental build: WIDE_NW wavefronts per alignment, one chunk each
-    if (b.lds.wide_nw == WIDE_NW) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, WIDE_NW>(b, stream) : launch_wide_gap<2, WIDE_NW>(b, stream);
-#endif
-    return hipSuccess;
+    return launch_team_rows(b, stream);      // dp_team_rows.hip
 }
 
 }  // namespace abpoa_hip

@@ -111,11 +111,16 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // wide row loop (dp_wide_rows.hip): alignments whose band half-width w is in [wide_w_lo, wide_w_hi] -- rows of 2..5 chunks of 64 columns --
     // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (320 columns; depth by what fits:
     // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
-    // the depth, ABPOA_HIP_WIDE_MW=1 selects the experimental multi-wavefront variant in builds that have it.
+    // the depth, ABPOA_HIP_TEAM=1|2|4 sets the wavefronts per alignment.
     L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0;
-    { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_WIDE_MW");
+    { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_TEAM");
       if (L.fr_cols && L.q_cap && !(nw_ && atoi(nw_))) {
-          L.wide_nw = (mw_ && atoi(mw_)) ? WIDE_NW : 1; L.wfr_cols = WIDE_RING_COLS; L.wfr_rows = 16;
+          // wavefronts per alignment: 1.  Teams of 2 / 4 (ABPOA_HIP_TEAM=2|4, dp_team_rows.hip) give identical results but are slower on gfx950
+          // as measured (3.9 k vs 3.1 k cycles per 5-chunk row): a row's ~370 instructions of scalar bookkeeping are repeated by every wavefront
+          // of the team and outweigh the ~28 instructions per chunk that the split saves (profiles/r2_team_vs_single.txt).
+          L.wide_nw = 1;
+          if (mw_ && (atoi(mw_) == 1 || atoi(mw_) == 2 || atoi(mw_) == 4)) L.wide_nw = atoi(mw_);
+          L.wfr_cols = WIDE_RING_COLS; L.wfr_rows = 16;
           L.wide_w_lo = 40; L.wide_w_hi = (L.wfr_cols - 2 * 8 - 1) / 2;
           { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");

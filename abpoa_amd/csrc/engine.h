@@ -41,9 +41,6 @@ struct AlnOut {
 };
 
 #define ALN_FAST_OK 1
-#ifndef WIDE_NW
-#define WIDE_NW 5          // wavefronts per alignment of the wide row loop (5 x 64 = 320 columns: 2 w + 1 + vector rounding + band drift of a 10 kb read)
-#endif
 #define WIDE_RING_COLS 320   // score-ring columns of the single-wave wide kernel (5 chunks of 64)
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
 

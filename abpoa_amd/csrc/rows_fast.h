@@ -486,146 +486,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         return 1;
     };
 
-    // ---- WIDE body (NW wavefronts per alignment): wavefront c owns columns [64 c, 64 c + 64) of the row's band, every wavefront computes
-    //      the same band scalars from its own copy of the per-row registers.  One exchange through LDS carries, per wavefront, the
-    //      total of its local F scan(s) and its arg-max candidate; the arg-max never depends on F (an F term is some H of the same row
-    //      minus at least o + e, reference :870-874 / :990-997), so candidates are taken from max(M + q, E) before the scans finish.
-    //      Returns 0 = not applicable (nothing touched), 1 = done, 2 = arena overflow.
-    constexpr int NWP = NW <= 2 ? 2 : (NW <= 4 ? 4 : 8);
-    const int relw = wid * 64 + lane;                               // this lane's column inside a wide row
-    const int le1w = relw * e1, le2w = relw * e2, cf1w = oe1 - e1 + le1w, cf2w = oe2 - e2 + le2w;
-    int qcw_beg_sn = -1, qoffw = 0;                                 // cached query code of column beg_sn * PN + relw
-    auto wide_body = [&](int row, int ti) __attribute__((always_inline)) -> int {
-        int mn_mi, mx_mi, min_pb, allring;
-        {
-            const int p = __builtin_amdgcn_readlane(tv_p0, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
-            mn_mi = mx_mi = __builtin_amdgcn_readlane(vg_mi, p & 63); min_pb = g_ & 0xfff; max_pe = (g_ >> 12) & 0xfff; allring = g_;
-        }
-        auto more = [&](int tvp) __attribute__((always_inline)) {
-            const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63), mi_ = __builtin_amdgcn_readlane(vg_mi, p & 63);
-            mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff); allring &= g_;
-        };
-        if (np > 1) { more(tv_p1); if (np > 2) { more(tv_p2); if (np > 3) { more(tv_p3); if (np > 4) { more(tv_p4); if (np > 5) { more(tv_p5); if (np > 6) { more(tv_p6); if (np > 7) more(tv_p7); } } } } } }
-        set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
-        const int nvr = end_sn - beg_sn + 1, Wr = nvr * PN, nch = (Wr + 63) >> 6;
-        // vectors beyond every predecessor's band take the literal masked scan after the exchange: they must sit in ONE wavefront
-        bool ok = (allring & GEO_RING) && nch <= NW && max_pe >= beg_sn;
-        if (!ok) { WCOUNT(nch > NW ? 3 : 2); return 0; }
-        if (end_sn > max_pe) ok = ok && ((max_pe + 1 - beg_sn) / NV == (end_sn - beg_sn) / NV);
-        if (!ok) { WCOUNT(4); return 0; }
-        if (cur + nvr * CW > cap_pn) return 2;
-        const int c = wid, vb = beg_sn + c * NV, col = beg_sn * PN + relw;
-        const bool active = c < nch, in_band = relw < Wr;
-        const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * relw;      // LDS byte address of this lane's cell in the row's ring slot
-        int Mv = inf, E1v = inf, E2v = inf, kb = 0, q = 0;
-        if (active) {
-            if (beg_sn != qcw_beg_sn) { qcw_beg_sn = beg_sn; qoffw = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m; }
-            q = s_mx[base * m1 + qoffw];
-            auto pred = [&](int k, int tvp) __attribute__((always_inline)) {
-                const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63);
-                if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1);
-            };
-            pred(0, tv_p0);
-            if (np > 1) { pred(1, tv_p1); if (np > 2) { pred(2, tv_p2); if (np > 3) { pred(3, tv_p3); if (np > 4) { pred(4, tv_p4); if (np > 5) { pred(5, tv_p5); if (np > 6) { pred(6, tv_p6); if (np > 7) pred(7, tv_p7); } } } } } }
-        }
-        const int h = wr(Mv + q);
-        int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
-        const int hsE = GAP == 1 ? imax(h, E1v) : hs;
-        const int nvec = imin(NV, end_sn - vb + 1);                 // <= 0: this wavefront holds no vector of the row
-        int nfast = imin(nvec, max_pe - vb + 1); if (nfast < 0) nfast = 0;
-        const bool wrap = __any(vvl < nfast && h < fast_lo);        // closed-form F not provably wrap-free: the row is redone by wavefront 0
-        // ---- local exclusive prefix maxima of g = hs + column * e (wavefront 0: seeded with `first - e` of the row, as chunk_tail)
-        const int g1 = hs + le1w, g2 = hs + le2w;
-        int s1 = wave_shr1(wid == 0 ? h - e1 : INT_MIN, g1), s2 = INT_MIN;
-        if (GAP == 2) s2 = wave_shr1(wid == 0 ? h - e2 : INT_MIN, g2);
-        // ---- arg-max candidate, reference :1043-1057 (same keys as chunk_tail / the row epilogue)
-        const int v = vb + vvl; const bool is_end = v == end_sn;
-        int cand = hsE; if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
-        unsigned key = 0; int aval = INT_MIN;
-        if (I16) {
-            key = in_band ? ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u) : 0u;
-            if (GAP == 2) wave_scan3_iiu(s1, s2, key); else wave_scan2_iu(s1, key);
-        } else {
-            aval = in_band ? cand : INT_MIN;
-            if (GAP == 2) wave_scan3_iii(s1, s2, aval); else wave_scan2_ii(s1, aval);
-            const int vmaxw = __builtin_amdgcn_readlane(aval, 63);
-            key = (in_band && cand == vmaxw) ? (((unsigned)(PN - 1 - l) << 27) | ((unsigned)is_end << 26) | (0x3FFFFFFu - (unsigned)v)) : 0u;
-            key = wave_max_u32_v(key);
-        }
-        // ---- exchange: lane 63 holds the wave totals
-        int4 *xs = xch + (row & 1) * 8;
-        if (lane == 63) xs[wid] = make_int4(imax(s1, g1), imax(s2, g2), wrap ? INT_MAX : aval, wrap ? (int)0xFFFFFFFFu : (int)key);
-        lds_barrier();
-        const int4 en = xs[lane & (NWP - 1)];
-        const bool before = (lane & (NWP - 1)) < wid;
-        const int carry1 = group_allmax_i32<NWP>(before ? en.x : INT_MIN), carry2 = GAP == 2 ? group_allmax_i32<NWP>(before ? en.y : INT_MIN) : INT_MIN;
-        unsigned kmax; int vmax = 0;
-        if (I16) {
-            kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)group_allmax_u32<NWP>((unsigned)en.w));
-            if (kmax == 0xFFFFFFFFu) { WCOUNT(5); return 0; }
-            vmax = (int)(kmax >> 16) - 32768;
-        } else {
-            const int vm = group_allmax_i32<NWP>(en.z);
-            vmax = __builtin_amdgcn_readfirstlane(vm);
-            if (vmax == INT_MAX) { WCOUNT(5); return 0; }
-            kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)group_allmax_u32<NWP>(en.z == vm ? (unsigned)en.w : 0u));
-        }
-        // ---- from here on the row is committed
-        off_pn = cur; cur += nvr * CW;
-        int Hout = inf, E1out = inf, E2out = inf;
-        if (active) {
-            const int S1 = imax(s1, carry1), S2 = imax(s2, carry2);
-            int F1 = imax(S1 - cf1w, inj1), F2 = inf;
-            if (GAP == 2) F2 = imax(S2 - cf2w, inj2);
-            if (nfast < nvec) {
-                int first, first2 = 0;
-                if (nfast > 0) {
-                    const int lastl = nfast * PN - 1;
-                    first = __builtin_amdgcn_readlane(imax(S1, g1), lastl) - (c * 64 + lastl) * e1;
-                    if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(S2, g2), lastl) - (c * 64 + lastl) * e2;
-                } else {                                            // the slow vectors open this wavefront's chunk (c > 0: max_pe >= beg_sn)
-                    first = __builtin_amdgcn_readfirstlane(carry1) - (c * 64 - 1) * e1;
-                    if (GAP == 2) first2 = __builtin_amdgcn_readfirstlane(carry2) - (c * 64 - 1) * e2;
-                }
-                T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
-                slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
-                F1 = (int)f1t; F2 = (int)f2t;
-            }
-            if (GAP == 1) {
-                const int tmp = imax(h, E1v);
-                Hout = imax(tmp, F1);
-                const int en_ = imax(wr(E1v - e1), wr(Hout - oe1));
-                E1out = (Hout == tmp) ? en_ : inf;
-            } else {
-                Hout = imax(hs, imax(F1, F2));
-                E1out = imax(wr(E1v - e1), wr(Hout - oe1));
-                E2out = imax(wr(E2v - e2), wr(Hout - oe2));
-            }
-            const int mflag = (Mv + q == Hout && kb <= 64) ? kb : 0;
-            // one record store per IN-BAND lane (another wavefront owns the cells behind the row's end: no stores past it)
-            if (in_band) {
-                T *H = io.planes + (long long)off_pn * PN + (long long)relw * CW;
-                const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
-                if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)H = rec; }
-                else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
-                else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)H = rec; }
-                else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
-            }
-        }
-        {   // ring slot of the row: every wavefront writes its 64 columns ("inf" outside the band)
-            int *qd = (int *)ring_at(qd_addr, 0);
-            if (I16) { qd[0] = in_band ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16)) : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
-            else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
-        }
-        mi = -1;
-        if (vmax > inf) {
-            if (I16) mi = (2047 - (int)(kmax & 0x7ff)) * PN + (PN - 1 - (int)((kmax >> 12) & 0xf));
-            else mi = (int)(0x3FFFFFFu - (kmax & 0x3FFFFFFu)) * PN + (PN - 1 - (int)(kmax >> 27));
-            if (mi > qlen) mi = -1;
-        }
-        return 1;
-    };
-
+    constexpr int NWP = NW <= 2 ? 2 : (NW <= 4 ? 4 : 8);            // exchange entries read per lane group
     // ---- MULTI-CHUNK body for wide bands (10 kb reads: 240-300 columns = 4-5 chunks of 64): every chunk of the row is in registers at once.
     //      The lane owns column (64 c + lane) of each chunk c, so the chunks are independent instruction streams that the scheduler interleaves
     //      (LDS reads of all chunks in flight together, DPP scans of all chunks back to back without wait states), and everything that is
@@ -634,8 +495,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     //      seed[0] = first - e, seed[c+1] = max(total[c], seed[c]) - 64 e, F = max(S, seed) - cf  (chunk_tail's closed form, carried in H units).
     //      The arg-max is taken from max(M + q, E): an F term is some H of the same row minus at least o + e (reference :870-874 / :990-997).
     //      ilp_band: 0 = not applicable, -2 = arena overflow, else the number of chunks; ilp_chunks: 0 = not applicable (nothing touched), 1 = done.
+    //      TEAMS (NW > 1 wavefronts per alignment): every wavefront runs the same row loop on its own copy of the per-row registers and takes a
+    //      contiguous share of the row's chunks (c0 .. c0 + cnt - 1); ONE exchange through LDS per row carries each wavefront's carry-chain result
+    //      (seed out of its last chunk, computed as if nothing came in: the chain is max-plus, the incoming seed is folded in afterwards), its
+    //      arg-max key and its wrap flag; a second barrier at the end of the row publishes the ring slot.
     constexpr int NCHX = 5;
-    int qcx_beg_sn = -1, qoffx[NCHX] = {0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk, for band start qcx_beg_sn
+    constexpr bool TEAM = NW > 1;
+    int qcx_beg_sn = -1, qcx_c0 = -1, qoffx[NCHX] = {0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk of this wavefront, for band start qcx_beg_sn
     int ilp_far = 0;                                                // bit k: predecessor k of the row is not in the score ring (older than its depth, or a row too wide for it): HBM gather
     auto ilp_band = [&](int row, int ti) __attribute__((always_inline)) -> int {
         int mn_mi, mx_mi, min_pb;
@@ -663,9 +529,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto ilp_chunks = [&](auto nchc, int nch, int row, int ti) __attribute__((always_inline)) -> int {
         constexpr int NCH = decltype(nchc)::value;
         const int Wr = (end_sn - beg_sn + 1) * PN;
-        const int colb = beg_sn * PN + lane;                        // this lane's column in chunk 0
-        if (__builtin_expect(beg_sn != qcx_beg_sn, 0)) {
-            qcx_beg_sn = beg_sn;
+        // this wavefront's chunks: c0 .. c0 + cnt - 1 (one wavefront: all of them; teams: nch / NW each, the first nch % NW one more)
+        int c0 = 0, cnt = nch;
+        if (TEAM) { const int bs_ = nch / NW, rm_ = nch - bs_ * NW; cnt = bs_ + (wid < rm_ ? 1 : 0); c0 = wid * bs_ + imin(wid, rm_); }
+        const int colb = beg_sn * PN + lane + 64 * c0;              // this lane's column in the wavefront's first chunk
+        if (__builtin_expect(beg_sn != qcx_beg_sn || (TEAM && c0 != qcx_c0), 0)) {
+            qcx_beg_sn = beg_sn; qcx_c0 = c0;
 #pragma unroll
             for (int c = 0; c < NCHX; ++c) { const int col = colb + 64 * c; qoffx[c] = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m; }
         }
@@ -695,6 +564,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN;
             const T *Hp = io.planes + (long long)(uint32_t)__builtin_amdgcn_readlane(vg_off, p & 63) * PN;
             gld_wait();                                              // (earlier score-plane stores of this wave are complete)
+            if (TEAM) lds_barrier();                                 // (... and of the other wavefronts of the team: the far flag is the same in all of them)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int x = colb + 64 * c - pb * PN, xh = med3i(x - 1, 0, Wp - 1), xe = med3i(x, 0, Wp - 1);
@@ -751,7 +621,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             hsE[c] = GAP == 1 ? imax(h[c], E1v[c]) : hs[c];
             lowest = imin(lowest, h[c]);
         }
-        if (__builtin_expect(__any(lowest < fast_lo), 0)) return 0;
+        const bool wrap_here = __any(lowest < fast_lo);
+        if (!TEAM && __builtin_expect(wrap_here, 0)) return 0;
         // ---- unseeded prefix maxima per chunk, all chains interleaved
         int g1[NCH], g2[NCH], s1[NCH], s2[NCH];
 #pragma unroll
@@ -764,12 +635,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int relv_end = end_sn - beg_sn;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int vb = beg_sn + c * NV;
-            const bool in_band = c < NCH - 2 ? true : c * 64 + lane < Wr, is_end = c < NCH - 2 ? false : (c * NV + vvl == relv_end);      // (the end vector is in the last chunk)
+            const int cg = c0 + c, vb = beg_sn + cg * NV;          // chunk index in the row
+            const bool in_band = (!TEAM && c < NCH - 2) ? true : cg * 64 + lane < Wr, is_end = (!TEAM && c < NCH - 2) ? false : (cg * NV + vvl == relv_end);      // (the end vector is in the last chunk)
             int cand = hsE[c]; if (end_sn == qlen_sn) cand = (is_end && colb + 64 * c > qlen) ? inf : cand;
             unsigned key;
             if (I16) key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
-            else key = ((unsigned)imin(imax(cand, vfloor) - vfloor, 0x1FFFFF) << 11) | (unsigned)(ktie - c * NV) | (is_end ? 64u : 0u);      // (max first: inf - floor must not wrap)
+            else key = ((unsigned)imin(imax(cand, vfloor) - vfloor, 0x1FFFFF) << 11) | (unsigned)(ktie - cg * NV) | (is_end ? 64u : 0u);      // (max first: inf - floor must not wrap)
             amk = (in_band && key > amk) ? key : amk;
         }
         // interleaved DPP chains: F scans of every chunk + the arg-max key
@@ -790,22 +661,58 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
             step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
         }
-        const unsigned kbst = (unsigned)__builtin_amdgcn_readlane((int)amk, 63);
-        if (!I16) { const unsigned tv = kbst >> 11; if (__builtin_expect(tv == 0u || tv == 0x1FFFFFu, 0)) return 0; }
+        unsigned kbst = (unsigned)__builtin_amdgcn_readlane((int)amk, 63);
         FSTAMP(2)
-        // ---- carry chain over the chunk totals (scalar), then F of every chunk
-        int seed1[NCH], seed2[NCH];
-        seed1[0] = __builtin_amdgcn_readlane(h[0], 0) - e1; if (GAP == 2) seed2[0] = seed1[0] + e1 - e2;
+        // ---- carry chain over the chunk totals (scalar), then F of every chunk.  seed[c] = "first - e" of chunk c; seed[c + 1] = max(total[c], seed[c]) - 64 e.
+        //      Wavefront 0 (or the only one) starts from the row's first column; the others start from "nothing" (INT_MIN: total[c] always wins the
+        //      max, so nothing wraps) and fold the seed that comes in from the wavefronts before them after the exchange.
+        //      (one wavefront: the chain runs in the vector unit on wave-uniform values -- the totals are read out of lane 63 back to back and the
+        //       dependent max / subtract steps need no trip through the scalar unit)
+        int seed1[NCH + 1], seed2[NCH + 1];
+        seed1[0] = (!TEAM || wid == 0) ? __builtin_amdgcn_readlane(h[0], 0) - e1 : INT_MIN; seed2[0] = (!TEAM || wid == 0) ? seed1[0] + e1 - e2 : INT_MIN;
+        if (!TEAM) { asm("" : "+v"(seed1[0])); if (GAP == 2) asm("" : "+v"(seed2[0])); }
 #pragma unroll
-        for (int c = 0; c + 1 < NCH; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             seed1[c + 1] = imax(__builtin_amdgcn_readlane(imax(s1[c], g1[c]), 63), seed1[c]) - 64 * e1;
-            if (GAP == 2) seed2[c + 1] = imax(__builtin_amdgcn_readlane(imax(s2[c], g2[c]), 63), seed2[c]) - 64 * e2;
+            if (GAP == 2) seed2[c + 1] = imax(__builtin_amdgcn_readlane(imax(s2[c], g2[c]), 63), seed2[c]) - 64 * e2; else seed2[c + 1] = INT_MIN;
         }
+        if constexpr (TEAM) {
+            // exchange entry of this wavefront: {chain result out of its last chunk (two planes), arg-max key, wrap flag}
+            int out1 = seed1[0], out2 = seed2[0];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) if (c < cnt) { out1 = seed1[c + 1]; out2 = seed2[c + 1]; }
+            int4 *xs = xch + (row & 1) * 8;
+            if (lane == 0) xs[wid] = make_int4(out1, out2, cnt > 0 ? (int)kbst : 0, wrap_here && cnt > 0 ? 1 : 0);
+            lds_barrier();
+            const int4 en = xs[lane & (NWP - 1)];
+            // incoming seed: fold the entries of the wavefronts before this one in order (saturating: INT_MIN stays "nothing")
+            int in1 = INT_MIN, in2 = INT_MIN, anywrap = 0; unsigned kall = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int a1 = __builtin_amdgcn_readlane(en.x, j), a2 = __builtin_amdgcn_readlane(en.y, j);
+                const unsigned kj = (unsigned)__builtin_amdgcn_readlane(en.z, j);
+                anywrap |= __builtin_amdgcn_readlane(en.w, j); kall = kj > kall ? kj : kall;
+                if (j < wid) {
+                    const int bs_ = nch / NW, rm_ = nch - bs_ * NW, cj = (bs_ + (j < rm_ ? 1 : 0)) * 64;
+                    in1 = imax(a1, imax(in1, INT_MIN + cj * e1) - cj * e1); in2 = imax(a2, imax(in2, INT_MIN + cj * e2) - cj * e2);
+                }
+            }
+            if (__builtin_expect(anywrap, 0)) return 0;
+            kbst = kall;
+            if (wid > 0) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    seed1[c] = imax(seed1[c], imax(in1, INT_MIN + c * 64 * e1) - c * 64 * e1);
+                    if (GAP == 2) seed2[c] = imax(seed2[c], imax(in2, INT_MIN + c * 64 * e2) - c * 64 * e2);
+                }
+            }
+        }
+        if (!I16) { const unsigned tv = kbst >> 11; if (__builtin_expect(tv == 0u || tv == 0x1FFFFFu, 0)) return 0; }
         FSTAMP(3)
         // ---- from here on the row is committed
         off_pn = cur; cur += (end_sn - beg_sn + 1) * CW;
-        T *const Hrow = io.planes + (long long)off_pn * PN + (long long)lane * CW;
-        int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * lane, 0);
+        T *const Hrow = io.planes + (long long)off_pn * PN + (long long)(lane + 64 * c0) * CW;
+        int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * (lane + 64 * c0), 0);
         // (nch is NCH - 1 or NCH: chunks 0 .. NCH - 3 are full, only the last two need band masks, only the last one a store guard)
         int F1[NCH], F2[NCH], S1[NCH], S2[NCH];
 #pragma unroll
@@ -815,15 +722,15 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         if (__builtin_expect(end_sn > max_pe, 0)) {                  // vectors beyond every predecessor's band: literal masked scan, last chunk only
 #pragma unroll
-            for (int c = NCH - 2; c < NCH; ++c) if (c == nch - 1) {
-                const int vb = beg_sn + c * NV;
+            for (int c = TEAM ? 0 : NCH - 2; c < NCH; ++c) if (c0 + c == nch - 1) {
+                const int vb = beg_sn + (c0 + c) * NV;
                 const int nvec = imin(NV, end_sn - vb + 1), nfast = imax(0, imin(nvec, max_pe - vb + 1));
                 int first, first2 = 0;
                 if (nfast > 0) {
                     const int lastl = nfast * PN - 1;
                     first = __builtin_amdgcn_readlane(imax(S1[c], g1[c]), lastl) - lastl * e1;
                     if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(S2[c], g2[c]), lastl) - lastl * e2;
-                } else { first = seed1[c] + e1; if (GAP == 2) first2 = seed2[c] + e2; }
+                } else { first = __builtin_amdgcn_readfirstlane(seed1[c]) + e1; if (GAP == 2) first2 = __builtin_amdgcn_readfirstlane(seed2[c]) + e2; }
                 T f1t = (T)F1[c], f2t = (T)F2[c], fi = (T)first, fi2 = (T)first2;
                 slow_f_vectors<T, GAP>(vb, end_sn, max_pe, nfast, l, vvl, (T)hs[c], (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
                 F1[c] = (int)f1t; F2[c] = (int)f2t;
@@ -831,7 +738,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const bool in_band = c < NCH - 2 ? true : c * 64 + lane < Wr;
+            const bool in_band = (!TEAM && c < NCH - 2) ? true : (c0 + c) * 64 + lane < Wr;
             int Hout, E1out, E2out = inf;
             if (GAP == 1) {
                 Hout = imax(hsE[c], F1[c]);
@@ -844,17 +751,23 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             const int mflag = (Mv[c] + q[c] == Hout && kb[c] <= 64) ? kb[c] : 0;
             const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
-            if (c < NCH - 1 || nch == NCH) {      // one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
+            if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {      // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
                 T *H = Hrow + c * 64 * CW;
                 if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1[c], 0x05040100u); *(int2 *)H = rec; }
                 else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1[c] << 16)); rec.z = F2[c] & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
                 else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1[c]; rec.w = mflag; *(int4 *)H = rec; }
                 else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1[c]; r1.x = F2[c]; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
             }
-            if (I16) { qd[c * 64] = in_band ? he : infw; if (GAP == 2) qd[RCS + c * 64] = in_band ? E2out : inf; }
-            else { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS + c * 64] = in_band ? E2out : inf; }
+            if (!TEAM || c < cnt) {
+                if (I16) { qd[c * 64] = in_band ? he : infw; if (GAP == 2) qd[RCS + c * 64] = in_band ? E2out : inf; }
+                else { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS + c * 64] = in_band ? E2out : inf; }
+            }
         }
-        for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; }      // "inf" up to the ring width
+        if (!TEAM) { for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; } }      // "inf" up to the ring width
+        else {                                                       // (teams: chunk c of the padding is written by wavefront c % NW)
+            int *const qrow = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * lane, 0);
+            for (int c = nch; c < (RC >> 6); ++c) if (c % NW == wid) { qrow[c * 64] = infw; if (NPW > 1) qrow[RCS + c * 64] = inf; if (NPW > 2) qrow[2 * RCS + c * 64] = inf; }
+        }
         FSTAMP(4)
         // ---- row arg-max
         mi = -1;
@@ -974,7 +887,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r_hi = imin(t0 + 64, gn - 1);
         auto commit_row = [&](int ti, bool ring) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
             const int geo_new = sgpr(beg_sn | (end_sn << 12) | (ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
-            if constexpr (WIDEB) {
+            if constexpr (WPLAN) {
                 const int vm_new = sgpr(rowmax);
                 asm volatile("s_mov_b32 m0, %8\n\ts_nop 3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
                              : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off), "+v"(vg_vm) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(vm_new), "s"(ti) : "m0");
@@ -992,9 +905,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
                 base = meta & 0xff; np = (meta >> 8) & 0xff;
                 int rc = 0;
-                if ((meta >> 19) & 1) rc = wide_body(row, ti); else WCOUNT(1);
-                if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                if ((meta >> 19) & 1) {
+                    const int nch_ = ilp_band(row, ti);
+                    if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                    if (nch_ >= 2) rc = ilp_chunks(std::integral_constant<int, (NCHX + NW - 1) / NW>{}, nch_, row, ti);
+                    if (rc != 1) WCOUNT(5);
+                } else WCOUNT(1);
                 if (rc == 1) { WCOUNT(0); commit_row(ti, true); lds_barrier(); ++row; continue; }      // (barrier: the ring slot is complete before any wavefront reads it)
+                rc = 0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the HBM gathers of the general body read cells other wavefronts stored
                 lds_barrier();
                 if (wid == 0) {
@@ -1010,9 +928,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                         if (I16) {
                             const unsigned kb = wave_max_u32_s(am_key);
                             const int vmax = (int)(kb >> 16) - 32768;
+                            rowmax = vmax;
                             if (vmax > inf) { mi = (2047 - (int)(kb & 0x7ff)) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)); if (mi > qlen) mi = -1; }
                         } else {
                             const int vmax = wave_max_i32_s(am_any ? am_val : INT_MIN);
+                            rowmax = vmax;
                             if (vmax > inf) {
                                 unsigned key = 0;
                                 if (am_any && am_val == vmax) key = ((unsigned)(PN - 1 - l) << 27) | ((unsigned)am_isend << 26) | (0x3FFFFFFu - (unsigned)am_v);
@@ -1022,12 +942,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                             }
                         }
                     }
-                    if (lane == 0) { bcast[0] = rc; bcast[1] = beg_sn; bcast[2] = end_sn; bcast[3] = off_pn; bcast[4] = mi; bcast[5] = to_ring ? 1 : 0; bcast[6] = cur; }
+                    if (lane == 0) { bcast[0] = rc; bcast[1] = beg_sn; bcast[2] = end_sn; bcast[3] = off_pn; bcast[4] = mi; bcast[5] = to_ring ? 1 : 0; bcast[6] = cur; bcast[7] = rowmax; }
                 }
                 lds_barrier();
                 rc = __builtin_amdgcn_readfirstlane(bcast[0]); beg_sn = __builtin_amdgcn_readfirstlane(bcast[1]); end_sn = __builtin_amdgcn_readfirstlane(bcast[2]);
                 off_pn = __builtin_amdgcn_readfirstlane(bcast[3]); mi = __builtin_amdgcn_readfirstlane(bcast[4]); to_ring = __builtin_amdgcn_readfirstlane(bcast[5]) != 0;
-                cur = __builtin_amdgcn_readfirstlane(bcast[6]);
+                cur = __builtin_amdgcn_readfirstlane(bcast[6]); rowmax = __builtin_amdgcn_readfirstlane(bcast[7]);
                 if (rc == 2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
                 commit_row(ti, to_ring);
                 lds_barrier();                                         // (bcast is free again)

@@ -17,7 +17,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     acc[r["Kernel_Name"][:48]][r["Counter_Name"]] += float(r["Counter_Value"])
 n = int(sys.argv[2])
 for k, v in acc.items():
-    if "dp_wide" in k or "dp_fast_kernel" in k:
+    if "dp_wide" in k or "dp_fast_kernel" in k or "dp_team" in k:
         if sum(v.values()) > 0: print(k, {c: round(x / 3 / n / rows, 1) for c, x in v.items()}, f"(per row; {rows} rows, 3 iterations x {n} alignments)")
 PY
 done
