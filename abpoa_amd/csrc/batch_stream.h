@@ -55,6 +55,7 @@ class BatchStream {
     abpoa_hip_scoring_t sc_{}; std::vector<int32_t> mat_;
     unsigned flags_ = 0; int n_ = 0, P_ = 1;
     std::vector<AlnDesc> desc_; std::vector<AlnOut> recs_; std::vector<int64_t> full_cells_;
+    std::vector<std::vector<uint8_t>> trace_arena_;     // BS_TRACE: arena of every finished alignment, copied out before a retry pass re-uses the device arenas
     int64_t rows_tot_ = 0, preds_tot_ = 0, outs_tot_ = 0, q_tot_ = 0, cig_tot_ = 0;
     size_t o_desc_ = 0, o_mat_ = 0, o_query_ = 0, o_base_ = 0, o_nid_ = 0, o_rem_ = 0, o_act_ = 0, o_poff_ = 0, o_pred_ = 0, o_ooff_ = 0, o_out_ = 0, in_bytes_ = 0;
     size_t o_rec_ = 0, o_left_ = 0, o_right_ = 0, o_bsn_ = 0, o_esn_ = 0, o_coff_ = 0, o_rmi_ = 0, o_cig_ = 0, out_bytes_ = 0;

@@ -143,7 +143,7 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
     flags_ = flags; n_ = n;
     P_ = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
     const bool banded = sc->wb >= 0;
-    desc_.resize(n); recs_.resize(n); full_cells_.resize(n);
+    desc_.resize(n); recs_.resize(n); full_cells_.resize(n); trace_arena_.clear();
     rows_tot_ = preds_tot_ = outs_tot_ = q_tot_ = cig_tot_ = 0;
     for (int i = 0; i < n; ++i) {
         AlnDesc &d = desc_[i];
@@ -158,7 +158,8 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
         // values per DP column in the arena: P planes (general kernel) or one padded cell record (fast loop: 4 / 8 values)
         const int pv = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
         full_cells_[i] = width * pv * d.n_rows;
-        const int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
+        int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
+        { const char *pct_ = getenv("ABPOA_HIP_ARENA_PCT"); if (pct_ && atoi(pct_) > 0 && atoi(pct_) < 100) est = std::max<int64_t>(pn, est * atoi(pct_) / 100); }      // (tests: force the overflow -> full-width retry path)
         d.plane_cap = std::min<int64_t>(full_cells_[i], width * pv + est * pv * (d.n_rows - 1));
     }
     size_t o = 0;
@@ -298,6 +299,12 @@ int BatchStream::run() {
                 again.push_back(i); continue;
             }
             recs_[i] = r;
+            // trace mode: the arena of a finished alignment is kept on the host now -- a retry pass of OTHER alignments re-uses the device arenas
+            if (trace) {
+                trace_arena_.resize(desc_.size());
+                trace_arena_[i].resize((size_t)r.cells_used * (d.bits / 8));
+                if (!trace_arena_[i].empty()) HIP_TRY(hipMemcpy(trace_arena_[i].data(), planes_.dev + d.plane_off, trace_arena_[i].size(), hipMemcpyDeviceToHost), ABPOA_HIP_ELAUNCH);
+            }
             stats_.n_alignments += 1; stats_.n_cells += r.n_cells;
             stats_.algo_bytes += r.n_cells * (d.bits / 8) * (P == 1 ? 2 : (P == 3 ? 5 : 8));
             g_dbg[0] += r.clk_dp; g_dbg[1] += r.clk_bt; g_dbg[2] += r.n_rows_done; g_dbg[3] += r.n_bt_steps; for (int q_ = 0; q_ < 6; ++q_) g_dbg[4 + q_] += r.seg[q_];
@@ -318,8 +325,8 @@ int BatchStream::fetch_trace(int i, const uint8_t *row_active, abpoa_hip_trace_t
     const int32_t *bsn = (const int32_t *)(ho + o_bsn_) + d.row0, *esn = (const int32_t *)(ho + o_esn_) + d.row0;
     const int64_t *coff = (const int64_t *)(ho + o_coff_) + d.row0;
     memcpy(T->row_max_i, (const int32_t *)(ho + o_rmi_) + d.row0, 4 * gn);
-    std::vector<uint8_t> arena((size_t)r.cells_used * (d.bits / 8));
-    if (!arena.empty()) HIP_TRY(hipMemcpy(arena.data(), planes_.dev + d.plane_off, arena.size(), hipMemcpyDeviceToHost), ABPOA_HIP_ELAUNCH);
+    if ((size_t)i >= trace_arena_.size()) { set_err("no trace kept for problem %d", i); return ABPOA_HIP_EINVAL; }
+    const std::vector<uint8_t> &arena = trace_arena_[i];          // saved when the alignment finished (BatchStream::run)
     int64_t tot = 0;
     for (int rr = 0; rr < gn; ++rr) {
         T->row_off[rr] = tot;

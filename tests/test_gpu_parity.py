@@ -49,3 +49,26 @@ def test_hip_batch_mixed_widths(engine):
             H.compare_with_golden(o, g, check_planes=False, label="batch " + label)
         nbatch += 1
     assert nbatch >= 3
+
+
+def test_arena_overflow_retry_keeps_traces(engine, monkeypatch):
+    """Batches whose arenas are under-sized on purpose (ABPOA_HIP_ARENA_PCT): alignments that overflow are re-run at full width in a second
+    pass that re-uses the device arenas; the planes of the alignments that finished in the first pass must still come back intact."""
+    monkeypatch.setenv("ABPOA_HIP_ARENA_PCT", "55")
+    groups = {}
+    for label, path in CASES:
+        g = H.read_abpg(path)
+        if int(g["wb"][0]) < 0 or int(g["align_mode"][0]) != 0 or "row_checksum" in g and len(g.get("planes", [])) == 0:
+            continue
+        key = (int(g["m"][0]), int(g["gap_mode"][0]), int(g["zdrop"][0]), tuple(g["mat"].tolist()), int(g["gap_open1"][0]), int(g["gap_ext1"][0]),
+               int(g["gap_open2"][0]), int(g["gap_ext2"][0]))
+        groups.setdefault(key, []).append((label, g))
+    n = 0
+    for key, items in groups.items():
+        if len(items) < 2:
+            continue
+        outs = H.run_hip([H.FlatCase(g) for _, g in items], want_trace=True)
+        for (label, g), o in zip(items, outs):
+            H.compare_with_golden(o, g, label="overflow-retry " + label)
+        n += 1
+    assert n >= 2
