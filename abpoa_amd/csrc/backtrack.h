@@ -259,6 +259,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         };
         uniformize();
         const long long t_walk0 = (long long)__builtin_amdgcn_s_memtime();
+        bool local_done = false;                                   // local mode: the walk reached a cell with H == 0 (reference :126)
         do {      // fast steps; one slow step whenever a fast one cannot be taken; back to fast steps
         // ---- lane-parallel step (cell-record arenas, i.e. the fast path).  The current row's record is carried in SGPRs; round
         //      trip 1 fetches its predecessor edge records (lane k = predecessor k), its own cells and the query code, round trip 2
@@ -267,7 +268,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         //      one-read-at-a-time walk below whenever a predecessor is outside the staged window or the row has > 64 of them.
         int4 cr = make_int4(0, 0, 0, 0); int cr2 = 0, cr_row = -1;               // rinfo / rinfo2 of row cr_row
         // two copies of the step loop: whole-row windows (narrow bands: no slice bookkeeping at all) and column-slice windows
-        while (CW > 0 && i > 0 && j > 0 && status == 0 && bt_walk_narrow) {
+        while (CW > 0 && i > 0 && j > 0 && status == 0 && bt_walk_narrow && !local_done) {
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; if (!win_narrow) { bt_walk_narrow = false; break; } }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr_row = i; }
             // ---- match run.  The row loop left "1 + index of the first predecessor whose diagonal cell gives H" in every cell record it
@@ -325,6 +326,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
             const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
+            if (local && Hij == 0) { local_done = true; break; }            // reference :126: the local walk ends on a zero cell
             const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
             // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
@@ -387,7 +389,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 cr_row = i;
             }
         }
-        while (CW > 0 && i > 0 && j > 0 && status == 0 && true) {
+        while (CW > 0 && i > 0 && j > 0 && status == 0 && !local_done) {
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }
             // ---- match run, as in the whole-row loop above; here a row's staged cells are the column slice cr2 = first column | count << 16
@@ -441,6 +443,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
             const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
+            if (local && Hij == 0) { local_done = true; break; }            // reference :126: the local walk ends on a zero cell
             const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
             // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
@@ -505,12 +508,12 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             }
         }
         int slow_budget = CW > 0 ? 1 : INT_MAX;
-        while (i > 0 && j > 0 && status == 0 && slow_budget-- > 0) {
+        while (i > 0 && j > 0 && status == 0 && !local_done && slow_budget-- > 0) {
             ++bt_slow_steps;
             if (CW == 0 && ((i < bt_lo + bt_margin && bt_lo > 0) || i > bt_hi || i < bt_lo)) load_window(i);
             const Geo gi = geo_of(i);
             const int Hij = cell(gi, 0, j);
-            if (local && Hij == 0) break;
+            if (local && Hij == 0) { local_done = true; break; }
             start_i = i; start_j = j; ++bt_steps;
             int ps, np, id, bs_;
             { const int t = gi.in_tile ? i - bt_lo : 0; ps = B.poff[t]; np = B.poff[t + 1] - ps; id = B.nid[t]; bs_ = B.base[t]; }
@@ -586,7 +589,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
         }
         if (CW > 0) uniformize();
-        } while (CW > 0 && i > 0 && j > 0 && status == 0);
+        } while (CW > 0 && i > 0 && j > 0 && status == 0 && !local_done);
         bt_win_ticks = win_ticks; bt_n_windows = n_windows; bt_wa = win_a; bt_wb = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);

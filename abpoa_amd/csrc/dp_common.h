@@ -314,6 +314,7 @@ static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int 
 hipError_t launch_fast_rows(const DevBatch &b, hipStream_t stream);       // dp_fast_rows.hip
 hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream);       // dp_wide_rows.hip
 hipError_t launch_team_rows(const DevBatch &b, hipStream_t stream);       // dp_team_rows.hip
+hipError_t launch_local_rows(const DevBatch &b, hipStream_t stream);      // dp_local_rows.hip
 hipError_t launch_fast_tail(const DevBatch &b, hipStream_t stream);       // dp_fast_tail.hip
 hipError_t launch_general(const DevBatch &b, hipStream_t stream);         // dp_general.hip
 

@@ -1,5 +1,6 @@
 // Tail kernels of the fast path: global best + backtrack over the cell-record arenas the row loops left in HBM (backtrack.h).
 #include "rows_fast.h"      // FastFmt (arena record format)
+#include "rows_local.h"    // takes_local
 #include "backtrack.h"
 
 namespace abpoa_hip {
@@ -14,6 +15,7 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     TailState ts;
     ts.status = out_rec->status; ts.n_cells = out_rec->n_cells; ts.cursor = out_rec->cells_used; ts.rows_done = out_rec->n_rows_done;
     ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;
+    if (b.align_mode == ABPOA_HIP_LOCAL_MODE) { ts.best_score = out_rec->best_score; ts.best_i = out_rec->best_row; ts.best_j = out_rec->best_col; }      // (the local row loop keeps the best cell)
     for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = out_rec->seg[i_];
     ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
     __syncthreads();
@@ -25,7 +27,7 @@ __global__ void __launch_bounds__(64) dp_fast_tail_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (!takes_fast(b, d) || d.bits != BITS) return;
+    if (!(takes_fast(b, d) || takes_local(b, d)) || d.bits != BITS) return;
     align_fast_tail<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP>(b, d, b.out + a);
 }
 

@@ -1,5 +1,6 @@
 // General kernel (any mode, any gap model, band on or off; plane-major arenas) and the launch entry points of the engine.
 #include "rows_general.h"
+#include "rows_local.h"
 
 namespace abpoa_hip {
 
@@ -11,7 +12,7 @@ __global__ void __launch_bounds__(64) dp_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (takes_fast(b, d)) return;            // dp_fast_kernel's
+    if (takes_fast(b, d) || takes_local(b, d)) return;            // the fast row loops'
     if (d.bits == 16) align_one<int16_t, GAP>(b, d, b.out + a);
     else align_one<int32_t, GAP>(b, d, b.out + a);
 }
@@ -28,8 +29,10 @@ hipError_t launch_general(const DevBatch &b, hipStream_t stream) {
 // (its SGPR budget above all) is not shared with the tail; the hand-over is the AlnOut record in HBM.
 hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows) {
     if (b.n <= 0) return hipSuccess;
-    hipError_t e = launch_fast_rows(b, stream);
+    hipError_t e = hipSuccess;
+    if (b.align_mode != ABPOA_HIP_LOCAL_MODE) e = launch_fast_rows(b, stream);
     if (e == hipSuccess && b.lds.wide_nw >= 1) e = launch_wide_rows(b, stream);
+    if (e == hipSuccess && b.lds.loc_cols > 0 && b.align_mode == ABPOA_HIP_LOCAL_MODE) e = launch_local_rows(b, stream);
     if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
     if (e == hipSuccess) e = launch_fast_tail(b, stream);
     return e;

@@ -108,6 +108,14 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
     L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
     L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes;
+    // local row loop (rows_local.h): unbanded local alignments of at most 9 x 64 columns, int16; ring depth by what 60 KB hold
+    L.loc_rows = L.loc_cols = L.total_local = 0;
+    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && P != 1 && L.q_cap && !(getenv("ABPOA_HIP_NOFAST") && atoi(getenv("ABPOA_HIP_NOFAST")))) {
+        const int lw = P == 3 ? 1 : 2;                 // ring words per column (int16: H | E1 packed, E2)
+        L.loc_cols = 9 * 64; L.loc_rows = 16;
+        while ((int64_t)L.loc_rows * lw * (L.loc_cols + 4) * 4 > 60 * 1024 - L.phase_off && L.loc_rows > 4) L.loc_rows /= 2;
+        L.total_local = L.phase_off + L.fr_off + (int)align_up((size_t)L.loc_rows * lw * (L.loc_cols + 4) * 4, 16) + 64;
+    }
     // wide row loop (dp_wide_rows.hip): alignments whose band half-width w is in [wide_w_lo, wide_w_hi] -- rows of 2..5 chunks of 64 columns --
     // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (320 columns; depth by what fits:
     // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
@@ -205,9 +213,9 @@ int BatchStream::run() {
     std::vector<AlnDesc> pass;
     // alignment-level eligibility for the register-resident row loop: every row active, band state at its reset value
     for (int i = 0; i < n; ++i) {
-        AlnDesc &d = desc_[i]; bool ok = banded;
+        AlnDesc &d = desc_[i]; bool ok = banded || (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0);      // (unbanded local: the local row loop; band state is not used)
         if (ok && memchr(hi + o_act_ + d.row0, 0, (size_t)d.n_rows)) ok = false;
-        if (ok && !fresh) {
+        if (ok && banded && !fresh) {
             const int32_t *l = (const int32_t *)(ho + o_left_) + d.row0, *r = (const int32_t *)(ho + o_right_) + d.row0;
             for (int k = 0; k < d.n_rows && ok; ++k) ok = l[k] == d.n_rows && r[k] == 0;
         }
@@ -273,6 +281,8 @@ int BatchStream::run() {
         int n_fast = 0;       // mirrors takes_fast() in dp_kernel.hip
         if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && b.lds.fr_cols > 0 && !(b.dbg & 64))
             for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.qlen <= b.lds.q_cap) ? 1 : 0;
+        if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && b.lds.loc_cols > 0 && !(b.dbg & 64))      // mirrors takes_local() in rows_local.h
+            for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.bits == 16 && (d.qlen / 16 + 1) * 16 <= b.lds.loc_cols && d.qlen <= b.lds.q_cap) ? 1 : 0;
         HIP_TRY(launch_dp(b, n_fast, stream_, ev_[4]), ABPOA_HIP_ELAUNCH);
         HIP_TRY(hipEventRecord(ev_[2], stream_), ABPOA_HIP_ELAUNCH);
         // results: records + cigars are adjacent at the start of the output blob; band state / trace arrays on demand

@@ -62,6 +62,8 @@ struct LdsPlan {
     int32_t wfr_rows, wfr_cols, wx_off, wide_nw;
     int32_t wide_w_lo, wide_w_hi; // an alignment takes the wide loop iff wide_w_lo <= its band half-width w <= wide_w_hi
     int32_t total_wide;           // dynamic LDS bytes of the wide row-loop kernel
+    // --- local row loop (rows_local.h): ring [loc_rows][words][loc_cols + 4] at phase_off + fr_off; loc_cols = 0: not used by this launch
+    int32_t loc_rows, loc_cols, total_local;
     int32_t mx_off;               // int32 [m*(m+1)]: score matrix with an extra all-zero query column (code m = "no query base")
     int32_t total;                // dynamic LDS bytes to request (general kernel: union of every phase)
     int32_t total_rows, total_tail;   // the two fast-path kernels request only what their phase needs (4+ workgroups per CU must fit)
