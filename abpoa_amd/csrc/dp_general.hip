@@ -30,7 +30,7 @@ hipError_t launch_general(const DevBatch &b, hipStream_t stream) {
 hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows) {
     if (b.n <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
-    if (b.align_mode != ABPOA_HIP_LOCAL_MODE) e = launch_fast_rows(b, stream);
+    if (b.align_mode != ABPOA_HIP_LOCAL_MODE && !b.lds.narrow_off) e = launch_fast_rows(b, stream);
     if (e == hipSuccess && b.lds.wide_nw >= 1) e = launch_wide_rows(b, stream);
     if (e == hipSuccess && b.lds.loc_cols > 0 && b.align_mode == ABPOA_HIP_LOCAL_MODE) e = launch_local_rows(b, stream);
     if (e == hipSuccess) e = hipEventRecord(after_rows, stream);

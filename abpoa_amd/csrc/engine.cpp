@@ -120,7 +120,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (320 columns; depth by what fits:
     // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
     // the depth, ABPOA_HIP_TEAM=1|2|4 sets the wavefronts per alignment.
-    L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0;
+    L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0; L.narrow_off = 0;
     { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_TEAM");
       if (L.fr_cols && L.q_cap && !(nw_ && atoi(nw_))) {
           // wavefronts per alignment: 1.  Teams of 2 / 4 (ABPOA_HIP_TEAM=2|4, dp_team_rows.hip) give identical results but are slower on gfx950
@@ -244,6 +244,10 @@ int BatchStream::run() {
             }
             make_lds_plan(sc, max_qlen, max_bits, est_cols, (int)pass.size(), &b.lds);
             for (const AlnDesc &d : pass) b.bits_mask |= d.bits == 16 ? 1 : 2;
+            bool any_wide = false, all_wide = true;
+            for (const AlnDesc &d : pass) { const bool wd = d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi; any_wide |= wd; all_wide &= wd; }
+            if (!any_wide) b.lds.wide_nw = 0;
+            b.lds.narrow_off = (b.lds.wide_nw >= 1 && all_wide) ? 1 : 0;
         }
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;

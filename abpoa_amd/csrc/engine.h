@@ -61,6 +61,7 @@ struct LdsPlan {
     //     then the exchange slots (wx_off, relative to phase_off); wide_nw = 0: not used by this launch
     int32_t wfr_rows, wfr_cols, wx_off, wide_nw;
     int32_t wide_w_lo, wide_w_hi; // an alignment takes the wide loop iff wide_w_lo <= its band half-width w <= wide_w_hi
+    int32_t narrow_off;           // 1: every alignment of the launch takes the wide loop -- the narrow row-loop kernels are not launched
     int32_t total_wide;           // dynamic LDS bytes of the wide row-loop kernel
     // --- local row loop (rows_local.h): ring [loc_rows][words][loc_cols + 4] at phase_off + fr_off; loc_cols = 0: not used by this launch
     int32_t loc_rows, loc_cols, total_local;

@@ -251,6 +251,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         for (int s = 0; s < n_sets; ++s) for (int r = 1; r < sets[s].n_reads; ++r) min_qlen = std::min(min_qlen, sets[s].lens[r]);
         const int min_bits = abpoa_hip_score_bits(sc, 3, min_qlen, &inf_dummy);
         b.bits_mask = (min_bits == 16 ? 1 : 0) | (max_bits == 32 ? 2 : 0);
+        // which row-loop kernels can have work at all: band half-widths of the reads that get aligned (w = b + f * length)
+        const int w_min = sc->wb + (int)(sc->wf * (float)min_qlen);
+        if (w_max < b.lds.wide_w_lo || w_min > b.lds.wide_w_hi) b.lds.wide_nw = 0;                       // no read takes the wide loop
+        b.lds.narrow_off = (b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_max <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
     }
     if (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
