@@ -72,3 +72,26 @@ def test_arena_overflow_retry_keeps_traces(engine, monkeypatch):
             H.compare_with_golden(o, g, label="overflow-retry " + label)
         n += 1
     assert n >= 2
+
+
+@pytest.mark.parametrize("env", [{"ABPOA_HIP_RING_ROWS": "4"}, {"ABPOA_HIP_TEAM": "2"}, {"ABPOA_HIP_TEAM": "4"}, {"ABPOA_HIP_NOWIDE": "1"}],
+                         ids=["ring4_hbm_gather", "team2", "team4", "nowide"])
+def test_wide_band_variants(engine, monkeypatch, env):
+    """The 10 kb goldens (4-5 chunks per row) through the other forms of the wide row loop: a 4-row score ring (every other row gathers a predecessor
+    from the HBM arena), teams of 2 / 4 wavefronts per alignment, and the chunk-by-chunk loop of the narrow kernel."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 0
+    for label, path in CASES:
+        if not label.startswith(("s10k_", "s20k_")):
+            continue
+        g = H.read_abpg(path)
+        h = H.run_hip([H.FlatCase(g)])[0]
+        H.compare_with_golden(h, g, label=f"{env} {label}")
+        n += 1
+    assert n >= 3
+    from abpoa_amd import api, synth, workloads as W
+    for wl in ("cfg3", "cfg4"):
+        w = W.WORKLOADS[wl]
+        r = api.msa_batch([synth.make_read_set(1, 2, **synth.CONFIGS[w["cfg"]])], api.Params(**w["params"]))[0]
+        assert r.status == 0 and W.output_sha(api.format_output(r)) == W.load_digests(wl)[2], f"{env} {wl} set 2"
