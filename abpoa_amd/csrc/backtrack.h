@@ -55,7 +55,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     if (status == 0 && b.ret_cigar) {
         BtLds &B = *(BtLds *)(lds_raw + b.lds.phase_off);
         T *bt = (T *)(lds_raw + b.lds.phase_off + b.lds.bt_off);
-        const long long bt_cells = b.lds.bt_bytes / (int)sizeof(T);
+        const long long bt_cells = (CW > 0 ? b.lds.bt_bytes_tail : b.lds.bt_bytes) / (int)sizeof(T);      // (the tail kernel's window is sized on its own: four of its workgroups per CU)
         int bt_lo = 1, bt_hi = 0, bt_pbase = 0, bt_margin = 0;   // window = rows [bt_lo, bt_hi], empty at start
         long long bt_c0 = 0;                                     // arena cell of B.coff[0]
         GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
@@ -113,7 +113,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             __syncthreads();
             const int max_rec = (int)(bt_cells / (CW > 0 ? CW : 1));
-            const int WC = max_rec >= 2048 ? 64 : 48;
+            // columns of a slice: a path advances one column per step but 1.5-2.5 rows (bubbles of the graph), and the window holds max_rec records,
+            // so slices are kept narrow enough for ~30 rows (measured on 10 kb reads: 32 columns with 16-byte records, 16 with 32-byte records;
+            // diagnostic override ABPOA_HIP_BT_WC)
+            const int WC = b.lds.bt_wc > 0 ? b.lds.bt_wc : (max_rec >= 2048 ? 64 : (max_rec >= 1536 ? 48 : (max_rec >= 768 ? 32 : 16)));
             // candidate rows: the 64 rows ending at hi (lane = row - lo64); how many of them are staged is decided below
             const int lo64 = imax(0, hi - BTR + 1), n64 = hi - lo64 + 1;
             const int r = lo64 + lane; const bool rv64 = lane < n64;

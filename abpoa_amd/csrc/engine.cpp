@@ -107,7 +107,12 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
     const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
     L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
-    L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes;
+    // the fast path's tail kernel: its own window size -- 24 KB, less when a long query already takes much of the 38 (62) KB that let four (two) of
+    // its workgroups share a CU; the general kernel's bt_bytes above also covers its score ring and would halve that residency
+    L.bt_bytes_tail = std::max(8 * 1024, std::min(24 * 1024, (longq ? 62 : 38) * 1024 - L.phase_off - L.bt_off)) & ~15;
+    { const char *tb_ = getenv("ABPOA_HIP_BT_BYTES"); if (tb_ && atoi(tb_) >= 4096 && atoi(tb_) <= 65536) L.bt_bytes_tail = atoi(tb_) & ~15; }
+    L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes_tail;
+    L.bt_wc = 0; { const char *wc_ = getenv("ABPOA_HIP_BT_WC"); if (wc_ && atoi(wc_) >= 8 && atoi(wc_) <= 64) L.bt_wc = atoi(wc_) & ~7; }
     // local row loop (rows_local.h): unbanded local alignments of at most 9 x 64 columns, int16; ring depth by what 60 KB hold
     L.loc_rows = L.loc_cols = L.total_local = 0;
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && P != 1 && L.q_cap && !(getenv("ABPOA_HIP_NOFAST") && atoi(getenv("ABPOA_HIP_NOFAST")))) {

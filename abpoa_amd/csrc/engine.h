@@ -55,6 +55,8 @@ struct LdsPlan {
     int32_t ring_off;             // (relative to phase_off)
     // --- backtrack phase ---
     int32_t bt_off, bt_bytes;     // arena tile (relative to phase_off)
+    int32_t bt_bytes_tail;        // arena window of the fast path's tail kernel (bt_bytes is the general kernel's, which shares the region with its score ring)
+    int32_t bt_wc;                // column-slice windows of the backtrack: columns per slice (0: the kernel's default)
     // --- fast row loop (dp_kernel.hip rows_fast): packed H|E score ring [fr_rows][words][fr_cols + 4] dwords at phase_off + fr_off
     int32_t fr_off, fr_rows, fr_cols;   // fr_rows: power of two <= 64; fr_cols: multiple of 64, 0 = fast loop disabled
     // --- wide row loop (NW wavefronts per alignment, rows_fast<.., NW>): its own score ring [wfr_rows][words][wfr_cols + 4] at phase_off + fr_off,
