@@ -446,7 +446,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
             const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
-            if (local && Hij == 0) { local_done = true; break; }            // reference :126: the local walk ends on a zero cell
+            if (local && Hij == 0 && (win_narrow || (unsigned)si < (unsigned)nsi)) { local_done = true; break; }      // reference :126: the local walk ends on a zero cell (a cell outside the staged slice is re-read after the reload below)
             const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
             // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
