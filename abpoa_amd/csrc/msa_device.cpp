@@ -95,6 +95,19 @@ void consensus_flat(int n, const int32_t *order, const uint8_t *base, const uint
 }
 }  // namespace
 
+void release_msa_device_caches() {
+    int cur = -1; (void)hipGetDevice(&cur);
+    for (int s = 0; s < MSA_DEVICE_SLOTS; ++s) {
+        std::lock_guard<std::mutex> lk(g_cache_mu[s]);
+        Cache &C = g_cache[s];
+        if (C.device < 0) continue;
+        (void)hipSetDevice(C.device);
+        if (C.stream) (void)hipStreamSynchronize(C.stream);
+        for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+}
+
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;

@@ -23,6 +23,8 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 // device < 0: the device the engine was initialised on.  slot: which of the per-worker pool caches to use (one worker = one device queue of
 // the multi-GPU batch call; workers may share a device); a slot runs one job at a time.
 constexpr int MSA_DEVICE_SLOTS = 16;
+// frees every cached pool of every device queue (abpoa_hip_trim)
+void release_msa_device_caches();
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
                    std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, int device = -1, int slot = 0);
 

@@ -176,4 +176,5 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
     return run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &g_timing);
 }
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
+void abpoa_hip_trim(void) { abpoa_hip::release_msa_device_caches(); }
 }

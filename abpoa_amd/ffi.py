@@ -49,7 +49,7 @@ FLAG_TRACE = 0x1
 # every symbol include/abpoa_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ["abpoa_hip_device_count", "abpoa_hip_init", "abpoa_hip_shutdown", "abpoa_hip_last_error",
            "abpoa_hip_get_stats", "abpoa_hip_reset_stats", "abpoa_hip_align_batch", "abpoa_hip_free_result",
-           "abpoa_hip_score_bits"]
+           "abpoa_hip_score_bits", "abpoa_hip_trim"]
 
 _lib = None
 

@@ -141,6 +141,8 @@ void abpoa_hip_shutdown(void);
 const char *abpoa_hip_last_error(void);
 void abpoa_hip_get_stats(abpoa_hip_stats_t *out);
 void abpoa_hip_reset_stats(void);
+/* Releases the device / pinned pools the read-set driver keeps between calls (a 10 kb job leaves >100 GB cached); the next call re-allocates. */
+void abpoa_hip_trim(void);
 
 /* ---- (1) flat batch API ----------------------------------------------------------------------- */
 /* Replaces: simd_abpoa_align_sequence_to_subgraph (src/simd_abpoa_align.c:1645-1712), N at a time.
