@@ -116,7 +116,11 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             // columns of a slice: a path advances one column per step but 1.5-2.5 rows (bubbles of the graph), and the window holds max_rec records,
             // so slices are kept narrow enough for ~30 rows (measured on 10 kb reads: 32 columns with 16-byte records, 16 with 32-byte records;
             // diagnostic override ABPOA_HIP_BT_WC)
-            const int WC = b.lds.bt_wc > 0 ? b.lds.bt_wc : (max_rec >= 2048 ? 64 : (max_rec >= 1536 ? 48 : (max_rec >= 768 ? 32 : 16)));
+            int WC = b.lds.bt_wc;
+            if (WC <= 0) {      // WC x R = max_rec with R / WC = rows per step: ~1.2 (5 % reads: 16-byte records here), ~2.4 (15 % reads: the convex default, 32-byte records)
+                const float rho = (CW * (int)sizeof(T) >= 32) ? 2.4f : 1.2f;
+                WC = imax(16, imin(64, ((int)__builtin_sqrtf((float)max_rec / rho) + 4) & ~7));
+            }
             // candidate rows: the 64 rows ending at hi (lane = row - lo64); how many of them are staged is decided below
             const int lo64 = imax(0, hi - BTR + 1), n64 = hi - lo64 + 1;
             const int r = lo64 + lane; const bool rv64 = lane < n64;

@@ -110,6 +110,10 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // the fast path's tail kernel: its own window size -- 24 KB, less when a long query already takes much of the 38 (62) KB that let four (two) of
     // its workgroups share a CU; the general kernel's bt_bytes above also covers its score ring and would halve that residency
     L.bt_bytes_tail = std::max(8 * 1024, std::min(24 * 1024, (longq ? 62 : 38) * 1024 - L.phase_off - L.bt_off)) & ~15;
+    // a launch with fewer alignments than 4 per CU can afford a larger window per workgroup (fewer window reloads on wide bands): 160 KB / CU
+    // divided by the workgroups a CU has to hold, capped at 56 KB
+    { const int per_cu = std::max(1, (n_aln + 255) / 256);
+      if (per_cu < 4 && L.fr_cols > 128) L.bt_bytes_tail = std::max(L.bt_bytes_tail, std::min(56 * 1024, 160 * 1024 / per_cu - 2048 - L.phase_off - L.bt_off) & ~15); }
     { const char *tb_ = getenv("ABPOA_HIP_BT_BYTES"); if (tb_ && atoi(tb_) >= 4096 && atoi(tb_) <= 65536) L.bt_bytes_tail = atoi(tb_) & ~15; }
     L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes_tail;
     L.bt_wc = 0; { const char *wc_ = getenv("ABPOA_HIP_BT_WC"); if (wc_ && atoi(wc_) >= 8 && atoi(wc_) <= 64) L.bt_wc = atoi(wc_) & ~7; }
