@@ -125,8 +125,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
         while ((int64_t)L.loc_rows * lw * (L.loc_cols + 4) * 4 > 60 * 1024 - L.phase_off && L.loc_rows > 4) L.loc_rows /= 2;
         L.total_local = L.phase_off + L.fr_off + (int)align_up((size_t)L.loc_rows * lw * (L.loc_cols + 4) * 4, 16) + 64;
     }
-    // wide row loop (dp_wide_rows.hip): alignments whose band half-width w is in [wide_w_lo, wide_w_hi] -- rows of 2..5 chunks of 64 columns --
-    // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (320 columns; depth by what fits:
+    // wide row loop (dp_wide_rows.hip): alignments whose band half-width w is in [wide_w_lo, wide_w_hi] -- rows of 2..7 chunks of 64 columns --
+    // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (448 columns; depth by what fits:
     // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
     // the depth, ABPOA_HIP_TEAM=1|2|4 sets the wavefronts per alignment.
     L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0; L.narrow_off = 0;
@@ -142,8 +142,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");
           if (rr_env_ && atoi(rr_env_) >= 4) L.wfr_rows = atoi(rr_env_) >= 16 ? 16 : (atoi(rr_env_) >= 8 ? 8 : 4); else rr_env_ = nullptr;
-          // (up to 96 KB per wavefront: a convex int32 ring of 16 rows is 62 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
-          const int budget = 96 * 1024 - L.phase_off - 512;
+          // (up to 120 KB per wavefront: a convex int32 ring of 16 rows is 87 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
+          const int budget = 120 * 1024 - L.phase_off - 512;
           while ((int64_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4 > budget && L.wfr_rows > 4) L.wfr_rows /= 2;
           // one wavefront per alignment: LDS is what limits how many alignments a CU holds (160 KB, 256 CUs) -- a shallower ring when the
           // launch has more alignments than fit (rows with an older predecessor take the HBM gather: 1 % of rows at depth 8 on 5 % reads)

@@ -41,7 +41,7 @@ struct AlnOut {
 };
 
 #define ALN_FAST_OK 1
-#define WIDE_RING_COLS 320   // score-ring columns of the single-wave wide kernel (5 chunks of 64)
+#define WIDE_RING_COLS 448   // score-ring columns of the single-wave wide kernel (7 chunks of 64)
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
 
 // LDS carve-up of one wavefront (= one workgroup), chosen on the host per launch.  Byte offsets from the

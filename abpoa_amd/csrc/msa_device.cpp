@@ -364,13 +364,22 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         if (dbg_sync && getenv("ABPOA_HIP_IMBAL")) {      // load balance of the round: ticks of the mean and of the slowest alignment
             std::vector<AlnOut> ho(n_sets); (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
             double sd = 0, sb = 0; long long md = 0, mb = 0, ms_ = 0; for (const AlnOut &o_ : ho) { sd += o_.clk_dp; sb += o_.clk_bt; md = std::max<long long>(md, o_.clk_dp); mb = std::max<long long>(mb, o_.clk_bt); ms_ = std::max<long long>(ms_, o_.clk_dp + o_.clk_bt); }
-            fprintf(stderr, "[poa-device] round %d balance: rows mean %.0f max %lld | tail mean %.0f max %lld | rows+tail mean %.0f max %lld\n", k, sd / n_sets, md, sb / n_sets, mb, (sd + sb) / n_sets, ms_);
+            float rows_ms_ = 0; (void)hipEventElapsedTime(&rows_ms_, e[0], e[1]);      // wall time of the row-loop launches: max ticks / this = tick rate the slowest wave saw
+            fprintf(stderr, "[poa-device] round %d balance: rows mean %.0f max %lld (%.2f ms on the stream, %.2f Gticks/s) | tail mean %.0f max %lld | rows+tail mean %.0f max %lld\n", k, sd / n_sets, md, rows_ms_, rows_ms_ > 0 ? md / rows_ms_ * 1e-6 : 0.0, sb / n_sets, mb, (sd + sb) / n_sets, ms_);
             static std::vector<double> tot_set; static double sum_max = 0;      // (debug) what lock-step costs: sum over rounds of the slowest set vs the slowest set's own total
             if (k == 1) { tot_set.assign(n_sets, 0.0); sum_max = 0; }
             for (int s_ = 0; s_ < n_sets; ++s_) tot_set[s_] += (double)ho[s_].clk_dp + (double)ho[s_].clk_bt;
             sum_max += (double)ms_;
             if (k == max_reads - 1) { double mx_ = 0, mean_ = 0; for (double v_ : tot_set) { mx_ = std::max(mx_, v_); mean_ += v_; } fprintf(stderr, "[poa-device] rows+tail ticks over all rounds: sum of per-round maxima %.0f | slowest set alone %.0f | mean set %.0f\n", sum_max, mx_, mean_ / n_sets); }
             double sg[6] = {0, 0, 0, 0, 0, 0}, st_ = 0; for (const AlnOut &o_ : ho) { for (int q_ = 0; q_ < 6; ++q_) sg[q_] += o_.seg[q_]; st_ += o_.n_bt_steps; }
+            if (b.dbg & 128) {      // placement report (row-loop seg[5] = HW_ID | XCC_ID << 32 survives the tail under dbg bit 7): how many alignments shared a SIMD, and how the sharers fared
+                std::vector<std::pair<unsigned long long, int>> pl; for (int s_ = 0; s_ < n_sets; ++s_) { const unsigned long long h_ = (unsigned long long)ho[s_].seg[5]; pl.push_back({((h_ >> 32) & 15) << 16 | (h_ & 0xff30) , s_}); }      // xcc | se, sh, cu | simd
+                std::sort(pl.begin(), pl.end()); double t_sh = 0, t_al = 0; int n_sh = 0, n_al = 0;
+                for (size_t i_ = 0; i_ < pl.size(); ++i_) { const bool sh_ = (i_ > 0 && pl[i_ - 1].first == pl[i_].first) || (i_ + 1 < pl.size() && pl[i_ + 1].first == pl[i_].first); (sh_ ? t_sh : t_al) += (double)ho[pl[i_].second].clk_dp; (sh_ ? n_sh : n_al)++; }
+                fprintf(stderr, "[poa-device] round %d placement: %d alignments alone on their SIMD (mean ticks %.0f), %d sharing one (mean ticks %.0f)\n", k, n_al, n_al ? t_al / n_al : 0.0, n_sh, n_sh ? t_sh / n_sh : 0.0);
+            }
+            if ((b.dbg & 128) && getenv("ABPOA_HIP_WIDE_COUNTERS")) { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_; const AlnOut &o_ = ho[w_];
+                fprintf(stderr, "[poa-device] round %d slowest row loop: set %d ticks %lld rows %d | all-chunk body %lld | not eligible %lld | ring-geometry %lld | > 5 chunks %lld | slow vectors straddle %lld | key window / wrap %lld\n", k, w_, (long long)o_.clk_dp, o_.n_rows_done, (long long)o_.seg[0], (long long)o_.seg[1], (long long)o_.seg[2], (long long)o_.seg[3], (long long)o_.seg[4], (long long)o_.seg[5]); }
             if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr, "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible (preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key window / wrap %.0f\n", k, sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);
             fprintf(stderr, "[poa-device] round %d tail means: steps %.0f  flag steps %.0f  slow steps %.0f  windows %.1f  window ticks %.0f (setup %.0f)  walk ticks %.0f\n", k, st_ / n_sets, sg[2] / n_sets / 1000, sg[3] / n_sets / 1000, sg[4] / n_sets / 1000, sg[5] / n_sets, sg[0] / n_sets, sg[1] / n_sets);
         }

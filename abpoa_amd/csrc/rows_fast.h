@@ -487,7 +487,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     };
 
     constexpr int NWP = NW <= 2 ? 2 : (NW <= 4 ? 4 : 8);            // exchange entries read per lane group
-    // ---- MULTI-CHUNK body for wide bands (10 kb reads: 240-300 columns = 4-5 chunks of 64): every chunk of the row is in registers at once.
+    // ---- MULTI-CHUNK body for wide bands (10 kb reads: 240-300 columns = 4-5 chunks of 64; where a read drifts against the graph the band
+    //      opens to 6, seldom 7 chunks for thousands of rows -- three instantiations: 2-3, 4-5 and 6-7 chunks): every chunk of the row is in registers at once.
     //      The lane owns column (64 c + lane) of each chunk c, so the chunks are independent instruction streams that the scheduler interleaves
     //      (LDS reads of all chunks in flight together, DPP scans of all chunks back to back without wait states), and everything that is
     //      per row -- band, conditions, arg-max reduction, commit -- is paid once for ~250 columns instead of once per 64.
@@ -499,9 +500,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     //      contiguous share of the row's chunks (c0 .. c0 + cnt - 1); ONE exchange through LDS per row carries each wavefront's carry-chain result
     //      (seed out of its last chunk, computed as if nothing came in: the chain is max-plus, the incoming seed is folded in afterwards), its
     //      arg-max key and its wrap flag; a second barrier at the end of the row publishes the ring slot.
-    constexpr int NCHX = 5;
+    constexpr int NCHX = 7;
     constexpr bool TEAM = NW > 1;
-    int qcx_beg_sn = -1, qcx_c0 = -1, qoffx[NCHX] = {0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk of this wavefront, for band start qcx_beg_sn
+    int qcx_beg_sn = -1, qcx_c0 = -1, qoffx[NCHX] = {0, 0, 0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk of this wavefront, for band start qcx_beg_sn
     int ilp_far = 0;                                                // bit k: predecessor k of the row is not in the score ring (older than its depth, or a row too wide for it): HBM gather
     auto ilp_band = [&](int row, int ti) __attribute__((always_inline)) -> int {
         int mn_mi, mx_mi, min_pb;
@@ -606,7 +607,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) merge(g1_, c, hb[c], eb1[c], eb2[c], 2);
                 } else { gather_pred(0, tv_p0); gather_pred(1, tv_p1); }
-                if (np > 2) { gather_pred(2, tv_p2); if (np > 3) { gather_pred(3, tv_p3); if (np > 4) { gather_pred(4, tv_p4); if (np > 5) { gather_pred(5, tv_p5); if (np > 6) { gather_pred(6, tv_p6); if (np > 7) gather_pred(7, tv_p7); } } } } }
+                // predecessors 3..8: ONE copy of the gather code in a run-time loop (code size: the kernel has to live in the 64 KB instruction cache that
+                // two CUs share, and on real graphs the wavefronts of a CU pair are at different places of it)
+                for (int k = 2; k < np; ++k) {
+                    const int tvk = k == 2 ? tv_p2 : (k == 3 ? tv_p3 : (k == 4 ? tv_p4 : (k == 5 ? tv_p5 : (k == 6 ? tv_p6 : tv_p7))));
+                    gather_pred(k, tvk);
+                }
             }
         }
         FSTAMP(1)
@@ -917,12 +923,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 lds_barrier();
                 if (wid == 0) {
                     am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
-                    if ((meta >> 16) & 1) {
-                        if (np == 1) rc = fast_body(std::integral_constant<int, 1>{}, row, ti);
-                        else if (np == 2) rc = fast_body(std::integral_constant<int, 2>{}, row, ti);
-                        else rc = fast_body(std::integral_constant<int, 4>{}, row, ti);
-                    }
-                    if (rc == 0) rc = general_body(row, ti);
+                    rc = general_body(row, ti);
                     mi = -1;
                     if (rc == 1) {
                         if (I16) {
@@ -982,7 +983,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int nch_ = ilp_band(row, ti);
                 if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
                 if (nch_ >= 2) {
-                    const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti);
+                    const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : (nch_ <= 5 ? ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 7>{}, nch_, row, ti));
                     if (ok2 == 1) { WCOUNT(0); commit_row(ti, true); FSTAMP(5) ++row; continue; }
                     WCOUNT(5);
                 }
@@ -990,7 +991,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             am_key = 0; am_val = INT_MIN; am_v = 0; am_isend = 0; am_any = false;
             int rc = 0;
             {
-                if ((meta >> 16) & 1) {
+                if (!WPLAN && ((meta >> 16) & 1)) {      // (the wide kernels keep only the general body as fall-back: code size)
                     if (np == 1) rc = fast_body(std::integral_constant<int, 1>{}, row, ti);
                     else if (np == 2) rc = fast_body(std::integral_constant<int, 2>{}, row, ti);
                     else rc = fast_body(std::integral_constant<int, 4>{}, row, ti);
@@ -1064,6 +1065,9 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     long long fseg[6] = {0, 0, 0, 0, 0, 0};
     rows_fast<T, GAP, NW, WIDEB>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
     const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
+#ifndef ABPOA_HIP_WIDE_COUNTERS
+    fseg[5] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);      // HW_ID | XCC_ID << 32: where the wave ran (ABPOA_HIP_IMBAL placement report)
+#endif
     if (threadIdx.x == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
 }
 
