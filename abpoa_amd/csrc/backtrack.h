@@ -33,7 +33,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     int status = ts.status, best_score = ts.best_score, best_i = ts.best_i, best_j = ts.best_j, bt_steps = 0;
     const long long cursor = ts.cursor, n_cells = ts.n_cells, clk0 = ts.clk0, clk1 = ts.clk1; const int rows_done = ts.rows_done;
     const long long *seg = ts.seg;
-    __syncthreads();       // all of this wave's plane / band stores have landed before the loads below
+    WG_SYNC();       // all of this wave's plane / band stores have landed before the loads below
 
     // ------------------------------------------------------------------ global best, reference :1028-1041
     if (status == 0 && b.align_mode == ABPOA_HIP_GLOBAL_MODE) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         long long win_ticks = 0, win_a = 0; int n_windows = 0;
         auto load_window = [&](int hi) __attribute__((always_inline)) {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
-            __syncthreads();
+            WG_SYNC();
             int lo = imax(0, hi - BTR + 1);
             const int r = lo + lane;
             int my_b = -1, my_e = -1; long long my_c = 0;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 B.poff[i] = pred_off[r]; B.nid[i] = row_node_id[r]; B.base[i] = row_base[r];
             }
             if (lane == 0) { B.coff[hi - lo + 1] = c_end; B.poff[hi - lo + 1] = pred_off[hi + 1]; }
-            __syncthreads();
+            WG_SYNC();
             bt_lo = lo; bt_hi = hi; bt_c0 = B.coff[0]; bt_pbase = B.poff[0]; bt_margin = imin(4, (hi - lo) / 2);
             const int pn_t = imin(BTP, B.poff[hi - lo + 1] - bt_pbase);
             for (int i = lane; i < pn_t; i += 64) B.pred[i] = pred_row[bt_pbase + i];
@@ -100,7 +100,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
             }
-            __syncthreads();
+            WG_SYNC();
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
         // ---- window of the lane-parallel walk (cell-record arenas): rows [hi - R + 1, hi] x columns [jtop - WC + 1, jtop].  The walk
@@ -111,7 +111,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         bool win_narrow = false;                                  // the window holds whole rows (every cell of a window row is staged)
         auto load_window_cols = [&](int hi, int jtop) __attribute__((always_inline)) {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
-            __syncthreads();
+            WG_SYNC();
             const int max_rec = (int)(bt_cells / (CW > 0 ? CW : 1));
             // columns of a slice: a path advances one column per step but 1.5-2.5 rows (bubbles of the graph), and the window holds max_rec records,
             // so slices are kept narrow enough for ~30 rows (measured on 10 kb reads: 32 columns with 16-byte records, 16 with 32-byte records;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 B.rinfo2[li] = sl | (ns << 16);
                 B.srcoff[li] = c_ + (long long)(sl - pbc) * CW;
             }
-            __syncthreads();
+            WG_SYNC();
             const long long tw1b = (long long)__builtin_amdgcn_s_memtime(); win_a += tw1b - tw1;       // (debug split: scan + LDS tables)
             // the window's predecessor rows travel with the cell copy below (issued here, waited for with the first batch of cells)
             int prv[BTP / 64];
@@ -161,23 +161,42 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 const long long c_lo = (long long)(unsigned)__builtin_amdgcn_readlane((int)(c_ & 0xffffffffll), l0) | ((long long)__builtin_amdgcn_readlane((int)(c_ >> 32), l0) << 32);
                 const int n16 = (int)((long long)__builtin_amdgcn_readlane(incl, 63) * CW * (int)sizeof(T) / 16);
                 const int4 *src = (const int4 *)(planes + c_lo); int4 *dst = (int4 *)bt;
-                constexpr int NB = 24;                       // 24 x 64 lanes x 16 bytes = the whole 24 KB window in one HBM round trip
-                for (int i0 = 0; i0 < n16; i0 += 64 * NB) {
-                    int4 v[NB];
+                // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at a wave-uniform LDS base + 16 * lane): the whole window is in flight in
+                // one HBM round trip and passes through no vector registers
+                // (the instruction takes its LDS base from M0: used only for windows that end below 64 KB of the workgroup's LDS; the large windows of
+                //  small launches go through registers, 12 x 16 bytes per lane and round trip)
+                const unsigned bt_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)bt;
+                if (bt_lds + (unsigned)n16 * 16u + 1024u <= 65536u) {
+                    for (int i0 = 0; i0 < n16; i0 += 64) {
+                        const int idx = i0 + lane;
+                        if (idx < n16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx), (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
+                    }
+                } else {
+                    constexpr int NB = 12;
+                    for (int i0 = 0; i0 < n16; i0 += 64 * NB) {
+                        int4 v[NB];
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; gld_async(v[u], src + (idx < n16 ? idx : 0)); }
-                    gld_wait();
+                        for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; gld_async(v[u], src + (idx < n16 ? idx : 0)); }
+                        gld_wait();
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
+                        for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
+                    }
                 }
             } else {
                 // slices: lane = column inside the slice, 16 rows per batch; the per-row constants travel by v_readlane, not through LDS
                 const int offv = off_rec * CW; const long long srcv = c_ + (long long)(sl - pbc) * CW;
                 const int src_lo = (int)(srcv & 0xffffffffll), src_hi = (int)(srcv >> 32);
-                for (int r0 = 0; r0 < nrow; r0 += 16) {
-                    RecT v[16][PIECES]; int nn[16], oo[16];
+                // rows per batch: 16; in the all-rounds kernel (128 vector registers per wavefront) as many as keep the batch within 32 registers --
+                // a register that is the target of a load in flight must never be spilled between the load and its wait
+#ifdef ABPOA_HIP_ONE_WAVE_PHASE
+                constexpr int RB = (int)(PIECES * sizeof(RecT)) >= 32 ? 4 : ((int)(PIECES * sizeof(RecT)) >= 16 ? 8 : 16);
+#else
+                constexpr int RB = 16;
+#endif
+                for (int r0 = 0; r0 < nrow; r0 += RB) {
+                    RecT v[RB][PIECES]; int nn[RB], oo[RB];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
+                    for (int u = 0; u < RB; ++u) {
                         const int rr = imin(r0 + u, nrow - 1) + (lo - lo64);
                         nn[u] = (r0 + u < nrow) ? __builtin_amdgcn_readlane(ns, rr) : 0; oo[u] = __builtin_amdgcn_readlane(offv, rr);
                         const long long so = (long long)(unsigned)__builtin_amdgcn_readlane(src_lo, rr) | ((long long)__builtin_amdgcn_readlane(src_hi, rr) << 32);
@@ -185,9 +204,9 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
 #pragma unroll                                                                                                           // conditional one is waited for at once)
                         for (int q_ = 0; q_ < PIECES; ++q_) gld_async(v[u][q_], src + q_);
                     }
-                    gld_wait();                             // all 16 loads in flight, one wait (hipcc pairs load / wait / store otherwise)
+                    gld_wait();                             // all loads of the batch in flight, one wait (hipcc pairs load / wait / store otherwise)
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
+                    for (int u = 0; u < RB; ++u) {
                         RecT *dst = (RecT *)(bt + oo[u]) + lane * PIECES;
 #pragma unroll
                         for (int q_ = 0; q_ < PIECES; ++q_) if (lane < nn[u]) dst[q_] = v[u][q_];
@@ -203,7 +222,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 const int4 ri_ = B.rinfo[ok ? pr_ - lo : 0];
                 B.edge[e] = make_int4(pr_, ok ? ri_.x : 0, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int4(ri_.z, ri_.w, B.rinfo2[ok ? pr_ - lo : 0], 0);      // (not staged: empty band)
             }
-            __syncthreads();
+            WG_SYNC();
             bt_lo = lo; bt_hi = hi; bt_pbase = pbase; win_i = hi; win_j = jtop; win_narrow = narrow;
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
         };
@@ -601,7 +620,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         if (status == 0) {
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
             if (n_cigar > 0) { const int base_ = ((n_cigar - 1) >> 6) << 6; flush_cigar(base_, n_cigar - base_); }
-            __syncthreads();
+            WG_SYNC();
             if (!b.rev_cigar) for (int k = lane; k < n_cigar >> 1; k += 64) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
             node_e = row_node_id[best_i]; query_e = best_j - 1;
             node_s = row_node_id[start_i]; query_s = start_j - 1;

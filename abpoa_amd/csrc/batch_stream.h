@@ -28,7 +28,7 @@ struct Blob {                   // device buffer with optional pinned host mirro
     void release();
 };
 
-struct StreamStats { int64_t n_launches = 0, n_alignments = 0, n_cells = 0, algo_bytes = 0; double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0, tail_ms = 0; };
+struct StreamStats { int64_t n_launches = 0, n_alignments = 0, n_cells = 0, algo_bytes = 0; double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0, tail_ms = 0, rounds_ms = 0; int64_t rounds_launches = 0, rounds_algo_bytes = 0; };
 
 class BatchStream {
   public:

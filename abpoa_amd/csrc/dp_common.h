@@ -194,7 +194,15 @@ template <int G> __device__ __forceinline__ unsigned group_allmax_u32(unsigned x
 }
 // workgroup barrier for LDS hand-overs only: waits for this wave's LDS operations, NOT for its outstanding global stores
 // (__syncthreads() would add s_waitcnt vmcnt(0), i.e. the HBM round trip of the score-plane stores, to every row)
+// ABPOA_HIP_ONE_WAVE_PHASE (poa_rounds.hip): the row loop and the tail run on ONE wavefront of a larger workgroup whose other wavefronts wait at
+// a workgroup barrier for it -- an s_barrier inside the phase would release them, so a "barrier" is then only the wait for this wave's own operations
+#ifdef ABPOA_HIP_ONE_WAVE_PHASE
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define WG_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define WG_SYNC() __syncthreads()
+#endif
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ int wave_scan_add_i32(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);

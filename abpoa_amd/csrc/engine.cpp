@@ -55,7 +55,7 @@ int engine_device() { return g.ready ? g.device : -1; }
 void add_global_stats(const StreamStats &s) {
     std::lock_guard<std::mutex> lk(g.stats_mu);
     g.stats.n_launches += s.n_launches; g.stats.n_alignments += s.n_alignments; g.stats.n_cells += s.n_cells;
-    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms; g.stats.tail_ms += s.tail_ms;
+    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms; g.stats.tail_ms += s.tail_ms; g.stats.rounds_ms += s.rounds_ms; g.stats.rounds_launches += s.rounds_launches; g.stats.rounds_algo_bytes += s.rounds_algo_bytes;
 }
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

@@ -63,7 +63,7 @@ struct Layout {                // byte offsets inside the three device blobs
     size_t o_cnode, o_ccov, o_cbase;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
-    size_t o_aln_desc, o_out_rec, o_rbase, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
+    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
 };
 
 // Heaviest-bundling consensus (reference src/abpoa_output.c:361-415, :343-356) straight from the flat device arrays, walking
@@ -185,6 +185,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * POA_ALN_CAP); L.o_row = take(4 * node_tot);
     L.graph_bytes = o;
     o = 0;
+    L.o_ticket = take(4 * POA_CU_TICKETS);
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
     L.o_rbase = take(node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
@@ -281,8 +282,29 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     b.dp_beg_sn = (int32_t *)(dr + L.o_bsn); b.dp_end_sn = (int32_t *)(dr + L.o_esn); b.row_cell_off = (int64_t *)(dr + L.o_coff); b.row_max_i = (int32_t *)(dr + L.o_rmi);
     b.planes = C.planes.dev; b.cigar = p.cigar;
 
-    // ---- the whole progressive alignment, queued back to back (ABPOA_HIP_DEVSYNC=1: synchronise and report after every kernel)
+    // ---- all-rounds kernel (poa_rounds.hip) for jobs whose reads all take the narrow row loop: round 1 runs as separate launches (the upload of the
+    //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
+    //      per phase and round throughout (what the wide-band jobs use, and the per-round diagnostics below).
     const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
+    bool use_rounds = !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
+    DevBatch b_r = b; size_t rounds_lds = 0;
+    if (use_rounds) {
+        auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), (size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0)); };
+        rounds_lds = dyn_of(b_r);
+        int st_lds = 0; int nb = poa_rounds_residency(sc->gap_mode, rounds_lds, &st_lds);
+        // four workgroups per CU when the job has that many sets: the kernel's static LDS (graph phases) comes out of the backtrack window
+        if (nb < 4 && n_sets > nb * 256) {
+            const int budget = 160 * 1024 / 4 - st_lds - 512, excess = (int)rounds_lds - budget;
+            if (excess > 0 && (size_t)b_r.lds.total_tail == rounds_lds && b_r.lds.bt_bytes_tail - ((excess + 15) & ~15) >= 8 * 1024) {
+                b_r.lds.bt_bytes_tail -= (excess + 15) & ~15; b_r.lds.total_tail -= (excess + 15) & ~15;
+                rounds_lds = dyn_of(b_r); nb = poa_rounds_residency(sc->gap_mode, rounds_lds, &st_lds);
+            }
+        }
+        if (nb < 1) use_rounds = false;
+        if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] all-rounds kernel: %s, %zu B dynamic + %d B static LDS per workgroup, %d workgroups per CU, backtrack window %d B\n", use_rounds ? "on" : "off", rounds_lds, st_lds, nb, b_r.lds.bt_bytes_tail);
+    }
+
+    // ---- the whole progressive alignment, queued back to back (ABPOA_HIP_DEVSYNC=1: synchronise and report after every kernel)
     auto stage = [&](const char *what, int k) -> int {
         if (!dbg_sync) return 0;
         fprintf(stderr, "[poa-device] round %d: %s queued\n", k, what); fflush(stderr);
@@ -354,6 +376,12 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             HIP_OK(hipStreamWaitEvent(st, C.ev_copy, 0), ABPOA_HIP_ELAUNCH);
             rest_up = true;
         }
+        if (use_rounds && k == 2) {      // rounds 2 .. n - 1 of every set in one launch
+            HIP_OK(hipEventRecord(C.ev[2], st), ABPOA_HIP_ELAUNCH);
+            HIP_OK(launch_poa_rounds(p, b_r, (int32_t *)(dr + L.o_ticket), slot, 2, rounds_lds, st), ABPOA_HIP_ELAUNCH);
+            HIP_OK(hipEventRecord(C.ev[3], st), ABPOA_HIP_ELAUNCH);
+            break;
+        }
         p.round = k;
         hipEvent_t *e = C.ev.data() + 4 * k;
         HIP_OK(launch_poa_prepare(p, st), ABPOA_HIP_ELAUNCH);
@@ -399,13 +427,21 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     if (stats) {
         float ms = 0;
         hipEvent_t prev = C.ev[1];
-        for (int k = 1; k < max_reads; ++k) {
+        for (int k = 1; k < (use_rounds ? 2 : max_reads); ++k) {
             hipEvent_t *e = C.ev.data() + 4 * k;
             (void)hipEventElapsedTime(&ms, prev, e[0]); stats->prepare_ms += ms;
             (void)hipEventElapsedTime(&ms, e[0], e[1]); stats->rows_ms += ms;
             (void)hipEventElapsedTime(&ms, e[1], e[2]); stats->tail_ms += ms;
             (void)hipEventElapsedTime(&ms, e[2], e[3]); stats->fuse_ms += ms;
             prev = e[3];
+        }
+        if (use_rounds) {      // the all-rounds kernel: its duration, split by the shader-clock ticks the sets spent in each phase (PoaState.t_phase)
+            (void)hipEventElapsedTime(&ms, C.ev[2], C.ev[3]); stats->rounds_ms = ms; stats->rounds_launches = 1;
+            const PoaState *hs_ = (const PoaState *)(C.graph.host + L.o_state);
+            double tp[4] = {0, 0, 0, 0}, tmax = 0; for (int s = 0; s < n_sets; ++s) { double t_ = 0; if (hs_[s].status == POA_ST_OK) stats->rounds_algo_bytes += hs_[s].algo_bytes - hs_[s].algo_bytes_before; for (int i = 0; i < 4; ++i) { tp[i] += (double)hs_[s].t_phase[i]; t_ += (double)hs_[s].t_phase[i]; } tmax = std::max(tmax, t_); }
+            const double tall = tp[0] + tp[1] + tp[2] + tp[3];
+            if (tall > 0) { stats->prepare_ms += ms * tp[0] / tall; stats->rows_ms += ms * tp[1] / tall; stats->tail_ms += ms * tp[2] / tall; stats->fuse_ms += ms * tp[3] / tall;
+                            for (int i = 0; i < 4; ++i) stats->rounds_mticks[i] = tp[i] / n_sets * 1e-6; stats->rounds_rows_share = tp[1] / tall; stats->rounds_mean_over_max = n_sets > 0 && tmax > 0 ? tall / n_sets / tmax : 0; }
         }
         stats->n_rounds = max_reads > 0 ? max_reads - 1 : 0; stats->device_s = t_done - t_queue;
     }

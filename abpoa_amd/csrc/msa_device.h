@@ -11,6 +11,11 @@ struct DeviceRunStats {
     double prepare_ms, rows_ms, tail_ms, fuse_ms;     // summed kernel durations (hipEvents on the job's stream)
     double device_s, cons_s, total_s;                 // wall: first launch -> graphs on the host; consensus; whole call
     int64_t n_cells, algo_bytes, n_alignments; int32_t n_rounds, pad;
+    // all-rounds kernel (poa_rounds.hip), when the job took it: launches, their duration, the share of the sets' clock ticks spent in the row loop, and
+    // mean set / slowest set (how much of the kernel's duration the average workgroup was busy); rows_ms .. fuse_ms above then hold the duration split by phase
+    double rounds_ms, rounds_rows_share, rounds_mean_over_max; int32_t rounds_launches, pad2;
+    int64_t rounds_algo_bytes;     // algorithmic bytes of the cells computed inside the all-rounds kernel
+    double rounds_mticks[4];      // mean per set: 10^6 shader-clock ticks in prepare / row loop / backtrack / fuse
 };
 
 // true when the scoring / output options can run on the device-resident path (global, banded, affine or convex gaps,

@@ -66,8 +66,10 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             DeviceRunStats &tot = R.tot;
             tot.prepare_ms += ds.prepare_ms; tot.rows_ms += ds.rows_ms; tot.tail_ms += ds.tail_ms; tot.fuse_ms += ds.fuse_ms; tot.device_s += ds.device_s; tot.cons_s += ds.cons_s;
             tot.total_s += ds.total_s; tot.n_cells += ds.n_cells; tot.algo_bytes += ds.algo_bytes; tot.n_alignments += ds.n_alignments; tot.n_rounds += ds.n_rounds;
+            tot.rounds_ms += ds.rounds_ms; tot.rounds_launches += ds.rounds_launches; tot.rounds_algo_bytes += ds.rounds_algo_bytes;
             if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %.0fx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
                                                      device, pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
+            if (getenv("ABPOA_HIP_VERBOSE") && ds.rounds_launches) fprintf(stderr, "[abpoa-hip]   all-rounds kernel: %.1f ms (the phase times above are its duration split by the sets' clock ticks); mean set busy %.0f %% of it; mean set, 10^6 ticks: prepare %.1f, row loop %.1f, backtrack %.1f, fuse %.1f\n", ds.rounds_ms, 100.0 * ds.rounds_mean_over_max, ds.rounds_mticks[0], ds.rounds_mticks[1], ds.rounds_mticks[2], ds.rounds_mticks[3]);
             at += nb;
         }
         if (R.device_ok) todo.swap(left);
@@ -150,6 +152,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
             todo.insert(todo.end(), R.left.begin(), R.left.end());
             tot.prepare_ms += R.tot.prepare_ms; tot.rows_ms += R.tot.rows_ms; tot.tail_ms += R.tot.tail_ms; tot.fuse_ms += R.tot.fuse_ms; tot.cons_s += R.tot.cons_s;
             tot.n_cells += R.tot.n_cells; tot.algo_bytes += R.tot.algo_bytes; tot.n_alignments += R.tot.n_alignments; tot.n_rounds += R.tot.n_rounds;
+            tot.rounds_ms += R.tot.rounds_ms; tot.rounds_launches += R.tot.rounds_launches; tot.rounds_algo_bytes += R.tot.rounds_algo_bytes;
             tot.device_s += R.tot.device_s; tot.total_s += R.tot.total_s;
         }
         if (rc_dev != ABPOA_HIP_OK) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); return rc_dev; }
@@ -157,7 +160,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
         if (device_ok) {
             std::sort(todo.begin(), todo.end());
             StreamStats ss; ss.n_launches = tot.n_rounds; ss.n_alignments = tot.n_alignments; ss.n_cells = tot.n_cells; ss.algo_bytes = tot.algo_bytes;
-            ss.kernel_ms = tot.rows_ms; ss.tail_ms = tot.tail_ms; add_global_stats(ss);
+            ss.kernel_ms = tot.rows_ms; ss.tail_ms = tot.tail_ms; ss.rounds_ms = tot.rounds_ms; ss.rounds_launches = tot.rounds_launches; ss.rounds_algo_bytes = tot.rounds_algo_bytes; add_global_stats(ss);
             memset(&g_timing, 0, sizeof(g_timing));
             g_timing.engine_s = tot.device_s; g_timing.cons_s = tot.cons_s; g_timing.total_s = tot.total_s; g_timing.n_rounds = tot.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = n_q;
             g_timing.host_sort_s = tot.prepare_ms / 1e3; g_timing.host_fuse_s = tot.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph

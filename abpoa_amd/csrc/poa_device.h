@@ -39,6 +39,8 @@ struct PoaState {                  // mutable per read-set
     int32_t cons_len, pad1;        // heaviest-bundling consensus length (poa_consensus_kernel)
     int64_t n_cells;               // DP cells over all alignments so far
     int64_t algo_bytes;            // cells * algorithmic bytes per cell (affine 5S, convex 8S; S = 2 | 4)
+    int64_t algo_bytes_before;     // algo_bytes when the all-rounds kernel took the set over (what it computed itself = algo_bytes - this)
+    int64_t t_phase[4];            // all-rounds kernel (poa_rounds.hip): shader-clock ticks this set spent in prepare / row loop / backtrack / fuse
 };
 
 struct PoaDev {                    // everything the poa_* kernels need; passed by value
@@ -68,5 +70,9 @@ hipError_t launch_poa_init(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s);
+// poa_rounds.hip: rounds k_lo .. n_reads - 1 of every set in one launch (narrow-band jobs), and how many of its workgroups a CU holds
+constexpr int POA_CU_TICKETS = 4096;      // per-CU ticket counters of the all-rounds kernel (index: XCC id, SE, SH, CU), zeroed by the launch
+hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_ticket, int slot, int k_lo, size_t lds_bytes, hipStream_t s);
+int poa_rounds_residency(int gap_mode, size_t lds_bytes, int *static_lds);
 
 }  // namespace abpoa_hip

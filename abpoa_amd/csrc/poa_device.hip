@@ -13,54 +13,9 @@
 // which topological order is used (predecessor lists keep their in_id order, band and remaining length are functions of
 // the graph), and the batch driver's tests check the consensus of every set against the host driver, which keeps the
 // reference's order.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <limits.h>
-#include "poa_device.h"
-#include "../../include/abpoa_hip.h"
+#include "poa_bodies.h"      // helpers, poa_prepare_body, poa_fuse_body
 
 namespace abpoa_hip {
-
-namespace {
-
-__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
-// loads of data that OTHER lanes of this wave stored earlier in the same kernel: agent scope = not served from this CU's L1
-__device__ __forceinline__ int ld_fresh(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// slot t of a node's edge lists (X = node0 + node id): the first POA_HOT slots are in the hot arrays
-__device__ __forceinline__ int32_t &in_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_in[X * POA_HOT + t] : p.nd_inx[X * (POA_IN_CAP - POA_HOT) + t - POA_HOT]; }
-__device__ __forceinline__ int32_t &out_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_out[X * POA_HOT + t] : p.nd_outx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT]; }
-__device__ __forceinline__ int32_t &outw_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_outw[X * POA_HOT + t] : p.nd_outwx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT]; }
-__device__ __forceinline__ int shfl(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-
-template <int CTRL> __device__ __forceinline__ int dpp_(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false); }
-// inclusive prefix sum / max over the 64 lanes
-__device__ __forceinline__ int wave_scan_add(int x) {
-    x += dpp_<0x111>(0, x); x += dpp_<0x112>(0, x); x += dpp_<0x114>(0, x); x += dpp_<0x118>(0, x);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
-    return x;
-}
-__device__ __forceinline__ int wave_scan_max(int x) {
-    x = imax_(x, dpp_<0x111>(x, x)); x = imax_(x, dpp_<0x112>(x, x)); x = imax_(x, dpp_<0x114>(x, x)); x = imax_(x, dpp_<0x118>(x, x));
-    x = imax_(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));
-    x = imax_(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
-    return x;
-}
-// value of lane-1, lane 0 receives `lane0`
-
-// reference src/simd_abpoa_align.c:1672-1683 (same arithmetic as abpoa_hip_score_bits in engine.cpp)
-__device__ __forceinline__ int score_bits(const PoaDev &p, int n_rows, int qlen, int *inf_min) {
-    const int oe1 = p.o1 + p.e1, oe2 = p.o2 + p.e2;
-    const int len = qlen > n_rows ? qlen : n_rows;
-    const int max_score = imax_(qlen * p.max_mat, len * p.e1 + p.o1);
-    int bits, lo;
-    if (max_score <= INT16_MAX - p.min_mis - oe1 - oe2) { bits = 16; lo = INT16_MIN; } else { bits = 32; lo = INT32_MIN; }
-    *inf_min = imax_(imax_(lo + p.min_mis, lo + oe1), lo + oe2) + 31 * imax_(p.e1, p.e2);
-    return bits;
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 // round 0: the first read of every set becomes the backbone chain (reference abpoa_add_graph_sequence, :486-502)
@@ -69,7 +24,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
-    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; }
+    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0; st->algo_bytes_before = 0; }
     if (S.n_reads <= 0) { if (lane == 0) { st->n_nodes = 2; st->status = POA_ST_OK; } return; }
     const int L = p.read_len[S.read0];
     const uint8_t *seq = p.reads + p.read_off[S.read0];
@@ -96,342 +51,15 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// before the DP of round k: remaining length, rows in order with their predecessor CSR, alignment descriptor
-// Four wavefronts per read-set: the row-parallel parts (heaviest edge, CSR) are latency-bound gathers, and four waves per SIMD hide
-// most of that latency; the reverse sweep of the remaining length is sequential over 64-row blocks and runs on wavefront 0.
-// workgroup size of the row-parallel graph kernels: 4 wavefronts per read-set (8 measured slower: the serial parts on wavefront 0 and the barriers dominate)
-constexpr int GT = 256, GW = GT / 64;
-
+// lock-step rounds: one launch per phase and round, every read-set at round p.round (bodies: poa_bodies.h)
 __global__ void __launch_bounds__(GT) poa_prepare_kernel(const PoaDev p) {
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (s >= p.n_sets) return;
-    const PoaSet S = p.sets[s];
-    PoaState *st = p.state + s;
-    AlnDesc *ad = p.aln + s;
-    const int k = p.round;
-    const int status = st->status, n = st->n_nodes;
-    // Early exit for sets that will outgrow their node slots: new nodes per read stay close to constant over the first reads
-    // (most errors are novel), so ten reads predict the final size well; failing at once saves the rest of a doomed pass.
-    bool doomed = false;
-    if (status == POA_ST_OK && (k == 10 || k == 5) && S.n_reads > 20) {      // (read 5: only a clear miss, 25 % over; read 10: any)
-        const int n0 = p.read_len[S.read0] + 2;
-        const long long projected = (long long)n + (long long)(n - n0) * (S.n_reads - k) * 8 / (10 * k);
-        doomed = k == 10 ? projected > S.node_cap : projected * 4 > (long long)S.node_cap * 5;
-        if (doomed && tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 6; }
-    }
-    if (status != POA_ST_OK || doomed || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it
-        if (tid == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
-        return;
-    }
-    const int64_t N0 = S.node0;
-    const int32_t *order = p.row_node[st->order_buf] + N0;
-    int32_t *nxt = p.scratch + S.scratch0;                 // [n] row of the heaviest successor
-    int32_t *remain = p.row_remain + N0;
-    // (1) heaviest out-edge per row (first maximum wins, reference :262-268)
-    extern __shared__ unsigned jump_lds[];                 // [n] remaining-length jump records (see (2)), when the launch provides them
-    const bool in_lds = p.pad > 0 && n <= p.pad;
-    uint8_t *np_lds = (uint8_t *)(jump_lds + p.pad);       // [n] in-degree per row (row 0: none), for (3)
-    if (in_lds) {
-        // four rows per thread and pass, every load level issued for all four before the next one: the chain order -> node -> edge
-        // slots -> row of the successor is four dependent HBM/L2 round trips, and a thread owns ~10 rows
-        for (int r0 = tid; r0 < n; r0 += 4 * GT) {
-            int u[4], no[4], ni[4], bs[4], best[4], nx[4]; int4 w4[4], o4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; u[j] = order[r < n ? r : 0]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t X = N0 + u[j];
-                no[j] = p.nd_nout[X]; ni[j] = p.nd_nin[X]; bs[j] = p.nd_base[X];
-                w4[j] = *(const int4 *)(p.nd_outw + X * POA_HOT); o4[j] = *(const int4 *)(p.nd_out + X * POA_HOT);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int bw = -1, bb = -1;
-                if (no[j] > 0 && w4[j].x > bw) { bw = w4[j].x; bb = o4[j].x; }
-                if (no[j] > 1 && w4[j].y > bw) { bw = w4[j].y; bb = o4[j].y; }
-                if (no[j] > 2 && w4[j].z > bw) { bw = w4[j].z; bb = o4[j].z; }
-                if (no[j] > 3 && w4[j].w > bw) { bw = w4[j].w; bb = o4[j].w; }
-                for (int t = POA_HOT; t < no[j]; ++t) { const int w = outw_slot(p, N0 + u[j], t); if (w > bw) { bw = w; bb = out_slot(p, N0 + u[j], t); } }
-                best[j] = bb;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nx[j] = best[j] >= 0 ? p.nd_row[N0 + best[j]] : -1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = r0 + j * GT;
-                if (r < n) {
-                    jump_lds[r] = nx[j] >= 0 ? ((unsigned)nx[j] << 16) | 1u : ((unsigned)r << 16);
-                    np_lds[r] = (uint8_t)(r > 0 ? ni[j] : 0);
-                    p.row_base[N0 + r] = (uint8_t)bs[j]; p.row_node_id[N0 + r] = u[j];
-                }
-            }
-        }
-    } else
-    for (int r = tid; r < n; r += GT) {
-        const int u = order[r];
-        const int no = p.nd_nout[N0 + u];
-        int best_w = -1, best = -1;
-        for (int t = 0; t < no; ++t) { const int w = outw_slot(p, N0 + u, t); if (w > best_w) { best_w = w; best = out_slot(p, N0 + u, t); } }
-        nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
-        p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
-    }
-    __syncthreads();
-    // (2) remaining length = (edges to the sink along heaviest successors) - 1, reference :233-274.
-    if (in_lds) {
-        // Pointer jumping over all rows at once in LDS.  A record "row of a later node on the chain << 16 | edges up to it" is one
-        // 32-bit word, so a row may read a neighbour's record while that neighbour is being advanced: either version is a valid jump.
-        for (int span = 1; span < n; span <<= 1) {
-            for (int r = tid; r < n; r += GT) {
-                const unsigned w = jump_lds[r]; const int t = (int)(w >> 16);
-                if (t != r) { const unsigned wt = jump_lds[t]; jump_lds[r] = (wt & 0xffff0000u) | ((w & 0xffffu) + (wt & 0xffffu)); }
-            }
-            __syncthreads();
-        }
-        for (int r = tid; r < n; r += GT) remain[r] = (int)(jump_lds[r] & 0xffffu) - 1;
-    } else
-    // (graphs too large for the LDS records) reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping
-    if (wave == 0) for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
-        const int r = t0 + lane;
-        int tgt = r < n ? ld_fresh(nxt + r) : -1, dist = 1, val = 0; bool done = r >= n;
-        if (!done && tgt < 0) { val = -1; done = true; }                         // the sink (reference :247)
-        if (!done && tgt >= t0 + 64) { val = ld_fresh(remain + tgt) + 1; done = true; }
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int src = (!done) ? tgt - t0 : lane;
-            const int t_tgt = shfl(tgt, src), t_dist = shfl(dist, src), t_val = shfl(val, src), t_done = shfl((int)done, src);
-            if (!done) {
-                if (t_done) { val = t_val + dist; done = true; }
-                else { tgt = t_tgt; dist += t_dist; }
-            }
-        }
-        if (r < n) remain[r] = val;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores are write-through: once acknowledged, later blocks read them from L2 (ld_fresh)
-    }
-    // (3) predecessor CSR in row order (in_id order kept, reference pre_index[][] :519-530)
-    __shared__ int wtot[GW];
-    int carry = 0; bool overflow = false;
-    for (int t0 = 0; t0 < n; t0 += GT) {
-        const int r = t0 + tid;
-        const int u = (r < n && !in_lds) ? order[r] : 0;
-        const int np = r < n ? (in_lds ? (int)np_lds[r] : (r > 0 ? (int)p.nd_nin[N0 + u] : 0)) : 0;
-        const int incl = wave_scan_add(np);
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        int before = 0, all = 0;
-#pragma unroll
-        for (int w_ = 0; w_ < GW; ++w_) { const int x_ = wtot[w_]; all += x_; before += w_ < wave ? x_ : 0; }
-        const int off = carry + before + incl - np;
-        if (r < n) p.pred_off[N0 + r] = off;
-        if (off + np > S.pred_cap) overflow = true;
-        else if (!in_lds) for (int t = 0; t < np; ++t) p.pred_row[S.pred0 + off + t] = p.nd_row[N0 + in_slot(p, N0 + u, t)];
-        carry += all;
-        __syncthreads();
-    }
-    if (in_lds) {      // the lists themselves, four rows per thread and pass (see (1)); pred_off is read back by the thread that wrote it
-        for (int r0 = tid; r0 < n; r0 += 4 * GT) {
-            int u[4], np[4], off[4]; int4 i4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; const bool ok = r < n; u[j] = order[ok ? r : 0]; np[j] = ok ? (int)np_lds[r] : 0; off[j] = p.pred_off[N0 + (ok ? r : 0)]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { if (off[j] + np[j] > S.pred_cap) np[j] = 0; i4[j] = *(const int4 *)(p.nd_in + (N0 + u[j]) * POA_HOT); }
-            int pr[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pr[j][0] = np[j] > 0 ? p.nd_row[N0 + i4[j].x] : 0; pr[j][1] = np[j] > 1 ? p.nd_row[N0 + i4[j].y] : 0;
-                pr[j][2] = np[j] > 2 ? p.nd_row[N0 + i4[j].z] : 0; pr[j][3] = np[j] > 3 ? p.nd_row[N0 + i4[j].w] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int32_t *dst = p.pred_row + S.pred0 + off[j];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) if (t < np[j]) dst[t] = pr[j][t];
-                for (int t = POA_HOT; t < np[j]; ++t) dst[t] = p.nd_row[N0 + in_slot(p, N0 + u[j], t)];
-            }
-        }
-    }
-    if (tid == 0) p.pred_off[N0 + n] = carry;
-    overflow = __syncthreads_or(overflow);
-    // (4) alignment descriptor of this round
-    if (tid == 0) {
-        AlnDesc d; memset(&d, 0, sizeof(d));
-        const int qlen = p.read_len[S.read0 + k];
-        d.n_rows = n; d.qlen = qlen;
-        d.bits = score_bits(p, n, qlen, &d.inf_min);
-        d.w = p.wb + (int)(p.wf * (float)qlen);            // reference :445 (float32 product)
-        d.cigar_cap = S.cigar_cap; d.flags = ALN_FAST_OK; d.pad0 = 0;
-        d.query_off = p.read_off[S.read0 + k]; d.row0 = N0; d.poff0 = N0; d.pred0 = S.pred0; d.out0 = 0;
-        d.plane_off = S.plane_off; d.plane_cap = S.plane_cap / (d.bits / 8); d.cigar_off = S.cigar_off;
-        if (overflow || n + qlen + 8 > S.cigar_cap) { st->status = POA_ST_FALLBACK; st->pad = overflow ? 2 : 3; d.flags = 0; d.n_rows = 3; }
-        p.aln[s] = d;
-        p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0;
-    }
+    if ((int)blockIdx.x >= p.n_sets) return;
+    poa_prepare_body(p, blockIdx.x, p.round);
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// after the backtrack of round k: fuse the graph cigar of read k into the graph and extend the row order
-// Four wavefronts per read-set; the walk over the query (F2) takes GT positions per pass.
 __global__ void __launch_bounds__(GT) poa_fuse_kernel(const PoaDev p) {
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_fail, sh_nodes, wtot[GW];
-    if (s >= p.n_sets) return;
-    const PoaSet S = p.sets[s];
-    PoaState *st = p.state + s;
-    const int k = p.round;
-    if (st->status != POA_ST_OK || k >= S.n_reads) return;
-    const AlnOut res = p.out[s];
-    if (res.status != 0) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 1000 + res.status; } return; }
-    const int64_t N0 = S.node0;
-    const int n_old = st->n_nodes, qlen = p.read_len[S.read0 + k], n_cigar = res.n_cigar;
-    const uint8_t *seq = p.reads + p.read_off[S.read0 + k];
-    const uint64_t *cg = p.cigar + S.cigar_off;
-    const int cur = st->order_buf;
-    const int32_t *order_old = p.row_node[cur] + N0; int32_t *order_new = p.row_node[cur ^ 1] + N0;
-    int32_t *cand = p.scratch + S.scratch0, *n_anchor = cand + p.max_qlen, *n_j = n_anchor + p.max_qlen, *addcnt = n_j + p.max_qlen;
-    if (n_cigar == 0) return;                                                   // reference :614-616
-    // F0/F1: node every query base is aligned to (-1: inserted base)
-    for (int q = tid; q < qlen; q += GT) cand[q] = -1;
-    for (int r = tid; r < n_old; r += GT) addcnt[r] = 0;
-    __syncthreads();
-    for (int i = tid; i < n_cigar; i += GT) {
-        const uint64_t w = cg[i];
-        if ((int)(w & 0xf) == ABPOA_HIP_CMATCH) cand[(int)((w >> 4) & 0x3fffffff)] = (int)((w >> 34) & 0x3fffffff);
-    }
-    __syncthreads();
-    // F2: walk the query in chunks of 64 positions
-    int n_nodes = n_old, prev_c = 0 /* source */, prev_new_c = 0, carry_ar = 0 /* row of the source */, carry_sq = -1;
-    bool fail = false;
-    // adds edge from -> to (both lane-private; `from_new` / `to_new`: the node was created by this read, its lists are still empty
-    // apart from what this very walk put there, which is known without a load)
-    auto add_edge = [&](bool act, int from, bool from_new, int to, bool to_new) {
-        if (!act) return;
-        const int64_t F = N0 + from, T = N0 + to;
-        int no = from_new ? 0 : (int)p.nd_nout[F];
-        int hit = -1;
-        if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (out_slot(p, F, t) == to) { hit = t; break; }
-        if (hit >= 0) outw_slot(p, F, hit) += 1;
-        else {
-            const int ni = to_new ? 0 : (int)p.nd_nin[T];
-            if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; return; }
-            out_slot(p, F, no) = to; outw_slot(p, F, no) = 1; p.nd_nout[F] = (uint8_t)(no + 1);
-            in_slot(p, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
-        }
-        p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
-    };
-    // all wavefronts walk the query together, GT positions per pass: per-position work (node lookup, new node, edge) is private to
-    // its thread; what flows along the path (new-node ids, previous node, the running maxima AR / sq) crosses wavefronts through LDS
-    __shared__ int sCnt[GW], sMax[GW], sSqm[GW], sNode[GT], sIsNew[GT], sAR[GT], sSq[GT];
-    for (int q0 = 0; q0 < qlen; q0 += GT) {
-        const int q = q0 + tid; const bool act = q < qlen;
-        const int c = act ? ld_fresh(cand + q) : -1;
-        const int b = act ? (int)seq[q] : 0;
-        int node = -1; bool isnew = act;
-        if (act && c >= 0) {
-            if ((int)p.nd_base[N0 + c] == b) { node = c; isnew = false; }
-            else {                                                              // reference abpoa_get_aligned_id :377-386
-                const int na = p.nd_naln[N0 + c];
-                for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + c) * POA_ALN_CAP + t]; if ((int)p.nd_base[N0 + a] == b) { node = a; isnew = false; break; } }
-            }
-        }
-        // group-end row of the aligned group that places this position in the row order (see the bookkeeping below); read before
-        // the group is extended
-        int gv = -1;
-        if (act && c >= 0) {
-            const int ref = isnew ? c : node;
-            gv = p.nd_row[N0 + ref];
-            const int na = p.nd_naln[N0 + ref];
-            for (int t = 0; t < na; ++t) gv = imax_(gv, p.nd_row[N0 + p.nd_aln[(N0 + ref) * POA_ALN_CAP + t]]);
-        }
-        // exchange 1: ids of the new nodes (path order) and the running maximum AR
-        const unsigned long long newmask = __ballot(isnew);
-        const int rank = __builtin_popcountll(newmask & ((1ull << lane) - 1));
-        const int gmax_w = wave_scan_max(gv);
-        if (lane == 63) { sCnt[wave] = __builtin_popcountll(newmask); sMax[wave] = gmax_w; }
-        __syncthreads();
-        int before_cnt = 0, n_new = 0, before_max = carry_ar;
-#pragma unroll
-        for (int w_ = 0; w_ < GW; ++w_) { const int x_ = sCnt[w_]; n_new += x_; if (w_ < wave) { before_cnt += x_; before_max = imax_(before_max, sMax[w_]); } }
-        if (n_nodes + n_new > S.node_cap) { fail = true; break; }                // (the same in every thread)
-        if (isnew) node = n_nodes + before_cnt + rank;
-        if (isnew) {
-            const int64_t Y = N0 + node;
-            p.nd_base[Y] = (uint8_t)b; p.nd_nin[Y] = 0; p.nd_nout[Y] = 0; p.nd_naln[Y] = 0; p.nd_nread[Y] = 0;
-            if (c >= 0) {                                                       // mismatch: new node joins c's aligned group, reference :393-401
-                const int na = p.nd_naln[N0 + c];
-                if (na + 1 > POA_ALN_CAP) fail = true;
-                else {
-                    for (int t = 0; t < na; ++t) {
-                        const int other = p.nd_aln[(N0 + c) * POA_ALN_CAP + t];
-                        const int no_ = p.nd_naln[N0 + other];                   // == na for every member of the group
-                        p.nd_aln[(N0 + other) * POA_ALN_CAP + no_] = node; p.nd_naln[N0 + other] = (uint8_t)(no_ + 1);
-                        p.nd_aln[Y * POA_ALN_CAP + t] = other;
-                    }
-                    p.nd_aln[(N0 + c) * POA_ALN_CAP + na] = node; p.nd_naln[N0 + c] = (uint8_t)(na + 1);
-                    p.nd_aln[Y * POA_ALN_CAP + na] = c; p.nd_naln[Y] = (uint8_t)(na + 1);
-                }
-            }
-        }
-        // row-order bookkeeping.  Invariant (the reference's Kahn walk keeps it too, abpoa_graph.c:213-224): the members of an
-        // aligned group are contiguous in the row order.  A new node is therefore spliced in right after the END of a group:
-        // the group of the node it mismatches (which it joins), or the group of the nearest old node before it on the path,
-        // whichever comes later -- i.e. after row AR = running maximum along the path of "group-end row" (old nodes: their own
-        // group; mismatch nodes: the group they join; inserted bases: none).  New nodes with the same AR form a run in path order.
-        const int AR = imax_(gmax_w, before_max);
-        // exchange 2: the previous position on the path (thread - 1; thread 0: last position of the previous pass).  The barrier also
-        // orders the new nodes' initialisation above before the edge updates below.
-        sNode[tid] = node; sIsNew[tid] = (int)isnew; sAR[tid] = AR;
-        __syncthreads();
-        const int prev = tid > 0 ? sNode[tid - 1] : prev_c, prev_new = tid > 0 ? sIsNew[tid - 1] : prev_new_c, prevAR = tid > 0 ? sAR[tid - 1] : carry_ar;
-        add_edge(act, prev, prev_new != 0, node, isnew);
-        const bool start = isnew && (prev_new == 0 || prevAR != AR);
-        const int sq_w = wave_scan_max(start ? q : -1);
-        if (lane == 63) sSqm[wave] = sq_w;
-        __syncthreads();
-        int sq = imax_(sq_w, carry_sq);
-#pragma unroll
-        for (int w_ = 0; w_ < GW; ++w_) if (w_ < wave) sq = imax_(sq, sSqm[w_]);
-        if (isnew) { n_anchor[node - n_old] = AR; n_j[node - n_old] = q - sq + 1; atomicAdd(addcnt + AR, 1); }
-        sSq[tid] = sq;
-        __syncthreads();
-        // carries into the next pass (from the last active position)
-        const int lt = imin_(GT - 1, qlen - 1 - q0);
-        prev_c = sNode[lt]; prev_new_c = sIsNew[lt]; carry_ar = sAR[lt]; carry_sq = sSq[lt];
-        n_nodes += n_new;
-    }
-    // F3: last node -> sink (reference :667)
-    bool any_fail = __syncthreads_or(fail);
-    if (!any_fail) { add_edge(tid == 0, prev_c, prev_new_c != 0, 1, false); any_fail = __syncthreads_or(fail); }
-    if (tid == 0) { sh_fail = any_fail ? 1 : 0; sh_nodes = n_nodes; }
-    __syncthreads();
-    if (sh_fail) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }
-    n_nodes = sh_nodes;
-    // F4: new row order = old order with every run of new nodes spliced in after its anchor
-    int carry = 0;
-    for (int t0 = 0; t0 < n_old; t0 += GT) {
-        const int r = t0 + tid;
-        const int cnt = r < n_old ? ld_fresh(addcnt + r) : 0;
-        const int incl = wave_scan_add(cnt);
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        int before = 0, all = 0;
-#pragma unroll
-        for (int w_ = 0; w_ < GW; ++w_) { const int x_ = wtot[w_]; all += x_; before += w_ < wave ? x_ : 0; }
-        const int shift = carry + before + incl - cnt;      // new nodes anchored at earlier rows
-        if (r < n_old) { const int u = order_old[r]; order_new[r + shift] = u; p.nd_row[N0 + u] = r + shift; addcnt[r] = shift; }
-        carry += all;
-        __syncthreads();
-    }
-    __syncthreads();
-    for (int i = tid; i < n_nodes - n_old; i += GT) {
-        const int ar = ld_fresh(n_anchor + i), j = ld_fresh(n_j + i);
-        const int nr = ar + ld_fresh(addcnt + ar) + j;
-        order_new[nr] = n_old + i; p.nd_row[N0 + n_old + i] = nr;
-    }
-    if (tid == 0) {
-        st->n_nodes = n_nodes; st->order_buf = cur ^ 1; st->n_cells += res.n_cells;
-        st->algo_bytes += res.n_cells * (p.aln[s].bits / 8) * (p.gap_mode == ABPOA_HIP_AFFINE_GAP ? 5 : 8);
-    }
+    if ((int)blockIdx.x >= p.n_sets) return;
+    poa_fuse_body(p, blockIdx.x, p.round);
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // after the last round: heaviest-bundling consensus, reference src/abpoa_output.c:361-415 (scores) and :343-356 (path).

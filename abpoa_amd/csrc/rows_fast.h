@@ -131,7 +131,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = tid; i < m * m1; i += NT) { const int bb = i / m1, qc = i - bb * m1; s_mx[i] = qc < m ? g_mat[bb * m + qc] : 0; } }
     for (int i = tid; i < RR * NPW * RCS; i += NT) { const int pl = (i / RCS) % NPW; fr[i] = (I16 && pl == 0) ? infw : inf; }
     if (NW > 1 && tid < 16) xch[tid] = make_int4(INT_MIN, INT_MIN, I16 ? 0 : INT_MIN, 0);      // entries of absent wavefronts stay neutral
-    __syncthreads();
+    WG_SYNC();
     auto ring_put = [&](int slot, int x, int H, int E1, int E2) __attribute__((always_inline)) {
         int *q = fr + slot * (NPW * RCS) + 2 + x;
         if (I16) { q[0] = (int)(((unsigned)H & 0xffffu) | ((unsigned)E1 << 16)); if (GAP == 2) q[RCS] = E2; }
@@ -166,7 +166,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         cur = (end_sn0 + 1) * CW;
         if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = 0; }     // source: successors get left = right = 1 (:556-561)
-        if (NW > 1) __syncthreads();               // ring row 0 was written by every wavefront
+        if (NW > 1) WG_SYNC();               // ring row 0 was written by every wavefront
     }
 
     // ------------------------------------------------------------------ static metadata, two tiles ahead
@@ -1030,7 +1030,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (rb <= last_done) { if (wid == 0) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
                                if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1; }
     }
-    __syncthreads();
+    WG_SYNC();
     // ---- max_pos_left/right as the reference leaves them (only when the caller reads them back)
     if (status == 0 && b.want_lr && wid == 0) {
         for (int r = lane; r < gn; r += 64) {
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     io.planes = (T *)(b.planes + d.plane_off);
     uint8_t *s_query = lds_raw + b.lds.q_off;
     { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = (NW > 1 ? (int)threadIdx.x : lane); i < d.qlen; i += NW * 64) s_query[i] = g_query[i]; }
-    __syncthreads();
+    WG_SYNC();
     long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
     const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
     long long fseg[6] = {0, 0, 0, 0, 0, 0};
@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
 #ifndef ABPOA_HIP_WIDE_COUNTERS
     fseg[5] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);      // HW_ID | XCC_ID << 32: where the wave ran (ABPOA_HIP_IMBAL placement report)
 #endif
-    if (threadIdx.x == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
+    if (NW > 1 ? threadIdx.x == 0 : lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
 }
 
 

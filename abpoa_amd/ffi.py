@@ -42,7 +42,8 @@ class Result(C.Structure):           # abpoa_hip_result_t
 
 class Stats(C.Structure):            # abpoa_hip_stats_t
     _fields_ = [("n_launches", C.c_int64), ("n_alignments", C.c_int64), ("n_cells", C.c_int64),
-                ("algo_bytes", C.c_int64), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("tail_ms", C.c_double)]
+                ("algo_bytes", C.c_int64), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("tail_ms", C.c_double),
+                ("rounds_ms", C.c_double), ("rounds_launches", C.c_int64), ("rounds_algo_bytes", C.c_int64)]
 
 
 FLAG_TRACE = 0x1

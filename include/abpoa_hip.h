@@ -132,6 +132,12 @@ typedef struct abpoa_hip_stats_t {
     double  h2d_ms, d2h_ms;      /* copy durations (same events)                                      */
     double  tail_ms;             /* fast path only: global-best + backtrack kernel (dp_fast_tail_kernel), timed apart
                                     from the row-loop kernel that kernel_ms then covers alone                          */
+    double  rounds_ms;           /* read-set driver, narrow-band jobs: duration of the all-rounds kernel launches
+                                    (poa_rounds_kernel: graph -> rows, row loop, backtrack, cigar -> graph of every round
+                                    after the first).  kernel_ms / tail_ms then hold the row loop's / backtrack's share of
+                                    it, split by the shader-clock ticks the read-sets spent in each phase             */
+    int64_t rounds_launches;
+    int64_t rounds_algo_bytes;   /* algorithmic bytes of the DP cells computed inside those launches                 */
 } abpoa_hip_stats_t;
 
 /* ---- engine life cycle ------------------------------------------------------------------------ */

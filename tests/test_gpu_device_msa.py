@@ -40,12 +40,18 @@ def engine():
     ("convex_default", dict(), (24, 12, 500, 0.10)),
     ("ragged_tiny", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (16, 5, 40, 0.05)),
 ])
-def test_device_driver_equals_host_driver(engine, name, kw, shape):
-    from abpoa_amd import api, synth
+@pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
+def test_device_driver_equals_host_driver(engine, monkeypatch, name, kw, shape, lockstep):
+    """Both forms of the device driver: every set through all its rounds in one kernel (poa_rounds.hip; ragged sets: the sets of a batch
+    have different numbers of reads), and one launch per phase and round (ABPOA_HIP_LOCKSTEP=1)."""
+    from abpoa_amd import api, ffi, synth
+    monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", str(lockstep))
     n_sets, n_reads, ln, err = shape
     sets = [synth.make_read_set(11, i, n_reads if i % 5 else max(2, n_reads // 2), ln, err) for i in range(n_sets)]
+    engine.abpoa_hip_reset_stats()
     host, dev, tm = _both(sets, api.Params(**kw))
     assert tm["n_groups"] == 1 and tm["pad"] == 0, f"device driver not used for every set: {tm}"
+    assert (ffi.stats()["rounds_launches"] > 0) == (lockstep == 0), ffi.stats()
     for i, (a, b) in enumerate(zip(dev, host)):
         assert a.status == 0 and b.status == 0
         assert a.cons_seq == b.cons_seq, f"{name}: consensus of set {i} differs"
