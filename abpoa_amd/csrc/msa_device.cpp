@@ -406,6 +406,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 for (size_t i_ = 0; i_ < pl.size(); ++i_) { const bool sh_ = (i_ > 0 && pl[i_ - 1].first == pl[i_].first) || (i_ + 1 < pl.size() && pl[i_ + 1].first == pl[i_].first); (sh_ ? t_sh : t_al) += (double)ho[pl[i_].second].clk_dp; (sh_ ? n_sh : n_al)++; }
                 fprintf(stderr, "[poa-device] round %d placement: %d alignments alone on their SIMD (mean ticks %.0f), %d sharing one (mean ticks %.0f)\n", k, n_al, n_al ? t_al / n_al : 0.0, n_sh, n_sh ? t_sh / n_sh : 0.0);
             }
+            if ((b.dbg & 128) && getenv("ABPOA_HIP_ROW_CENSUS")) {      // (library built with -DABPOA_HIP_ROW_CENSUS) rows and ticks per body of the narrow row loop, mean per alignment
+                double rw[6] = {0, 0, 0, 0, 0, 0}, tk[6] = {0, 0, 0, 0, 0, 0}; for (const AlnOut &o_ : ho) for (int q_ = 0; q_ < 6; ++q_) { rw[q_] += (double)(o_.seg[q_] >> 40); tk[q_] += (double)(o_.seg[q_] & ((1ll << 40) - 1)); }
+                const char *nm_[5] = {"1 predecessor", "2 predecessors", "3-4 predecessors", "exact bodies", "tile switches"};
+                fprintf(stderr, "[poa-device] round %d narrow-loop census per alignment:", k);
+                for (int q_ = 0; q_ < 5; ++q_) fprintf(stderr, " %s %.0f x %.0f ticks |", nm_[q_], rw[q_] / n_sets, rw[q_] > 0 ? tk[q_] / rw[q_] : 0.0);
+                double why[3] = {0, 0, 0}; for (const AlnOut &o_ : ho) { why[0] += (double)(o_.seg[5] >> 40); why[1] += (double)((o_.seg[5] >> 20) & 0xfffff); why[2] += (double)(o_.seg[5] & 0xfffff); }
+                fprintf(stderr, " exact-body rows: > 4 predecessors %.0f, straight-line body declined %.0f, predecessor beyond the ring %.0f\n", why[0] / n_sets, why[1] / n_sets, why[2] / n_sets);
+            }
             if ((b.dbg & 128) && getenv("ABPOA_HIP_WIDE_COUNTERS")) { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_; const AlnOut &o_ = ho[w_];
                 fprintf(stderr, "[poa-device] round %d slowest row loop: set %d ticks %lld rows %d | all-chunk body %lld | not eligible %lld | ring-geometry %lld | > 5 chunks %lld | slow vectors straddle %lld | key window / wrap %lld\n", k, w_, (long long)o_.clk_dp, o_.n_rows_done, (long long)o_.seg[0], (long long)o_.seg[1], (long long)o_.seg[2], (long long)o_.seg[3], (long long)o_.seg[4], (long long)o_.seg[5]); }
             if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr, "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible (preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key window / wrap %.0f\n", k, sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);

@@ -71,6 +71,15 @@ __device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pr
 // Timing-only ablation switches (tools/kernel_bench.py with ABPOA_HIP_DBG=bits on the "prof" build): results are wrong on purpose.
 // Diagnostic builds (-DABPOA_HIP_WIDE_COUNTERS, with ABPOA_HIP_DBG=128 so that the tail keeps them): rows per path of the wide loop in AlnOut.seg --
 // 0 wide body, 1 not eligible (predecessor count / distance), 2 ring / geometry, 3 wider than NW chunks, 4 slow vectors span two wavefronts, 5 wrap guard
+// -DABPOA_HIP_ROW_CENSUS (same hand-over): rows and clock ticks per body of the NARROW loop -- seg[i] = rows << 40 | ticks for i = 0 one predecessor
+// (tight loop), 1 two predecessors (tight loop), 2 three / four predecessors (straight-line body), 3 the exact bodies (fast / general); 4 = tile switches
+#ifdef ABPOA_HIP_ROW_CENSUS
+#define CENSUS_T0() const long long cen_t0 = (long long)__builtin_amdgcn_s_memtime();
+#define CENSUS(I) { fseg[I] += (1ll << 40) + ((long long)__builtin_amdgcn_s_memtime() - cen_t0); }
+#else
+#define CENSUS_T0()
+#define CENSUS(I)
+#endif
 #ifdef ABPOA_HIP_WIDE_COUNTERS
 #define WCOUNT(I) { fseg[I] += 1; }
 #else
@@ -194,7 +203,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int dk = myrow - b1.p[k]; fastrow = fastrow && dk >= 1 && dk < RR; }
         tv_meta = (a1.base & 0xff) | (imin(np, 255) << 8) | (fastrow ? (1 << 16) : 0);
-        if (!WPLAN) tv_meta |= ((fastrow && np <= 2 && RC <= 128) ? (1 << 17) : 0) | ((fastrow && np >= 3 && RC <= 128) ? (1 << 18) : 0);      // bit 17: straight-line body (pads 128 ring columns)
+        if (!WPLAN) {
+            tv_meta |= ((fastrow && np <= 2 && RC <= 128) ? (1 << 17) : 0) | ((fastrow && np >= 3 && RC <= 128) ? (1 << 18) : 0);      // bit 17: straight-line body (pads 128 ring columns)
+            bool row8 = np >= 5 && np <= 8 && myrow < gn - 1 && myrow >= 1 && RC <= 128;      // bit 20: five to eight predecessors, all in the score ring: the straight-line body's widest copy
+#pragma unroll
+            for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; row8 = row8 && dk >= 1 && dk < RR; }
+            tv_meta |= row8 ? (1 << 20) : 0;
+        }
         else {                                       // bit 19: the row may take the wide body (1..8 predecessors, all inside the score ring)
             bool widerow = np >= 1 && np <= 8 && myrow < gn - 1 && myrow >= 1;
 #pragma unroll
@@ -336,7 +351,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int lane4 = lane * 4;
     // arg-max key constants (normal / end_sn vector): lane residue, vector priority, and -- never decisive, it only saves the decoding -- the lane
     const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)(NV - 1 - vvl) << 8) | (unsigned)lane), kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (8u << 8) | (unsigned)lane);
-    auto turbo_body = [&](auto npc, int row, int ti) __attribute__((always_inline)) -> int {
+    auto turbo_body = [&](auto npc, auto slowc, int row, int ti) __attribute__((always_inline)) -> int {
+        constexpr bool SLOWV = decltype(slowc)::value;      // handles vectors beyond every predecessor's band (the tight loop's copies do not: they decline and the row comes back here)
         constexpr int NPC = decltype(npc)::value;
         const int tb = __builtin_amdgcn_readlane(tv_tb, ti);
         const int p0 = row - (tb & 0xff);
@@ -349,18 +365,30 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             g1 = __builtin_amdgcn_readlane(vg_geo, p1 & 63); const int m1_ = __builtin_amdgcn_readlane(vg_mi, p1 & 63);
             mn = sgpr(imin(m0, m1_)); mx = sgpr(imax(m0, m1_)); min_pb = imin(pb0, g1 & 0xfff); max_pe = imax(pe0, (g1 >> 12) & 0xfff); ring &= g1;
         }
-        if (NPC == 4) {      // three or four predecessors (np at run time); a missing fourth repeats the third
+        if (NPC >= 4) {      // three or four predecessors (np at run time); a missing fourth repeats the third
             p2 = __builtin_amdgcn_readlane(tv_p2, ti); p3 = np > 3 ? __builtin_amdgcn_readlane(tv_p3, ti) : p2;
             g2 = __builtin_amdgcn_readlane(vg_geo, p2 & 63); g3 = __builtin_amdgcn_readlane(vg_geo, p3 & 63);
             const int m2_ = __builtin_amdgcn_readlane(vg_mi, p2 & 63), m3_ = __builtin_amdgcn_readlane(vg_mi, p3 & 63);
             mn = sgpr(imin(mn, imin(m2_, m3_))); mx = sgpr(imax(mx, imax(m2_, m3_)));
             min_pb = imin(min_pb, imin(g2 & 0xfff, g3 & 0xfff)); max_pe = imax(max_pe, imax((g2 >> 12) & 0xfff, (g3 >> 12) & 0xfff)); ring &= g2 & g3;
         }
+        int px[4] = {p0, p0, p0, p0}, gx[4] = {g0, g0, g0, g0};
+        if (NPC == 8) {      // five to eight predecessors: the list entries past the last one repeat it (load_b), so all eight are read
+            px[0] = __builtin_amdgcn_readlane(tv_p4, ti); px[1] = __builtin_amdgcn_readlane(tv_p5, ti); px[2] = __builtin_amdgcn_readlane(tv_p6, ti); px[3] = __builtin_amdgcn_readlane(tv_p7, ti);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gx[j] = __builtin_amdgcn_readlane(vg_geo, px[j] & 63); const int mj_ = __builtin_amdgcn_readlane(vg_mi, px[j] & 63);
+                mn = imin(mn, mj_); mx = imax(mx, mj_); min_pb = imin(min_pb, gx[j] & 0xfff); max_pe = imax(max_pe, (gx[j] >> 12) & 0xfff); ring &= gx[j];
+            }
+            mn = sgpr(mn); mx = sgpr(mx);
+        }
         set_band(std::true_type{}, mn, mx, min_pb);
         const int nvr = end_sn - beg_sn + 1;
         // all conditions as sign bits: (x <= y) <=> (x - y - 1) < 0
         // (arena room: checked for a full-width row, cap_turbo = cap_pn - NV * CW)
-        const int okbits = (nvr - NV - 1) & (end_sn - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7);      // GEO_RING (bit 24) -> bit 31
+        // (vectors beyond every predecessor's band -- one new vector every PN rows as the band moves right -- are taken below with the literal
+        //  masked scan; the closed form needs at least the first vector inside: max_pe >= beg_sn)
+        const int okbits = (nvr - NV - 1) & ((SLOWV ? beg_sn : end_sn) - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7);      // GEO_RING (bit 24) -> bit 31
         if (__builtin_expect(okbits >= 0, 0)) return 0;
         const int Wr = nvr * PN;
         if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
@@ -380,7 +408,17 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // the second predecessor's words go out with the first one's: both LDS reads are in flight together
         int rb0 = 0, rb1 = 0, rb2 = inf, x1 = 0, Wp1 = 0;
         int rc0 = 0, rc1 = 0, rc2 = inf, x2 = 0, Wp2 = 0, rd0 = 0, rd1 = 0, rd2 = inf, x3 = 0, Wp3 = 0;
-        if (NPC == 4) {
+        int re0[4] = {0, 0, 0, 0}, re1[4] = {0, 0, 0, 0}, re2[4] = {inf, inf, inf, inf}, xe[4] = {0, 0, 0, 0}, We[4] = {0, 0, 0, 0};
+        if (NPC == 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pbj = gx[j] & 0xfff; We[j] = (((gx[j] >> 12) & 0xfff) - pbj + 1) * PN; xe[j] = colrel - pbj * PN;
+                const int *sj = ring_at(__builtin_amdgcn_readlane(vslot, px[j]), med3i(xe[j] - 1, -2, RC));
+                if (I16) { re0[j] = sj[0]; re1[j] = sj[1]; if (GAP == 2) re2[j] = sj[RCS + 1]; }
+                else { re0[j] = sj[0]; re1[j] = sj[RCS + 1]; if (GAP == 2) re2[j] = sj[2 * RCS + 1]; }
+            }
+        }
+        if (NPC >= 4) {
             const int pb2 = g2 & 0xfff, pb3 = g3 & 0xfff; Wp2 = (((g2 >> 12) & 0xfff) - pb2 + 1) * PN; Wp3 = (((g3 >> 12) & 0xfff) - pb3 + 1) * PN;
             x2 = colrel - pb2 * PN; x3 = colrel - pb3 * PN;
             const int *s2 = ring_at(__builtin_amdgcn_readlane(vslot, p2), med3i(x2 - 1, -2, RC)), *s3 = ring_at(__builtin_amdgcn_readlane(vslot, p3), med3i(x3 - 1, -2, RC));
@@ -409,7 +447,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int hm1, ev1, ev2 = inf;
             if (I16) { hm1 = (int)(short)r0_; ev1 = r1_ >> 16; ev2 = r2_; } else { hm1 = r0_; ev1 = r1_; ev2 = r2_; }
             const bool inH = (unsigned)x_ < (unsigned)(Wp_ + PN), inE = (unsigned)x_ < (unsigned)Wp_;
-            if (NPC == 4) kfirst = (inH && hm1 > Mv) ? kidx : kfirst;
+            if (NPC >= 4) kfirst = (inH && hm1 > Mv) ? kidx : kfirst;
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         };
         if (NPC >= 2) {
@@ -417,11 +455,17 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (GAP == 2) asm volatile("" : "+v"(rb2));
             merge_pred(rb0, rb1, rb2, x1, Wp1, 2);
         }
-        if (NPC == 4) {
+        if (NPC >= 4) {
             asm volatile("" : "+v"(rc0), "+v"(rc1), "+v"(rd0), "+v"(rd1));
             if (GAP == 2) asm volatile("" : "+v"(rc2), "+v"(rd2));
             merge_pred(rc0, rc1, rc2, x2, Wp2, 3);
             merge_pred(rd0, rd1, rd2, x3, Wp3, 4);                 // (np == 3: the third predecessor again -- no change, kfirst keeps 3 or less)
+        }
+        if (NPC == 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(re0[j]), "+v"(re1[j])); if (GAP == 2) asm volatile("" : "+v"(re2[j])); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) merge_pred(re0[j], re1[j], re2[j], xe[j], We[j], 5 + j);      // (a repeated last predecessor changes nothing: strict > keeps kfirst)
         }
         const int h = Mv + q;                                      // no wrap possible once the check below passes
         int lowest = imin(h, E1v); if (GAP == 2) lowest = imin(lowest, E2v);
@@ -444,6 +488,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         int F1 = imax(s1_ - cf1, inj1), F2 = inf;
         if (GAP == 2) F2 = imax(s2_ - cf2, inj2);
         if (__builtin_expect(near_wrap, 0)) return 0;
+        if (SLOWV && end_sn > max_pe) {                             // vectors beyond every predecessor's band: literal masked scan (reference :859-875 / :978-997), as chunk_tail
+            const int nfast = max_pe - beg_sn + 1, lastl = nfast * PN - 1;      // 1 <= nfast < nvr
+            const int first = __builtin_amdgcn_readlane(imax(s1_, hs + le1), lastl) - lastl * e1;
+            int first2 = 0; if (GAP == 2) first2 = __builtin_amdgcn_readlane(imax(s2_, hs + le2), lastl) - lastl * e2;
+            T f1t = (T)F1, f2t = (T)F2, fi = (T)first, fi2 = (T)first2;
+            slow_f_vectors<T, GAP>(beg_sn, end_sn, max_pe, nfast, l, vvl, (T)hs, (T)inf, (T)e1, (T)oe1, (T)o1, (T)e2, (T)oe2, (T)o2, f1t, f2t, fi, fi2);
+            F1 = (int)f1t; F2 = (int)f2t;
+        }
         // ---- from here on the row is committed
         off_pn = cur; cur += nvr * CW;
         int Hout, E1out, E2out = inf;
@@ -461,7 +513,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // match flag for the backtrack (spare slot of the record, finish_alignment PL_FLAG): 1 + index of the first predecessor k (list order) with
         // H[k][col-1] + q == H[col], 0 = none.  Only a predecessor that supplies the maximum Mv can satisfy it, and only when H == Mv + q.
         // (A predecessor value read from outside its band is `inf`: the backtrack re-checks the column range before it trusts the flag.)
-        const int mflag = (h == Hout) ? (NPC == 4 ? kfirst : ((NPC == 2 && Mv != Mv_first) ? 2 : 1)) : 0;
+        const int mflag = (h == Hout) ? (NPC >= 4 ? kfirst : ((NPC == 2 && Mv != Mv_first) ? 2 : 1)) : 0;
         if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
@@ -885,11 +937,17 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     fseg_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
     for (int t0 = 0; t0 < gn - 1 && status == 0; t0 += 64) {
+#ifdef ABPOA_HIP_ROW_CENSUS
+        const long long cen_ts = (long long)__builtin_amdgcn_s_memtime();
+#endif
         if (t0 > 0) {       // geometry of the finished tile goes to HBM in one coalesced burst (older predecessors, backtrack, trace)
             const int rb = t0 - 64 + lane; if (wid == 0) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
             if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1;
         }
         switch_tile(t0);
+#ifdef ABPOA_HIP_ROW_CENSUS
+        { asm volatile("" :: "v"(tv_meta), "v"(tv_p0), "v"(tv_tb), "v"(tv_rterm)); fseg[4] += (1ll << 40) + ((long long)__builtin_amdgcn_s_memtime() - cen_ts); }
+#endif
         const int r_hi = imin(t0 + 64, gn - 1);
         auto commit_row = [&](int ti, bool ring) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
             const int geo_new = sgpr(beg_sn | (end_sn << 12) | (ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
@@ -962,22 +1020,33 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int ti_ = row & 63;
                 const int meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
                 if (!__builtin_expect((meta_ >> 17) & 1, 1)) break;
+                CENSUS_T0()
                 rterm = __builtin_amdgcn_readlane(tv_rterm, ti_);
                 base = meta_ & 0xff; np = (meta_ >> 8) & 0xff;
-                ok_ = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, row, ti_) : turbo_body(std::integral_constant<int, 2>{}, row, ti_);
+                ok_ = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, std::false_type{}, row, ti_) : turbo_body(std::integral_constant<int, 2>{}, std::false_type{}, row, ti_);
                 if (__builtin_expect(ok_ != 1, 0)) break;
                 commit_row(ti_, true);
+                CENSUS(np == 1 ? 0 : 1)
                 if (++row >= r_hi) break;
             }
             last_done = row - 1;
             if (row >= r_hi) break;
             const int ti = row & 63;
             last_done = row;
+            CENSUS_T0()
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
             if (!WPLAN && ((meta >> 18) & 1)) {                       // three or four predecessors: the straight-line body, outside the tight loop
-                if (turbo_body(std::integral_constant<int, 4>{}, row, ti)) { commit_row(ti, true); ++row; continue; }
+                if (turbo_body(std::integral_constant<int, 4>{}, std::true_type{}, row, ti)) { commit_row(ti, true); CENSUS(2) ++row; continue; }
+            }
+            if (!WPLAN && ((meta >> 20) & 1)) {                       // five to eight predecessors
+                if (turbo_body(std::integral_constant<int, 8>{}, std::true_type{}, row, ti)) { commit_row(ti, true); CENSUS(2) ++row; continue; }
+            }
+            if (!WPLAN && ((meta >> 17) & 1)) {                       // one or two predecessors and the tight loop declined: most often the row's band reaches one
+                                                                      // vector beyond its predecessors' (every PN-th row of a chain) -- the copies that take those vectors
+                const int ok3 = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, std::true_type{}, row, ti) : turbo_body(std::integral_constant<int, 2>{}, std::true_type{}, row, ti);
+                if (ok3) { commit_row(ti, true); CENSUS(np == 1 ? 0 : 1) ++row; continue; }
             }
             if (WIDEB && ((meta >> 19) & 1)) {                        // wide band: every chunk of the row at once
                 const int nch_ = ilp_band(row, ti);
@@ -1020,6 +1089,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             commit_row(ti, to_ring);
             FSTAMP(4)
+            CENSUS(3)
+#ifdef ABPOA_HIP_ROW_CENSUS
+            fseg[5] += np > 4 ? (1ll << 40) : (((meta >> 16) & 1) ? (1ll << 20) : 1ll);      // why the exact bodies: > 4 predecessors | straight-line body declined | a predecessor beyond the ring
+#endif
             ++row;
         }
         if (status != 0) break;
@@ -1065,7 +1138,7 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     long long fseg[6] = {0, 0, 0, 0, 0, 0};
     rows_fast<T, GAP, NW, WIDEB>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
     const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
-#ifndef ABPOA_HIP_WIDE_COUNTERS
+#if !defined(ABPOA_HIP_WIDE_COUNTERS) && !defined(ABPOA_HIP_ROW_CENSUS)
     fseg[5] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);      // HW_ID | XCC_ID << 32: where the wave ran (ABPOA_HIP_IMBAL placement report)
 #endif
     if (NW > 1 ? threadIdx.x == 0 : lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
