@@ -25,7 +25,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if c == "FETCH_SIZE": launches[k] += 1
 line = json.loads(open("/tmp/pmc_log_WRITE_SIZE.txt").read().strip().split("\n")[-1])
 rounds = line["roofline"]["launches"]
-rows = {k: v for k, v in per_kernel.items() if k.startswith(("dp_fast_kernel", "dp_wide_kernel", "dp_team_kernel", "dp_local_kernel"))}
+# the kernel the bench line's roofline is about: the all-rounds kernel where the job took it (narrow bands), else the row-loop kernels of a round
+all_rounds = "poa_rounds_kernel" in line["roofline"]["kernel"]
+rows = {k: v for k, v in per_kernel.items() if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_team_kernel", "dp_local_kernel"))}
 fetch_kb = sum(v["FETCH_SIZE"] for v in rows.values()); write_kb = sum(v["WRITE_SIZE"] for v in rows.values())
 hbm = (2 * fetch_kb + write_kb) * 1024 / max(1, rounds)
 sys.path.insert(0, root)
@@ -34,7 +36,8 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "rounds
        "hbm_bytes_per_launch": int(hbm), "algo_bytes_per_launch": line["roofline"]["algo_bytes_per_launch"],
        "FETCH_SIZE_KB_raw_per_launch": round(fetch_kb / max(1, rounds), 1), "WRITE_SIZE_KB_per_launch": round(write_kb / max(1, rounds), 1),
        "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies 128-B requests at 64 B)",
-       "launch": "one round of the progressive alignment = the row-loop kernels of that round (all score widths)",
+       "launch": ("one launch of abpoa_hip::poa_rounds_kernel = rounds 2..n of every read-set (graph phases, row loop and backtrack inside: its traffic includes the backtrack's re-read of the arenas)"
+                  if all_rounds else "one round of the progressive alignment = the row-loop kernels of that round (all score widths)"),
        "row_loop_sha": bench.row_loop_sha(),
        "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("ABPOA_COMMIT", "working tree"),
        "all_kernels_MB_per_launch": {k: {"fetch_x2": round(2 * v["FETCH_SIZE"] / 1024 / max(1, rounds), 1), "write": round(v["WRITE_SIZE"] / 1024 / max(1, rounds), 1)} for k, v in per_kernel.items()},
