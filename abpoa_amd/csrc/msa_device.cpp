@@ -58,7 +58,7 @@ Cache g_cache[MSA_DEVICE_SLOTS]; std::mutex g_cache_mu[MSA_DEVICE_SLOTS];      /
 
 struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
-    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, in_bytes;
+    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, in_bytes;
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
     size_t o_cnode, o_ccov, o_cbase;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
@@ -172,7 +172,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     }
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
-    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m);
+    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m); L.o_rargs = take(poa_rounds_args_bytes());      // (o_rargs: host-side staging only)
     L.o_reads = take(tot_bases + 64); L.in_bytes = o;      // reads last: they go up in two parts
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
@@ -300,7 +300,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 rounds_lds = dyn_of(b_r); nb = poa_rounds_residency(sc->gap_mode, rounds_lds, &st_lds);
             }
         }
-        if (nb < 1) use_rounds = false;
+        // The kernel pays when every read-set of the job is resident at once (one workgroup each; 4 per CU): a larger job runs faster with one
+        // launch per phase and round, whose single-wavefront row-loop kernel then has several alignments per SIMD to hide latency behind
+        // (measured, 1 kb reads: 1000 sets 13.0 k vs 10.4 k read-sets/s; 2000 sets 12.9 k vs 13.6 k; 4000 sets 13.2 k vs 17.4 k)
+        int n_cu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cu = pr.multiProcessorCount; }
+        if (nb < 1 || n_sets > nb * n_cu) use_rounds = false;
         if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] all-rounds kernel: %s, %zu B dynamic + %d B static LDS per workgroup, %d workgroups per CU, backtrack window %d B\n", use_rounds ? "on" : "off", rounds_lds, st_lds, nb, b_r.lds.bt_bytes_tail);
     }
 
@@ -378,7 +382,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         }
         if (use_rounds && k == 2) {      // rounds 2 .. n - 1 of every set in one launch
             HIP_OK(hipEventRecord(C.ev[2], st), ABPOA_HIP_ELAUNCH);
-            HIP_OK(launch_poa_rounds(p, b_r, (int32_t *)(dr + L.o_ticket), slot, 2, rounds_lds, st), ABPOA_HIP_ELAUNCH);
+            HIP_OK(launch_poa_rounds(p, b_r, (int32_t *)(dr + L.o_ticket), C.in.host + L.o_rargs, slot, 2, rounds_lds, st), ABPOA_HIP_ELAUNCH);
             HIP_OK(hipEventRecord(C.ev[3], st), ABPOA_HIP_ELAUNCH);
             break;
         }

@@ -72,7 +72,9 @@ hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s);
 // poa_rounds.hip: rounds k_lo .. n_reads - 1 of every set in one launch (narrow-band jobs), and how many of its workgroups a CU holds
 constexpr int POA_CU_TICKETS = 4096;      // per-CU ticket counters of the all-rounds kernel (index: XCC id, SE, SH, CU), zeroed by the launch
-hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_ticket, int slot, int k_lo, size_t lds_bytes, hipStream_t s);
+// host_args: poa_rounds_args_bytes() of pinned host memory that stays valid until the stream has passed the launch (8-byte aligned)
+size_t poa_rounds_args_bytes();
+hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_ticket, void *host_args, int slot, int k_lo, size_t lds_bytes, hipStream_t s);
 int poa_rounds_residency(int gap_mode, size_t lds_bytes, int *static_lds);
 
 }  // namespace abpoa_hip

@@ -96,13 +96,15 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
 }
 
 // dynamic LDS: the largest phase (row loop, backtrack window, the prepare body's per-row records)
-hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_ticket, int slot, int k_lo, size_t lds_bytes, hipStream_t s) {
+size_t poa_rounds_args_bytes() { return sizeof(RoundsArgs); }
+hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_ticket, void *host_args, int slot, int k_lo, size_t lds_bytes, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
     if (slot < 0 || slot >= MSA_DEVICE_SLOTS) return hipErrorInvalidValue;
-    RoundsArgs a; a.p = p; a.b = b; a.cu_ticket = cu_ticket;
+    RoundsArgs &a = *(RoundsArgs *)host_args;      // (the caller's pinned staging memory: it outlives the asynchronous copy)
+    a.p = p; a.b = b; a.cu_ticket = cu_ticket;
     hipError_t e = hipMemsetAsync(cu_ticket, 0, 4 * POA_CU_TICKETS, s);
     if (e != hipSuccess) return e;
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rounds), &a, sizeof(a), sizeof(RoundsArgs) * (size_t)slot, hipMemcpyHostToDevice, s);      // (pageable source: staged by the runtime before the call returns)
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rounds), &a, sizeof(a), sizeof(RoundsArgs) * (size_t)slot, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     if (lds_bytes > 65536) {      // (above 64 KB the kernel's dynamic-LDS limit has to be raised; without it the launch gets 64 KB and the phases read and write past it)
         e = hipFuncSetAttribute(b.gap_mode == ABPOA_HIP_AFFINE_GAP ? (const void *)poa_rounds_kernel<1> : (const void *)poa_rounds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
