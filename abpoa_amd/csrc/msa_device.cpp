@@ -415,6 +415,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 const char *nm_[5] = {"1 predecessor", "2 predecessors", "3-4 predecessors", "exact bodies", "tile switches"};
                 fprintf(stderr, "[poa-device] round %d narrow-loop census per alignment:", k);
                 for (int q_ = 0; q_ < 5; ++q_) fprintf(stderr, " %s %.0f x %.0f ticks |", nm_[q_], rw[q_] / n_sets, rw[q_] > 0 ? tk[q_] / rw[q_] : 0.0);
+                { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_; const AlnOut &o_ = ho[w_];
+                  fprintf(stderr, "\n[poa-device] round %d slowest row loop (set %d, %lld ticks):", k, w_, (long long)o_.clk_dp);
+                  for (int q_ = 0; q_ < 5; ++q_) fprintf(stderr, " %s %lld x %.0f |", nm_[q_], (long long)(o_.seg[q_] >> 40), (o_.seg[q_] >> 40) ? (double)(o_.seg[q_] & ((1ll << 40) - 1)) / (double)(o_.seg[q_] >> 40) : 0.0);
+                  fprintf(stderr, " exact-body rows: > 4 predecessors %lld, straight-line declined %lld, beyond the ring %lld;", (long long)(o_.seg[5] >> 40), (long long)((o_.seg[5] >> 20) & 0xfffff), (long long)(o_.seg[5] & 0xfffff)); }
                 double why[3] = {0, 0, 0}; for (const AlnOut &o_ : ho) { why[0] += (double)(o_.seg[5] >> 40); why[1] += (double)((o_.seg[5] >> 20) & 0xfffff); why[2] += (double)(o_.seg[5] & 0xfffff); }
                 fprintf(stderr, " exact-body rows: > 4 predecessors %.0f, straight-line body declined %.0f, predecessor beyond the ring %.0f\n", why[0] / n_sets, why[1] / n_sets, why[2] / n_sets);
             }

@@ -210,10 +210,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; row8 = row8 && dk >= 1 && dk < RR; }
             tv_meta |= row8 ? (1 << 20) : 0;
         }
-        else {                                       // bit 19: the row may take the wide body (1..8 predecessors, all inside the score ring)
+        {                                            // bit 19: the row may take the all-chunks body (1..8 predecessors, all inside the 64-row geometry ring)
             bool widerow = np >= 1 && np <= 8 && myrow < gn - 1 && myrow >= 1;
 #pragma unroll
-            for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < (WIDEB ? 64 : RR); }      // (single-wave wide loop: older ones come from HBM)
+            for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < ((WIDEB || !WPLAN) ? 64 : RR); }      // (single-wave loops: older ones come from HBM)
             tv_meta |= widerow ? (1 << 19) : 0;
         }
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
@@ -389,7 +389,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // (vectors beyond every predecessor's band -- one new vector every PN rows as the band moves right -- are taken below with the literal
         //  masked scan; the closed form needs at least the first vector inside: max_pe >= beg_sn)
         const int okbits = (nvr - NV - 1) & ((SLOWV ? beg_sn : end_sn) - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7);      // GEO_RING (bit 24) -> bit 31
-        if (__builtin_expect(okbits >= 0, 0)) return 0;
+        // (declined: 0 when the copy that takes vectors beyond the predecessors' bands would accept the row, else -1 -- the caller then goes straight to the exact bodies)
+        if (__builtin_expect(okbits >= 0, 0)) return (!SLOWV && ((nvr - NV - 1) & (beg_sn - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7)) < 0) ? 0 : -1;
         const int Wr = nvr * PN;
         if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
             qc_beg_sn = beg_sn;
@@ -487,7 +488,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else { if (GAP == 2) wave_scan3_iii(s1_, s2_, aval); else wave_scan2_ii(s1_, aval); }
         int F1 = imax(s1_ - cf1, inj1), F2 = inf;
         if (GAP == 2) F2 = imax(s2_ - cf2, inj2);
-        if (__builtin_expect(near_wrap, 0)) return 0;
+        if (__builtin_expect(near_wrap, 0)) return -1;
         if (SLOWV && end_sn > max_pe) {                             // vectors beyond every predecessor's band: literal masked scan (reference :859-875 / :978-997), as chunk_tail
             const int nfast = max_pe - beg_sn + 1, lastl = nfast * PN - 1;      // 1 <= nfast < nvr
             const int first = __builtin_amdgcn_readlane(imax(s1_, hs + le1), lastl) - lastl * e1;
@@ -530,6 +531,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             mi = ((int)(kb >> 16) - 32768 > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
         } else {
             const int vmax = __builtin_amdgcn_readlane(aval, 63);
+            rowmax = vmax;
             const unsigned key = (am_ok && hsE_ == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
             const unsigned kb = wave_max_u32_s(key);
             const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
@@ -554,6 +556,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     //      arg-max key and its wrap flag; a second barrier at the end of the row publishes the ring slot.
     constexpr int NCHX = 7;
     constexpr bool TEAM = NW > 1;
+    int two_chunk_streak = 0;                                       // (narrow kernel) the last row took the two-chunk body with a band of 65-128 columns: the next one tries it first
     int qcx_beg_sn = -1, qcx_c0 = -1, qoffx[NCHX] = {0, 0, 0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk of this wavefront, for band start qcx_beg_sn
     int ilp_far = 0;                                                // bit k: predecessor k of the row is not in the score ring (older than its depth, or a row too wide for it): HBM gather
     auto ilp_band = [&](int row, int ti) __attribute__((always_inline)) -> int {
@@ -951,7 +954,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r_hi = imin(t0 + 64, gn - 1);
         auto commit_row = [&](int ti, bool ring) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
             const int geo_new = sgpr(beg_sn | (end_sn << 12) | (ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
-            if constexpr (WPLAN) {
+            if constexpr (WPLAN || !I16) {            // (vg_vm: the all-chunks body centres its int32 arg-max keys on the first predecessor's row maximum)
                 const int vm_new = sgpr(rowmax);
                 asm volatile("s_mov_b32 m0, %8\n\ts_nop 3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
                              : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off), "+v"(vg_vm) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(vm_new), "s"(ti) : "m0");
@@ -1015,7 +1018,19 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             // ---- tight loop over consecutive straight-line rows: only these merge at its back edge (in one loop with the other row
             //      bodies every row paid ~30 register copies for the merge of all paths)
-            int ok_ = 0;
+            int ok_ = 1;
+            if constexpr (!WPLAN) if (__builtin_expect(two_chunk_streak, 0)) {      // the band is 65-128 columns wide at the moment: straight to the two-chunk body
+                const int ti_ = row & 63, meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
+                if ((meta_ >> 19) & 1) {
+                    CENSUS_T0()
+                    last_done = row;
+                    rterm = __builtin_amdgcn_readlane(tv_rterm, ti_); base = meta_ & 0xff; np = (meta_ >> 8) & 0xff;
+                    const int nch_ = ilp_band(row, ti_);
+                    if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                    if (nch_ == 2 && ilp_chunks(std::integral_constant<int, 2>{}, nch_, row, ti_) == 1) { commit_row(ti_, true); CENSUS(3) ++row; continue; }
+                }
+                two_chunk_streak = 0;
+            }
             if constexpr (!WPLAN) for (;;) {
                 const int ti_ = row & 63;
                 const int meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
@@ -1038,15 +1053,21 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
             if (!WPLAN && ((meta >> 18) & 1)) {                       // three or four predecessors: the straight-line body, outside the tight loop
-                if (turbo_body(std::integral_constant<int, 4>{}, std::true_type{}, row, ti)) { commit_row(ti, true); CENSUS(2) ++row; continue; }
+                if (turbo_body(std::integral_constant<int, 4>{}, std::true_type{}, row, ti) == 1) { commit_row(ti, true); CENSUS(2) ++row; continue; }
             }
             if (!WPLAN && ((meta >> 20) & 1)) {                       // five to eight predecessors
-                if (turbo_body(std::integral_constant<int, 8>{}, std::true_type{}, row, ti)) { commit_row(ti, true); CENSUS(2) ++row; continue; }
+                if (turbo_body(std::integral_constant<int, 8>{}, std::true_type{}, row, ti) == 1) { commit_row(ti, true); CENSUS(2) ++row; continue; }
             }
-            if (!WPLAN && ((meta >> 17) & 1)) {                       // one or two predecessors and the tight loop declined: most often the row's band reaches one
+            if (!WPLAN && ((meta >> 17) & 1) && ok_ == 0) {                       // one or two predecessors and the tight loop declined: most often the row's band reaches one
                                                                       // vector beyond its predecessors' (every PN-th row of a chain) -- the copies that take those vectors
                 const int ok3 = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, std::true_type{}, row, ti) : turbo_body(std::integral_constant<int, 2>{}, std::true_type{}, row, ti);
-                if (ok3) { commit_row(ti, true); CENSUS(np == 1 ? 0 : 1) ++row; continue; }
+                if (ok3 == 1) { commit_row(ti, true); CENSUS(np == 1 ? 0 : 1) ++row; continue; }
+            }
+            if (!WPLAN && ((meta >> 19) & 1)) {                       // narrow kernel, the straight-line bodies declined (a band of 65-128 columns for a stretch of
+                                                                      // rows, a predecessor beyond the score ring, ...): the all-chunks body with two chunks
+                const int nch_ = ilp_band(row, ti);
+                if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
+                if (nch_ >= 1 && nch_ <= 2 && ilp_chunks(std::integral_constant<int, 2>{}, nch_, row, ti) == 1) { two_chunk_streak = nch_ == 2; commit_row(ti, true); CENSUS(3) ++row; continue; }
             }
             if (WIDEB && ((meta >> 19) & 1)) {                        // wide band: every chunk of the row at once
                 const int nch_ = ilp_band(row, ti);
