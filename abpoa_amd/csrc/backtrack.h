@@ -136,7 +136,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int R = narrow ? r_full : imin(n64, imax(4, max_rec / WC));
             const int lo = hi - R + 1, nrow = R, li = lane - (lo - lo64);           // li: index of this lane's row inside the window
             const bool rv = rv64 && li >= 0;
-            const int sl = narrow ? pbc : imax(pbc, jtop - WC + 1), sh = narrow ? pbc + W : imin(pbc + W, jtop + 1), ns = rv ? imax(0, sh - sl) : 0;
+            // (8-byte records: a slice starts and ends on an even column, so that it is a whole number of 16-byte pieces at a 16-byte address -- the band
+            //  starts on a multiple of PN columns and is a multiple of PN wide)
+            constexpr int EVEN = (CW * (int)sizeof(T) == 8) ? 1 : 0;
+            const int sl = narrow ? pbc : imax(pbc, (jtop - WC + 1) & ~EVEN), sh = narrow ? pbc + W : imin(pbc + W, (jtop + 1 + EVEN) & ~EVEN), ns = rv ? imax(0, sh - sl) : 0;
             const int incl = wave_scan_add_i32(ns);
             const int off_rec = incl - ns;
             const int pbase = __builtin_amdgcn_readlane(po, lo - lo64);
@@ -153,8 +156,6 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
 #pragma unroll
             for (int k_ = 0; k_ < BTP / 64; ++k_) { const int e_ = k_ * 64 + lane; gld_async(prv[k_], (const int32_t *)pred_row + pbase + (e_ < pn_t ? e_ : 0)); }
             // staged records: 8 rows per batch, lane = column inside the slice
-            typedef typename std::conditional<(CW * sizeof(T) == 8), int2, int4>::type RecT;       // 8-byte or 16-byte pieces (CW * sizeof(T) = 8, 16 or 32)
-            constexpr int PIECES = (int)(CW * sizeof(T) / sizeof(RecT));
             // narrow bands: every slice is a whole row, and the rows are adjacent in the arena -> one contiguous 16-byte-wide copy
             if (narrow) {
                 const int l0 = lo - lo64;
@@ -163,54 +164,24 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 const int4 *src = (const int4 *)(planes + c_lo); int4 *dst = (int4 *)bt;
                 // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at a wave-uniform LDS base + 16 * lane): the whole window is in flight in
                 // one HBM round trip and passes through no vector registers
-                // (the instruction takes its LDS base from M0: used only for windows that end below 64 KB of the workgroup's LDS; the large windows of
-                //  small launches go through registers, 12 x 16 bytes per lane and round trip)
-                const unsigned bt_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)bt;
-                if (bt_lds + (unsigned)n16 * 16u + 1024u <= 65536u) {
-                    for (int i0 = 0; i0 < n16; i0 += 64) {
-                        const int idx = i0 + lane;
-                        if (idx < n16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx), (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
-                    }
-                } else {
-                    constexpr int NB = 12;
-                    for (int i0 = 0; i0 < n16; i0 += 64 * NB) {
-                        int4 v[NB];
-#pragma unroll
-                        for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; gld_async(v[u], src + (idx < n16 ? idx : 0)); }
-                        gld_wait();
-#pragma unroll
-                        for (int u = 0; u < NB; ++u) { const int idx = i0 + u * 64 + lane; if (idx < n16) dst[idx] = v[u]; }
-                    }
+                // (M0 carries the LDS base; tools/probes/glds_high_lds.hip: it reaches all of the workgroup's LDS, also above 64 KB)
+                for (int i0 = 0; i0 < n16; i0 += 64) {
+                    const int idx = i0 + lane;
+                    if (idx < n16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx), (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
                 }
             } else {
-                // slices: lane = column inside the slice, 16 rows per batch; the per-row constants travel by v_readlane, not through LDS
-                const int offv = off_rec * CW; const long long srcv = c_ + (long long)(sl - pbc) * CW;
+                // slices: one LDS-DMA per row and 1 KB of slice (lane = 16-byte piece of the slice; a slice is contiguous in the arena and in the window);
+                // every row of the window in flight together, no vector registers; the per-row constants travel by v_readlane, not through LDS
+                constexpr int REC = (int)(CW * sizeof(T));               // bytes per cell record: 8, 16 or 32 (8: slices start and end on even columns, below)
+                const int offb = off_rec * REC; const long long srcv = c_ + (long long)(sl - pbc) * CW;
                 const int src_lo = (int)(srcv & 0xffffffffll), src_hi = (int)(srcv >> 32);
-                // rows per batch: 16; in the all-rounds kernel (128 vector registers per wavefront) as many as keep the batch within 32 registers --
-                // a register that is the target of a load in flight must never be spilled between the load and its wait
-#ifdef ABPOA_HIP_ONE_WAVE_PHASE
-                constexpr int RB = (int)(PIECES * sizeof(RecT)) >= 32 ? 4 : ((int)(PIECES * sizeof(RecT)) >= 16 ? 8 : 16);
-#else
-                constexpr int RB = 16;
-#endif
-                for (int r0 = 0; r0 < nrow; r0 += RB) {
-                    RecT v[RB][PIECES]; int nn[RB], oo[RB];
-#pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const int rr = imin(r0 + u, nrow - 1) + (lo - lo64);
-                        nn[u] = (r0 + u < nrow) ? __builtin_amdgcn_readlane(ns, rr) : 0; oo[u] = __builtin_amdgcn_readlane(offv, rr);
-                        const long long so = (long long)(unsigned)__builtin_amdgcn_readlane(src_lo, rr) | ((long long)__builtin_amdgcn_readlane(src_hi, rr) << 32);
-                        const RecT *src = (const RecT *)(planes + so) + (long long)(lane < nn[u] ? lane : 0) * PIECES;      // unconditional loads (a
-#pragma unroll                                                                                                           // conditional one is waited for at once)
-                        for (int q_ = 0; q_ < PIECES; ++q_) gld_async(v[u][q_], src + q_);
-                    }
-                    gld_wait();                             // all loads of the batch in flight, one wait (hipcc pairs load / wait / store otherwise)
-#pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        RecT *dst = (RecT *)(bt + oo[u]) + lane * PIECES;
-#pragma unroll
-                        for (int q_ = 0; q_ < PIECES; ++q_) if (lane < nn[u]) dst[q_] = v[u][q_];
-                    }
+                for (int u = 0; u < nrow; ++u) {
+                    const int rr = u + (lo - lo64);
+                    const int np16 = __builtin_amdgcn_readlane(ns, rr) * REC / 16, ob = __builtin_amdgcn_readlane(offb, rr);
+                    const long long so = (long long)(unsigned)__builtin_amdgcn_readlane(src_lo, rr) | ((long long)__builtin_amdgcn_readlane(src_hi, rr) << 32);
+                    const int4 *src = (const int4 *)(planes + so); unsigned char *dstb = (unsigned char *)bt + ob;
+                    for (int i0 = 0; i0 < np16; i0 += 64)
+                        if (i0 + lane < np16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane), (__attribute__((address_space(3))) void *)(dstb + i0 * 16), 16, 0, 0);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
