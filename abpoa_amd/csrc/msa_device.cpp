@@ -289,7 +289,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     bool use_rounds = !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
     DevBatch b_r = b; size_t rounds_lds = 0;
     if (use_rounds) {
-        auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), (size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0)); };
+        auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), std::max<size_t>((size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), (size_t)16 * 256)); };      // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
         rounds_lds = dyn_of(b_r);
         int st_lds = 0; int nb = poa_rounds_residency(sc->gap_mode, rounds_lds, &st_lds);
         // four workgroups per CU when the job has that many sets: the kernel's static LDS (graph phases) comes out of the backtrack window

@@ -273,7 +273,9 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     };
     // all wavefronts walk the query together, GT positions per pass: per-position work (node lookup, new node, edge) is private to
     // its thread; what flows along the path (new-node ids, previous node, the running maxima AR / sq) crosses wavefronts through LDS
-    __shared__ int sCnt[GW], sMax[GW], sSqm[GW], sNode[GT], sIsNew[GT], sAR[GT], sSq[GT];
+    __shared__ int sCnt[GW], sMax[GW], sSqm[GW];
+    extern __shared__ int fuse_dyn[];                       // dynamic LDS of the launch (4 * GT ints; in the all-rounds kernel the other phases' space)
+    int *const sNode = fuse_dyn, *const sIsNew = fuse_dyn + GT, *const sAR = fuse_dyn + 2 * GT, *const sSq = fuse_dyn + 3 * GT;
     for (int q0 = 0; q0 < qlen; q0 += GT) {
         const int q = q0 + tid; const bool act = q < qlen;
         const int c = act ? ld_fresh(cand + q) : -1;

@@ -166,7 +166,7 @@ hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) {
 }
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
-    hipLaunchKernelGGL(poa_fuse_kernel, dim3(p.n_sets), dim3(GT), 0, s, p);
+    hipLaunchKernelGGL(poa_fuse_kernel, dim3(p.n_sets), dim3(GT), (size_t)16 * GT, s, p);      // (path-exchange records of the fuse body: 4 ints per thread)
     return hipGetLastError();
 }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
