@@ -10,14 +10,16 @@ __global__ void __launch_bounds__(64) dp_fast_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (!takes_fast(b, d) || d.bits != BITS || takes_wide(b, d)) return;           // dp_kernel's, the other width's, or the wide row loop's
-    align_fast_rows<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP>(b, d, b.out + a);
+    if (!takes_fast(b, d) || (BITS != 0 && d.bits != BITS) || takes_wide(b, d)) return;           // dp_kernel's, the other width's, or the wide row loop's
+    if (BITS == 16 || (BITS == 0 && d.bits == 16)) align_fast_rows<int16_t, GAP>(b, d, b.out + a);      // (BITS == 0: both widths in one launch, see dp_wide_rows.hip)
+    else align_fast_rows<int32_t, GAP>(b, d, b.out + a);
 }
 
 template <int GAP>
 static hipError_t launch_rows_gap(const DevBatch &b, hipStream_t stream) {
     const int mask = b.bits_mask ? b.bits_mask : 3;
     hipError_t e = hipSuccess;
+    if (mask == 3) return launch_one(dp_fast_kernel<GAP, 0>, b, stream, b.lds.total_rows);
     if (mask & 1) e = launch_one(dp_fast_kernel<GAP, 16>, b, stream, b.lds.total_rows);
     if (e == hipSuccess && (mask & 2)) e = launch_one(dp_fast_kernel<GAP, 32>, b, stream, b.lds.total_rows);
     return e;

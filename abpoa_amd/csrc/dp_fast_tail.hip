@@ -8,14 +8,16 @@ __global__ void __launch_bounds__(64) dp_fast_tail_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (!(takes_fast(b, d) || takes_local(b, d)) || d.bits != BITS) return;
-    align_fast_tail<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP>(b, d, b.out + a);
+    if (!(takes_fast(b, d) || takes_local(b, d)) || (BITS != 0 && d.bits != BITS)) return;
+    if (BITS == 16 || (BITS == 0 && d.bits == 16)) align_fast_tail<int16_t, GAP>(b, d, b.out + a);      // (BITS == 0: both widths in one launch, see dp_wide_rows.hip)
+    else align_fast_tail<int32_t, GAP>(b, d, b.out + a);
 }
 
 template <int GAP>
 static hipError_t launch_tail_gap(const DevBatch &b, hipStream_t stream) {
     const int mask = b.bits_mask ? b.bits_mask : 3;
     hipError_t e = hipSuccess;
+    if (mask == 3) return launch_one(dp_fast_tail_kernel<GAP, 0>, b, stream, b.lds.total_tail);
     if (mask & 1) e = launch_one(dp_fast_tail_kernel<GAP, 16>, b, stream, b.lds.total_tail);
     if (e == hipSuccess && (mask & 2)) e = launch_one(dp_fast_tail_kernel<GAP, 32>, b, stream, b.lds.total_tail);
     return e;

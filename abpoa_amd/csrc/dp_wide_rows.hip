@@ -12,8 +12,11 @@ __global__ void __launch_bounds__(NW * 64) dp_wide_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (!takes_fast(b, d) || d.bits != BITS || !takes_wide(b, d)) return;
-    align_fast_rows<typename std::conditional<BITS == 16, int16_t, int32_t>::type, GAP, NW, NW == 1>(b, d, b.out + a);
+    if (!takes_fast(b, d) || (BITS != 0 && d.bits != BITS) || !takes_wide(b, d)) return;
+    // BITS == 0: both score widths in one launch.  A job whose graphs outgrow int16 on the way has a few rounds in which some read-sets are still
+    // int16 and the others already int32; two launches (one per width) would run one after the other, each with the other's SIMDs idle.
+    if (BITS == 16 || (BITS == 0 && d.bits == 16)) align_fast_rows<int16_t, GAP, NW, NW == 1>(b, d, b.out + a);
+    else align_fast_rows<int32_t, GAP, NW, NW == 1>(b, d, b.out + a);
 }
 
 template <int GAP, int NW>
@@ -27,6 +30,7 @@ static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, dp_wide_kernel<GAP, 32, NW>, NW * 64, (size_t)b.lds.total_wide);
         fprintf(stderr, "[abpoa-hip] wide row loop: %d wavefronts per alignment, %d B of LDS per workgroup, ring %d rows x %d columns, workgroups per CU: %d (int16) %d (int32)\n", NW, b.lds.total_wide, b.lds.wfr_rows, b.lds.wfr_cols, nb16, nb32);
     }
+    if (mask == 3 && NW == 1) return launch_one(dp_wide_kernel<GAP, 0, NW>, b, stream, b.lds.total_wide, NW * 64);
     if (mask & 1) e = launch_one(dp_wide_kernel<GAP, 16, NW>, b, stream, b.lds.total_wide, NW * 64);
     if (e == hipSuccess && (mask & 2)) e = launch_one(dp_wide_kernel<GAP, 32, NW>, b, stream, b.lds.total_wide, NW * 64);
     return e;
