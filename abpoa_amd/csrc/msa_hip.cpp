@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <vector>
 
 namespace abpoa_hip {
@@ -50,7 +51,16 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
     PassOut R; memset(&R.tot, 0, sizeof(R.tot));
     std::vector<int> todo = idx, left;
     const double factors[2] = {3.0, 6.0};
-    for (int pass = 0; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
+    // What the process learned about jobs of this shape (longest read by power of two, reads per set): when most sets of the last such job outgrew
+    // the 3x pass and the 6x pass ran in one piece, the next one starts at 6x (noisy long reads: 50 x 10 kb at 15 % error grow to 3.9x; the doomed
+    // first pass is ~3 % of such a job).  Results do not depend on it.  ABPOA_HIP_NO_PASS_HINT=1: always start at 3x.
+    static std::mutex hint_mu; static std::map<int, int> hint;
+    int key = 0; { int mx = 1, nr = 0; for (int i : idx) { nr = std::max(nr, sets[i].n_reads); for (int r = 0; r < sets[i].n_reads; ++r) mx = std::max(mx, sets[i].lens[r]); }
+                   int lg = 0; while ((1 << lg) < mx) ++lg; key = lg * 1024 + std::min(nr, 1023); }
+    int first_pass = 0;
+    if (!(getenv("ABPOA_HIP_NO_PASS_HINT") && atoi(getenv("ABPOA_HIP_NO_PASS_HINT")))) { std::lock_guard<std::mutex> lk(hint_mu); auto it = hint.find(key); if (it != hint.end()) first_pass = it->second; }
+    bool most_outgrew = false;
+    for (int pass = first_pass; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
         size_t chunk = todo.size();
         for (size_t at = 0; at < todo.size() && R.device_ok;) {
@@ -72,6 +82,8 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             if (getenv("ABPOA_HIP_VERBOSE") && ds.rounds_launches) fprintf(stderr, "[abpoa-hip]   all-rounds kernel: %.1f ms (the phase times above are its duration split by the sets' clock ticks); mean set busy %.0f %% of it; mean set, 10^6 ticks: prepare %.1f, row loop %.1f, backtrack %.1f, fuse %.1f\n", ds.rounds_ms, 100.0 * ds.rounds_mean_over_max, ds.rounds_mticks[0], ds.rounds_mticks[1], ds.rounds_mticks[2], ds.rounds_mticks[3]);
             at += nb;
         }
+        if (R.device_ok && pass == 0) most_outgrew = left.size() * 2 >= todo.size();
+        if (R.device_ok && pass == 1 && most_outgrew && chunk == todo.size()) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = 1; }
         if (R.device_ok) todo.swap(left);
     }
     R.left = todo;

@@ -15,6 +15,14 @@ for r in rows:
     if "dp_" not in k: continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     out.append((k.split("abpoa_hip::")[1].split("(")[0], d))
+# idle time on the GPU between consecutive kernels of the step (launch gaps, host stalls), and time per kernel family
+allk = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
+gap = sum(max(0, allk[i + 1][1] - max(e for _, _, e in allk[:i + 1][-4:])) for i in range(len(allk) - 1)) / 1e6
+span = (max(e for _, _, e in allk) - allk[0][1]) / 1e6
+fam = {}
+for k, s_, e in allk:
+    n = k.split("abpoa_hip::")[-1].split("(")[0].split("<")[0]; fam[n] = fam.get(n, 0) + (e - s_) / 1e6
+print(f"GPU span {span:.1f} ms, idle between kernels {gap:.1f} ms, by kernel (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(fam.items(), key=lambda x: -x[1])))
 # print compactly: one line per round = consecutive kernels until the next first-row kernel
 line = []
 for k, d in out:
