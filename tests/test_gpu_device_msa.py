@@ -91,3 +91,23 @@ def test_multi_queue_batch_call_matches_single_queue(engine):
         del os.environ["ABPOA_GPU_DEVICES"], os.environ["ABPOA_GPU_BATCHES_PER_DEVICE"]
     for a, b in zip(one, two):
         assert (a.status, a.cons_seq, a.cons_cov, a.n_cells) == (0, b.cons_seq, b.cons_cov, b.n_cells)
+
+
+def test_job_shape_hint_skips_the_doomed_pass(engine):
+    """Noisy reads outgrow the 3x node estimate of the first device pass; the second such job of the process starts at 6x.  Same results either
+    way, equal to the host driver's.  (Child process: the hint is process-wide state and the passes are reported on stderr.)"""
+    code = ("import os,sys; sys.path.insert(0, %r)\n"
+            "from abpoa_amd import api, ffi, synth\n"
+            "lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
+            "sets = [synth.make_read_set(5, i, 30, 2000, 0.30) for i in range(6)]\n"
+            "p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)\n"
+            "a = api.msa_batch(sets, p, n_threads=4); sys.stderr.write('SECOND CALL\\n'); b = api.msa_batch(sets, p, n_threads=4)\n"
+            "os.environ['ABPOA_HIP_HOSTGRAPH'] = '1'; h = api.msa_batch(sets, p, n_threads=4)\n"
+            "print('OK', all(x.status == 0 and x.cons_seq == y.cons_seq == z.cons_seq and x.cons_cov == y.cons_cov == z.cons_cov for x, y, z in zip(a, b, h)))\n" % ROOT)
+    env = dict(os.environ, ABPOA_HIP_VERBOSE="1", ABPOA_HIP_HOSTGRAPH="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "OK True" in p.stdout, p.stdout
+    first, second = p.stderr.split("SECOND CALL")
+    assert "pass 1, node slots 3x" in first and "pass 2, node slots 6x" in first, first[-1500:]
+    assert "node slots 3x" not in second and "node slots 6x" in second, second[-1500:]
