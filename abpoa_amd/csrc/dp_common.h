@@ -46,7 +46,7 @@ constexpr int RL = 256;     // max_pos_left/right window (two halves of 128 rows
 constexpr int RLH = RL / 2;
 constexpr int MAX_RING_ROWS = 32;
 constexpr int BTR = 64;     // backtrack tile: rows
-constexpr int BTP = 256;    // backtrack tile: predecessor entries
+constexpr int BTP = 128;    // backtrack tile: predecessor entries (a window of 30-64 rows has 45-100; more -> the one-read-at-a-time step; 256 cost 4 KB more LDS per tail workgroup)
 
 struct __attribute__((aligned(16))) DpLds {   // fixed part of the DP-phase LDS image; 16-byte records = one ds_read_b128 each
     int4 t_rec[TS + 1];     // static tile, per row: {pred_off, out_off, remain, base | active << 8}; entry [TS] = end offsets

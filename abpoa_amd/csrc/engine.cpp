@@ -114,6 +114,9 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // divided by the workgroups a CU has to hold, capped at 56 KB
     { const int per_cu = std::max(1, (n_aln + 255) / 256);
       if (per_cu < 4 && L.fr_cols > 128) L.bt_bytes_tail = std::max(L.bt_bytes_tail, std::min(56 * 1024, 160 * 1024 / per_cu - 2048 - L.phase_off - L.bt_off) & ~15); }
+    // more alignments than a GPU holds tail workgroups at the 24 KB window (4 per CU): a 12 KB window doubles the residency, and the tail kernel of such
+    // a launch runs in as many turns as it has workgroups per resident set (8000 x 1 kb alignments: tail 153 -> 127 ms per step)
+    if (n_aln > 4 * 256 && L.fr_cols && L.fr_cols <= 128) L.bt_bytes_tail = std::min(L.bt_bytes_tail, 12 * 1024);
     { const char *tb_ = getenv("ABPOA_HIP_BT_BYTES"); if (tb_ && atoi(tb_) >= 4096 && atoi(tb_) <= 65536) L.bt_bytes_tail = atoi(tb_) & ~15; }
     L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes_tail;
     L.bt_wc = 0; { const char *wc_ = getenv("ABPOA_HIP_BT_WC"); if (wc_ && atoi(wc_) >= 8 && atoi(wc_) <= 64) L.bt_wc = atoi(wc_) & ~7; }
