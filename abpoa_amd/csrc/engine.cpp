@@ -107,9 +107,9 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
     const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
     L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
-    // the fast path's tail kernel: its own window size -- 24 KB, less when a long query already takes much of the 38 (62) KB that let four (two) of
+    // the fast path's tail kernel: its own window size -- 28 KB, less when a long query already takes much of the 38 (62) KB that let four (two) of
     // its workgroups share a CU; the general kernel's bt_bytes above also covers its score ring and would halve that residency
-    L.bt_bytes_tail = std::max(8 * 1024, std::min(24 * 1024, (longq ? 62 : 38) * 1024 - L.phase_off - L.bt_off)) & ~15;
+    L.bt_bytes_tail = std::max(8 * 1024, std::min(28 * 1024, (longq ? 62 : 38) * 1024 - L.phase_off - L.bt_off)) & ~15;
     // a launch with fewer alignments than 4 per CU can afford a larger window per workgroup (fewer window reloads on wide bands): 160 KB / CU
     // divided by the workgroups a CU has to hold, capped at 56 KB
     { const int per_cu = std::max(1, (n_aln + 255) / 256);
