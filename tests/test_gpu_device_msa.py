@@ -111,3 +111,33 @@ def test_job_shape_hint_skips_the_doomed_pass(engine):
     first, second = p.stderr.split("SECOND CALL")
     assert "pass 1, node slots 3x" in first and "pass 2, node slots 6x" in first, first[-1500:]
     assert "node slots 3x" not in second and "node slots 6x" in second, second[-1500:]
+
+
+@pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
+def test_device_driver_equals_oracle_backed_host_run(engine, monkeypatch, lockstep):
+    """An independent check of the device-resident driver and its row-loop bodies (straight-line copies for 1-8 predecessors and for vectors beyond
+    the predecessors' bands, the two-chunk body, the exact bodies): the same read-sets through the CPU build of the host layer whose aligner is the
+    plain-C oracle (tests/cpu_shim.cpp).  Shapes chosen to leave the common path: narrow and wide extra bands (-b / -f), 2-25 % errors with
+    deletion- and insertion-heavy mixes, convex and affine gaps, ragged read counts, reads of 150-1400 bases."""
+    import helpers as H
+    from abpoa_amd import api, ffi, synth
+    monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", str(lockstep))
+    shim = H.cpu_shim_lib()
+    cases = [
+        (dict(gap_open1=4, gap_open2=0, gap_ext1=2), [(12 + i % 9, 150 + 97 * i, 0.02 + 0.02 * (i % 6), None) for i in range(10)]),
+        (dict(), [(10 + i % 7, 300 + 130 * i, 0.12, (0.02, 0.08, 0.02) if i % 2 else (0.02, 0.02, 0.08)) for i in range(8)]),
+        (dict(gap_open1=4, gap_open2=0, gap_ext1=2, extra_b=5, extra_f=0.02), [(16, 400 + 150 * i, 0.25, None) for i in range(6)]),
+        (dict(gap_open1=6, gap_open2=30, gap_ext1=3, gap_ext2=1, extra_b=30, extra_f=0.03, match=3, mismatch=5), [(9 + i, 500 + 60 * i, 0.10, None) for i in range(6)]),
+    ]
+    for kw, shapes in cases:
+        sets = [synth.make_read_set(23, i, n, ln, err, rates=rt) for i, (n, ln, err, rt) in enumerate(shapes)]
+        p = api.Params(**kw)
+        engine.abpoa_hip_reset_stats()
+        dev = api.msa_batch(sets, p, n_threads=4)
+        assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+        w_max = p.wb + int(p.wf * max(ln for _, ln, _, _ in shapes))      # (a band half-width of 40 or more takes the wide row loop: one launch per phase and round)
+        assert (ffi.stats()["rounds_launches"] > 0) == (lockstep == 0 and w_max < 40)
+        ref = api.msa_batch(sets, p, n_threads=4, lib=shim)
+        for i, (a, b) in enumerate(zip(dev, ref)):
+            assert a.status == 0 and b.status == 0
+            assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{kw}: set {i} differs from the oracle-backed run"
