@@ -22,10 +22,15 @@ struct ProblemSlots {           // host pointers for one problem; sizes from its
 
 // What the read-set driver needs from "something that aligns a batch": the product implements it on a BatchStream
 // (HIP), the CPU test shim on the oracle.
+enum { GA_BAND_FRESH = 0, GA_BAND_KEEP = 1, GA_BAND_SEEDED = 2 };
 class GroupAligner {
   public:
     virtual ~GroupAligner() {}
-    virtual int prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *shapes) = 0;
+    // band: GA_BAND_FRESH = max_pos_left/right start at their reset value (n_rows, 0) and are not read back; GA_BAND_KEEP = fresh start, and
+    // left(i) / right(i) hold the state the DP left behind after run(); GA_BAND_SEEDED = the caller fills slots(i).left / .right with the start state
+    virtual int prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *shapes, int band = 0) = 0;
+    virtual const int32_t *left(int i) = 0;
+    virtual const int32_t *right(int i) = 0;
     virtual ProblemSlots slots(int i) = 0;
     virtual int run() = 0;
     virtual int status(int i) = 0;

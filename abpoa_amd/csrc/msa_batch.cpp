@@ -102,7 +102,9 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
             const int s = active[a];
             shapes[a] = BatchShape{graphs[s].n_nodes(), sets[s].lens[k], graphs[s].n_edges(), graphs[s].n_edges()};
         }
-        int rc = al->prepare(&scoring, (int)active.size(), shapes.data());
+        // (-s: the reverse-complement retry starts from the band state the forward DP leaves behind, see below)
+        const bool carry_band = amb_strand && scoring.wb >= 0;
+        int rc = al->prepare(&scoring, (int)active.size(), shapes.data(), carry_band ? GA_BAND_KEEP : GA_BAND_FRESH);
         if (rc) return rc;
         pool.run((int)active.size(), [&](int a) {
             const int s = active[a];
@@ -121,6 +123,9 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
         // ---- ambiguous strand (reference abpoa_poa, src/abpoa_align.c:315-336): reads that score below a third of the best possible are
         //      aligned again as their reverse complement, on the SAME rows (the reference calls the DP without re-sorting); the strand
         //      with the strictly better score goes into the graph.  The forward cigars are saved first: the aligner is run again.
+        //      max_pos_left/right are reset only by the topological sort (abpoa_graph.c:303-308), which the retry does not repeat (:329 calls
+        //      simd_abpoa_align_sequence_to_graph directly): the retry's adaptive band starts from the bounds the forward pass pushed and can only
+        //      widen them (row 0 re-assigns its successors to 1, simd_abpoa_align.c:556-561).
         std::vector<int> retry;
         std::vector<std::vector<uint64_t>> fwd_cig;
         std::vector<std::vector<uint8_t>> rc_seq; std::vector<std::vector<int32_t>> rc_w;
@@ -141,8 +146,12 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
                 fwd_cig[a].assign(al->cigar((int)a), al->cigar((int)a) + al->n_cigar((int)a));
             }
             std::vector<BatchShape> sh2(retry.size());
-            for (size_t t = 0; t < retry.size(); ++t) sh2[t] = shapes[retry[t]];
-            rc = al->prepare(&scoring, (int)retry.size(), sh2.data());
+            std::vector<std::vector<int32_t>> fwd_l(retry.size()), fwd_r(retry.size());
+            for (size_t t = 0; t < retry.size(); ++t) {
+                sh2[t] = shapes[retry[t]];
+                if (carry_band) { const int gn = sh2[t].n_rows; fwd_l[t].assign(al->left(retry[t]), al->left(retry[t]) + gn); fwd_r[t].assign(al->right(retry[t]), al->right(retry[t]) + gn); }
+            }
+            rc = al->prepare(&scoring, (int)retry.size(), sh2.data(), carry_band ? GA_BAND_SEEDED : GA_BAND_FRESH);
             if (rc) return rc;
             pool.run((int)retry.size(), [&](int t) {
                 const int a = retry[t], s = active[a], qlen = sets[s].lens[k];
@@ -153,6 +162,7 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
                     ProblemSlots sl = al->slots(t);
                     memcpy(sl.query, rc_seq[a].data(), qlen);
                     graphs[s].flatten_into(with_remain, sl.row_base, sl.row_node_id, sl.row_remain, sl.pred_off, sl.pred_row, sl.out_off, sl.out_row);
+                    if (carry_band) { memcpy(sl.left, fwd_l[t].data(), 4 * fwd_l[t].size()); memcpy(sl.right, fwd_r[t].data(), 4 * fwd_r[t].size()); }
                 } catch (...) { fail.store(1); }
             });
             if (fail.load()) return ABPOA_HIP_EINVAL;
@@ -203,7 +213,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     if (n_groups <= 0) n_groups = n_sets >= 512 ? 4 : (n_sets >= 128 ? 2 : 1);
     if (n_groups > n_threads) n_groups = n_threads;
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
-    const bool amb_strand = (flags & ABPOA_HIP_AMB_STRAND) && sc->m <= 5;      // (nucleotides only: the complement is 3 - code)
+    const bool amb_strand = flags & ABPOA_HIP_AMB_STRAND;      // (any alphabet, as the reference: codes 0..3 are complemented, every other code becomes 4, src/abpoa_align.c:318-321)
     abpoa_hip_scoring_t scoring = *sc;
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE) scoring.wb = -1;        // reference abpoa_post_set_para, abpoa_align.c:150
     scoring.ret_cigar = 1; scoring.rev_cigar = 0;

@@ -507,7 +507,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     }
     if (stats) {
         stats->cons_s = now_s() - t_done; stats->total_s = now_s() - t_begin;
-        for (int s = 0; s < n_sets; ++s) if (!need_fb[s]) { stats->n_cells += hs[s].n_cells; stats->algo_bytes += hs[s].algo_bytes; stats->n_alignments += std::max(0, sets[s].n_reads - 1); }
+        for (int s = 0; s < n_sets; ++s) if (!need_fb[s]) {
+            stats->n_cells += hs[s].n_cells; stats->algo_bytes += hs[s].algo_bytes; stats->n_alignments += std::max(0, sets[s].n_reads - 1);
+            int mx = 0; for (int r = 0; r < sets[s].n_reads; ++r) mx = std::max(mx, sets[s].lens[r]);
+            if ((int64_t)hs[s].n_nodes <= 2 + (int64_t)(3.0 * mx) + 1024) stats->n_fit_3x += 1;
+        }
     }
     return ABPOA_HIP_OK;
 }

@@ -10,7 +10,7 @@ namespace abpoa_hip {
 struct DeviceRunStats {
     double prepare_ms, rows_ms, tail_ms, fuse_ms;     // summed kernel durations (hipEvents on the job's stream)
     double device_s, cons_s, total_s;                 // wall: first launch -> graphs on the host; consensus; whole call
-    int64_t n_cells, algo_bytes, n_alignments; int32_t n_rounds, pad;
+    int64_t n_cells, algo_bytes, n_alignments; int32_t n_rounds, n_fit_3x;      // n_fit_3x: finished sets whose graph would also have fitted 3x the longest read in node slots
     // all-rounds kernel (poa_rounds.hip), when the job took it: launches, their duration, the share of the sets' clock ticks spent in the row loop, and
     // mean set / slowest set (how much of the kernel's duration the average workgroup was busy); rows_ms .. fuse_ms above then hold the duration split by phase
     double rounds_ms, rounds_rows_share, rounds_mean_over_max; int32_t rounds_launches, pad2;

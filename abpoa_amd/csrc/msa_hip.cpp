@@ -20,7 +20,11 @@ class HipGroupAligner : public GroupAligner {
   public:
     int init() { return bs_.open(engine_device()); }
     ~HipGroupAligner() override { add_global_stats(bs_.take_stats()); bs_.close(); }
-    int prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *shapes) override { return bs_.prepare(sc, n, shapes, BS_FRESH_BAND); }
+    int prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *shapes, int band) override {
+        return bs_.prepare(sc, n, shapes, band == GA_BAND_FRESH ? BS_FRESH_BAND : (band == GA_BAND_KEEP ? (BS_FRESH_BAND | BS_WANT_BAND_STATE) : BS_WANT_BAND_STATE));
+    }
+    const int32_t *left(int i) override { return bs_.left(i); }
+    const int32_t *right(int i) override { return bs_.right(i); }
     ProblemSlots slots(int i) override { return bs_.slots(i); }
     int run() override { return bs_.run(); }
     int status(int i) override { return bs_.rec(i).status; }
@@ -59,7 +63,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
                    int lg = 0; while ((1 << lg) < mx) ++lg; key = lg * 1024 + std::min(nr, 1023); }
     int first_pass = 0;
     if (!(getenv("ABPOA_HIP_NO_PASS_HINT") && atoi(getenv("ABPOA_HIP_NO_PASS_HINT")))) { std::lock_guard<std::mutex> lk(hint_mu); auto it = hint.find(key); if (it != hint.end()) first_pass = it->second; }
-    bool most_outgrew = false;
+    bool most_outgrew = false; int n_small = 0, n_done = 0;      // (sets that finished / that would also have fitted the 3x estimate)
     for (int pass = first_pass; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
         size_t chunk = todo.size();
@@ -70,13 +74,19 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             std::vector<int> fb; DeviceRunStats ds;
             const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], device, slot);
             if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; continue; }           // split and retry this chunk
-            if (rc != ABPOA_HIP_OK) { if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; } R.device_ok = false; break; }
+            if (rc != ABPOA_HIP_OK) {
+                if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; }
+                // not a job for the device path (does not fit even alone / shape): what is still open -- the leftovers of the chunks already done in this
+                // pass and everything from here on -- goes back to the caller; finished results stay in out[]
+                R.device_ok = false; for (size_t i = at; i < todo.size(); ++i) left.push_back(todo[i]); todo.swap(left); break;
+            }
             for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
             for (int f : fb) left.push_back(todo[at + f]);
             DeviceRunStats &tot = R.tot;
             tot.prepare_ms += ds.prepare_ms; tot.rows_ms += ds.rows_ms; tot.tail_ms += ds.tail_ms; tot.fuse_ms += ds.fuse_ms; tot.device_s += ds.device_s; tot.cons_s += ds.cons_s;
             tot.total_s += ds.total_s; tot.n_cells += ds.n_cells; tot.algo_bytes += ds.algo_bytes; tot.n_alignments += ds.n_alignments; tot.n_rounds += ds.n_rounds;
             tot.rounds_ms += ds.rounds_ms; tot.rounds_launches += ds.rounds_launches; tot.rounds_algo_bytes += ds.rounds_algo_bytes;
+            n_small += ds.n_fit_3x; n_done += (int)nb - (int)fb.size();
             if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %.0fx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
                                                      device, pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
             if (getenv("ABPOA_HIP_VERBOSE") && ds.rounds_launches) fprintf(stderr, "[abpoa-hip]   all-rounds kernel: %.1f ms (the phase times above are its duration split by the sets' clock ticks); mean set busy %.0f %% of it; mean set, 10^6 ticks: prepare %.1f, row loop %.1f, backtrack %.1f, fuse %.1f\n", ds.rounds_ms, 100.0 * ds.rounds_mean_over_max, ds.rounds_mticks[0], ds.rounds_mticks[1], ds.rounds_mticks[2], ds.rounds_mticks[3]);
@@ -84,6 +94,9 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
         }
         if (R.device_ok && pass == 0) most_outgrew = left.size() * 2 >= todo.size();
         if (R.device_ok && pass == 1 && most_outgrew && chunk == todo.size()) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = 1; }
+        // the hint is dropped again when a job that started at 6x because of it turns out to fit 3x (a cleaner job of the same shape): twice the graph
+        // and arena memory for nothing otherwise, for as long as the process lives
+        if (R.device_ok && pass == 1 && first_pass == 1 && n_done > 0 && n_small * 2 > n_done) { std::lock_guard<std::mutex> lk(hint_mu); hint.erase(key); }
         if (R.device_ok) todo.swap(left);
     }
     R.left = todo;
@@ -131,7 +144,9 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
             std::vector<int> order(n_sets); for (int s = 0; s < n_sets; ++s) order[s] = s;
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
             int per_q = 2; { const char *e_ = getenv("ABPOA_GPU_BATCHES_PER_DEVICE"); if (e_ && atoi(e_) > 0) per_q = atoi(e_); }
-            int nb = std::max(n_q, std::min(n_q * per_q, n_sets / 256));      // batches below ~256 sets leave a GPU's 1024 SIMDs idle
+            // a batch should hold >= 1024 sets when the job allows: the device kernels run one wavefront per read-set, a GPU has 1024 SIMDs, and the
+            // all-rounds kernel of the narrow-band jobs is at its best with ~1000 resident sets; never fewer batches than queues
+            int nb = std::max(n_q, std::min(n_q * per_q, n_sets / 1024));
             nb = std::max(1, std::min(nb, n_sets));
             batches.resize(nb);
             for (int i = 0; i < n_sets; ++i) batches[i % nb].push_back(order[i]);
@@ -155,12 +170,13 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
         for (auto &t : th) t.join();
         (void)hipSetDevice(engine_device());
         DeviceRunStats tot; memset(&tot, 0, sizeof(tot));
-        bool device_ok = true; int rc_dev = ABPOA_HIP_OK;
+        const bool device_ok = true; int rc_dev = ABPOA_HIP_OK;
         std::vector<int> todo;
         for (size_t b_ = 0; b_ < batches.size(); ++b_) {
             const PassOut &R = results[b_];
             if (R.rc != ABPOA_HIP_OK && rc_dev == ABPOA_HIP_OK) rc_dev = R.rc;
-            if (!R.device_ok) device_ok = false;
+            // a batch the device path could not take (it does not fit even alone, or its shape is not the device driver's): only THAT batch's open
+            // sets go to the host driver -- R.left holds them -- the finished results of the other batches stay
             todo.insert(todo.end(), R.left.begin(), R.left.end());
             tot.prepare_ms += R.tot.prepare_ms; tot.rows_ms += R.tot.rows_ms; tot.tail_ms += R.tot.tail_ms; tot.fuse_ms += R.tot.fuse_ms; tot.cons_s += R.tot.cons_s;
             tot.n_cells += R.tot.n_cells; tot.algo_bytes += R.tot.algo_bytes; tot.n_alignments += R.tot.n_alignments; tot.n_rounds += R.tot.n_rounds;
@@ -169,6 +185,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
         }
         if (rc_dev != ABPOA_HIP_OK) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); return rc_dev; }
         if (n_q > 1) { tot.device_s = tot.total_s = *std::max_element(q_busy.begin(), q_busy.end()); }      // queues ran side by side: the busiest one is the wall time
+        if (n_q > 1 && getenv("ABPOA_HIP_VERBOSE")) { fprintf(stderr, "[abpoa-hip] %d device queues, %zu batches; busy seconds per queue:", n_q, batches.size()); for (int q = 0; q < n_q; ++q) fprintf(stderr, " dev%d %.3f", devs[q], q_busy[q]); fprintf(stderr, "\n"); }
         if (device_ok) {
             std::sort(todo.begin(), todo.end());
             StreamStats ss; ss.n_launches = tot.n_rounds; ss.n_alignments = tot.n_alignments; ss.n_cells = tot.n_cells; ss.algo_bytes = tot.algo_bytes;

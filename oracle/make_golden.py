@@ -69,6 +69,11 @@ def cases(tmp):
     synth.write_fasta(rcfa, [r[::-1].translate(comp) if i in (2, 5, 8) else r for i, r in enumerate(rs)])
     out.append(("out_rc_cons", rcfa, AG + ["-s"], "none", 0, None))
     out.append(("out_rc_msa", rcfa, ["-s", "-r", "2"], "none", 0, None))
+    # ... and on long noisy reads under the default adaptive band (-b 10 -f 0.01): the retry starts from the band bounds the forward DP left behind
+    rcl = os.path.join(tmp, "rc_long.fa")
+    rl = synth.make_read_set(21, 0, 8, 2500, 0.15)
+    synth.write_fasta(rcl, [r[::-1].translate(comp) if i in (2, 5) else r for i, r in enumerate(rl)])
+    out.append(("out_rc_long_msa", rcl, ["-s", "-r", "2"], "none", 0, None))
     qfq = os.path.join(tmp, "qv.fq")
     rng = synth.SplitMix64(99)
     with open(qfq, "w") as f:

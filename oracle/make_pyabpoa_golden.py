@@ -3,8 +3,9 @@
 module.
 
 The reference's python/pyabpoa.pyx is cythonized and built against the reference's C sources where they lie under /root/reference (same
-flags as oracle/Makefile: gcc -O3 -mavx2 -fno-strict-aliasing, no -DUSE_SIMDE); every generated file goes to oracle/_ref/pyabpoa/
-(git-ignored, never shipped as source).  The module is imported here only to record inputs -> outputs as JSON fixtures under
+flags as oracle/Makefile: gcc -O3 -mavx2 -fno-strict-aliasing, no -DUSE_SIMDE) in a temporary directory OUTSIDE the repository, which is
+removed as soon as the fixtures are written: neither the generated C nor the compiled module ever sits in the tree (so it cannot travel to
+a GPU box with a snapshot of it).  The module is imported here only to record inputs -> outputs as JSON fixtures under
 tests/golden/pyabpoa/, which the CPU and GPU front-end tests read.  Only runs where /root/reference exists.
 
 usage: python oracle/make_pyabpoa_golden.py
@@ -16,15 +17,14 @@ import shutil
 import subprocess
 import sys
 import sysconfig
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-OUT = os.path.join(ROOT, "oracle", "_ref", "pyabpoa")
 sys.path.insert(0, ROOT)
 
 
-def build():
-    os.makedirs(OUT, exist_ok=True)
+def build(OUT):
     c_file = os.path.join(OUT, "pyabpoa.c")
     subprocess.check_call([sys.executable, "-m", "cython", "-3", "-I", os.path.join(REF, "python"), os.path.join(REF, "python", "pyabpoa.pyx"), "-o", c_file])
     srcs = [os.path.join(REF, "src", f + ".c") for f in ("abpoa_align", "abpoa_graph", "abpoa_output", "abpoa_plot", "abpoa_seed", "abpoa_seq", "kalloc",
@@ -42,8 +42,16 @@ def record(res):
 
 
 def main():
-    build()
-    sys.path.insert(0, OUT)
+    OUT = tempfile.mkdtemp(prefix="pyabpoa_ref_")      # outside the repository
+    try:
+        build(OUT)
+        sys.path.insert(0, OUT)
+        capture()
+    finally:
+        shutil.rmtree(OUT, ignore_errors=True)
+
+
+def capture():
     import pyabpoa as pa          # the REFERENCE's module
     from abpoa_amd import seqio, synth
     data = os.path.join(ROOT, "tests", "golden", "data")

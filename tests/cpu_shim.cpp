@@ -15,7 +15,10 @@ using namespace abpoa_hip;
 class OracleGroupAligner : public GroupAligner {
   public:
     ~OracleGroupAligner() override { clear(); }
-    int prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *sh) override {
+    const int32_t *left(int i) override { return p_[i].left.data(); }
+    const int32_t *right(int i) override { return p_[i].right.data(); }
+    int prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape *sh, int band) override {
+        (void)band;      // (the oracle updates max_pos_left/right in place: a seeded start is whatever the caller writes into the slots after this)
         clear(); sc_ = *sc; n_ = n; p_.resize(n); res_.assign(n, abpoa_hip_result_t());
         for (int i = 0; i < n; ++i) {
             P &p = p_[i]; const int gn = sh[i].n_rows;

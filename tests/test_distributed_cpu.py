@@ -75,3 +75,25 @@ def test_shard_rules():
     assert sorted(i for part in q for i in part) == list(range(23))
     loads = [sum(costs[i] for i in part) for part in q]
     assert max(loads) - min(loads) <= max(costs)
+
+
+def test_bench_self_launch_over_gloo():
+    """`python bench.py --gpus 2` as the driver types it (no torchrun in front): bench.py starts its ranks as a child torch.distributed.run,
+    every rank takes its shard and rank 0 prints what the result collective gathered.  --backend gloo --dry-run is the CPU rehearsal of exactly
+    that path (no engine call: the DP has no CPU fallback).  On a node with fewer GPUs than asked for, the nccl form must refuse with a clear
+    message instead of dying on an assert.  (Two DIFFERENT device ordinals inside one process -- ABPOA_GPU_DEVICES=0,1 -- cannot be exercised on
+    this pool's one-GPU boxes; tests/test_gpu_device_msa.py runs the two-queue path with the list 0,0.)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--scaling", "strong", "--sets", "5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["max_rank_plus_1"] == 2.0
+    assert rec["sets_all_ranks"] == rec["total_sets"] == 40 and rec["sum_of_first_indices"] == shard_range(40, 2, 1)[0]
+    if torch.cuda.device_count() < 2:
+        q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sets", "8"], capture_output=True, text=True, env=env, timeout=300)
+        assert q.returncode == 2 and "nothing was launched" in q.stderr and "Traceback" not in q.stderr

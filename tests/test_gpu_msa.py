@@ -105,6 +105,8 @@ def test_ambiguous_strand_and_quality_weights():
     txt, r = _run_fx(fa, api.Params(**AG), True, False, amb=True)
     assert txt == _golden("out_rc_cons") and [i for i, f in enumerate(r.is_rc) if f] == [2, 5, 8]
     assert _run_fx(fa, api.Params(), True, True, amb=True)[0] == _golden("out_rc_msa")
+    txt, r = _run_fx(os.path.join(D, "out_rc_long_msa", "input.fa"), api.Params(), True, True, amb=True)      # long noisy reads: the retry inherits the forward pass's band state
+    assert txt == _golden("out_rc_long_msa") and [i for i, f in enumerate(r.is_rc) if f] == [2, 5]
     fq = os.path.join(D, "out_qv_cons", "input.fq")
     assert _run_fx(fq, api.Params(**AG), True, False, qv=True)[0] == _golden("out_qv_cons")
     assert _run_fx(fq, api.Params(), True, True, qv=True)[0] == _golden("out_qv_msa")

@@ -74,6 +74,14 @@ def test_ambiguous_strand_retry():              # reference -s, src/abpoa_align.
     assert no_retry != _golden("out_rc_cons")       # the retry matters on this input
 
 
+def test_ambiguous_strand_retry_long_noisy_reads():
+    """8 x 2.5 kb reads at 15 % error, two of them reverse complements, default adaptive band: the retry DP starts from the band bounds the forward
+    DP pushed (the reference re-sorts -- and resets them -- only once per read, src/abpoa_align.c:329 / abpoa_graph.c:303-308)."""
+    fa = os.path.join(D, "out_rc_long_msa", "input.fa")
+    txt, r = _run_fx(fa, api.Params(), True, True, amb=True)
+    assert txt == _golden("out_rc_long_msa") and [i for i, f in enumerate(r.is_rc) if f] == [2, 5]
+
+
 def test_quality_weights():                     # reference -Q, src/abpoa_align.c:462-467, abpoa_graph.c:486-499 / :634-667
     fq = os.path.join(D, "out_qv_cons", "input.fq")
     txt, _ = _run_fx(fq, api.Params(**AG), True, False, qv=True)
