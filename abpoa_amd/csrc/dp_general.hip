@@ -1,11 +1,12 @@
 // General kernel (any mode, any gap model, band on or off; plane-major arenas) and the launch entry points of the engine.
 #include "rows_general.h"
 #include "rows_local.h"
+#include "backtrack_dir.h"
 
 namespace abpoa_hip {
 
 int lds_fixed_bytes_dp() { return (int)((sizeof(DpLds) + 15) & ~15u); }
-int lds_fixed_bytes_bt() { return (int)((sizeof(BtLds) + 15) & ~15u); }
+int lds_fixed_bytes_bt() { return (int)(((sizeof(BtLds) > sizeof(DirBt) ? sizeof(BtLds) : sizeof(DirBt)) + 15) & ~15u); }      // (the two backtracks' row / edge tables; the arena window follows)
 
 template <int GAP>
 __global__ void __launch_bounds__(64) dp_kernel(const DevBatch b) {

@@ -15,6 +15,7 @@
 #include <vector>
 #include <algorithm>
 #include "batch_stream.h"
+#include "dir_plane.h"
 
 namespace abpoa_hip {
 
@@ -50,6 +51,7 @@ struct Engine {
 };
 static Engine g;
 long long g_dbg[10] = {0};
+long long g_dir_counts[2] = {0, 0};      // alignments whose backtrack walked a direction plane; alignments redone with score records (NEED_SCORES)
 
 int engine_device() { return g.ready ? g.device : -1; }
 void add_global_stats(const StreamStats &s) {
@@ -163,7 +165,7 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
     flags_ = flags; n_ = n;
     P_ = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
     const bool banded = sc->wb >= 0;
-    desc_.resize(n); recs_.resize(n); full_cells_.resize(n); trace_arena_.clear();
+    desc_.resize(n); recs_.resize(n); full_cells_.resize(n); est_cells_.resize(n); dir_full_cells_.resize(n); dir_est_cells_.resize(n); trace_arena_.clear();
     rows_tot_ = preds_tot_ = outs_tot_ = q_tot_ = cig_tot_ = 0;
     for (int i = 0; i < n; ++i) {
         AlnDesc &d = desc_[i];
@@ -181,11 +183,17 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
         int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
         { const char *pct_ = getenv("ABPOA_HIP_ARENA_PCT"); if (pct_ && atoi(pct_) > 0 && atoi(pct_) < 100) est = std::max<int64_t>(pn, est * atoi(pct_) / 100); }      // (tests: force the overflow -> full-width retry path)
         d.plane_cap = std::min<int64_t>(full_cells_[i], width * pv + est * pv * (d.n_rows - 1));
+        est_cells_[i] = d.plane_cap;
+        // direction-plane arenas (dir_plane.h; run() decides whether a pass uses them): words of DB bytes per column for every row, score records for the
+        // first row and about one row in four (cells of the score width: DB bytes = DB * 8 / bits cells); full = every row at full width with its records
+        const int64_t dbc = (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4) * 8 / d.bits + 1;
+        dir_full_cells_[i] = width * (pv + dbc) * d.n_rows + 64;
+        dir_est_cells_[i] = std::min<int64_t>(dir_full_cells_[i], width * (pv + dbc) + (est * dbc + est * pv / 4 + 2 * pn) * (d.n_rows - 1));
     }
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
     o_desc_ = take(sizeof(AlnDesc) * n); o_mat_ = take(sizeof(int32_t) * sc->m * sc->m); o_query_ = take(q_tot_ + 1);
-    o_base_ = take(rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
+    o_base_ = take(rows_tot_); o_sdist_ = take(rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
     o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1) + 4 * 512);   // slack: tile prefetch over-reads up to TP entries
     in_bytes_ = o;
     o = 0;
@@ -223,6 +231,10 @@ int BatchStream::run() {
     std::vector<int32_t> saved_lr;              // caller's band state, needed again if an alignment is retried
     bool first_pass = true; int rc;
     std::vector<AlnDesc> pass;
+    // direction-plane arenas for the fast row loops (dir_plane.h) unless the caller wants the score planes back (trace), the penalties do not fit the
+    // words, or ABPOA_HIP_NODIR=1; an alignment whose backtrack meets the one case the words cannot decide is redone with score records
+    bool dir = !trace && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) &&
+               !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) && !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
     // alignment-level eligibility for the register-resident row loop: every row active, band state at its reset value
     for (int i = 0; i < n; ++i) {
         AlnDesc &d = desc_[i]; bool ok = banded || (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0);      // (unbanded local: the local row loop; band state is not used)
@@ -233,12 +245,26 @@ int BatchStream::run() {
         }
         d.flags = ok ? ALN_FAST_OK : 0; d.pad0 = 0;
     }
+    if (dir) {      // how far down the row order every row's scores are still needed (DevBatch.row_sdist); a row with more predecessors than a word can name keeps the alignment off the fast loops
+        for (int i = 0; i < n; ++i) {
+            AlnDesc &d = desc_[i];
+            if (!(d.flags & ALN_FAST_OK)) continue;
+            const int32_t *po = (const int32_t *)(hi + o_poff_) + d.poff0, *pr = (const int32_t *)(hi + o_pred_) + d.pred0; uint8_t *sd = hi + o_sdist_ + d.row0;
+            memset(sd, 0, (size_t)d.n_rows);
+            bool ok = true;
+            for (int r = 1; r < d.n_rows && ok; ++r) {
+                if (po[r + 1] - po[r] > DIR_K_MAX && r < d.n_rows - 1) ok = false;
+                for (int k = po[r]; k < po[r + 1]; ++k) { const int p_ = pr[k], dist = r == d.n_rows - 1 ? 255 : std::min(255, r - p_); if (dist > sd[p_]) sd[p_] = (uint8_t)dist; }
+            }
+            if (!ok) d.flags = 0;
+        }
+    }
     while (!todo.empty()) {
         int64_t plane_bytes = 0;
         pass.resize(todo.size());
         for (size_t t = 0; t < todo.size(); ++t) {
             AlnDesc &d = desc_[todo[t]];
-            if (!first_pass) d.plane_cap = full_cells_[todo[t]];
+            d.plane_cap = dir ? (first_pass ? dir_est_cells_[todo[t]] : dir_full_cells_[todo[t]]) : (first_pass ? est_cells_[todo[t]] : full_cells_[todo[t]]);
             d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8) + 64 * 8 * 4);   // + 64 records of slack (fast loop stores whole 64-lane chunks)
             pass[t] = d;
         }
@@ -264,6 +290,8 @@ int BatchStream::run() {
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
+        if (b.lds.wide_nw > 1) dir = false;
+        b.dir_mode = dir ? 1 : 0; b.row_sdist = di + o_sdist_;
         b.want_lr = (trace || (flags_ & BS_WANT_BAND_STATE)) ? 1 : 0;
         { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
         b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);
@@ -317,14 +345,16 @@ int BatchStream::run() {
         // records are indexed by position in this pass; cigar / per-row slots by alignment, so a retry pass cannot
         // clobber the results of alignments that finished earlier
         const AlnOut *got = (const AlnOut *)(ho + o_rec_);
-        std::vector<int> again;
+        std::vector<int> again; bool need_scores = false;
         for (size_t t = 0; t < todo.size(); ++t) {
             const int i = todo[t]; const AlnOut &r = got[t]; const AlnDesc &d = desc_[i];
+            if (r.status == ABPOA_HIP_STATUS_NEED_SCORES && dir) { need_scores = true; again.push_back(i); stats_.n_need_scores += 1; __atomic_fetch_add(&g_dir_counts[1], 1, __ATOMIC_RELAXED); continue; }
             if (r.status == ABPOA_HIP_STATUS_OVERFLOW) {
-                if (d.plane_cap >= full_cells_[i]) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
+                if (d.plane_cap >= (dir ? dir_full_cells_[i] : full_cells_[i])) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
                 again.push_back(i); continue;
             }
             recs_[i] = r;
+            if (r.pad < 0) __atomic_fetch_add(&g_dir_counts[0], 1, __ATOMIC_RELAXED);
             // trace mode: the arena of a finished alignment is kept on the host now -- a retry pass of OTHER alignments re-uses the device arenas
             if (trace) {
                 trace_arena_.resize(desc_.size());
@@ -336,6 +366,7 @@ int BatchStream::run() {
             g_dbg[0] += r.clk_dp; g_dbg[1] += r.clk_bt; g_dbg[2] += r.n_rows_done; g_dbg[3] += r.n_bt_steps; for (int q_ = 0; q_ < 6; ++q_) g_dbg[4 + q_] += r.seg[q_];
         }
         todo.swap(again); first_pass = false;
+        if (need_scores) dir = false;                 // the retry pass runs with score records (full width: simplest, and rare)
     }
     return ABPOA_HIP_OK;
 }
@@ -416,6 +447,7 @@ void abpoa_hip_shutdown(void) {
 
 const char *abpoa_hip_last_error(void) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err_copy, g_err, sizeof(g_err)); return g_err_copy; }
 void abpoa_hip_get_stats(abpoa_hip_stats_t *out) { std::lock_guard<std::mutex> lk(g.stats_mu); *out = g.stats; }
+void abpoa_hip__dir_counts(long long *out) { out[0] = __atomic_exchange_n(&g_dir_counts[0], 0, __ATOMIC_RELAXED); out[1] = __atomic_exchange_n(&g_dir_counts[1], 0, __ATOMIC_RELAXED); }
 void abpoa_hip__debug_clocks(long long *out) { for (int i = 0; i < 10; ++i) { out[i] = g_dbg[i]; g_dbg[i] = 0; } }
 void abpoa_hip_reset_stats(void) { std::lock_guard<std::mutex> lk(g.stats_mu); memset(&g.stats, 0, sizeof(g.stats)); }
 

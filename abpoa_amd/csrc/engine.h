@@ -43,6 +43,7 @@ struct AlnOut {
 #define ALN_FAST_OK 1
 #define WIDE_RING_COLS 448   // score-ring columns of the single-wave wide kernel (7 chunks of 64)
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
+#define ABPOA_HIP_STATUS_NEED_SCORES 2   // direction-plane arenas (dir_plane.h): the backtrack met the one case the plane cannot decide -> redo with score records
 
 // LDS carve-up of one wavefront (= one workgroup), chosen on the host per launch.  Byte offsets from the
 // dynamic-LDS base; every region is 16-byte aligned.
@@ -83,6 +84,8 @@ struct DevBatch {
     int32_t fresh_band;          // max_pos_left/right start as (n_rows, 0): initialise them on the device
     int32_t want_lr;             // the caller reads max_pos_left/right back (the fast row loop derives them in a post-pass)
     int32_t bits_mask;           // score widths that may occur among the fast alignments: 1 = int16, 2 = int32, 3 = both (one kernel per width)
+    int32_t dir_mode;            // 1: the fast row loops write direction words (dir_plane.h) instead of score records, the tail walks those
+    int32_t pad1;
     LdsPlan lds;
     const int32_t *mat;          // [m*m]
     const AlnDesc *aln;          // [n]
@@ -92,6 +95,8 @@ struct DevBatch {
     const int32_t *row_node_id;
     const int32_t *row_remain;
     const uint8_t *row_active;
+    const uint8_t *row_sdist;    // dir_mode: per row min(255, largest row distance to a successor), 255 for a predecessor of the sink: rows whose H / E
+                                 // some later row (beyond the LDS score ring) or the global best will read from HBM keep a score record besides the direction words
     const int32_t *pred_off;     // (n_rows+1) per alignment
     const int32_t *pred_row;
     const int32_t *out_off;

@@ -4,10 +4,11 @@
 #include "rows_fast.h"      // FastFmt (arena record format)
 #include "rows_local.h"    // takes_local
 #include "backtrack.h"
+#include "backtrack_dir.h"
 
 namespace abpoa_hip {
 
-template <typename T, int GAP>
+template <typename T, int GAP, bool DIR = false>
 __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
     const int lane = threadIdx.x & 63;
     uint8_t *s_query = lds_raw + b.lds.q_off;
@@ -21,7 +22,8 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = out_rec->seg[i_];
     ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
     WG_SYNC();
-    finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
+    if constexpr (DIR) finish_alignment_dir<T, GAP>(b, d, out_rec, ts);
+    else finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
 }
 
 }  // namespace abpoa_hip

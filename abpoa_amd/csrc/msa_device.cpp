@@ -17,6 +17,7 @@
 #include "msa_device.h"
 #include "poa_device.h"
 #include "poa_graph.h"
+#include "dir_plane.h"
 
 namespace abpoa_hip {
 
@@ -63,7 +64,7 @@ struct Layout {                // byte offsets inside the three device blobs
     size_t o_cnode, o_ccov, o_cbase;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
-    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
+    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
 };
 
 // Heaviest-bundling consensus (reference src/abpoa_output.c:361-415, :343-356) straight from the flat device arrays, walking
@@ -139,6 +140,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     if (stats) memset(stats, 0, sizeof(*stats));
     const double t_begin = now_s();
     const int P = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5, CW = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8;
+    // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
+    const bool dir = dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
+                     !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
+    const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
 
     // ---- sizes
     int max_reads = 0, max_qlen = 0; int64_t tot_reads = 0, tot_bases = 0;
@@ -166,7 +171,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         const int64_t width = (int64_t)((mx + pn) / pn) * pn;
         const int w = sc->wb + (int)(sc->wf * (float)mx);
         const int64_t est = std::min<int64_t>(width, 2LL * w + 3 * pn + 32);
-        const int64_t bytes = (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
+        // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
+        //  global best will read from HBM; a set that needs more is flagged and redone like any other capacity miss)
+        const int64_t bytes = dir ? (int64_t)up((size_t)(width * (DB + CW * (bits / 8)) + (est * DB + est * CW * (bits / 8) / 4 + 32) * (cap - 1) + 64 * 8 * 4))
+                                  : (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
         S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
         max_node_cap = std::max(max_node_cap, (int)cap);
     }
@@ -187,7 +195,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     o = 0;
     L.o_ticket = take(4 * POA_CU_TICKETS);
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
-    L.o_rbase = take(node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
+    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
     L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot); L.rows_bytes = o;
 
@@ -250,7 +258,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
     p.scratch = (int32_t *)(dr + L.o_scratch);
     p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
-    p.row_base = dr + L.o_rbase; p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
+    p.row_base = dr + L.o_rbase; p.row_sdist = dr + L.o_rsd; p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
     p.pred_off = (int32_t *)(dr + L.o_poff); p.pred_row = (int32_t *)(dr + L.o_pred); p.cigar = (uint64_t *)(dr + L.o_cigar);
     p.cons_node = (int32_t *)(dg + L.o_cnode); p.cons_cov = (int32_t *)(dg + L.o_ccov); p.cons_base = dg + L.o_cbase;
 
@@ -276,6 +284,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
     { const char *dbg_ = getenv("ABPOA_HIP_DBG"); if (dbg_) b.dbg = atoi(dbg_); }      // (diagnostics: bit 7 keeps the row loop's counters in AlnOut.seg)
     b.mat = (const int32_t *)(di + L.o_mat); b.aln = p.aln; b.out = p.out;
+    b.dir_mode = (dir && b.lds.wide_nw <= 1) ? 1 : 0; b.row_sdist = p.row_sdist;
     b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
     b.pred_off = p.pred_off; b.pred_row = p.pred_row; b.out_off = p.pred_off; b.out_row = p.pred_row;
     b.left = p.scratch; b.right = p.scratch;

@@ -112,10 +112,25 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) nx[j] = best[j] >= 0 ? p.nd_row[N0 + best[j]] : -1;
+            // how far down the row order the row's scores are still needed (DevBatch.row_sdist): the row of every out-edge (one more load per edge, same level as nx)
+            int sd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + j * GT; int far = 0;
+                if (no[j] == 1) far = nx[j];
+                else {
+                    int rr[4] = {0, 0, 0, 0};
+                    if (no[j] > 0) rr[0] = p.nd_row[N0 + o4[j].x]; if (no[j] > 1) rr[1] = p.nd_row[N0 + o4[j].y]; if (no[j] > 2) rr[2] = p.nd_row[N0 + o4[j].z]; if (no[j] > 3) rr[3] = p.nd_row[N0 + o4[j].w];
+                    far = imax_(imax_(rr[0], rr[1]), imax_(rr[2], rr[3]));
+                    for (int t = POA_HOT; t < no[j]; ++t) far = imax_(far, p.nd_row[N0 + out_slot(p, N0 + u[j], t)]);
+                }
+                sd[j] = far >= n - 1 ? 255 : imin_(imax_(far - r, 0), 255);      // (the sink is the last row)
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = r0 + j * GT;
                 if (r < n) {
+                    p.row_sdist[N0 + r] = (uint8_t)sd[j];
                     jump_lds[r] = nx[j] >= 0 ? ((unsigned)nx[j] << 16) | 1u : ((unsigned)r << 16);
                     np_lds[r] = (uint8_t)(r > 0 ? ni[j] : 0);
                     p.row_base[N0 + r] = (uint8_t)bs[j]; p.row_node_id[N0 + r] = u[j];
@@ -126,8 +141,9 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
     for (int r = tid; r < n; r += GT) {
         const int u = order[r];
         const int no = p.nd_nout[N0 + u];
-        int best_w = -1, best = -1;
-        for (int t = 0; t < no; ++t) { const int w = outw_slot(p, N0 + u, t); if (w > best_w) { best_w = w; best = out_slot(p, N0 + u, t); } }
+        int best_w = -1, best = -1, far = 0;
+        for (int t = 0; t < no; ++t) { const int w = outw_slot(p, N0 + u, t), o = out_slot(p, N0 + u, t); if (w > best_w) { best_w = w; best = o; } far = imax_(far, p.nd_row[N0 + o]); }
+        p.row_sdist[N0 + r] = (uint8_t)(far >= n - 1 ? 255 : imin_(imax_(far - r, 0), 255));
         nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
         p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
     }

@@ -13,7 +13,8 @@
 
 namespace abpoa_hip {
 
-constexpr int POA_IN_CAP = 16;     // in-edges per node kept on the device (more -> the set falls back to the host driver)
+constexpr int POA_IN_CAP = 15;     // in-edges per node kept on the device (more -> the set falls back to the host driver); = DIR_K_MAX of dir_plane.h: a
+                                   // direction word names a predecessor by 1 + its list index in 4 bits
 constexpr int POA_OUT_CAP = 16;    // out-edges per node
 constexpr int POA_HOT = 4;         // slots of every edge list in the hot arrays (16-byte records: most nodes have 1-2 edges, and the graph
                                    // kernels stream the whole graph every round); the other slots live in the cold arrays
@@ -61,6 +62,7 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     // DP inputs produced by the prepare kernel (same arrays DevBatch points at)
     AlnDesc *aln; AlnOut *out;
     uint8_t *row_base; int32_t *row_node_id, *row_remain, *pred_off, *pred_row;
+    uint8_t *row_sdist;            // per row: min(255, largest row distance to a successor), 255 for a predecessor of the sink (DevBatch.row_sdist)
     uint64_t *cigar;
     // consensus results (poa_consensus_kernel), indexed cons0 + position
     int32_t *cons_node, *cons_cov; uint8_t *cons_base;

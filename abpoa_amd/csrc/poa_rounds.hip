@@ -36,18 +36,19 @@ __device__ __forceinline__ AlnDesc uniform_desc(const AlnDesc *g) {
     return d;
 }
 // row loop, then global best + backtrack, on the calling wavefront; returns the clock between the two
-template <typename T, int GAP>
+// (DIR: direction-plane arenas, rows_fast.h DirFmt / backtrack_dir.h -- what the device-resident driver uses whenever the penalties allow it)
+template <typename T, int GAP, bool DIR>
 __device__ __noinline__ long long rounds_rows(const int slot, const int s_) {
     const DevBatch &b = g_rounds[UNI(slot)].b; const int s = UNI(s_);
     const AlnDesc d = uniform_desc(b.aln + s);
-    align_fast_rows<T, GAP>(b, d, b.out + s);
+    align_fast_rows<T, GAP, 1, false, DIR>(b, d, b.out + s);
     return (long long)__builtin_amdgcn_s_memtime();
 }
-template <typename T, int GAP>
+template <typename T, int GAP, bool DIR>
 __device__ __noinline__ void rounds_tail(const int slot, const int s_) {
     const DevBatch &b = g_rounds[UNI(slot)].b; const int s = UNI(s_);
     const AlnDesc d = uniform_desc(b.aln + s);
-    align_fast_tail<T, GAP>(b, d, b.out + s);
+    align_fast_tail<T, GAP, DIR>(b, d, b.out + s);
 }
 
 template <int GAP>
@@ -82,8 +83,11 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
         if ((tid >> 6) == worker) {
             const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags;
             if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {      // (the host launches this kernel only for jobs whose reads all take the narrow loop)
-                if (bits == 16) { c2 = rounds_rows<int16_t, GAP>(slot, s); rounds_tail<int16_t, GAP>(slot, s); }
-                else { c2 = rounds_rows<int32_t, GAP>(slot, s); rounds_tail<int32_t, GAP>(slot, s); }
+                if (b.dir_mode) {
+                    if (bits == 16) { c2 = rounds_rows<int16_t, GAP, true>(slot, s); rounds_tail<int16_t, GAP, true>(slot, s); }
+                    else { c2 = rounds_rows<int32_t, GAP, true>(slot, s); rounds_tail<int32_t, GAP, true>(slot, s); }
+                } else if (bits == 16) { c2 = rounds_rows<int16_t, GAP, false>(slot, s); rounds_tail<int16_t, GAP, false>(slot, s); }
+                else { c2 = rounds_rows<int32_t, GAP, false>(slot, s); rounds_tail<int32_t, GAP, false>(slot, s); }
             } else if ((tid & 63) == 0) b.out[s].status = ABPOA_HIP_EINVAL;       // -> poa_fuse_body marks the set for the fall-back
         }
         __syncthreads();                                    // graph cigar and result record are complete

@@ -1,5 +1,6 @@
 #pragma once
 #include "dp_common.h"
+#include "dir_plane.h"
 
 namespace abpoa_hip {
 
@@ -27,8 +28,27 @@ namespace abpoa_hip {
 // (convex), plane id = index in the record -- so that a row chunk is ONE wide store per lane instead of 3-5 two-byte ones
 // (vector-memory instruction issue, not bytes, is what a lone wave pays for).
 template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 1 ? 4 : 8; };
+// Direction-plane arenas (DIR = true, dir_plane.h): a row owns ONE word per column -- 2 bytes (affine) or 4 (convex) -- that records every
+// decision the backtrack takes at that cell; only rows whose scores a later reader needs from HBM (a successor beyond the LDS score ring,
+// the global best at the sink's predecessors, a row too wide for the ring) append their cell records behind the words.  Units of the arena
+// cursor stay 32 bytes (one reference SIMD vector of scores); a row of nv vectors takes dir_units(nv) of them for its words.
+template <typename T, int GAP> struct DirFmt {
+    static constexpr int DB = GAP == 1 ? 2 : 4;                            // bytes per direction word
+    static constexpr int UPV2 = Width<T>::PN * DB / 16;                    // 16-byte halves of a unit per vector of words: 2 / 1 (affine int16 / int32), 4 / 2 (convex)
+    __device__ __host__ static constexpr int units(int nv) { return (nv * UPV2 + 1) >> 1; }
+};
+template <int GAP> __device__ __forceinline__ unsigned dir_pack(unsigned kM, unsigned kE1, unsigned kE2, unsigned u1, unsigned u2, unsigned d1, unsigned d2) {
+    if (GAP == 1) return kM | kE1 << DIRA_KE1_SH | u1 << DIRA_UE1_SH | d1 << DIRA_DF1_SH;
+    return kM | kE1 << DIRC_KE1_SH | kE2 << DIRC_KE2_SH | u1 << DIRC_UE1_SH | u2 << DIRC_UE2_SH | d1 << DIRC_DF1_SH | d2 << DIRC_DF2_SH;
+}
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+// The reference's own comparisons for where F[j] came from (src/simd_abpoa_align.c:260-300), as the literal override of dir_plane.h; Hm1 / Fm1 =
+// values of column j-1 of the same row
+template <typename T> __device__ __forceinline__ unsigned dir_literal(int Hm1, int Fm1, int F, int oe, int e) {
+    return (int)(T)(Hm1 - oe) == F ? (unsigned)DIR_LIT_OPEN : ((int)(T)(Fm1 - e) == F ? (unsigned)DIR_LIT_EXT : (unsigned)DIR_LIT_NEITHER);
+}
 template <typename T> struct FastIO {
-    GLOBAL_AS const uint8_t *row_base; GLOBAL_AS const int32_t *row_remain, *pred_off, *pred_row;
+    GLOBAL_AS const uint8_t *row_base, *row_sdist; GLOBAL_AS const int32_t *row_remain, *pred_off, *pred_row;
     GLOBAL_AS int32_t *g_bsn, *g_esn, *row_max_i, *g_left, *g_right; GLOBAL_AS int64_t *g_coff;
     T *planes;
 };
@@ -90,7 +110,7 @@ __device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pr
 #else
 #define ABL(BIT) false
 #endif
-template <typename T, int GAP, int NW = 1, bool WIDEB = false>
+template <typename T, int GAP, int NW = 1, bool WIDEB = false, bool DIR = false>
 __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, const FastIO<T> &io, const uint8_t *s_query,
                                           long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done, long long *fseg) {
 #ifdef ABPOA_HIP_PROFILE
@@ -98,6 +118,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #endif
     constexpr int PN = Width<T>::PN, NV = 64 / PN;
     constexpr int CW = FastFmt<T, GAP>::CW;          // values per arena cell record
+    static_assert(!(DIR && NW > 1), "teams of wavefronts keep the score-record arenas");
+    constexpr int DB = DirFmt<T, GAP>::DB, CAPF1 = GAP == 1 ? DIRA_CAP1 : DIRC_CAP1, CAPF2 = DIRC_CAP2;
+    auto dir_units = [](int nv) __attribute__((always_inline)) { return DirFmt<T, GAP>::units(nv); };
+    // arena units of a row of nv vectors (spill: the row also keeps its score records)
+    auto row_units = [&](int nv, bool spill) __attribute__((always_inline)) { return DIR ? dir_units(nv) + (spill ? nv * CW : 0) : nv * CW; };
+    bool row_spill = false;                          // (DIR) the current row keeps its score records: set by the row loop before a body runs
     constexpr bool I16 = sizeof(T) == 2;
     constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? 3 : 2);
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
@@ -149,7 +175,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 
     int cur = 0, n_vec_lane = 0;                    // arena cursor in units of PN cells (one reference SIMD vector); cell count: per-lane sums of the flushed rows' vectors
     const int cap_pn = (int)(d.plane_cap / PN > 0x7fffffffLL ? 0x7fffffffLL : d.plane_cap / PN);
-    const int cap_turbo = cap_pn - NV * CW;       // arena room test of the straight-line rows (at most NV vectors)
+    const int cap_turbo = cap_pn - (DIR ? dir_units(NV) + NV * CW : NV * CW);       // arena room test of the straight-line rows (at most NV vectors)
     const int remain_end = __builtin_amdgcn_readfirstlane(io.row_remain[gn - 1]);
     // ------------------------------------------------------------------ row 0, reference :553-662
     int vg_geo = 0, vg_mi = 0, vg_off = 0;          // lane = row & 63: beg_sn | end_sn << 12 | in-ring << 24, arg-max column, arena offset / PN
@@ -158,9 +184,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r = __builtin_amdgcn_readfirstlane(io.row_remain[0]) - remain_end - 1;
         const int dp_end0 = imin(qlen, imax(0, qlen - r) + w);
         const int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
-        if ((long long)W0 * CW > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
+        // (DIR: row 0 has no decisions to record; it keeps its score records -- behind the room of its words, as every row that keeps them --
+        //  because new branches anywhere in the graph start at the source)
+        const int u0 = DIR ? dir_units(end_sn0 + 1) : 0;
+        if (((long long)u0 * PN + (long long)W0 * CW) > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
         const bool ring0 = W0 <= RC;
-        T *H = io.planes;
+        T *H = io.planes + (long long)u0 * PN;
         for (int i = tid; i < W0; i += NT) {
             int h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
             if (GAP == 1) { const int g = wr(-o1 - e1 * i); h = i == 0 ? 0 : g; x1 = i == 0 ? wr(-oe1) : inf; f1 = i == 0 ? inf : g; }
@@ -173,18 +202,19 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
             if (ring0) ring_put(0, i, h, x1, x2);
         }
-        cur = (end_sn0 + 1) * CW;
+        cur = u0 + (end_sn0 + 1) * CW;
         if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = 0; }     // source: successors get left = right = 1 (:556-561)
         if (NW > 1) WG_SYNC();               // ring row 0 was written by every wavefront
     }
 
     // ------------------------------------------------------------------ static metadata, two tiles ahead
-    struct MetaA { int ps, pe, base, rem; };
+    struct MetaA { int ps, pe, base, rem, sd; };
     constexpr int NPM = 8;                          // predecessors kept in registers per row (wide rows: up to 8 take the common path)
     struct MetaB { int p[NPM]; };
     auto load_a = [&](int t0) __attribute__((always_inline)) {
         MetaA a; const int r = imin(t0 + lane, gn - 1);
-        a.ps = io.pred_off[r]; a.pe = io.pred_off[r + 1]; a.base = io.row_base[r]; a.rem = io.row_remain[r];
+        a.ps = io.pred_off[r]; a.pe = io.pred_off[r + 1]; a.base = io.row_base[r]; a.rem = io.row_remain[r]; a.sd = 0;
+        if constexpr (DIR) a.sd = io.row_sdist[r];
         return a;
     };
     auto load_b = [&](const MetaA &a) __attribute__((always_inline)) {
@@ -216,6 +246,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < ((WIDEB || !WPLAN) ? 64 : RR); }      // (single-wave loops: older ones come from HBM)
             tv_meta |= widerow ? (1 << 19) : 0;
         }
+        if constexpr (DIR) tv_meta |= a1.sd >= RR ? (1 << 21) : 0;      // bit 21: a successor beyond the score ring (or the sink) will read this row's H / E from HBM: it keeps its score records
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
         tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
@@ -252,22 +283,25 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     };
     // one predecessor's contribution from the score ring (k == 0: unmasked, see the header comment)
     // kb: 1 + list index of the first predecessor that supplies the maximum of H[.][col-1] (kidx = this one's 1 + list index): the match flag
-    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v, int &kb, int kidx) __attribute__((always_inline)) {
+    // kE1 / kE2 (DIR): 1 + list index of the first predecessor that holds the maximum of E1 / E2 entering the cell (dir_plane.h)
+    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v, int &kb, int kidx, int &kE1, int &kE2) __attribute__((always_inline)) {
         const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
         const int x = col - pb * PN;
         const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p), med3i(x - 1, -2, RC));
         int hm1, ev1, ev2 = inf;
         if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
         else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
-        if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; kb = kidx; }
+        if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; kb = kidx; kE1 = kidx; kE2 = kidx; }
         else {
             const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
             kb = (inH && hm1 > Mv) ? kidx : kb;
+            if (DIR) { kE1 = (inE && ev1 > E1v) ? kidx : kE1; if (GAP == 2) kE2 = (inE && ev2 > E2v) ? kidx : kE2; }
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         }
     };
     // everything of a chunk after the predecessor gather: F, H, E, stores, ring, arg-max candidate (reference :854-883 / :972-1008)
-    auto chunk_tail = [&](int c, int nch, int Wr, int Mv, int E1v, int E2v, int q, int kb, int &first, int &first2, T *H, int my_slot) __attribute__((always_inline)) {
+    int ct_pH = 0, ct_pF1 = 0, ct_pF2 = 0;          // (DIR) H / F1 / F2 of the previous chunk's last column: the left neighbour of this chunk's first one
+    auto chunk_tail = [&](int c, int nch, int Wr, int Mv, int E1v, int E2v, int q, int kb, int &first, int &first2, T *H, int my_slot, int kE1 = 1, int kE2 = 1) __attribute__((always_inline)) {
         const int rel = c * 64 + lane, col = beg_sn * PN + rel, vb = beg_sn + c * NV, v = vb + vvl;
         const bool in_band = rel < Wr;
         const int h = wr(Mv + q);
@@ -308,11 +342,31 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));      // int16: also the score-ring word
         // match flag for the backtrack (see turbo_body): compared without wrapping, as the reference's backtrack does (:130-160)
         const int mflag = (Mv + q == Hout && kb <= 64) ? kb : 0;
-        if (ABL(1)) {}
-        else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + (long long)rel * CW) = rec; }
-        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)(H + (long long)rel * CW) = rec; }
-        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + (long long)rel * CW) = rec; }
-        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + (long long)rel * CW); dst[0] = r0; dst[1] = r1; }
+        T *Hrec = H;                                  // where the row's score records go
+        if constexpr (DIR) {
+            // the exact bodies record every comparison literally (dir_plane.h): H == Ein, E opened from H, H == F, and -- as the override -- where F came
+            // from, with the reference's own tests on the stored neighbours (:260-300); the left neighbour of the chunk's first column is carried over
+            Hrec = H + (long long)dir_units(end_sn - beg_sn + 1) * PN;
+            const int Hm1 = wave_shr1(ct_pH, Hout), F1m1 = wave_shr1(ct_pF1, F1);
+            const unsigned u1 = Hout == E1v ? (unsigned)o1 : (E1out == wr(Hout - oe1) ? 0u : (o1 > 1 ? 1u : 0u));
+            const unsigned d1 = Hout == F1 ? 0u : (unsigned)CAPF1;
+            unsigned l1 = rel >= 1 ? dir_literal<T>(Hm1, F1m1, F1, oe1, e1) : 0u, l2 = 0, u2 = 0, d2 = 0;
+            if (GAP == 2) {
+                const int F2m1 = wave_shr1(ct_pF2, F2);
+                u2 = Hout == E2v ? (unsigned)o2 : (E2out == wr(Hout - oe2) ? 0u : (o2 > 1 ? 1u : 0u));
+                d2 = Hout == F2 ? 0u : (unsigned)CAPF2;
+                l2 = rel >= 1 ? dir_literal<T>(Hm1, F2m1, F2, oe2, e2) : 0u;
+            }
+            const unsigned wd = dir_pack<GAP>((unsigned)mflag, (unsigned)kE1, (unsigned)kE2, u1, u2, d1, d2) | (GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH));
+            // (lanes past the band write words the next row overwrites -- same wave, program order -- except in a row that keeps its records right behind its words)
+            if (!row_spill || in_band) { if (GAP == 1) *(uint16_t *)((char *)H + rel * DB) = (uint16_t)wd; else *(uint32_t *)((char *)H + rel * DB) = wd; }
+            ct_pH = __builtin_amdgcn_readlane(Hout, 63); ct_pF1 = __builtin_amdgcn_readlane(F1, 63); if (GAP == 2) ct_pF2 = __builtin_amdgcn_readlane(F2, 63);
+        }
+        if (ABL(1) || (DIR && !row_spill)) {}
+        else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(Hrec + (long long)rel * CW) = rec; }
+        else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
+        else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
+        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(Hrec + (long long)rel * CW); dst[0] = r0; dst[1] = r1; }
         if (to_ring && !ABL(2)) {
             int *qd = fr + my_slot + 2 + rel;
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
@@ -337,8 +391,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // reserve the row's arena cells; false = overflow
     auto reserve = [&]() __attribute__((always_inline)) {
         const int nvr = end_sn - beg_sn + 1;
-        if (cur + nvr * CW > cap_pn) return false;
-        off_pn = cur; cur += nvr * CW;
+        if (cur + row_units(nvr, row_spill) > cap_pn) return false;
+        off_pn = cur; cur += row_units(nvr, row_spill);
         return true;
     };
 
@@ -438,17 +492,20 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const bool in_band = lane < Wr;
         const int key_c = (vvl == nvr - 1) ? kE : kN;
         const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * lane;                                       // LDS byte address of this lane's ring cell
-        const unsigned rec_off = (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));            // arena byte offset of this lane's record (cur = the row's offset once committed)
+        // arena byte offset of this lane's record -- DIR: of its direction word -- (cur = the row's offset once committed)
+        const unsigned rec_off = DIR ? (unsigned)(cur * 32 + lane * DB) : (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));
         asm volatile("" :: "v"(key_c), "v"(qd_addr), "v"(rec_off));      // (materialised here, not sunk to their uses)
         __builtin_amdgcn_sched_barrier(0);
         if (I16) { Mv = (int)(short)raw0; E1v = raw1 >> 16; E2v = raw2; } else { Mv = raw0; E1v = raw1; E2v = raw2; }
         const int Mv_first = Mv;                                   // (match flag below: which predecessor supplies the diagonal)
         int kfirst = 1;                                            // 1 + index of the first predecessor that reaches the running maximum of H[.][col-1]
+        int kE1 = 1, kE2 = 1;                                      // (DIR) ... of E1 / E2 at this column
         auto merge_pred = [&](int r0_, int r1_, int r2_, int x_, int Wp_, int kidx) __attribute__((always_inline)) {
             int hm1, ev1, ev2 = inf;
             if (I16) { hm1 = (int)(short)r0_; ev1 = r1_ >> 16; ev2 = r2_; } else { hm1 = r0_; ev1 = r1_; ev2 = r2_; }
             const bool inH = (unsigned)x_ < (unsigned)(Wp_ + PN), inE = (unsigned)x_ < (unsigned)Wp_;
             if (NPC >= 4) kfirst = (inH && hm1 > Mv) ? kidx : kfirst;
+            if (DIR) { kE1 = (inE && ev1 > E1v) ? kidx : kE1; if (GAP == 2) kE2 = (inE && ev2 > E2v) ? kidx : kE2; }
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         };
         if (NPC >= 2) {
@@ -498,24 +555,44 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             F1 = (int)f1t; F2 = (int)f2t;
         }
         // ---- from here on the row is committed
-        off_pn = cur; cur += nvr * CW;
-        int Hout, E1out, E2out = inf;
+        off_pn = cur; cur += row_units(nvr, row_spill);
+        int Hout, E1out, E2out = inf, en1 = 0;
         if (GAP == 1) {
             const int tmp = imax(h, E1v);
             Hout = imax(tmp, F1);
-            E1out = (Hout == tmp) ? imax(E1v - e1, Hout - oe1) : inf;
+            en1 = imax(E1v - e1, Hout - oe1);
+            E1out = (Hout == tmp) ? en1 : inf;
         } else {
             Hout = imax(hs, imax(F1, F2));
             E1out = imax(E1v - e1, Hout - oe1); E2out = imax(E2v - e2, Hout - oe2);
         }
         // record address = arena base + a 32-bit byte offset (an arena is far below 4 GB): one VALU add, no 64-bit pointer arithmetic per row
-        T *const H = (T *)((char *)io.planes + (size_t)rec_off) - lane * CW;
+        // (DIR: the row's records, if it keeps them, start behind the room of its direction words)
+        T *const H = DIR ? (T *)((char *)io.planes + (size_t)(off_pn + dir_units(nvr)) * 32) : (T *)((char *)io.planes + (size_t)rec_off) - lane * CW;
         const int he = I16 ? (int)__builtin_amdgcn_perm((unsigned)E1out, (unsigned)Hout, 0x05040100u) : 0;      // H | E1 << 16 (int16: also the score-ring word)
         // match flag for the backtrack (spare slot of the record, finish_alignment PL_FLAG): 1 + index of the first predecessor k (list order) with
         // H[k][col-1] + q == H[col], 0 = none.  Only a predecessor that supplies the maximum Mv can satisfy it, and only when H == Mv + q.
         // (A predecessor value read from outside its band is `inf`: the backtrack re-checks the column range before it trusts the flag.)
         const int mflag = (h == Hout) ? (NPC >= 4 ? kfirst : ((NPC == 2 && Mv != Mv_first) ? 2 : 1)) : 0;
-        if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
+        if constexpr (DIR) {
+            // the cell's direction word (dir_plane.h): uE = E's own maximum minus its "opened from H" term = max(o - (H - Ein), 0), dF = min(H - F, cap);
+            // where F came from is decided from the left neighbour's word -- except in the vectors of the reference's masked scan, which get the literal test
+            const unsigned u1 = (unsigned)((GAP == 1 ? en1 : E1out) - (Hout - oe1)), d1 = umin_((unsigned)(Hout - F1), (unsigned)CAPF1);
+            unsigned u2 = 0, d2 = 0;
+            if (GAP == 2) { u2 = (unsigned)(E2out - (Hout - oe2)); d2 = umin_((unsigned)(Hout - F2), (unsigned)CAPF2); }
+            unsigned wd = dir_pack<GAP>((unsigned)mflag, NPC >= 2 ? (unsigned)kE1 : 1u, NPC >= 2 ? (unsigned)kE2 : 1u, u1, u2, d1, d2);
+            if (SLOWV && end_sn > max_pe) {
+                const int nfast_ = max_pe - beg_sn + 1;
+                const int Hm1 = wave_shr1(Hout, Hout), F1m1 = wave_shr1(F1, F1);
+                unsigned l1 = dir_literal<T>(Hm1, F1m1, F1, oe1, e1), l2 = 0;
+                if (GAP == 2) { const int F2m1 = wave_shr1(F2, F2); l2 = dir_literal<T>(Hm1, F2m1, F2, oe2, e2); }
+                if (vvl >= nfast_) wd |= GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH);      // (lane 0 of the band -- no stored left neighbour -- is never a masked-scan vector here: nfast_ >= 1)
+            }
+            char *const dp = (char *)io.planes + (size_t)rec_off;
+            if (!row_spill || in_band) { if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd; }
+        }
+        if (DIR && !row_spill) {}
+        else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(H + lane * CW); dst[0] = r0; dst[1] = r1; }
@@ -579,7 +656,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // vectors beyond every predecessor's band (literal masked scan) must all sit in the row's last chunk
         if (end_sn > max_pe) ok = ok && ((max_pe + 1 - beg_sn) / NV == nch - 1);
         if (!ok) { WCOUNT(4); return 0; }
-        if (cur + nvr * CW > cap_pn) return -2;
+        if (cur + row_units(nvr, row_spill) > cap_pn) return -2;
         return nch;
     };
     auto ilp_chunks = [&](auto nchc, int nch, int row, int ti) __attribute__((always_inline)) -> int {
@@ -597,6 +674,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         FSTAMP(0)
         const int *mrow = s_mx + base * m1;
         int q[NCH], Mv[NCH], E1v[NCH], E2v[NCH], kb[NCH];
+        int kE1[NCH], kE2[NCH];                                     // (DIR) 1 + list index of the first predecessor holding the maximum E1 / E2 of the column
 #pragma unroll
         for (int c = 0; c < NCH; ++c) q[c] = mrow[qoffx[c]];
         // ---- predecessor gather: the first one unmasked (guard cells and padding of the ring row yield what the reference reads), the others
@@ -612,13 +690,15 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN, x = colb + 64 * c - pb * PN;
             const bool inH = (unsigned)x < (unsigned)(Wp + PN), inE = (unsigned)x < (unsigned)Wp;
             kb[c] = (inH && hm1 > Mv[c]) ? kidx : kb[c];
+            if (DIR) { kE1[c] = (inE && ev1 > E1v[c]) ? kidx : kE1[c]; if (GAP == 2) kE2[c] = (inE && ev2 > E2v[c]) ? kidx : kE2[c]; }
             Mv[c] = inH ? imax(Mv[c], hm1) : Mv[c]; E1v[c] = inE ? imax(E1v[c], ev1) : E1v[c]; if (GAP == 2) E2v[c] = inE ? imax(E2v[c], ev2) : E2v[c];
         };
         // a predecessor outside the ring: its cells come from the arena in HBM (records this wave stored at least RR rows ago), every
         // chunk's loads in flight together; outside its band the reference reads / assigns "inf", exactly what the ring's guards and padding give
         auto hbm_read_all = [&](int p, int g_, int *hc, int *ec1, int *ec2) __attribute__((always_inline)) {
             const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN;
-            const T *Hp = io.planes + (long long)(uint32_t)__builtin_amdgcn_readlane(vg_off, p & 63) * PN;
+            // (DIR: the predecessor kept its score records -- tile bit 21 / a row too wide for the ring -- behind the room of its direction words)
+            const T *Hp = io.planes + (long long)(uint32_t)(__builtin_amdgcn_readlane(vg_off, p & 63) + (DIR ? dir_units(((g_ >> 12) & 0xfff) - pb + 1) : 0)) * PN;
             gld_wait();                                              // (earlier score-plane stores of this wave are complete)
             if (TEAM) lds_barrier();                                 // (... and of the other wavefronts of the team: the far flag is the same in all of them)
 #pragma unroll
@@ -645,20 +725,20 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 for (int c = 0; c < NCH; ++c) ring_read(p, g_, c, hc[c], ec1[c], ec2[c]);
             }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { if (k == 0) { Mv[c] = hc[c]; E1v[c] = ec1[c]; E2v[c] = ec2[c]; kb[c] = 1; } else merge(g_, c, hc[c], ec1[c], ec2[c], k + 1); }
+            for (int c = 0; c < NCH; ++c) { if (k == 0) { Mv[c] = hc[c]; E1v[c] = ec1[c]; E2v[c] = ec2[c]; kb[c] = 1; kE1[c] = 1; kE2[c] = 1; } else merge(g_, c, hc[c], ec1[c], ec2[c], k + 1); }
         };
         {
             const int p0 = __builtin_amdgcn_readlane(tv_p0, ti), g0 = __builtin_amdgcn_readlane(vg_geo, p0 & 63);
             if (np == 1 && !ilp_far) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; }
+                for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; kE1[c] = 1; kE2[c] = 1; }
             } else if (np == 1) gather_pred(0, tv_p0);
             else {
                 if (!(ilp_far & 3)) {                               // the first two predecessors' ring reads go out together
                     const int p1 = __builtin_amdgcn_readlane(tv_p1, ti), g1_ = __builtin_amdgcn_readlane(vg_geo, p1 & 63);
                     int hb[NCH], eb1[NCH], eb2[NCH];
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; ring_read(p1, g1_, c, hb[c], eb1[c], eb2[c]); }
+                    for (int c = 0; c < NCH; ++c) { ring_read(p0, g0, c, Mv[c], E1v[c], E2v[c]); kb[c] = 1; kE1[c] = 1; kE2[c] = 1; ring_read(p1, g1_, c, hb[c], eb1[c], eb2[c]); }
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) merge(g1_, c, hb[c], eb1[c], eb2[c], 2);
                 } else { gather_pred(0, tv_p0); gather_pred(1, tv_p1); }
@@ -771,8 +851,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (!I16) { const unsigned tv = kbst >> 11; if (__builtin_expect(tv == 0u || tv == 0x1FFFFFu, 0)) return 0; }
         FSTAMP(3)
         // ---- from here on the row is committed
-        off_pn = cur; cur += (end_sn - beg_sn + 1) * CW;
-        T *const Hrow = io.planes + (long long)off_pn * PN + (long long)(lane + 64 * c0) * CW;
+        off_pn = cur; cur += row_units(end_sn - beg_sn + 1, row_spill);
+        T *const Hrow = io.planes + (long long)(off_pn + (DIR ? dir_units(end_sn - beg_sn + 1) : 0)) * PN + (long long)(lane + 64 * c0) * CW;
+        char *const Drow = (char *)io.planes + (size_t)off_pn * 32 + (size_t)(lane + 64 * c0) * DB;      // (DIR) this lane's direction word in the wavefront's first chunk
         int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * (lane + 64 * c0), 0);
         // (nch is NCH - 1 or NCH: chunks 0 .. NCH - 3 are full, only the last two need band masks, only the last one a store guard)
         int F1[NCH], F2[NCH], S1[NCH], S2[NCH];
@@ -812,7 +893,29 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             const int mflag = (Mv[c] + q[c] == Hout && kb[c] <= 64) ? kb[c] : 0;
             const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
-            if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {      // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
+            if constexpr (DIR) if (c < NCH - 1 || nch == NCH) {
+                // direction word of the column (dir_plane.h; as in the straight-line body of the narrow loop)
+                const unsigned u1 = (unsigned)((GAP == 1 ? imax(wr(E1v[c] - e1), wr(Hout - oe1)) : E1out) - (Hout - oe1)), d1 = umin_((unsigned)(Hout - F1[c]), (unsigned)CAPF1);
+                unsigned u2 = 0, d2 = 0;
+                if (GAP == 2) { u2 = (unsigned)(E2out - (Hout - oe2)); d2 = umin_((unsigned)(Hout - F2[c]), (unsigned)CAPF2); }
+                unsigned wd = dir_pack<GAP>((unsigned)mflag, (unsigned)kE1[c], (unsigned)kE2[c], u1, u2, d1, d2);
+                if (c >= NCH - 2) if (__builtin_expect(end_sn > max_pe, 0) && c == nch - 1) {      // the vectors of the reference's masked F scan (last chunk only): the literal test
+                    const int vb = beg_sn + c * NV, nfast_ = imax(0, imin(imin(NV, end_sn - vb + 1), max_pe - vb + 1));
+                    int pH = Hout, pF1 = F1[c], pF2 = F2[c];                             // left neighbour of the chunk's first column: the previous chunk's last one
+                    if (c > 0) {
+                        const int Hp_ = GAP == 1 ? imax(hsE[c > 0 ? c - 1 : 0], F1[c > 0 ? c - 1 : 0]) : imax(hs[c > 0 ? c - 1 : 0], imax(F1[c > 0 ? c - 1 : 0], F2[c > 0 ? c - 1 : 0]));
+                        pH = __builtin_amdgcn_readlane(Hp_, 63); pF1 = __builtin_amdgcn_readlane(F1[c > 0 ? c - 1 : 0], 63); pF2 = __builtin_amdgcn_readlane(F2[c > 0 ? c - 1 : 0], 63);
+                    }
+                    const int Hm1 = wave_shr1(pH, Hout), F1m1 = wave_shr1(pF1, F1[c]);
+                    unsigned l1 = dir_literal<T>(Hm1, F1m1, F1[c], oe1, e1), l2 = 0;
+                    if (GAP == 2) { const int F2m1 = wave_shr1(pF2, F2[c]); l2 = dir_literal<T>(Hm1, F2m1, F2[c], oe2, e2); }
+                    if (vvl >= nfast_ && (c > 0 || lane > 0)) wd |= GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH);
+                }
+                char *const dp = Drow + c * 64 * DB;
+                if (!row_spill || in_band) { if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd; }
+            }
+            if (DIR && !row_spill) {}
+            else if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {      // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
                 T *H = Hrow + c * 64 * CW;
                 if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1[c], 0x05040100u); *(int2 *)H = rec; }
                 else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1[c] << 16)); rec.z = F2[c] & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
@@ -875,12 +978,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int qc = c == 0 ? qoff0 : qoff1;
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
             const int q = mrow[qc];
-            int Mv = lane, E1v = inf, E2v = inf, kb = 0;
-            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v, kb, 1);
-            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v, kb, 2);
-            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v, kb, 3); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v, kb, 4); }
+            int Mv = lane, E1v = inf, E2v = inf, kb = 0, kE1 = 1, kE2 = 1;
+            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v, kb, 1, kE1, kE2);
+            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v, kb, 2, kE1, kE2);
+            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v, kb, 3, kE1, kE2); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v, kb, 4, kE1, kE2); }
             FSTAMP(1)
-            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot);
+            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot, kE1, kE2);
         }
         pad_ring(nch, my_slot);
         return 1;
@@ -898,8 +1001,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (np == 0) min_pb = 0;
         set_band(std::false_type{}, mn_mi, mx_mi, min_pb);
         const int Wr = (end_sn - beg_sn + 1) * PN;
-        if (!reserve()) return 2;
         to_ring = Wr <= RC;
+        if (DIR && !to_ring) row_spill = true;                      // a row too wide for the score ring: its successors read it from HBM
+        if (!reserve()) return 2;
         T *H = io.planes + (long long)off_pn * PN;
         const int my_slot = (row & (RR - 1)) * (NPW * RCS);
         const int nch = (Wr + 63) >> 6;
@@ -913,24 +1017,25 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int qc = c == 0 ? qoff0 : qoff1;
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
             const int q = mrow[qc];
-            int Mv = inf, E1v = inf, E2v = inf, kb = 0;
+            int Mv = inf, E1v = inf, E2v = inf, kb = 0, kE1 = 1, kE2 = 1;
             for (int k = 0; k < np; ++k) {
                 int g_, mi_, off_; const int p = __builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)); geo_of(p, row, g_, mi_, off_);
                 if ((g_ & GEO_RING) && row - p < RR) {
-                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1);
+                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1, kE1, kE2); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1, kE1, kE2);
                 } else {
                     const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
                     const int x = col - pb * PN;
                     const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
-                    const T *Hp = io.planes + (long long)(uint32_t)off_ * PN;
+                    const T *Hp = io.planes + (long long)(uint32_t)(off_ + (DIR ? dir_units(pe - pb + 1) : 0)) * PN;      // (DIR: its score records, behind its direction words)
                     int hval = inf, ev1 = inf, ev2 = inf;
                     if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CW));
                     if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E2)); }
-                    if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; kb = 1; }
-                    else { kb = (inH && hval > Mv) ? k + 1 : kb; Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
+                    if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; kb = 1; kE1 = 1; kE2 = 1; }
+                    else { kb = (inH && hval > Mv) ? k + 1 : kb; if (DIR) { kE1 = (inE && ev1 > E1v) ? k + 1 : kE1; if (GAP == 2) kE2 = (inE && ev2 > E2v) ? k + 1 : kE2; }
+                           Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }
                 }
             }
-            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot);
+            chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot, kE1, kE2);
         }
         if (to_ring) pad_ring(nch, my_slot);
         return 1;
@@ -1021,6 +1126,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             int ok_ = 1;
             if constexpr (!WPLAN) if (__builtin_expect(two_chunk_streak, 0)) {      // the band is 65-128 columns wide at the moment: straight to the two-chunk body
                 const int ti_ = row & 63, meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
+                if constexpr (DIR) row_spill = (meta_ >> 21) & 1;
                 if ((meta_ >> 19) & 1) {
                     CENSUS_T0()
                     last_done = row;
@@ -1035,6 +1141,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int ti_ = row & 63;
                 const int meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
                 if (!__builtin_expect((meta_ >> 17) & 1, 1)) break;
+                if constexpr (DIR) row_spill = (meta_ >> 21) & 1;
                 CENSUS_T0()
                 rterm = __builtin_amdgcn_readlane(tv_rterm, ti_);
                 base = meta_ & 0xff; np = (meta_ >> 8) & 0xff;
@@ -1052,6 +1159,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int meta = __builtin_amdgcn_readlane(tv_meta, ti);
             rterm = __builtin_amdgcn_readlane(tv_rterm, ti);
             base = meta & 0xff; np = (meta >> 8) & 0xff;
+            if constexpr (DIR) row_spill = (meta >> 21) & 1;
             if (!WPLAN && ((meta >> 18) & 1)) {                       // three or four predecessors: the straight-line body, outside the tight loop
                 if (turbo_body(std::integral_constant<int, 4>{}, std::true_type{}, row, ti) == 1) { commit_row(ti, true); CENSUS(2) ++row; continue; }
             }
@@ -1142,11 +1250,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 
 // The fast path is two kernels -- row loop, then global best + backtrack -- so that the row loop's register allocation
 // (its SGPR budget above all) is not shared with the tail; the hand-over is the AlnOut record in HBM.
-template <typename T, int GAP, int NW = 1, bool WIDEB = false>
+template <typename T, int GAP, int NW = 1, bool WIDEB = false, bool DIR = false>
 __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
     const int lane = threadIdx.x & 63;
     FastIO<T> io;
-    io.row_base = vgpr_ptr(b.row_base + d.row0); io.row_remain = vgpr_ptr(b.row_remain + d.row0);
+    io.row_base = vgpr_ptr(b.row_base + d.row0); io.row_remain = vgpr_ptr(b.row_remain + d.row0); io.row_sdist = vgpr_ptr((DIR ? b.row_sdist : b.row_base) + d.row0);
     io.pred_off = vgpr_ptr(b.pred_off + d.poff0); io.pred_row = vgpr_ptr(b.pred_row + d.pred0);
     io.g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0); io.g_esn = vgpr_ptr(b.dp_end_sn + d.row0); io.row_max_i = vgpr_ptr(b.row_max_i + d.row0);
     io.g_left = vgpr_ptr(b.left + d.row0); io.g_right = vgpr_ptr(b.right + d.row0); io.g_coff = vgpr_ptr(b.row_cell_off + d.row0);
@@ -1157,7 +1265,7 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
     const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
     long long fseg[6] = {0, 0, 0, 0, 0, 0};
-    rows_fast<T, GAP, NW, WIDEB>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
+    rows_fast<T, GAP, NW, WIDEB, DIR>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
     const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
 #if !defined(ABPOA_HIP_WIDE_COUNTERS) && !defined(ABPOA_HIP_ROW_CENSUS)
     fseg[5] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);      // HW_ID | XCC_ID << 32: where the wave ran (ABPOA_HIP_IMBAL placement report)

@@ -38,6 +38,13 @@ int  abpoa_oracle_align(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t
                         abpoa_hip_result_t *res, abpoa_oracle_trace_t *trace);
 void abpoa_oracle_free_trace(abpoa_oracle_trace_t *t);
 
+/* oracle/dir_model.c: builds the direction plane of abpoa_amd/csrc/dir_plane.h from a trace and walks it (global mode, banded, affine /
+ * convex); res->cigar (malloc'ed) must equal abpoa_oracle_align's.  stats[8]: cells, cells in masked-scan vectors, derived-vs-literal F
+ * origin mismatches, arithmetic-vs-literal E mismatches, walk steps, steps decided by a literal override, cells of the undecidable class, walk
+ * steps whose F origin differs from the reference's comparisons (must be 0). */
+int  abpoa_oracle_dir_walk(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p, const abpoa_oracle_trace_t *t,
+                           int best_i, int best_j, abpoa_hip_result_t *res, int64_t *stats);
+
 /* Same arithmetic as abpoa_hip_score_bits (reference src/simd_abpoa_align.c:1672-1683). */
 int  abpoa_oracle_score_bits(const abpoa_hip_scoring_t *sc, int n_rows, int qlen, int32_t *inf_min);
 

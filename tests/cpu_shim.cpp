@@ -10,8 +10,11 @@ extern "C" {
 #include "../oracle/abpoa_dp_oracle.h"
 }
 
+#include <atomic>
+#include <stdio.h>
 namespace {
 using namespace abpoa_hip;
+std::atomic<long long> n_dir_checked{0}, n_dir_steps{0}, n_dir_ambig{0}, n_dir_lit{0};
 class OracleGroupAligner : public GroupAligner {
   public:
     ~OracleGroupAligner() override { clear(); }
@@ -41,7 +44,25 @@ class OracleGroupAligner : public GroupAligner {
             pb.n_rows = p.gn; pb.qlen = p.qlen; pb.query = p.query.data(); pb.row_base = p.base.data(); pb.row_node_id = p.nid.data();
             pb.row_remain = p.remain.data(); pb.row_active = p.active.data(); pb.pred_off = p.poff.data(); pb.pred_row = p.pred.data();
             pb.out_off = p.ooff.data(); pb.out_row = p.out.data(); pb.max_pos_left = p.left.data(); pb.max_pos_right = p.right.data();
-            int rc = abpoa_oracle_align(&sc_, &pb, &res_[i], 0);
+            // ABPOA_SHIM_DIR_CHECK=1: keep the trace and let oracle/dir_model.c build and walk the direction plane of this alignment;
+            // its cigar and result fields must equal the value-comparing backtrack's (tests/test_dir_model.py)
+            static const bool dir_check = getenv("ABPOA_SHIM_DIR_CHECK") && atoi(getenv("ABPOA_SHIM_DIR_CHECK"));
+            abpoa_oracle_trace_t tr; memset(&tr, 0, sizeof(tr));
+            int rc = abpoa_oracle_align(&sc_, &pb, &res_[i], dir_check ? &tr : 0);
+            if (dir_check && rc == 0 && res_[i].status == 0) {
+                abpoa_hip_result_t r2; int64_t st[10];
+                const int rc2 = abpoa_oracle_dir_walk(&sc_, &pb, &tr, res_[i].best_row, res_[i].best_col, &r2, st);
+                if (rc2 == 0) {
+                    const abpoa_hip_result_t &a = res_[i];
+                    bool same = a.n_cigar == r2.n_cigar && a.node_s == r2.node_s && a.node_e == r2.node_e && a.query_s == r2.query_s && a.query_e == r2.query_e &&
+                                a.n_aln_bases == r2.n_aln_bases && a.n_matched_bases == r2.n_matched_bases && st[2] == 0 && st[3] == 0 && st[7] == 0;
+                    for (int k = 0; same && k < a.n_cigar; ++k) same = a.cigar[k] == r2.cigar[k];
+                    free(r2.cigar);
+                    if (!same) { fprintf(stderr, "[cpu shim] direction-plane model differs from the oracle backtrack (rows %d, qlen %d; derived-F mismatches %lld, uE mismatches %lld)\n", p.gn, p.qlen, (long long)st[2], (long long)st[3]); abpoa_oracle_free_trace(&tr); return ABPOA_HIP_EBACKTRACK; }
+                    n_dir_checked.fetch_add(1); n_dir_steps.fetch_add(st[4]); n_dir_ambig.fetch_add(st[8]); n_dir_lit.fetch_add(st[5]);
+                } else if (rc2 != ABPOA_HIP_EINVAL) { abpoa_oracle_free_trace(&tr); return rc2; }
+            }
+            if (dir_check) abpoa_oracle_free_trace(&tr);
             if (rc && res_[i].status == 0) return rc;
         }
         return 0;
@@ -65,5 +86,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
     return abpoa_hip::run_msa_batch(sc, n_sets, sets, out, flags, n_threads, n_sets >= 4 ? 2 : 1, make_oracle_aligner, &g_timing);
 }
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = g_timing; }
+void abpoa_shim_dir_counts(long long *o) { o[0] = n_dir_steps.exchange(0); o[1] = n_dir_ambig.exchange(0); o[2] = n_dir_lit.exchange(0); }
+long long abpoa_shim_dir_checked(void) { return n_dir_checked.exchange(0); }      // alignments the direction-plane model confirmed since the last call
 const char *abpoa_hip_last_error(void) { return "cpu shim"; }
 }

@@ -99,8 +99,8 @@ def oracle_lib():
     global _oracle
     if _oracle is None:
         so = os.path.join(ORACLE_DIR, "liboracle_dp.so")
-        src = os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("abpoa_dp_oracle.c", "abpoa_dp_oracle.h", "dir_model.c")] + [os.path.join(ROOT, "abpoa_amd", "csrc", "dir_plane.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle_dp"])
         lib = C.CDLL(so)
         lib.abpoa_oracle_align.argtypes = [C.POINTER(Scoring), C.POINTER(Problem), C.POINTER(Result), C.POINTER(OracleTrace)]
@@ -108,6 +108,8 @@ def oracle_lib():
         lib.abpoa_oracle_free_trace.argtypes = [C.POINTER(OracleTrace)]
         lib.abpoa_oracle_score_bits.argtypes = [C.POINTER(Scoring), C.c_int, C.c_int, C.POINTER(C.c_int32)]
         lib.abpoa_oracle_score_bits.restype = C.c_int
+        lib.abpoa_oracle_dir_walk.argtypes = [C.POINTER(Scoring), C.POINTER(Problem), C.POINTER(OracleTrace), C.c_int, C.c_int, C.POINTER(Result), C.POINTER(C.c_int64)]
+        lib.abpoa_oracle_dir_walk.restype = C.c_int
         _oracle = lib
     return _oracle
 
@@ -159,6 +161,29 @@ def run_oracle(case, want_trace=True):
         o.active = act
         lib.abpoa_oracle_free_trace(C.byref(tr))
     return o
+
+
+def run_dir_model(case):
+    """oracle/dir_model.c on a FlatCase: the oracle's alignment (trace kept), then the direction plane built from that trace and walked.
+    Returns (oracle result fields, model result fields, stats[6]); rc_model == ABPOA_HIP_EINVAL where the plane does not apply."""
+    lib = oracle_lib()
+    case.reset()
+    res, tr = Result(), OracleTrace()
+    rc = lib.abpoa_oracle_align(C.byref(case.sc), C.byref(case.pb), C.byref(res), C.byref(tr))
+    assert rc == 0 and res.status == 0
+    FIELDS = ("best_row", "best_col", "node_s", "node_e", "query_s", "query_e", "n_aln_bases", "n_matched_bases", "n_cigar")
+
+    def grab(r):
+        d = {k: getattr(r, k) for k in FIELDS}
+        d["cigar"] = np.ctypeslib.as_array(r.cigar, (r.n_cigar,)).copy() if r.n_cigar > 0 else np.zeros(0, np.uint64)
+        if r.cigar:
+            _libc.free(C.cast(r.cigar, C.c_void_p))
+        return d
+    res2, stats = Result(), (C.c_int64 * 10)()
+    rc2 = lib.abpoa_oracle_dir_walk(C.byref(case.sc), C.byref(case.pb), C.byref(tr), res.best_row, res.best_col, C.byref(res2), stats)
+    a, b = grab(res), (grab(res2) if rc2 == 0 else None)
+    lib.abpoa_oracle_free_trace(C.byref(tr))
+    return rc2, a, b, list(stats)
 
 
 def mix64(x):
@@ -316,12 +341,14 @@ def cpu_shim_lib():
         so = os.path.join(bdir, "libcpu_shim.so")
         srcs = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.cpp"),
                 os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.cpp")]
-        deps = srcs + [os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "batch_types.h"),
+        deps = srcs + [os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c"), os.path.join(ORACLE_DIR, "dir_model.c"), os.path.join(ORACLE_DIR, "abpoa_dp_oracle.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "dir_plane.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "batch_types.h"),
                        os.path.join(ROOT, "include", "abpoa_hip.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-            obj = os.path.join(bdir, "oracle.o")
-            subprocess.check_call(["gcc", "-O2", "-fPIC", "-c", "-I" + os.path.join(ROOT, "include"), "-o", obj,
-                                   os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c")])
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", so] + srcs + [obj])
+            objs = []
+            for f in ("abpoa_dp_oracle", "dir_model"):
+                objs.append(os.path.join(bdir, f + ".o"))
+                subprocess.check_call(["gcc", "-O2", "-fPIC", "-c", "-I" + os.path.join(ROOT, "include"), "-o", objs[-1], os.path.join(ORACLE_DIR, f + ".c")])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", so] + srcs + objs)
         _shim = C.CDLL(so)
+        _shim.abpoa_shim_dir_checked.restype = C.c_longlong
     return _shim

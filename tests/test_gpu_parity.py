@@ -28,6 +28,22 @@ def test_hip_matches_golden_and_oracle(engine, label, path):
     h = H.run_hip([case])[0]
     H.compare_with_golden(h, g, label="hip-vs-golden " + label)
     H.compare_outs(h, o, label="hip-vs-oracle " + label)
+    # without the trace the fast row loops write direction words instead of score records (dir_plane.h) and the backtrack walks those: best cell, cigar,
+    # every abpoa_res_t field and the band state must not change
+    _dir_counts(engine)
+    h2 = H.run_hip([case], want_trace=False)[0]
+    H.compare_with_golden(h2, g, check_planes=False, label="hip-dir-vs-golden " + label)
+    assert np.array_equal(h2.cigar, o.cigar) and h2.best_score == o.best_score
+    walked, redone = _dir_counts(engine)
+    if label.startswith(("s1k_", "s10k_", "s20k_", "seq_ag_gb", "heter_ag_gb", "heter_cg_gb")):      # global, banded, default penalties: the plane must have been used
+        assert walked == 1 and redone == 0, (label, walked, redone)
+
+
+def _dir_counts(lib):
+    import ctypes
+    out = (ctypes.c_longlong * 2)()
+    lib.abpoa_hip__dir_counts(out)
+    return out[0], out[1]
 
 
 def test_hip_batch_mixed_widths(engine):
@@ -88,6 +104,8 @@ def test_wide_band_variants(engine, monkeypatch, env):
         g = H.read_abpg(path)
         h = H.run_hip([H.FlatCase(g)])[0]
         H.compare_with_golden(h, g, label=f"{env} {label}")
+        h2 = H.run_hip([H.FlatCase(g)], want_trace=False)[0]      # direction-plane arenas (not with teams): with a 4-row ring most rows read a predecessor's kept score record from HBM
+        H.compare_with_golden(h2, g, check_planes=False, label=f"{env} dir {label}")
         n += 1
     assert n >= 3
     from abpoa_amd import api, synth, workloads as W
