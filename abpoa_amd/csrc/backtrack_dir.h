@@ -7,45 +7,52 @@
 namespace abpoa_hip {
 
 // Global best + backtrack over DIRECTION-PLANE arenas (dir_plane.h): the row loops left one word per cell that records every comparison the
-// reference backtrack (src/simd_abpoa_align.c:109-429) would make there, so the walk reads 2 / 4 bytes per step, never a score, and every kind of
-// step -- match, deletion, insertion -- is the same single LDS round trip: the cell's word, the word of its left neighbour and the row's
-// predecessor edge records (lane k = predecessor k, each carrying the predecessor's own row record), then scalar decisions in the reference's
-// priority order.  oracle/dir_model.c is the CPU statement of exactly this walk (checked against the value-comparing backtrack on every golden).
+// reference backtrack (src/simd_abpoa_align.c:109-429) would make there, so the walk never reads a score.  oracle/dir_model.c is the CPU statement of
+// exactly this walk (checked against the value-comparing backtrack on every golden).
 //
-// Windows: rows [lo, hi] of the arena staged in LDS by LDS-DMA, up to DBTR rows with their row / edge tables built once per window.
-//   * narrow bands: whole rows, one contiguous copy (rows are adjacent in the arena; a row that also keeps its score records drags them along);
-//   * wide bands: a TRIANGLE of column slices -- a match step goes one column back and at least one row up, a deletion only up, so from (hi, jtop)
-//     the walk reaches columns [jtop - (hi - r), jtop] of row r unless insertions (one column back in the same row) push it further left: row r stages
-//     DIR_TRI_SLACK more columns than that (a path advances 1.2 - 2.4 rows per column, so the slack grows on its own with the distance; the one
-//     column an insertion step looks left is part of it).  A walk that does leave a slice re-centres the window on its cell.
+// Window: rows [lo, hi] of words staged in LDS by LDS-DMA, up to DBTR rows, and one 16-byte record per row:
+//     { row distances to the first four predecessors, a byte each  (DevBatch.row_pd, made once per alignment by the graph phase),
+//       A0 | A1 << 16,  A2 | A3 << 16   where the words of predecessor k sit in the window: word of column c at word index A_k + (c - cref); DIR_NA = not staged,
+//       first staged column | left-cut flag << 15 | staged columns << 16 }
+//   so a step needs ONE LDS round trip -- the cell's word and its row's record, both at addresses the previous step already knew -- and scalar
+//   arithmetic: the word names the predecessor (kM), the record gives its row distance and where its words are.  No per-step table lookups, no
+//   cross-lane traffic; node ids, the matched-base count and the reversal are one lane-parallel pass over the finished cigar.
+//   * narrow bands: whole rows, ONE contiguous copy (rows are adjacent in the arena; a row that also keeps its score records drags them along): 256 rows
+//     of 1 kb reads are 32 KB;
+//   * wide bands: a triangle of column slices, one DMA per row -- a match step goes one column back and at least one row up, a deletion only up, so from
+//     (hi, jtop) the walk reaches columns [jtop - (hi - r), jtop] of row r unless insertions push it further left: row r stages DIR_TRI_SLACK more
+//     columns than that (the rows-per-column ratio of a path, 1.2 - 2.4, adds slack of its own).  A walk that leaves a slice re-centres the window.
+//   Runs of match steps record only the ROW they pass (one v_writelane); their cigar words are made 64 at a time, a lane each.
 // The one situation the plane cannot decide (dir_plane.h: F origin under an F-term H with dF > o) ends the walk with ABPOA_HIP_STATUS_NEED_SCORES and
 // the host redoes that alignment with score records; oracle/dir_model.c counts it: 0 in 250 000 steps of noisy 1-5 kb reads.
-constexpr int DBTR = 128;     // rows per window
-constexpr int DBTP = 192;     // predecessor edges per window
+constexpr int DBTR = 256;     // most rows of a window
 constexpr int DIR_TRI_SLACK = 9;
-struct __attribute__((aligned(16))) DirBt {
-    // rinfo = {first band column | band columns << 16, LDS byte offset of the row's first STAGED word, edge index | n_pred << 16 | base << 24, node id}
-    // rinfo2 = first staged column | staged columns << 16
-    // edge = {predecessor row, its rinfo.x, its rinfo.y, inside the window?}; edge2 = {its rinfo.z, its rinfo.w, its rinfo2, -}
-    int4 rinfo[DBTR]; int4 edge[DBTP]; int4 edge2[DBTP]; int32_t rinfo2[DBTR];
-};
+constexpr int DIR_NA = -32768;
+struct __attribute__((aligned(16))) DirBt { int4 rec[DBTR]; int32_t rowA[DBTR]; };      // the walk's LDS image: row records, scratch for building them; the words follow
 
 template <typename T, int GAP>
 __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts) {
     constexpr int PN = Width<T>::PN, CW = FastFmt<T, GAP>::CW, DB = DirFmt<T, GAP>::DB, S = (int)sizeof(T);
     constexpr int ALIGN = 16 / DB;                    // columns per 16-byte piece of a row of words
+    constexpr int DBL = DB == 2 ? 1 : 2;
+    constexpr int NQ = DBTR / 64;
     typedef typename std::conditional<GAP == 1, uint16_t, uint32_t>::type DW;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+    typedef __attribute__((address_space(3))) DW lds_dw_t;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4i_t lds_i4_t;
     const int lane = threadIdx.x & 63;
     const int gn = d.n_rows, qlen = d.qlen;
     const int o1 = b.o1, o2 = b.o2;
     GLOBAL_AS const uint8_t *row_base = vgpr_ptr(b.row_base + d.row0);
     GLOBAL_AS const int32_t *row_node_id = vgpr_ptr(b.row_node_id + d.row0);
+    GLOBAL_AS const uint32_t *row_pd = vgpr_ptr(b.row_pd + d.row0);
     GLOBAL_AS const int32_t *pred_off = vgpr_ptr(b.pred_off + d.poff0), *pred_row = vgpr_ptr(b.pred_row + d.pred0);
     GLOBAL_AS int32_t *g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0), *g_esn = vgpr_ptr(b.dp_end_sn + d.row0);
     GLOBAL_AS int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
     T *planes = (T *)(b.planes + d.plane_off);
     const unsigned char *arena = (const unsigned char *)planes;
-    uint8_t *s_query = lds_raw + b.lds.q_off;
+    const uint8_t *s_query = lds_raw + b.lds.q_off;
     int status = ts.status, best_score = ts.best_score, best_i = ts.best_i, best_j = ts.best_j, bt_steps = 0;
     WG_SYNC();       // all of this wave's arena / band stores have landed before the loads below
 
@@ -61,149 +68,182 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     }
 
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
-    long long win_ticks = 0, walk_ticks = 0; int n_windows = 0;
+    long long win_ticks = 0, walk_ticks = 0; int n_windows = 0, n_general = 0;
+    if (status == 0 && b.ret_cigar && d.cigar_cap < gn + qlen + 2) status = ABPOA_HIP_EBACKTRACK;      // (a walk emits at most one word per row or column it leaves: no per-step capacity test)
     if (status == 0 && b.ret_cigar) {
         DirBt &B = *(DirBt *)(lds_raw + b.lds.phase_off);
-        unsigned char *bt = lds_raw + b.lds.phase_off + b.lds.bt_off;
-        const int bt_bytes = b.lds.bt_bytes_tail;
+        unsigned char *win = lds_raw + b.lds.phase_off + (int)sizeof(DirBt);
+        const int win_bytes = b.lds.bt_off + b.lds.bt_bytes_tail - (int)sizeof(DirBt);
         GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
-        const int cap = d.cigar_cap;
-        uint64_t last_word = 0;
-        int bt_lo = 1, bt_hi = 0;                                 // window = rows [bt_lo, bt_hi], empty at start
-        // ---- window of rows [hi - R + 1, hi] for a walk that stands at (hi, jtop)
-        auto load_window = [&](int hi, int jtop) __attribute__((always_inline)) {
+        int w_lo = 1, w_hi = 0, w_cref = 0;                     // window = rows [w_lo, w_hi], empty at start; column origin of the A values
+        // ---- stage the window for a walk that stands at (hi, jtop); returns A of row hi
+        auto load_window = [&](int hi, int jtop) __attribute__((always_inline)) -> int {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             WG_SYNC();
-            // candidates: lane l holds row hi - l ("a") and row hi - 64 - l ("b"): descending rows, so that cumulative sizes are plain prefix sums
-            const int ra = hi - lane, rb = hi - 64 - lane; const bool va = ra >= 0, vb = rb >= 0;
-            int ba = 0, ea = -1, poa = 0, po1a = 0, nida = 0, bsa = 0, bb = 0, eb_ = -1, pob = 0, po1b = 0, nidb = 0, bsb = 0; long long ca = 0, cb = 0;
-            if (va) { ba = g_bsn[ra]; ea = g_esn[ra]; ca = g_coff[ra]; poa = pred_off[ra]; po1a = pred_off[ra + 1]; nida = row_node_id[ra]; bsa = row_base[ra]; }
-            if (vb) { bb = g_bsn[rb]; eb_ = g_esn[rb]; cb = g_coff[rb]; pob = pred_off[rb]; po1b = pred_off[rb + 1]; nidb = row_node_id[rb]; bsb = row_base[rb]; }
-            const int Wa = va ? (ea - ba + 1) * PN : 0, Wb = vb ? (eb_ - bb + 1) * PN : 0, pca = ba * PN, pcb = bb * PN;
-            // arena byte offsets fit 32 bits (an arena is far below 4 GB)
-            const unsigned sa = (unsigned)(ca * S), sb = (unsigned)(cb * S);
-            const unsigned end_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(sa + (unsigned)(Wa * DB)));
-            const int pend_hi = __builtin_amdgcn_readfirstlane(po1a);
-            // whole rows: rows are adjacent in the arena, [start of row r, end of row hi) must fit the window; edges of rows r .. hi must fit the table
-            const bool fa = va && end_hi - sa <= (unsigned)bt_bytes && pend_hi - poa <= DBTP, fb = vb && end_hi - sb <= (unsigned)bt_bytes && pend_hi - pob <= DBTP;
-            const int r_full = __builtin_popcountll(__ballot(fa)) + __builtin_popcountll(__ballot(fb));
-            const bool narrow = r_full >= imin(16, hi + 1);
-            // triangle of column slices (see the header comment); slices start and end on 16-byte pieces of the row
-            const int tla = imax(pca, (jtop - lane - DIR_TRI_SLACK) & ~(ALIGN - 1)), tha = imin(pca + Wa, (jtop + ALIGN) & ~(ALIGN - 1));
-            const int tlb = imax(pcb, (jtop - 64 - lane - DIR_TRI_SLACK) & ~(ALIGN - 1)), thb = imin(pcb + Wb, (jtop + ALIGN) & ~(ALIGN - 1));
-            const int sla = narrow ? pca : tla, nsa = va ? (narrow ? Wa : imax(0, tha - tla)) : 0;
-            const int slb = narrow ? pcb : tlb, nsb = vb ? (narrow ? Wb : imax(0, thb - tlb)) : 0;
-            int R, offa, offb;                                    // rows in the window; LDS byte offset of each candidate row's staged words
-            if (narrow) { R = r_full; }
-            else {
-                const int ia = wave_scan_add_i32(nsa * DB), ta = __builtin_amdgcn_readlane(ia, 63), ib = ta + wave_scan_add_i32(nsb * DB);
-                const bool ga = va && ia <= bt_bytes && pend_hi - poa <= DBTP, gb = vb && ib <= bt_bytes && pend_hi - pob <= DBTP;
-                R = __builtin_popcountll(__ballot(ga)) + __builtin_popcountll(__ballot(gb));
-                if (R < 1) R = 1;                                  // (a single row's slice always fits: a few 16-byte pieces)
-                offa = ia - nsa * DB; offb = ib - nsb * DB;
+            const int cref = jtop - 4096;                       // (below every staged column: A values stay in 16 bits)
+            // candidates: lane l holds rows hi - l - 64 q (descending rows: cumulative sizes are plain prefix sums); every load of every candidate in flight together
+            int bs[NQ], es[NQ]; long long co[NQ]; unsigned pdv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int r = hi - 64 * q - lane, rc = imax(r, 1);
+                bs[q] = g_bsn[rc]; es[q] = g_esn[rc]; co[q] = g_coff[rc]; pdv[q] = row_pd[rc];
+            }
+            int W[NQ], pc[NQ]; unsigned sa[NQ]; bool vq[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { vq[q] = hi - 64 * q - lane >= 1; W[q] = (es[q] - bs[q] + 1) * PN; pc[q] = bs[q] * PN; sa[q] = (unsigned)(co[q] * S); }      // (arena byte offsets fit 32 bits)
+            const unsigned end_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(sa[0] + (unsigned)(W[0] * DB)));
+            // whole rows: rows are adjacent in the arena, [start of row r, end of row hi) must fit
+            int r_full = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) r_full += __builtin_popcountll(__ballot(vq[q] && end_hi - sa[q] <= (unsigned)win_bytes));
+            const bool narrow = r_full >= imin(16, hi);
+            int sl[NQ], ns[NQ], off[NQ], R;
+            unsigned s_lo = 0;
+            if (narrow) {
+                R = r_full;
+                const int ql = (R - 1) >> 6, ll = (R - 1) & 63;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) if (q == ql) s_lo = (unsigned)__builtin_amdgcn_readlane((int)sa[q], ll);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { sl[q] = pc[q]; ns[q] = W[q]; off[q] = (int)(sa[q] - s_lo); }
+            } else {
+                int run = 0; R = 0;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int tl = imax(pc[q], (jtop - 64 * q - lane - DIR_TRI_SLACK) & ~(ALIGN - 1)), th = imin(pc[q] + W[q], (jtop + ALIGN) & ~(ALIGN - 1));
+                    sl[q] = tl; ns[q] = vq[q] ? imax(0, th - tl) : 0;
+                    const int incl = run + wave_scan_add_i32(ns[q] * DB);
+                    off[q] = incl - ns[q] * DB; run = __builtin_amdgcn_readlane(incl, 63);
+                    R += __builtin_popcountll(__ballot(vq[q] && incl <= win_bytes));
+                }
+                if (R < 1) R = 1;
             }
             const int lo = hi - R + 1;
-            if (narrow) {      // offsets relative to the start of row lo
-                const unsigned s_lo = (unsigned)(R <= 64 ? __builtin_amdgcn_readlane((int)sa, (R - 1) & 63) : __builtin_amdgcn_readlane((int)sb, (R - 65) & 63));
-                offa = (int)(sa - s_lo); offb = (int)(sb - s_lo);
-            }
-            const int pbase = R <= 64 ? __builtin_amdgcn_readlane(poa, (R - 1) & 63) : __builtin_amdgcn_readlane(pob, (R - 65) & 63);
-            if (va && lane < R) {
-                const int li = ra - lo;
-                B.rinfo[li] = make_int4(pca | (Wa << 16), offa, ((poa - pbase) & 0xffff) | (imin(po1a - poa, 255) << 16) | (bsa << 24), nida);
-                B.rinfo2[li] = sla | (nsa << 16);
-            }
-            if (vb && lane + 64 < R) {
-                const int li = rb - lo;
-                B.rinfo[li] = make_int4(pcb | (Wb << 16), offb, ((pob - pbase) & 0xffff) | (imin(po1b - pob, 255) << 16) | (bsb << 24), nidb);
-                B.rinfo2[li] = slb | (nsb << 16);
-            }
-            // the window's predecessor rows (and the band of the ones outside it) travel with the word copy below
-            const int pn_t = imin(DBTP, pend_hi - pbase);
-            int prv[DBTP / 64];
-#pragma unroll
-            for (int k_ = 0; k_ < DBTP / 64; ++k_) { const int e_ = k_ * 64 + lane; gld_async(prv[k_], (const int32_t *)pred_row + pbase + (e_ < pn_t ? e_ : 0)); }
+            // ---- the words: LDS-DMA, issued now, waited for at the end (the records are built meanwhile)
             if (narrow) {
-                const unsigned s_lo = (unsigned)(R <= 64 ? __builtin_amdgcn_readlane((int)sa, (R - 1) & 63) : __builtin_amdgcn_readlane((int)sb, (R - 65) & 63));
                 const int n16 = (int)((end_hi - s_lo) >> 4);
-                const int4 *src = (const int4 *)(arena + s_lo); int4 *dst = (int4 *)bt;
+                const int4 *src = (const int4 *)(arena + s_lo); int4 *dst = (int4 *)win;
                 for (int i0 = 0; i0 < n16; i0 += 64) {
                     const int idx = i0 + lane;
                     if (idx < n16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx), (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
                 }
             } else {
-                // one LDS-DMA per row and KB of slice; the per-row constants travel by v_readlane
-                const unsigned srca = sa + (unsigned)((sla - pca) * DB), srcb = sb + (unsigned)((slb - pcb) * DB);
-                for (int u = 0; u < R; ++u) {
-                    const int ln = u & 63;
-                    const int np16 = (u < 64 ? __builtin_amdgcn_readlane(nsa, ln) : __builtin_amdgcn_readlane(nsb, ln)) * DB / 16;
-                    const int ob = u < 64 ? __builtin_amdgcn_readlane(offa, ln) : __builtin_amdgcn_readlane(offb, ln);
-                    const unsigned so = (unsigned)(u < 64 ? __builtin_amdgcn_readlane((int)srca, ln) : __builtin_amdgcn_readlane((int)srcb, ln));
-                    const int4 *src = (const int4 *)(arena + so); unsigned char *dstb = bt + ob;
-                    for (int i0 = 0; i0 < np16; i0 += 64)
-                        if (i0 + lane < np16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane), (__attribute__((address_space(3))) void *)(dstb + i0 * 16), 16, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const unsigned srcq = sa[q] + (unsigned)((sl[q] - pc[q]) * DB);
+                    const int nrow = imin(64, R - 64 * q);
+                    for (int u = 0; u < nrow; ++u) {
+                        const int n_ = __builtin_amdgcn_readlane(ns[q], u) * DB / 16, ob = __builtin_amdgcn_readlane(off[q], u);
+                        const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)srcq, u);
+                        const int4 *sp = (const int4 *)(arena + so); unsigned char *dp = win + ob;
+                        for (int i0 = 0; i0 < n_; i0 += 64)
+                            if (i0 + lane < n_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + i0 + lane), (__attribute__((address_space(3))) void *)(dp + i0 * 16), 16, 0, 0);
+                    }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            WG_SYNC();                                            // tables and words are in LDS
-            // edge records: a predecessor inside the window brings its row record along; one outside brings its band (for the range test of a step
-            // that leaves the window through it) from the per-row arrays
+            // ---- row records: A of every window row first, then each row's predecessors look theirs up
+            int A[NQ];
 #pragma unroll
-            for (int k_ = 0; k_ < DBTP / 64; ++k_) {
-                const int e = k_ * 64 + lane; if (e >= pn_t) continue;
-                const int pr_ = prv[k_]; const bool ok = pr_ >= lo && pr_ <= hi;
-                int4 ri_ = B.rinfo[ok ? pr_ - lo : 0]; int ri2_ = B.rinfo2[ok ? pr_ - lo : 0];
-                if (!ok) { const int pb_ = g_bsn[pr_], pe_ = g_esn[pr_]; ri_ = make_int4((pb_ * PN) | (((pe_ - pb_ + 1) * PN) << 16), 0, 0, 0); ri2_ = 0; }
-                B.edge[e] = make_int4(pr_, ri_.x, ri_.y, ok ? 1 : 0); B.edge2[e] = make_int4(ri_.z, ri_.w, ri2_, 0);
+            for (int q = 0; q < NQ; ++q) {
+                A[q] = (off[q] >> DBL) - (sl[q] - cref);
+                const int li = hi - 64 * q - lane - lo;
+                if (vq[q] && li >= 0) B.rowA[li] = A[q];
             }
             WG_SYNC();
-            bt_lo = lo; bt_hi = hi;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int r = hi - 64 * q - lane, li = r - lo;
+                if (!(vq[q] && li >= 0)) continue;
+                int Ak[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int dk = (int)((pdv[q] >> (8 * k)) & 0xffu), pr = r - dk; Ak[k] = (dk != 255 && pr >= lo) ? B.rowA[pr - lo] : DIR_NA; }
+                const int cut = sl[q] > pc[q] ? 1 : 0;
+                B.rec[li] = make_int4((int)pdv[q], (Ak[0] & 0xffff) | (Ak[1] << 16), (Ak[2] & 0xffff) | (Ak[3] << 16), (sl[q] & 0x7fff) | (cut << 15) | (ns[q] << 16));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WG_SYNC();
+            w_lo = lo; w_hi = hi; w_cref = cref;
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            return __builtin_amdgcn_readfirstlane(A[0]);
         };
-        // cigar words are collected 64 at a time in a VGPR pair (lane = word index & 63) and written out as one coalesced store per 64 words (backtrack.h)
-        int cgw_lo = 0, cgw_hi = 0;
-        auto flush_cigar = [&](int base, int n) __attribute__((always_inline)) {
-            if (lane < n) cg[base + lane] = ((uint64_t)(unsigned)cgw_hi << 32) | (uint64_t)(unsigned)cgw_lo;
+        // ---- cigar: a word is stored once, when the next one starts (an insertion run keeps growing in `last_word` until then); words carry the ROW
+        //      where the reference has the node id -- the final pass below replaces it
+        uint64_t last_word = 0; bool have_pending = false;
+        auto store_word = [&](int idx, uint64_t wv) __attribute__((always_inline)) {      // (every lane stores the same value to the same address: one transaction, no exec juggling)
+            GLOBAL_AS uint64_t *p_ = cg + idx;
+            const int lo_ = (int)(wv & 0xffffffffull), hi_ = (int)(wv >> 32);
+            asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p_), "v"(make_int2(lo_, hi_)) : "memory");
         };
-        auto push = [&](int op, int len, int node_id, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
-            uint64_t L = (uint64_t)(int64_t)len;
+        auto push = [&](int op, int len, int node_row, int query_id) __attribute__((always_inline)) {      // reference abpoa_align.h:54-73
+            const uint64_t L = (uint64_t)(int64_t)len;
             if (n_cigar == 0 || op != ABPOA_HIP_CINS || op != (int)(last_word & 0xf)) {
-                if (n_cigar >= cap) { status = ABPOA_HIP_EBACKTRACK; return; }
-                if (n_cigar > 0 && (n_cigar & 63) == 0) flush_cigar(n_cigar - 64, 64);      // the previous 64 words are final now
-                uint64_t n_id = (uint64_t)(int64_t)node_id, q_id = (uint64_t)(int64_t)query_id, wv;
-                if (op == ABPOA_HIP_CMATCH) wv = n_id << 34 | q_id << 4 | (uint64_t)op;
-                else if (op == ABPOA_HIP_CINS) wv = q_id << 34 | L << 4 | (uint64_t)op;
-                else wv = n_id << 34 | L << 4 | (uint64_t)op;
-                last_word = wv; ++n_cigar;
+                if (have_pending) store_word(n_cigar - 1, last_word);
+                const uint64_t n_id = (uint64_t)(int64_t)node_row, q_id = (uint64_t)(int64_t)query_id;
+                if (op == ABPOA_HIP_CMATCH) last_word = n_id << 34 | q_id << 4 | (uint64_t)op;
+                else if (op == ABPOA_HIP_CINS) last_word = q_id << 34 | L << 4 | (uint64_t)op;
+                else last_word = n_id << 34 | L << 4 | (uint64_t)op;
+                have_pending = true; ++n_cigar;
             } else last_word += L << 4;
-            const int w_lo = sgpr((int)(last_word & 0xffffffffull)), w_hi = sgpr((int)(last_word >> 32)), w_idx = sgpr((n_cigar - 1) & 63);
-            asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                         : "+v"(cgw_lo), "+v"(cgw_hi) : "s"(w_lo), "s"(w_hi), "s"(w_idx) : "m0");
+        };
+        // a run of match steps: rows in `runv` (lane = step), first step at column run_j; its words are made and stored here, a lane each
+        int runv = 0, run_n = 0, run_j = 0;
+        auto flush_run = [&]() __attribute__((always_inline)) {
+            if (run_n == 0) return;
+            if (have_pending) { store_word(n_cigar - 1, last_word); have_pending = false; }
+            if (lane < run_n) cg[n_cigar + lane] = (uint64_t)(unsigned)runv << 34 | (uint64_t)(unsigned)(run_j - 1 - lane) << 4 | (uint64_t)ABPOA_HIP_CMATCH;
+            n_cigar += run_n; n_aln += run_n; bt_steps += run_n; run_n = 0;
+            last_word = (uint64_t)ABPOA_HIP_CMATCH;            // (the last word so far is a match: the next insertion starts a word of its own)
         };
 
         int i = sgpr(best_i), j = sgpr(best_j), start_i = i, start_j = j, cur_op = OP_ALL, indel_first = 1, pend = 0;
         if (j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
         const long long t_walk0 = (long long)__builtin_amdgcn_s_memtime();
-        int4 cr = make_int4(0, 0, 0, 0); int cr2 = 0, cr_row = -1; bool reloaded = false;
+        const int win_a = (int)(unsigned)(size_t)(lds_byte_t *)win, rec_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.rec;      // LDS byte addresses
+        auto lds_w = [&](int addr) __attribute__((always_inline)) { return (int)*(const lds_dw_t *)(size_t)(unsigned)addr; };
+        auto lds_r = [&](int addr) __attribute__((always_inline)) { const v4i_t v = *(const lds_i4_t *)(size_t)(unsigned)addr; return make_int4(v.x, v.y, v.z, v.w); };
+        auto a16 = [](int packed, int hi_half) __attribute__((always_inline)) { return hi_half ? packed >> 16 : (int)(short)packed; };      // A value of a record half
+        int Ai = 0; bool reloaded = false, restage = true;        // A of row i; restage: row i is not (known to be) in the window
         while (i > 0 && j > 0 && status == 0) {
-            if (i > bt_hi || i < bt_lo) { load_window(i, j); cr_row = -1; reloaded = true; }
-            if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }
-            const int pbi = cr.x & 0xffff, Wi = (int)((unsigned)cr.x >> 16);
-            const int eb = cr.z & 0xffff, np = (cr.z >> 16) & 0xff, bs_ = (int)((unsigned)cr.z >> 24), id = cr.w;
-            const int sli = cr2 & 0xffff, nsi = (int)((unsigned)cr2 >> 16), si = j - sli;
-            if ((unsigned)(j - pbi) >= (unsigned)Wi || np > DIR_K_MAX) { status = ABPOA_HIP_EBACKTRACK; break; }      // outside the row's band: no such cell
-            if ((unsigned)si >= (unsigned)nsi || (si == 0 && j - 1 >= pbi)) {      // the cell (or its stored left neighbour) is not staged: re-centre the window on (i, j) once
-                if (reloaded) { status = ABPOA_HIP_EBACKTRACK; break; }
-                load_window(i, j); cr_row = -1; reloaded = true; continue;
+            if (restage || i > w_hi || i < w_lo) { flush_run(); Ai = load_window(i, j); restage = false; reloaded = true; }
+            // ---- match run: while a match is what the reference tries first (M allowed, indel_first == 0) and the word names a predecessor
+            if ((cur_op & OP_M) && indel_first == 0 && pend == 0) {
+                if (run_n == 0) run_j = j;
+                for (;;) {
+                    int4 rc_v = lds_r(rec_a + ((i - w_lo) << 4)); int w_v = lds_w(win_a + ((Ai + (j - w_cref)) << DBL));
+                    asm volatile("" : "+v"(w_v), "+v"(rc_v.x), "+v"(rc_v.y), "+v"(rc_v.z), "+v"(rc_v.w));
+                    const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane(rc_v.w);
+                    if ((unsigned)(j - (int)(rw & 0x7fffu)) >= (rw >> 16)) break;      // the cell is not staged (or outside the row's band): the full step sorts it out
+                    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(w_v);
+                    const int k = (int)(w & 15u);
+                    if (k == 0 || k > 4) break;                  // no match at this cell (or a predecessor beyond the record): the full step below
+                    const unsigned pdw = (unsigned)__builtin_amdgcn_readfirstlane(rc_v.x);
+                    const int dk = (int)((pdw >> (8 * (k - 1))) & 0xffu);
+                    if (dk == 255) break;
+                    const int An = a16(__builtin_amdgcn_readfirstlane(k <= 2 ? rc_v.y : rc_v.z), (k - 1) & 1);
+                    if (run_n == 64) { flush_run(); run_j = j; }
+                    { const int slot = sgpr(run_n), row_s = sgpr(i);
+                      asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(runv) : "s"(row_s), "s"(slot) : "m0"); }
+                    ++run_n; start_i = i; start_j = j; cur_op = OP_ALL; reloaded = false;
+                    i -= dk; --j; Ai = An;
+                    if (An == DIR_NA) { restage = true; break; }
+                    if (i <= 0 || j <= 0) break;
+                }
+                if (restage || i <= 0 || j <= 0) continue;
+            }
+            // ---- full step: any state, the reference's priority order (:109-429) decided from the words (oracle/dir_model.c)
+            flush_run(); ++n_general;
+            int4 rc_v = lds_r(rec_a + ((i - w_lo) << 4));
+            const int4 rc = uniform4(rc_v);
+            const int sli = rc.w & 0x7fff, cut = (rc.w >> 15) & 1, nsi = (int)((unsigned)rc.w >> 16), si = j - sli;
+            if ((unsigned)si >= (unsigned)nsi || (si == 0 && cut)) {      // the cell (or, possibly, its stored left neighbour) is not staged: re-centre the window on (i, j) once
+                if (reloaded) { status = ABPOA_HIP_EBACKTRACK; break; }      // ... it is not there: outside the row's band, no such cell
+                restage = true; continue;
             }
             reloaded = false;
-            // ---- the step's one LDS round trip: the cell's word, its left neighbour's, the query code, the row's edge records (lane k = predecessor k)
-            const DW *wp = (const DW *)(bt + cr.y) + si;
-            int w_v = (int)wp[0], wl_v = (int)wp[si > 0 ? -1 : 0], qc_v = (int)s_query[j - 1];
-            const int e_idx = eb + (lane < np ? lane : 0);
-            int4 er = B.edge[e_idx < DBTP ? e_idx : 0], er2 = B.edge2[e_idx < DBTP ? e_idx : 0];
-            asm volatile("" : "+v"(w_v), "+v"(wl_v), "+v"(qc_v), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er.w), "+v"(er2.x), "+v"(er2.y), "+v"(er2.z));      // every load issued before the one wait
-            const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(w_v);
+            const int waddr = win_a + ((Ai + (j - w_cref)) << DBL);
+            int w_v = lds_w(waddr), wl_v = lds_w(si > 0 ? waddr - DB : waddr);
+            asm volatile("" : "+v"(w_v), "+v"(wl_v));
+            const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(w_v), wl = si > 0 ? (unsigned)__builtin_amdgcn_readfirstlane(wl_v) : 0u;      // (wl == 0: column j - 1 is not stored)
             const int kM = (int)(w & 15u);
             int kE[2], uE[2], dF[2], lF[2];
             if (GAP == 1) { kE[0] = (w >> DIRA_KE1_SH) & 15; uE[0] = (w >> DIRA_UE1_SH) & 7; dF[0] = (w >> DIRA_DF1_SH) & 7; lF[0] = (w >> DIRA_LF1_SH) & 3; kE[1] = 0; uE[1] = 0; dF[1] = 0; lF[1] = 0; }
@@ -211,34 +251,43 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                    dF[0] = (w >> DIRC_DF1_SH) & 7; dF[1] = (w >> DIRC_DF2_SH) & 31; lF[0] = (w >> DIRC_LF1_SH) & 3; lF[1] = (w >> DIRC_LF2_SH) & 3; }
             if (pend) { cur_op = uE[pend - 1] == 0 ? (OP_M | OP_F) : (pend == 1 ? OP_E1 : OP_E2); pend = 0; }      // the deletion that led here: was this cell's E opened from its H? (reference :200)
             start_i = i; start_j = j; ++bt_steps;
-            int hit = 0, k_sel = -1;
-            auto in_pred_band = [&](int k, int col) __attribute__((always_inline)) { const int ery = __builtin_amdgcn_readlane(er.y, k); return (unsigned)(col - (ery & 0xffff)) < ((unsigned)ery >> 16); };
+            int hit = 0;
+            // move to predecessor k (0-based list index) of row i: from the record, else (more than four predecessors / a far one) from the CSR arrays
+            auto go_pred = [&](int k) __attribute__((always_inline)) -> bool {
+                const int dk = k < 4 ? (int)(((unsigned)rc.x >> (8 * k)) & 0xffu) : 255;
+                if (dk != 255) { Ai = a16(k < 2 ? rc.y : rc.z, k & 1); i -= dk; if (Ai == DIR_NA) restage = true; return true; }
+                const int po = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i)), po1 = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i + 1));
+                if (k >= po1 - po) return false;
+                i = __builtin_amdgcn_readfirstlane(gld_i32(pred_row + po + k)); restage = true; return true;
+            };
             auto do_match = [&](int set_indel) __attribute__((always_inline)) {
-                if (kM >= 1 && kM <= np && eb + kM <= DBTP && in_pred_band(kM - 1, j - 1)) {
-                    k_sel = kM - 1; cur_op = OP_ALL; hit = 1;
-                    push(ABPOA_HIP_CMATCH, 1, id, j - 1);
-                    n_match += (bs_ == __builtin_amdgcn_readfirstlane(qc_v)) ? 1 : 0; --j; ++n_aln;
-                    if (set_indel) indel_first = 0;
-                }
+                if (kM == 0) return;
+                const int row_ = i;
+                if (!go_pred(kM - 1)) return;
+                cur_op = OP_ALL; hit = 1;
+                push(ABPOA_HIP_CMATCH, 1, row_, j - 1);
+                --j; ++n_aln;
+                if (set_indel) indel_first = 0;
             };
             if ((cur_op & OP_M) && indel_first == 0) do_match(0);
             if (!hit && (cur_op & OP_E)) {
                 const bool viaM = cur_op & OP_M; int kk0 = 64, kk1 = 64;
-                if ((cur_op & OP_E1) && kE[0] >= 1 && kE[0] <= np && (!viaM || uE[0] == o1) && in_pred_band(kE[0] - 1, j)) kk0 = kE[0];
-                if (GAP == 2 && (cur_op & OP_E2) && kE[1] >= 1 && kE[1] <= np && (!viaM || uE[1] == o2) && in_pred_band(kE[1] - 1, j)) kk1 = kE[1];
+                if ((cur_op & OP_E1) && kE[0] >= 1 && (!viaM || uE[0] == o1)) kk0 = kE[0];
+                if (GAP == 2 && (cur_op & OP_E2) && kE[1] >= 1 && (!viaM || uE[1] == o2)) kk1 = kE[1];
                 if (kk0 != 64 || kk1 != 64) {                    // first predecessor in list order, E1 before E2 for the same one
-                    const bool use1 = kk0 <= kk1; k_sel = (use1 ? kk0 : kk1) - 1;
-                    cur_op = use1 ? OP_E1 : OP_E2; pend = use1 ? 1 : 2;      // (M|F instead if the predecessor's E was opened from its H: decided when its word is read)
-                    hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1);
+                    const bool use1 = kk0 <= kk1; const int row_ = i;
+                    if (go_pred((use1 ? kk0 : kk1) - 1)) {
+                        cur_op = use1 ? OP_E1 : OP_E2; pend = use1 ? 1 : 2;      // (M|F instead if the predecessor's E was opened from its H: decided when its word is read)
+                        hit = 1; push(ABPOA_HIP_CDEL, 1, row_, j - 1);
+                    }
                 }
             }
             if (!hit && (cur_op & OP_F)) {
-                const unsigned wl = (unsigned)__builtin_amdgcn_readfirstlane(wl_v);
                 for (int x = 0; x < (GAP == 2 ? 2 : 1) && !hit; ++x) {
                     const int bit = x == 0 ? OP_F1 : OP_F2, ox = x == 0 ? o1 : o2;
                     if (!(cur_op & bit)) continue;
                     if ((cur_op & OP_M) && dF[x] != 0) continue;                 // H == F
-                    if (j - 1 < pbi) continue;                                    // column j - 1 is not stored
+                    if (wl == 0u) continue;                                       // column j - 1 is not stored
                     int lit = lF[x];
                     if (lit == DIR_LIT_NONE) {
                         int kMl, uEl0, uEl1, dFl;
@@ -252,22 +301,35 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                     else if (lit == DIR_LIT_EXT) { cur_op = bit; hit = 1; }
                 }
                 if (status != 0) break;
-                if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
+                if (hit) { push(ABPOA_HIP_CINS, 1, i, j - 1); --j; ++n_aln; }
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
-            if (k_sel >= 0) {                                     // move to the chosen predecessor: its row record comes along (outside the window: the next turn stages a new one)
-                i = __builtin_amdgcn_readlane(er.x, k_sel);
-                cr = make_int4(__builtin_amdgcn_readlane(er.y, k_sel), __builtin_amdgcn_readlane(er.z, k_sel), __builtin_amdgcn_readlane(er2.x, k_sel), __builtin_amdgcn_readlane(er2.y, k_sel));
-                cr2 = __builtin_amdgcn_readlane(er2.z, k_sel); cr_row = __builtin_amdgcn_readlane(er.w, k_sel) ? i : -1;
-            }
         }
         walk_ticks = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {
+            flush_run();
             if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
-            if (n_cigar > 0) { const int base_ = ((n_cigar - 1) >> 6) << 6; flush_cigar(base_, n_cigar - base_); }
+            if (have_pending) store_word(n_cigar - 1, last_word);
             WG_SYNC();
-            if (!b.rev_cigar) for (int k = lane; k < n_cigar >> 1; k += 64) { uint64_t t = cg[k]; cg[k] = cg[n_cigar - 1 - k]; cg[n_cigar - 1 - k] = t; }
+            // ---- final pass, a lane per word: row -> node id, matched bases, reversal (reference abpoa_reverse_cigar, abpoa_align.h:88-96)
+            const bool q_in_lds = qlen <= b.lds.q_cap;
+            GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
+            auto fix = [&](uint64_t wv, int &nm) __attribute__((always_inline)) -> uint64_t {
+                const int op = (int)(wv & 0xf);
+                if (op == ABPOA_HIP_CINS) return wv;
+                const int row_ = (int)(wv >> 34);
+                if (op == ABPOA_HIP_CMATCH) { const int q = (int)((wv >> 4) & 0x3fffffffu); nm += (int)row_base[row_] == (q_in_lds ? (int)s_query[q] : (int)g_query[q]) ? 1 : 0; }
+                return (wv & 0x3ffffffffull) | ((uint64_t)(int64_t)row_node_id[row_] << 34);
+            };
+            int nm = 0;
+            const int half = n_cigar >> 1;
+            for (int k = lane; k < half; k += 64) {
+                uint64_t a = fix(cg[k], nm), c_ = fix(cg[n_cigar - 1 - k], nm);
+                if (b.rev_cigar) { cg[k] = a; cg[n_cigar - 1 - k] = c_; } else { cg[k] = c_; cg[n_cigar - 1 - k] = a; }
+            }
+            if ((n_cigar & 1) && lane == 0) cg[half] = fix(cg[half], nm);
+            n_match = __builtin_amdgcn_readlane(wave_scan_add_i32(nm), 63);
             node_e = row_node_id[best_i]; query_e = best_j - 1;
             node_s = row_node_id[start_i]; query_s = start_j - 1;
         }
@@ -278,7 +340,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         o.node_s = node_s; o.node_e = node_e; o.query_s = query_s; o.query_e = query_e;
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = -DB;      // pad < 0: direction-plane arena (bytes per word)
         o.n_cells = ts.n_cells; o.cells_used = ts.cursor;
-        if (!(b.dbg & 128)) { o.seg[5] = win_ticks; o.seg[4] = (long long)n_windows * 1000; o.seg[3] = 0; o.seg[0] = 0; o.seg[1] = walk_ticks; o.seg[2] = (long long)bt_steps * 1000; }
+        if (!(b.dbg & 128)) { o.seg[5] = win_ticks; o.seg[4] = (long long)n_windows * 1000; o.seg[3] = (long long)n_general * 1000; o.seg[0] = 0; o.seg[1] = walk_ticks; o.seg[2] = (long long)bt_steps * 1000; }
         o.clk_dp = ts.clk1 - ts.clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - ts.clk1; o.n_rows_done = ts.rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }

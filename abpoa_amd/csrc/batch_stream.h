@@ -57,7 +57,7 @@ class BatchStream {
     std::vector<AlnDesc> desc_; std::vector<AlnOut> recs_; std::vector<int64_t> full_cells_, est_cells_, dir_full_cells_, dir_est_cells_;      // arena capacities (cells): score records full width / estimate, direction-plane arenas likewise
     std::vector<std::vector<uint8_t>> trace_arena_;     // BS_TRACE: arena of every finished alignment, copied out before a retry pass re-uses the device arenas
     int64_t rows_tot_ = 0, preds_tot_ = 0, outs_tot_ = 0, q_tot_ = 0, cig_tot_ = 0;
-    size_t o_desc_ = 0, o_mat_ = 0, o_query_ = 0, o_base_ = 0, o_sdist_ = 0, o_nid_ = 0, o_rem_ = 0, o_act_ = 0, o_poff_ = 0, o_pred_ = 0, o_ooff_ = 0, o_out_ = 0, in_bytes_ = 0;
+    size_t o_desc_ = 0, o_mat_ = 0, o_query_ = 0, o_base_ = 0, o_sdist_ = 0, o_pd_ = 0, o_nid_ = 0, o_rem_ = 0, o_act_ = 0, o_poff_ = 0, o_pred_ = 0, o_ooff_ = 0, o_out_ = 0, in_bytes_ = 0;
     size_t o_rec_ = 0, o_left_ = 0, o_right_ = 0, o_bsn_ = 0, o_esn_ = 0, o_coff_ = 0, o_rmi_ = 0, o_cig_ = 0, out_bytes_ = 0;
     StreamStats stats_;
 };

@@ -193,7 +193,7 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
     o_desc_ = take(sizeof(AlnDesc) * n); o_mat_ = take(sizeof(int32_t) * sc->m * sc->m); o_query_ = take(q_tot_ + 1);
-    o_base_ = take(rows_tot_); o_sdist_ = take(rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
+    o_base_ = take(rows_tot_); o_sdist_ = take(rows_tot_); o_pd_ = take(4 * rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
     o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1) + 4 * 512);   // slack: tile prefetch over-reads up to TP entries
     in_bytes_ = o;
     o = 0;
@@ -250,11 +250,19 @@ int BatchStream::run() {
             AlnDesc &d = desc_[i];
             if (!(d.flags & ALN_FAST_OK)) continue;
             const int32_t *po = (const int32_t *)(hi + o_poff_) + d.poff0, *pr = (const int32_t *)(hi + o_pred_) + d.pred0; uint8_t *sd = hi + o_sdist_ + d.row0;
+            uint32_t *pdw = (uint32_t *)(hi + o_pd_) + d.row0;      // row distances to the first four predecessors (DevBatch.row_pd)
             memset(sd, 0, (size_t)d.n_rows);
             bool ok = true;
-            for (int r = 1; r < d.n_rows && ok; ++r) {
-                if (po[r + 1] - po[r] > DIR_K_MAX && r < d.n_rows - 1) ok = false;
-                for (int k = po[r]; k < po[r + 1]; ++k) { const int p_ = pr[k], dist = r == d.n_rows - 1 ? 255 : std::min(255, r - p_); if (dist > sd[p_]) sd[p_] = (uint8_t)dist; }
+            for (int r = 0; r < d.n_rows && ok; ++r) {
+                const int np_ = po[r + 1] - po[r];
+                if (np_ > DIR_K_MAX && r < d.n_rows - 1) ok = false;
+                uint32_t pdv = np_ <= 4 ? 0u : 0xffffffffu;
+                for (int k = po[r]; k < po[r + 1]; ++k) {
+                    const int p_ = pr[k], dist = r == d.n_rows - 1 ? 255 : std::min(255, r - p_); if (dist > sd[p_]) sd[p_] = (uint8_t)dist;
+                    if (np_ <= 4) { if (r - p_ > 254) pdv = 0xffffffffu; else if (pdv != 0xffffffffu) pdv |= (uint32_t)(r - p_) << (8 * (k - po[r])); }
+                }
+                if (np_ <= 4 && pdv != 0xffffffffu) for (int k = np_; k < 4; ++k) pdv |= 255u << (8 * k);
+                pdw[r] = pdv;
             }
             if (!ok) d.flags = 0;
         }
@@ -291,7 +299,7 @@ int BatchStream::run() {
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
         if (b.lds.wide_nw > 1) dir = false;
-        b.dir_mode = dir ? 1 : 0; b.row_sdist = di + o_sdist_;
+        b.dir_mode = dir ? 1 : 0; b.row_sdist = di + o_sdist_; b.row_pd = (const uint32_t *)(di + o_pd_);
         b.want_lr = (trace || (flags_ & BS_WANT_BAND_STATE)) ? 1 : 0;
         { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
         b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);

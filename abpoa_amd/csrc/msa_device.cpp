@@ -64,7 +64,7 @@ struct Layout {                // byte offsets inside the three device blobs
     size_t o_cnode, o_ccov, o_cbase;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
-    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
+    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
 };
 
 // Heaviest-bundling consensus (reference src/abpoa_output.c:361-415, :343-356) straight from the flat device arrays, walking
@@ -195,7 +195,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     o = 0;
     L.o_ticket = take(4 * POA_CU_TICKETS);
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
-    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
+    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rpd = take(4 * node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
     L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot); L.rows_bytes = o;
 
@@ -258,7 +258,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
     p.scratch = (int32_t *)(dr + L.o_scratch);
     p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
-    p.row_base = dr + L.o_rbase; p.row_sdist = dr + L.o_rsd; p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
+    p.row_base = dr + L.o_rbase; p.row_sdist = dr + L.o_rsd; p.row_pd = (uint32_t *)(dr + L.o_rpd); p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
     p.pred_off = (int32_t *)(dr + L.o_poff); p.pred_row = (int32_t *)(dr + L.o_pred); p.cigar = (uint64_t *)(dr + L.o_cigar);
     p.cons_node = (int32_t *)(dg + L.o_cnode); p.cons_cov = (int32_t *)(dg + L.o_ccov); p.cons_base = dg + L.o_cbase;
 
@@ -284,7 +284,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
     { const char *dbg_ = getenv("ABPOA_HIP_DBG"); if (dbg_) b.dbg = atoi(dbg_); }      // (diagnostics: bit 7 keeps the row loop's counters in AlnOut.seg)
     b.mat = (const int32_t *)(di + L.o_mat); b.aln = p.aln; b.out = p.out;
-    b.dir_mode = (dir && b.lds.wide_nw <= 1) ? 1 : 0; b.row_sdist = p.row_sdist;
+    b.dir_mode = (dir && b.lds.wide_nw <= 1) ? 1 : 0; b.row_sdist = p.row_sdist; b.row_pd = p.row_pd;
     b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
     b.pred_off = p.pred_off; b.pred_row = p.pred_row; b.out_off = p.pred_off; b.out_row = p.pred_row;
     b.left = p.scratch; b.right = p.scratch;
