@@ -10,13 +10,15 @@ namespace abpoa_hip {
 // reference backtrack (src/simd_abpoa_align.c:109-429) would make there, so the walk never reads a score.  oracle/dir_model.c is the CPU statement of
 // exactly this walk (checked against the value-comparing backtrack on every golden).
 //
-// Window: rows [lo, hi] of words staged in LDS by LDS-DMA, up to DBTR rows, and one 16-byte record per row:
-//     { row distances to the first four predecessors, a byte each  (DevBatch.row_pd, made once per alignment by the graph phase),
-//       A0 | A1 << 16,  A2 | A3 << 16   where the words of predecessor k sit in the window: word of column c at word index A_k + (c - cref); DIR_NA = not staged,
-//       first staged column | left-cut flag << 15 | staged columns << 16 }
-//   so a step needs ONE LDS round trip -- the cell's word and its row's record, both at addresses the previous step already knew -- and scalar
-//   arithmetic: the word names the predecessor (kM), the record gives its row distance and where its words are.  No per-step table lookups, no
-//   cross-lane traffic; node ids, the matched-base count and the reversal are one lane-parallel pass over the finished cigar.
+// Window: rows [lo, hi] of words staged in LDS by LDS-DMA, up to DBTR rows, and per row
+//     rec  { p0, p1 }: for each of the first two predecessors its row distance (a byte; 255 = none / further than 254 rows / not in the window) and,
+//          above it, 16 bits, half the byte offset AB of its words in the window: the word of column c sits at window + AB + (c - cref) * DB;
+//     pd   the row distances to the first four predecessors, a byte each (DevBatch.row_pd, made once per alignment by the graph phase);
+//     stg  first staged column | left-cut flag << 15 | staged columns << 16;   rowA  the row's own AB
+//   so a match step -- 85-97 % of a walk -- needs ONE LDS round trip (the cell's word and its row's rec, both at addresses the previous step already
+//   knew) and a dozen scalar instructions: the word names the predecessor (kM), rec gives its row distance and where its words are.  Any other
+//   step, and a match through the third or a later predecessor, takes the full step below (pd / stg / rowA).  No cross-lane traffic anywhere;
+//   node ids, the matched-base count and the reversal are one lane-parallel pass over the finished cigar.
 //   * narrow bands: whole rows, ONE contiguous copy (rows are adjacent in the arena; a row that also keeps its score records drags them along): 256 rows
 //     of 1 kb reads are 32 KB;
 //   * wide bands: a triangle of column slices, one DMA per row -- a match step goes one column back and at least one row up, a deletion only up, so from
@@ -28,7 +30,7 @@ namespace abpoa_hip {
 constexpr int DBTR = 256;     // most rows of a window
 constexpr int DIR_TRI_SLACK = 9;
 constexpr int DIR_NA = -32768;
-struct __attribute__((aligned(16))) DirBt { int4 rec[DBTR]; int32_t rowA[DBTR]; };      // the walk's LDS image: row records, scratch for building them; the words follow
+struct __attribute__((aligned(16))) DirBt { int2 rec[DBTR]; int32_t pd[DBTR], stg[DBTR], rowA[DBTR]; };      // the walk's LDS image; the words follow
 
 template <typename T, int GAP>
 __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts) {
@@ -39,8 +41,9 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     typedef typename std::conditional<GAP == 1, uint16_t, uint32_t>::type DW;
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     typedef __attribute__((address_space(3))) DW lds_dw_t;
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4i_t lds_i4_t;
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2i_t lds_i2_t;
+    typedef __attribute__((address_space(3))) int lds_i32_t;
     const int lane = threadIdx.x & 63;
     const int gn = d.n_rows, qlen = d.qlen;
     const int o1 = b.o1, o2 = b.o2;
@@ -62,20 +65,21 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             const int in_row = pred_row[k];
             const int pe = g_esn[in_row], pb = g_bsn[in_row];
             const int dpe = (pe + 1) * PN - 1, end = qlen > dpe ? dpe : qlen;
-            const int score = (int)planes[g_coff[in_row] + (long long)DirFmt<T, GAP>::units(pe - pb + 1) * PN + (long long)(end - pb * PN) * CW];
+            const int score = (int)planes[g_coff[in_row] - (long long)(pe - pb + 1) * CW * PN + (long long)(end - pb * PN) * CW];      // (its records sit in front of its words)
             if (score > best_score) { best_score = score; best_i = in_row; best_j = end; }
         }
     }
 
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
     long long win_ticks = 0, walk_ticks = 0; int n_windows = 0, n_general = 0;
+    long long dbg_why = 0, dbg_a = 0, dbg_b = 0;      // (dead end of the walk: where and on what, for AlnOut.seg under ABPOA_HIP_DBG bit 8)
     if (status == 0 && b.ret_cigar && d.cigar_cap < gn + qlen + 2) status = ABPOA_HIP_EBACKTRACK;      // (a walk emits at most one word per row or column it leaves: no per-step capacity test)
     if (status == 0 && b.ret_cigar) {
         DirBt &B = *(DirBt *)(lds_raw + b.lds.phase_off);
         unsigned char *win = lds_raw + b.lds.phase_off + (int)sizeof(DirBt);
         const int win_bytes = b.lds.bt_off + b.lds.bt_bytes_tail - (int)sizeof(DirBt);
         GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
-        int w_lo = 1, w_hi = 0, w_cref = 0;                     // window = rows [w_lo, w_hi], empty at start; column origin of the A values
+        int w_lo = 1, w_hi = 0, w_cref = 0; bool w_tri = false;    // window = rows [w_lo, w_hi], empty at start; column origin of the AB values; column slices (not whole rows)?
         // ---- stage the window for a walk that stands at (hi, jtop); returns A of row hi
         auto load_window = [&](int hi, int jtop) __attribute__((always_inline)) -> int {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
@@ -145,25 +149,28 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             int A[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                A[q] = (off[q] >> DBL) - (sl[q] - cref);
+                A[q] = off[q] - ((sl[q] - cref) << DBL);
                 const int li = hi - 64 * q - lane - lo;
-                if (vq[q] && li >= 0) B.rowA[li] = A[q];
+                if (vq[q] && li >= 0) { B.rowA[li] = A[q]; B.pd[li] = (int)pdv[q]; B.stg[li] = (sl[q] & 0x7fff) | ((sl[q] > pc[q] ? 1 : 0) << 15) | (ns[q] << 16); }
             }
             WG_SYNC();
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int r = hi - 64 * q - lane, li = r - lo;
                 if (!(vq[q] && li >= 0)) continue;
-                int Ak[4];
+                int pk[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int dk = (int)((pdv[q] >> (8 * k)) & 0xffu), pr = r - dk; Ak[k] = (dk != 255 && pr >= lo) ? B.rowA[pr - lo] : DIR_NA; }
-                const int cut = sl[q] > pc[q] ? 1 : 0;
-                B.rec[li] = make_int4((int)pdv[q], (Ak[0] & 0xffff) | (Ak[1] << 16), (Ak[2] & 0xffff) | (Ak[3] << 16), (sl[q] & 0x7fff) | (cut << 15) | (ns[q] << 16));
+                for (int k = 0; k < 2; ++k) {
+                    const int dk = (int)((pdv[q] >> (8 * k)) & 0xffu), pr = r - dk; const bool in = dk != 255 && pr >= lo;
+                    pk[k] = in ? (dk | (((B.rowA[pr - lo] >> 1) & 0xffff) << 8)) : 255;      // (AB is even: kept halved, windows of up to 64 KB)
+                }
+                B.rec[li] = make_int2(pk[0], pk[1]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             WG_SYNC();
             w_lo = lo; w_hi = hi; w_cref = cref;
             win_ticks += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            w_tri = !narrow;
             return __builtin_amdgcn_readfirstlane(A[0]);
         };
         // ---- cigar: a word is stored once, when the next one starts (an insertion run keeps growing in `last_word` until then); words carry the ROW
@@ -191,6 +198,10 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             if (run_n == 0) return;
             if (have_pending) { store_word(n_cigar - 1, last_word); have_pending = false; }
             if (lane < run_n) cg[n_cigar + lane] = (uint64_t)(unsigned)runv << 34 | (uint64_t)(unsigned)(run_j - 1 - lane) << 4 | (uint64_t)ABPOA_HIP_CMATCH;
+            // every cell a run passed must lie in its row's staged band (whole-row windows do not test it step by step; the rows of a run are all in the
+            // current window: a run is flushed before the window changes): a cell outside is a dead end of the walk
+            { const int st_ = B.stg[lane < run_n ? runv - w_lo : 0];
+              if (__any(lane < run_n && (unsigned)(run_j - lane - (st_ & 0x7fff)) >= ((unsigned)st_ >> 16))) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 1; dbg_a = ((long long)run_n << 32) | (unsigned)run_j; dbg_b = ((long long)w_lo << 32) | (unsigned)w_hi; } }
             n_cigar += run_n; n_aln += run_n; bt_steps += run_n; run_n = 0;
             last_word = (uint64_t)ABPOA_HIP_CMATCH;            // (the last word so far is a match: the next insertion starts a word of its own)
         };
@@ -199,48 +210,51 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         if (j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
         const long long t_walk0 = (long long)__builtin_amdgcn_s_memtime();
         const int win_a = (int)(unsigned)(size_t)(lds_byte_t *)win, rec_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.rec;      // LDS byte addresses
+        const int stg_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.stg;
         auto lds_w = [&](int addr) __attribute__((always_inline)) { return (int)*(const lds_dw_t *)(size_t)(unsigned)addr; };
-        auto lds_r = [&](int addr) __attribute__((always_inline)) { const v4i_t v = *(const lds_i4_t *)(size_t)(unsigned)addr; return make_int4(v.x, v.y, v.z, v.w); };
-        auto a16 = [](int packed, int hi_half) __attribute__((always_inline)) { return hi_half ? packed >> 16 : (int)(short)packed; };      // A value of a record half
+        auto lds_i = [&](int addr) __attribute__((always_inline)) { return (int)*(const lds_i32_t *)(size_t)(unsigned)addr; };
+        auto lds_r = [&](int addr) __attribute__((always_inline)) { const v2i_t v = *(const lds_i2_t *)(size_t)(unsigned)addr; return make_int2(v.x, v.y); };
         int Ai = 0; bool reloaded = false, restage = true;        // A of row i; restage: row i is not (known to be) in the window
         while (i > 0 && j > 0 && status == 0) {
             if (restage || i > w_hi || i < w_lo) { flush_run(); Ai = load_window(i, j); restage = false; reloaded = true; }
-            // ---- match run: while a match is what the reference tries first (M allowed, indel_first == 0) and the word names a predecessor
+            // ---- match run: while a match is what the reference tries first (M allowed, indel_first == 0) and the word names one of the first two predecessors
             if ((cur_op & OP_M) && indel_first == 0 && pend == 0) {
+                if (run_n == 64) flush_run();
                 if (run_n == 0) run_j = j;
+                int recp = rec_a + ((i - w_lo) << 3), wb = win_a + ((j - w_cref) << DBL), budget = imin(64 - run_n, j), i_prev = i;
+                const int n0 = run_n;
                 for (;;) {
-                    int4 rc_v = lds_r(rec_a + ((i - w_lo) << 4)); int w_v = lds_w(win_a + ((Ai + (j - w_cref)) << DBL));
-                    asm volatile("" : "+v"(w_v), "+v"(rc_v.x), "+v"(rc_v.y), "+v"(rc_v.z), "+v"(rc_v.w));
-                    const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane(rc_v.w);
-                    if ((unsigned)(j - (int)(rw & 0x7fffu)) >= (rw >> 16)) break;      // the cell is not staged (or outside the row's band): the full step sorts it out
-                    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(w_v);
-                    const int k = (int)(w & 15u);
-                    if (k == 0 || k > 4) break;                  // no match at this cell (or a predecessor beyond the record): the full step below
-                    const unsigned pdw = (unsigned)__builtin_amdgcn_readfirstlane(rc_v.x);
-                    const int dk = (int)((pdw >> (8 * (k - 1))) & 0xffu);
-                    if (dk == 255) break;
-                    const int An = a16(__builtin_amdgcn_readfirstlane(k <= 2 ? rc_v.y : rc_v.z), (k - 1) & 1);
-                    if (run_n == 64) { flush_run(); run_j = j; }
+                    int2 rc_v = lds_r(recp); int w_v = lds_w(wb + Ai), st_v = 0;
+                    if (w_tri) st_v = lds_i(stg_a + ((recp - rec_a) >> 1));
+                    asm volatile("" : "+v"(w_v), "+v"(rc_v.x), "+v"(rc_v.y), "+v"(st_v));
+                    if (w_tri) { const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane(st_v); if ((unsigned)(j - (int)(st & 0x7fffu)) >= (st >> 16)) break; }      // not staged: the full step sorts it out
+                    const unsigned k1 = ((unsigned)__builtin_amdgcn_readfirstlane(w_v) & 15u) - 1u;
+                    if (k1 > 1u) break;                          // no match at this cell, or one through a later predecessor: the full step below
+                    const unsigned long long pp = ((unsigned long long)(unsigned)rc_v.y << 32) | (unsigned long long)(unsigned)rc_v.x;
+                    const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pp >> (k1 << 5)));
+                    const int dk = (int)(pk & 0xffu);
+                    if (dk == 255) break;                        // ... not in the window (or far away): the full step
                     { const int slot = sgpr(run_n), row_s = sgpr(i);
                       asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(runv) : "s"(row_s), "s"(slot) : "m0"); }
-                    ++run_n; start_i = i; start_j = j; cur_op = OP_ALL; reloaded = false;
-                    i -= dk; --j; Ai = An;
-                    if (An == DIR_NA) { restage = true; break; }
-                    if (i <= 0 || j <= 0) break;
+                    ++run_n; i_prev = i;
+                    i -= dk; --j; recp -= dk << 3; wb -= DB; Ai = ((int)(pk << 8) >> 16) << 1;
+                    if (--budget == 0) break;
                 }
-                if (restage || i <= 0 || j <= 0) continue;
+                if (run_n != n0) { start_i = i_prev; start_j = j + 1; cur_op = OP_ALL; reloaded = false; }
+                if (i <= 0 || j <= 0) continue;
+                if (run_n == 64) continue;                       // (the run buffer is full: flush at the top, then on with the run)
             }
             // ---- full step: any state, the reference's priority order (:109-429) decided from the words (oracle/dir_model.c)
             flush_run(); ++n_general;
-            int4 rc_v = lds_r(rec_a + ((i - w_lo) << 4));
-            const int4 rc = uniform4(rc_v);
-            const int sli = rc.w & 0x7fff, cut = (rc.w >> 15) & 1, nsi = (int)((unsigned)rc.w >> 16), si = j - sli;
+            if (status != 0) break;
+            const int stw = __builtin_amdgcn_readfirstlane(B.stg[i - w_lo]), pdw = __builtin_amdgcn_readfirstlane(B.pd[i - w_lo]);
+            const int sli = stw & 0x7fff, cut = (stw >> 15) & 1, nsi = (int)((unsigned)stw >> 16), si = j - sli;
             if ((unsigned)si >= (unsigned)nsi || (si == 0 && cut)) {      // the cell (or, possibly, its stored left neighbour) is not staged: re-centre the window on (i, j) once
-                if (reloaded) { status = ABPOA_HIP_EBACKTRACK; break; }      // ... it is not there: outside the row's band, no such cell
+                if (reloaded) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 2; dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)stw << 32) | (unsigned)Ai; break; }      // ... it is not there: outside the row's band, no such cell
                 restage = true; continue;
             }
             reloaded = false;
-            const int waddr = win_a + ((Ai + (j - w_cref)) << DBL);
+            const int waddr = win_a + Ai + ((j - w_cref) << DBL);
             int w_v = lds_w(waddr), wl_v = lds_w(si > 0 ? waddr - DB : waddr);
             asm volatile("" : "+v"(w_v), "+v"(wl_v));
             const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(w_v), wl = si > 0 ? (unsigned)__builtin_amdgcn_readfirstlane(wl_v) : 0u;      // (wl == 0: column j - 1 is not stored)
@@ -254,8 +268,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             int hit = 0;
             // move to predecessor k (0-based list index) of row i: from the record, else (more than four predecessors / a far one) from the CSR arrays
             auto go_pred = [&](int k) __attribute__((always_inline)) -> bool {
-                const int dk = k < 4 ? (int)(((unsigned)rc.x >> (8 * k)) & 0xffu) : 255;
-                if (dk != 255) { Ai = a16(k < 2 ? rc.y : rc.z, k & 1); i -= dk; if (Ai == DIR_NA) restage = true; return true; }
+                const int dk = k < 4 ? (int)(((unsigned)pdw >> (8 * k)) & 0xffu) : 255;
+                if (dk != 255) { i -= dk; if (i >= w_lo) Ai = __builtin_amdgcn_readfirstlane(B.rowA[i - w_lo]); else restage = true; return true; }
                 const int po = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i)), po1 = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i + 1));
                 if (k >= po1 - po) return false;
                 i = __builtin_amdgcn_readfirstlane(gld_i32(pred_row + po + k)); restage = true; return true;
@@ -304,7 +318,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 if (hit) { push(ABPOA_HIP_CINS, 1, i, j - 1); --j; ++n_aln; }
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
-            if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
+            if (!hit && status == 0) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 3 | ((long long)cur_op << 8) | ((long long)indel_first << 16) | ((long long)n_general << 32); dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)w << 32) | (unsigned)pdw; }
         }
         walk_ticks = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {
@@ -340,7 +354,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         o.node_s = node_s; o.node_e = node_e; o.query_s = query_s; o.query_e = query_e;
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = -DB;      // pad < 0: direction-plane arena (bytes per word)
         o.n_cells = ts.n_cells; o.cells_used = ts.cursor;
-        if (!(b.dbg & 128)) { o.seg[5] = win_ticks; o.seg[4] = (long long)n_windows * 1000; o.seg[3] = (long long)n_general * 1000; o.seg[0] = 0; o.seg[1] = walk_ticks; o.seg[2] = (long long)bt_steps * 1000; }
+        if (b.dbg & 256) { o.seg[0] = dbg_why; o.seg[1] = dbg_a; o.seg[2] = dbg_b; o.seg[3] = ((long long)best_i << 32) | (unsigned)best_j; o.seg[4] = n_cigar; o.seg[5] = bt_steps; }
+        else if (!(b.dbg & 128)) { o.seg[5] = win_ticks; o.seg[4] = (long long)n_windows * 1000; o.seg[3] = (long long)n_general * 1000; o.seg[0] = 0; o.seg[1] = walk_ticks; o.seg[2] = (long long)bt_steps * 1000; }
         o.clk_dp = ts.clk1 - ts.clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - ts.clk1; o.n_rows_done = ts.rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }

@@ -233,7 +233,9 @@ int BatchStream::run() {
     std::vector<AlnDesc> pass;
     // direction-plane arenas for the fast row loops (dir_plane.h) unless the caller wants the score planes back (trace), the penalties do not fit the
     // words, or ABPOA_HIP_NODIR=1; an alignment whose backtrack meets the one case the words cannot decide is redone with score records
-    bool dir = !trace && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) &&
+    // (tests: ABPOA_HIP_DIRTRACE=1 keeps the direction plane in trace mode; the trace then carries the WORDS of every cell in plane 0)
+    const bool dirtrace = trace && getenv("ABPOA_HIP_DIRTRACE") && atoi(getenv("ABPOA_HIP_DIRTRACE"));
+    bool dir = (!trace || dirtrace) && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) &&
                !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) && !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
     // alignment-level eligibility for the register-resident row loop: every row active, band state at its reset value
     for (int i = 0; i < n; ++i) {
@@ -404,10 +406,22 @@ int BatchStream::fetch_trace(int i, const uint8_t *row_active, abpoa_hip_trace_t
     }
     T->row_off[gn] = tot;
     T->planes = malloc((size_t)std::max<int64_t>(tot, 1) * (d.bits / 8));
-    const int cw = r.pad;          // arena cell stride: 0 = plane-major rows (general kernel), else cell records (fast loop)
+    const int cw = r.pad;          // arena cell stride: 0 = plane-major rows (general kernel), > 0 cell records (fast loop), < 0 direction words of -cw bytes
     for (int rr = 0; rr < gn; ++rr) {
         if (T->dp_beg_sn[rr] < 0) continue;
         const int64_t nv = T->row_off[rr + 1] - T->row_off[rr];
+        if (cw < 0) {      // (ABPOA_HIP_DIRTRACE) plane 0 = the cell's direction word, the other planes 0; row 0 has no words
+            const int64_t W = nv / P;
+            for (int64_t x = 0; x < nv; ++x) { if (d.bits == 16) ((int16_t *)T->planes)[T->row_off[rr] + x] = 0; else ((int32_t *)T->planes)[T->row_off[rr] + x] = 0; }
+            if (rr == 0) continue;
+            const uint8_t *src = arena.data() + coff[rr] * (d.bits / 8);
+            for (int64_t x = 0; x < W; ++x) {
+                const uint32_t wv = cw == -2 ? (uint32_t)((const uint16_t *)src)[x] : ((const uint32_t *)src)[x];
+                if (d.bits == 16) { ((int16_t *)T->planes)[T->row_off[rr] + x] = (int16_t)wv; if (cw == -4) ((int16_t *)T->planes)[T->row_off[rr] + W + x] = (int16_t)(wv >> 16); }      // (32-bit words in 16-bit planes: low half in plane 0, high half in plane 1)
+                else ((int32_t *)T->planes)[T->row_off[rr] + x] = (int32_t)wv;
+            }
+            continue;
+        }
         if (cw == 0) { memcpy((uint8_t *)T->planes + T->row_off[rr] * (d.bits / 8), arena.data() + coff[rr] * (d.bits / 8), (size_t)nv * (d.bits / 8)); continue; }
         const int64_t W = nv / P;
         for (int pl = 0; pl < P; ++pl) for (int64_t x = 0; x < W; ++x) {

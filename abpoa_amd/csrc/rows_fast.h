@@ -30,16 +30,22 @@ namespace abpoa_hip {
 template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 1 ? 4 : 8; };
 // Direction-plane arenas (DIR = true, dir_plane.h): a row owns ONE word per column -- 2 bytes (affine) or 4 (convex) -- that records every
 // decision the backtrack takes at that cell; only rows whose scores a later reader needs from HBM (a successor beyond the LDS score ring,
-// the global best at the sink's predecessors, a row too wide for the ring) append their cell records behind the words.  Units of the arena
-// cursor stay 32 bytes (one reference SIMD vector of scores); a row of nv vectors takes dir_units(nv) of them for its words.
+// the global best at the sink's predecessors, a row too wide for the ring) also keep their cell records, IN FRONT of the words (a row's arena
+// offset is that of its words; the lanes past the band then write words that the next row overwrites, as the records always did).  Units of
+// the arena cursor stay 32 bytes (one reference SIMD vector of scores); a row of nv vectors takes dir_units(nv) of them for its words.
 template <typename T, int GAP> struct DirFmt {
     static constexpr int DB = GAP == 1 ? 2 : 4;                            // bytes per direction word
     static constexpr int UPV2 = Width<T>::PN * DB / 16;                    // 16-byte halves of a unit per vector of words: 2 / 1 (affine int16 / int32), 4 / 2 (convex)
     __device__ __host__ static constexpr int units(int nv) { return (nv * UPV2 + 1) >> 1; }
 };
+// a word from its predecessor fields kf = kM | kE1 << 4 (| kE2 << 8) and its uE / dF fields, nested so that every step is one shift-and-or (v_lshl_or_b32)
+template <int GAP> __device__ __forceinline__ unsigned dir_word(unsigned kf, unsigned u1, unsigned u2, unsigned d1, unsigned d2) {
+    static_assert(DIRA_DF1_SH - DIRA_UE1_SH == 3 && DIRC_UE2_SH - DIRC_UE1_SH == 3 && DIRC_DF2_SH - DIRC_DF1_SH == 3 && DIRC_DF1_SH - DIRC_UE1_SH == 8, "field layout of dir_plane.h");
+    if (GAP == 1) return (((d1 << 3) | u1) << DIRA_UE1_SH) | kf;
+    return (((((d2 << 3) | d1) << 8) | ((u2 << 3) | u1)) << DIRC_UE1_SH) | kf;
+}
 template <int GAP> __device__ __forceinline__ unsigned dir_pack(unsigned kM, unsigned kE1, unsigned kE2, unsigned u1, unsigned u2, unsigned d1, unsigned d2) {
-    if (GAP == 1) return kM | kE1 << DIRA_KE1_SH | u1 << DIRA_UE1_SH | d1 << DIRA_DF1_SH;
-    return kM | kE1 << DIRC_KE1_SH | kE2 << DIRC_KE2_SH | u1 << DIRC_UE1_SH | u2 << DIRC_UE2_SH | d1 << DIRC_DF1_SH | d2 << DIRC_DF2_SH;
+    return dir_word<GAP>(GAP == 1 ? (kE1 << DIRA_KE1_SH) | kM : (((kE2 << 4) | kE1) << DIRC_KE1_SH) | kM, u1, u2, d1, d2);
 }
 __device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
 // The reference's own comparisons for where F[j] came from (src/simd_abpoa_align.c:260-300), as the literal override of dir_plane.h; Hm1 / Fm1 =
@@ -184,12 +190,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r = __builtin_amdgcn_readfirstlane(io.row_remain[0]) - remain_end - 1;
         const int dp_end0 = imin(qlen, imax(0, qlen - r) + w);
         const int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
-        // (DIR: row 0 has no decisions to record; it keeps its score records -- behind the room of its words, as every row that keeps them --
-        //  because new branches anywhere in the graph start at the source)
-        const int u0 = DIR ? dir_units(end_sn0 + 1) : 0;
-        if (((long long)u0 * PN + (long long)W0 * CW) > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
+        // (DIR: row 0 has no decisions to record; it keeps its score records because new branches anywhere in the graph start at the source)
+        if ((long long)W0 * CW > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
         const bool ring0 = W0 <= RC;
-        T *H = io.planes + (long long)u0 * PN;
+        T *H = io.planes;
         for (int i = tid; i < W0; i += NT) {
             int h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
             if (GAP == 1) { const int g = wr(-o1 - e1 * i); h = i == 0 ? 0 : g; x1 = i == 0 ? wr(-oe1) : inf; f1 = i == 0 ? inf : g; }
@@ -202,8 +206,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
             if (ring0) ring_put(0, i, h, x1, x2);
         }
-        cur = u0 + (end_sn0 + 1) * CW;
-        if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = 0; }     // source: successors get left = right = 1 (:556-561)
+        cur = (end_sn0 + 1) * CW;
+        if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = DIR ? cur : 0; }      // (DIR: a row's offset is that of its -- here absent -- words, its records sit in front of them)     // source: successors get left = right = 1 (:556-561)
         if (NW > 1) WG_SYNC();               // ring row 0 was written by every wavefront
     }
 
@@ -346,7 +350,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if constexpr (DIR) {
             // the exact bodies record every comparison literally (dir_plane.h): H == Ein, E opened from H, H == F, and -- as the override -- where F came
             // from, with the reference's own tests on the stored neighbours (:260-300); the left neighbour of the chunk's first column is carried over
-            Hrec = H + (long long)dir_units(end_sn - beg_sn + 1) * PN;
+            Hrec = H - (long long)(end_sn - beg_sn + 1) * CW * PN;      // (a row that keeps its records has them in front of its words)
             const int Hm1 = wave_shr1(ct_pH, Hout), F1m1 = wave_shr1(ct_pF1, F1);
             const unsigned u1 = Hout == E1v ? (unsigned)o1 : (E1out == wr(Hout - oe1) ? 0u : (o1 > 1 ? 1u : 0u));
             const unsigned d1 = Hout == F1 ? 0u : (unsigned)CAPF1;
@@ -358,11 +362,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 l2 = rel >= 1 ? dir_literal<T>(Hm1, F2m1, F2, oe2, e2) : 0u;
             }
             const unsigned wd = dir_pack<GAP>((unsigned)mflag, (unsigned)kE1, (unsigned)kE2, u1, u2, d1, d2) | (GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH));
-            // (lanes past the band write words the next row overwrites -- same wave, program order -- except in a row that keeps its records right behind its words)
-            if (!row_spill || in_band) { if (GAP == 1) *(uint16_t *)((char *)H + rel * DB) = (uint16_t)wd; else *(uint32_t *)((char *)H + rel * DB) = wd; }
+            // (lanes past the band write words the next row overwrites: same wave, program order)
+            if (GAP == 1) *(uint16_t *)((char *)H + rel * DB) = (uint16_t)wd; else *(uint32_t *)((char *)H + rel * DB) = wd;
             ct_pH = __builtin_amdgcn_readlane(Hout, 63); ct_pF1 = __builtin_amdgcn_readlane(F1, 63); if (GAP == 2) ct_pF2 = __builtin_amdgcn_readlane(F2, 63);
         }
-        if (ABL(1) || (DIR && !row_spill)) {}
+        // (DIR: only a row that keeps its records stores them, and only its in-band lanes do: the row's words start right behind its last record)
+        if (ABL(1) || (DIR && !(row_spill && in_band))) {}
         else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(Hrec + (long long)rel * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
@@ -392,7 +397,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto reserve = [&]() __attribute__((always_inline)) {
         const int nvr = end_sn - beg_sn + 1;
         if (cur + row_units(nvr, row_spill) > cap_pn) return false;
-        off_pn = cur; cur += row_units(nvr, row_spill);
+        off_pn = cur + ((DIR && row_spill) ? nvr * CW : 0); cur += row_units(nvr, row_spill);
         return true;
     };
 
@@ -493,7 +498,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int key_c = (vvl == nvr - 1) ? kE : kN;
         const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * lane;                                       // LDS byte address of this lane's ring cell
         // arena byte offset of this lane's record -- DIR: of its direction word -- (cur = the row's offset once committed)
-        const unsigned rec_off = DIR ? (unsigned)(cur * 32 + lane * DB) : (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));
+        const unsigned rec_off = DIR ? (unsigned)((cur + (row_spill ? nvr * CW : 0)) * 32 + lane * DB) : (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));
         asm volatile("" :: "v"(key_c), "v"(qd_addr), "v"(rec_off));      // (materialised here, not sunk to their uses)
         __builtin_amdgcn_sched_barrier(0);
         if (I16) { Mv = (int)(short)raw0; E1v = raw1 >> 16; E2v = raw2; } else { Mv = raw0; E1v = raw1; E2v = raw2; }
@@ -555,20 +560,22 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             F1 = (int)f1t; F2 = (int)f2t;
         }
         // ---- from here on the row is committed
-        off_pn = cur; cur += row_units(nvr, row_spill);
-        int Hout, E1out, E2out = inf, en1 = 0;
+        const int rec_pn = cur;                                    // (DIR, a row that keeps its records: they start here, the words follow)
+        off_pn = cur + ((DIR && row_spill) ? nvr * CW : 0); cur += row_units(nvr, row_spill);
+        int Hout, E1out, E2out = inf, en1 = 0, t2a = 0, t2b = 0;
         if (GAP == 1) {
             const int tmp = imax(h, E1v);
             Hout = imax(tmp, F1);
-            en1 = imax(E1v - e1, Hout - oe1);
+            t2a = Hout - oe1; if (DIR) asm("" : "+v"(t2a));       // (kept as a value of its own: the word's uE field is E's maximum minus this term)
+            en1 = imax(E1v - e1, t2a);
             E1out = (Hout == tmp) ? en1 : inf;
         } else {
             Hout = imax(hs, imax(F1, F2));
-            E1out = imax(E1v - e1, Hout - oe1); E2out = imax(E2v - e2, Hout - oe2);
+            t2a = Hout - oe1; t2b = Hout - oe2; if (DIR) asm("" : "+v"(t2a), "+v"(t2b));
+            E1out = imax(E1v - e1, t2a); E2out = imax(E2v - e2, t2b);
         }
         // record address = arena base + a 32-bit byte offset (an arena is far below 4 GB): one VALU add, no 64-bit pointer arithmetic per row
-        // (DIR: the row's records, if it keeps them, start behind the room of its direction words)
-        T *const H = DIR ? (T *)((char *)io.planes + (size_t)(off_pn + dir_units(nvr)) * 32) : (T *)((char *)io.planes + (size_t)rec_off) - lane * CW;
+        T *const H = DIR ? (T *)((char *)io.planes + (size_t)rec_pn * 32) : (T *)((char *)io.planes + (size_t)rec_off) - lane * CW;
         const int he = I16 ? (int)__builtin_amdgcn_perm((unsigned)E1out, (unsigned)Hout, 0x05040100u) : 0;      // H | E1 << 16 (int16: also the score-ring word)
         // match flag for the backtrack (spare slot of the record, finish_alignment PL_FLAG): 1 + index of the first predecessor k (list order) with
         // H[k][col-1] + q == H[col], 0 = none.  Only a predecessor that supplies the maximum Mv can satisfy it, and only when H == Mv + q.
@@ -577,10 +584,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if constexpr (DIR) {
             // the cell's direction word (dir_plane.h): uE = E's own maximum minus its "opened from H" term = max(o - (H - Ein), 0), dF = min(H - F, cap);
             // where F came from is decided from the left neighbour's word -- except in the vectors of the reference's masked scan, which get the literal test
-            const unsigned u1 = (unsigned)((GAP == 1 ? en1 : E1out) - (Hout - oe1)), d1 = umin_((unsigned)(Hout - F1), (unsigned)CAPF1);
+            const unsigned u1 = (unsigned)((GAP == 1 ? en1 : E1out) - t2a), d1 = umin_((unsigned)(Hout - F1), (unsigned)CAPF1);
             unsigned u2 = 0, d2 = 0;
-            if (GAP == 2) { u2 = (unsigned)(E2out - (Hout - oe2)); d2 = umin_((unsigned)(Hout - F2), (unsigned)CAPF2); }
-            unsigned wd = dir_pack<GAP>((unsigned)mflag, NPC >= 2 ? (unsigned)kE1 : 1u, NPC >= 2 ? (unsigned)kE2 : 1u, u1, u2, d1, d2);
+            if (GAP == 2) { u2 = (unsigned)(E2out - t2b); d2 = umin_((unsigned)(Hout - F2), (unsigned)CAPF2); }
+            // kM | kE1 << 4 (| kE2 << 8): one predecessor -- two constants
+            const unsigned kf = NPC == 1 ? ((h == Hout) ? (GAP == 1 ? 0x11u : 0x111u) : (GAP == 1 ? 0x10u : 0x110u))
+                                         : (GAP == 1 ? ((unsigned)kE1 << 4) | (unsigned)mflag : ((((unsigned)kE2 << 4) | (unsigned)kE1) << 4) | (unsigned)mflag);
+            unsigned wd = dir_word<GAP>(kf, u1, u2, d1, d2);
             if (SLOWV && end_sn > max_pe) {
                 const int nfast_ = max_pe - beg_sn + 1;
                 const int Hm1 = wave_shr1(Hout, Hout), F1m1 = wave_shr1(F1, F1);
@@ -589,9 +599,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 if (vvl >= nfast_) wd |= GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH);      // (lane 0 of the band -- no stored left neighbour -- is never a masked-scan vector here: nfast_ >= 1)
             }
             char *const dp = (char *)io.planes + (size_t)rec_off;
-            if (!row_spill || in_band) { if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd; }
+            if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd;
         }
         if (DIR && !row_spill) {}
+        else if (DIR && !in_band) {}      // (the row's words start right behind its last record)
         else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
@@ -697,8 +708,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // chunk's loads in flight together; outside its band the reference reads / assigns "inf", exactly what the ring's guards and padding give
         auto hbm_read_all = [&](int p, int g_, int *hc, int *ec1, int *ec2) __attribute__((always_inline)) {
             const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN;
-            // (DIR: the predecessor kept its score records -- tile bit 21 / a row too wide for the ring -- behind the room of its direction words)
-            const T *Hp = io.planes + (long long)(uint32_t)(__builtin_amdgcn_readlane(vg_off, p & 63) + (DIR ? dir_units(((g_ >> 12) & 0xfff) - pb + 1) : 0)) * PN;
+            // (DIR: the predecessor kept its score records -- tile bit 21 / a row too wide for the ring -- in front of its direction words)
+            const T *Hp = io.planes + (long long)(uint32_t)(__builtin_amdgcn_readlane(vg_off, p & 63) - (DIR ? (((g_ >> 12) & 0xfff) - pb + 1) * CW : 0)) * PN;
             gld_wait();                                              // (earlier score-plane stores of this wave are complete)
             if (TEAM) lds_barrier();                                 // (... and of the other wavefronts of the team: the far flag is the same in all of them)
 #pragma unroll
@@ -851,8 +862,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (!I16) { const unsigned tv = kbst >> 11; if (__builtin_expect(tv == 0u || tv == 0x1FFFFFu, 0)) return 0; }
         FSTAMP(3)
         // ---- from here on the row is committed
-        off_pn = cur; cur += row_units(end_sn - beg_sn + 1, row_spill);
-        T *const Hrow = io.planes + (long long)(off_pn + (DIR ? dir_units(end_sn - beg_sn + 1) : 0)) * PN + (long long)(lane + 64 * c0) * CW;
+        T *const Hrow = io.planes + (long long)cur * PN + (long long)(lane + 64 * c0) * CW;
+        off_pn = cur + ((DIR && row_spill) ? (end_sn - beg_sn + 1) * CW : 0); cur += row_units(end_sn - beg_sn + 1, row_spill);
         char *const Drow = (char *)io.planes + (size_t)off_pn * 32 + (size_t)(lane + 64 * c0) * DB;      // (DIR) this lane's direction word in the wavefront's first chunk
         int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * (lane + 64 * c0), 0);
         // (nch is NCH - 1 or NCH: chunks 0 .. NCH - 3 are full, only the last two need band masks, only the last one a store guard)
@@ -881,23 +892,25 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const bool in_band = (!TEAM && c < NCH - 2) ? true : (c0 + c) * 64 + lane < Wr;
-            int Hout, E1out, E2out = inf;
+            int Hout, E1out, E2out = inf, t2a, t2b = 0, en_a = 0;
             if (GAP == 1) {
                 Hout = imax(hsE[c], F1[c]);
-                const int en_ = imax(wr(E1v[c] - e1), wr(Hout - oe1));
-                E1out = (Hout == hsE[c]) ? en_ : inf;
+                t2a = wr(Hout - oe1); if (DIR) asm("" : "+v"(t2a));      // (kept as a value of its own: the word's uE field is E's maximum minus this term)
+                en_a = imax(wr(E1v[c] - e1), t2a);
+                E1out = (Hout == hsE[c]) ? en_a : inf;
             } else {
                 Hout = imax(hs[c], imax(F1[c], F2[c]));
-                E1out = imax(wr(E1v[c] - e1), wr(Hout - oe1));
-                E2out = imax(wr(E2v[c] - e2), wr(Hout - oe2));
+                t2a = wr(Hout - oe1); t2b = wr(Hout - oe2); if (DIR) asm("" : "+v"(t2a), "+v"(t2b));
+                E1out = imax(wr(E1v[c] - e1), t2a);
+                E2out = imax(wr(E2v[c] - e2), t2b);
             }
             const int mflag = (Mv[c] + q[c] == Hout && kb[c] <= 64) ? kb[c] : 0;
             const int he = (int)(((unsigned)Hout & 0xffffu) | ((unsigned)E1out << 16));
             if constexpr (DIR) if (c < NCH - 1 || nch == NCH) {
                 // direction word of the column (dir_plane.h; as in the straight-line body of the narrow loop)
-                const unsigned u1 = (unsigned)((GAP == 1 ? imax(wr(E1v[c] - e1), wr(Hout - oe1)) : E1out) - (Hout - oe1)), d1 = umin_((unsigned)(Hout - F1[c]), (unsigned)CAPF1);
+                const unsigned u1 = (unsigned)((GAP == 1 ? en_a : E1out) - t2a), d1 = umin_((unsigned)(Hout - F1[c]), (unsigned)CAPF1);
                 unsigned u2 = 0, d2 = 0;
-                if (GAP == 2) { u2 = (unsigned)(E2out - (Hout - oe2)); d2 = umin_((unsigned)(Hout - F2[c]), (unsigned)CAPF2); }
+                if (GAP == 2) { u2 = (unsigned)(E2out - t2b); d2 = umin_((unsigned)(Hout - F2[c]), (unsigned)CAPF2); }
                 unsigned wd = dir_pack<GAP>((unsigned)mflag, (unsigned)kE1[c], (unsigned)kE2[c], u1, u2, d1, d2);
                 if (c >= NCH - 2) if (__builtin_expect(end_sn > max_pe, 0) && c == nch - 1) {      // the vectors of the reference's masked F scan (last chunk only): the literal test
                     const int vb = beg_sn + c * NV, nfast_ = imax(0, imin(imin(NV, end_sn - vb + 1), max_pe - vb + 1));
@@ -912,9 +925,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     if (vvl >= nfast_ && (c > 0 || lane > 0)) wd |= GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH);
                 }
                 char *const dp = Drow + c * 64 * DB;
-                if (!row_spill || in_band) { if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd; }
+                if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd;
             }
             if (DIR && !row_spill) {}
+            else if (DIR && !in_band) {}      // (the row's words start right behind its last record)
             else if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {      // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
                 T *H = Hrow + c * 64 * CW;
                 if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1[c], 0x05040100u); *(int2 *)H = rec; }
@@ -1026,7 +1040,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
                     const int x = col - pb * PN;
                     const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
-                    const T *Hp = io.planes + (long long)(uint32_t)(off_ + (DIR ? dir_units(pe - pb + 1) : 0)) * PN;      // (DIR: its score records, behind its direction words)
+                    const T *Hp = io.planes + (long long)(uint32_t)(off_ - (DIR ? (pe - pb + 1) * CW : 0)) * PN;      // (DIR: its score records, in front of its direction words)
                     int hval = inf, ev1 = inf, ev2 = inf;
                     if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CW));
                     if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E2)); }

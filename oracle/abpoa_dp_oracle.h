@@ -45,6 +45,8 @@ void abpoa_oracle_free_trace(abpoa_oracle_trace_t *t);
 int  abpoa_oracle_dir_walk(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p, const abpoa_oracle_trace_t *t,
                            int best_i, int best_j, abpoa_hip_result_t *res, int64_t *stats);
 
+int  abpoa_oracle_dir_words(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p, const abpoa_oracle_trace_t *t, int best_i, int best_j, uint32_t *words);
+
 /* Same arithmetic as abpoa_hip_score_bits (reference src/simd_abpoa_align.c:1672-1683). */
 int  abpoa_oracle_score_bits(const abpoa_hip_scoring_t *sc, int n_rows, int qlen, int32_t *inf_min);
 

@@ -44,6 +44,7 @@ typedef struct {
     int convex, pn, inf, e1, oe1, o1, e2, oe2, o2;
     int pE1, pE2, pF1, pF2;
     uint32_t **rows;       /* words of row i, column dp_beg[i] + x */
+    uint32_t *words_out;   /* NULL, or [n_rows * width] */
     int32_t *hv_row;       /* H before the F terms are merged in (max of the match and E terms) of the row being built, by column - dp_beg */
     int64_t *stats;
 } model_t;
@@ -132,9 +133,23 @@ static dw_t decode(const model_t *m, uint32_t w) {
 
 /* Global mode, banded, affine / convex.  Fills res (cigar malloc'ed; fields as the oracle's backtrack) and stats[8].
  * Returns 0, ABPOA_HIP_EINVAL when the direction plane does not apply, ABPOA_HIP_EBACKTRACK on a dead end. */
+static uint32_t *g_words_out = NULL;
+int abpoa_oracle_dir_walk(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p, const abpoa_oracle_trace_t *t,
+                          int best_i, int best_j, abpoa_hip_result_t *res, int64_t *stats);
+/* the words of every cell (row-major, t->width columns per row, 0 outside the bands), as the row loops must write them -- except that the model takes
+ * the literal F-origin override only in the masked-scan vectors, while the exact row bodies of the kernels write it everywhere (compare with the lF fields masked) */
+int abpoa_oracle_dir_words(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p, const abpoa_oracle_trace_t *t, int best_i, int best_j, uint32_t *words) {
+    abpoa_hip_result_t r; int64_t st[10];
+    memset(words, 0, (size_t)p->n_rows * t->width * sizeof(uint32_t));
+    g_words_out = words;
+    const int rc = abpoa_oracle_dir_walk(sc, p, t, best_i, best_j, &r, st);
+    g_words_out = NULL;
+    if (rc == 0) free(r.cigar);
+    return rc;
+}
 int abpoa_oracle_dir_walk(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p, const abpoa_oracle_trace_t *t,
                           int best_i, int best_j, abpoa_hip_result_t *res, int64_t *stats) {
-    model_t M; memset(&M, 0, sizeof(M)); memset(stats, 0, 10 * sizeof(int64_t));
+    model_t M; memset(&M, 0, sizeof(M)); M.words_out = g_words_out; memset(stats, 0, 10 * sizeof(int64_t));
     if (sc->align_mode != ABPOA_HIP_GLOBAL_MODE || sc->wb < 0 || sc->gap_mode == ABPOA_HIP_LINEAR_GAP || !dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2)) return ABPOA_HIP_EINVAL;
     const int gn = p->n_rows, qlen = p->qlen; int i, j, k;
     for (i = 0; i < gn; ++i) if (p->pred_off[i + 1] - p->pred_off[i] > DIR_K_MAX) return ABPOA_HIP_EINVAL;
@@ -151,6 +166,9 @@ int abpoa_oracle_dir_walk(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem
         M.rows[i] = (uint32_t *)malloc((size_t)W * sizeof(uint32_t));
         M.hv_row = (int32_t *)realloc(M.hv_row, (size_t)W * sizeof(int32_t));
         for (j = t->dp_beg[i]; j <= t->dp_end[i]; ++j) M.rows[i][j - t->dp_beg[i]] = cell_word(&M, i, j, max_pre_end_sn);
+    }
+    if (M.words_out) {      /* (abpoa_oracle_dir_words: the caller wants the words themselves, full-width rows of t->width columns, 0 outside the bands) */
+        for (i = 1; i < gn - 1; ++i) if (M.rows[i]) for (j = t->dp_beg[i]; j <= t->dp_end[i]; ++j) M.words_out[(int64_t)i * t->width + j] = M.rows[i][j - t->dp_beg[i]];
     }
     /* ---- the walk: reference order (:109-429), decisions from the words only */
     cig_t cg = {0, 0, 0};

@@ -25,4 +25,6 @@ for it in range(3):
     for i in range(N): lib.abpoa_hip_free_result(C.byref(res[i]))
 rows = g["n_rows"][0]
 print(f"{case_name} x{N} dbg={os.environ.get('ABPOA_HIP_DBG','0')} cigar={ret_cigar}: kernel {st['kernel_ms']:.2f} ms  rows {rows}  dp ticks/row {d[0]/max(1,d[2]):.0f}  bt ticks/step {d[1]/max(1,d[3]):.0f}  Gcells/s {st['n_cells']/st['kernel_ms']/1e6:.2f}")
+if int(os.environ.get("ABPOA_HIP_DBG", "0")) & 256:
+    print("   raw seg sums / N:", [hex(int(d[4 + i] // N)) for i in range(6)], "status of first:", res[0].status)
 print("   segments ticks/row: " + "  ".join(f"s{i} {d[4+i]/max(1,d[2]):.0f}" for i in range(6)))
