@@ -221,25 +221,30 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             if ((cur_op & OP_M) && indel_first == 0 && pend == 0) {
                 if (run_n == 64) flush_run();
                 if (run_n == 0) run_j = j;
-                int recp = rec_a + ((i - w_lo) << 3), wb = win_a + ((j - w_cref) << DBL), budget = imin(64 - run_n, j), i_prev = i;
+                int recp = rec_a + ((i - w_lo) << 3), wb = win_a + ((j - w_cref) << DBL), budget = imin(64 - run_n, j);
                 const int n0 = run_n;
-                for (;;) {
-                    int2 rc_v = lds_r(recp); int w_v = lds_w(wb + Ai), st_v = 0;
-                    if (w_tri) st_v = lds_i(stg_a + ((recp - rec_a) >> 1));
-                    asm volatile("" : "+v"(w_v), "+v"(rc_v.x), "+v"(rc_v.y), "+v"(st_v));
-                    if (w_tri) { const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane(st_v); if ((unsigned)(j - (int)(st & 0x7fffu)) >= (st >> 16)) break; }      // not staged: the full step sorts it out
-                    const unsigned k1 = ((unsigned)__builtin_amdgcn_readfirstlane(w_v) & 15u) - 1u;
-                    if (k1 > 1u) break;                          // no match at this cell, or one through a later predecessor: the full step below
-                    const unsigned long long pp = ((unsigned long long)(unsigned)rc_v.y << 32) | (unsigned long long)(unsigned)rc_v.x;
-                    const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pp >> (k1 << 5)));
-                    const int dk = (int)(pk & 0xffu);
-                    if (dk == 255) break;                        // ... not in the window (or far away): the full step
-                    { const int slot = sgpr(run_n), row_s = sgpr(i);
-                      asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(runv) : "s"(row_s), "s"(slot) : "m0"); }
-                    ++run_n; i_prev = i;
-                    i -= dk; --j; recp -= dk << 3; wb -= DB; Ai = ((int)(pk << 8) >> 16) << 1;
-                    if (--budget == 0) break;
-                }
+                // (two copies of the loop: whole-row windows need no "is the cell staged" test -- every cell of a window row is, and a cell outside its row's
+                //  band is caught when the run is flushed)
+                auto run_loop = [&](auto tric) __attribute__((always_inline)) {
+                    constexpr bool TRI = decltype(tric)::value;
+                    do {
+                        int2 rc_v = lds_r(recp); int w_v = lds_w(wb + Ai), st_v = 0;
+                        if (TRI) st_v = lds_i(stg_a + ((recp - rec_a) >> 1));
+                        asm volatile("" : "+v"(w_v), "+v"(rc_v.x), "+v"(rc_v.y), "+v"(st_v));
+                        if (TRI) { const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane(st_v); if ((unsigned)(j - (int)(st & 0x7fffu)) >= (st >> 16)) break; }      // not staged: the full step sorts it out
+                        const unsigned k1 = ((unsigned)__builtin_amdgcn_readfirstlane(w_v) & 15u) - 1u;
+                        if (k1 > 1u) break;                      // no match at this cell, or one through a later predecessor: the full step below
+                        const unsigned long long pp = ((unsigned long long)(unsigned)rc_v.y << 32) | (unsigned long long)(unsigned)rc_v.x;
+                        const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pp >> (k1 << 5)));
+                        const int dk = (int)(pk & 0xffu);
+                        if (dk == 255) break;                    // ... not in the window (or far away): the full step
+                        { const int slot = sgpr(run_n), row_s = sgpr(i);
+                          asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(runv) : "s"(row_s), "s"(slot) : "m0"); }
+                        ++run_n; i -= dk; --j; recp -= dk << 3; wb -= DB; Ai = ((int)(pk << 8) >> 16) << 1;
+                    } while (--budget != 0);
+                };
+                if (w_tri) run_loop(std::true_type{}); else run_loop(std::false_type{});
+                const int i_prev = run_n != n0 ? __builtin_amdgcn_readlane(runv, (run_n - 1) & 63) : i;      // (the row of the run's last step)
                 if (run_n != n0) { start_i = i_prev; start_j = j + 1; cur_op = OP_ALL; reloaded = false; }
                 if (i <= 0 || j <= 0) continue;
                 if (run_n == 64) continue;                       // (the run buffer is full: flush at the top, then on with the run)

@@ -308,6 +308,11 @@ __device__ __forceinline__ bool takes_wide(const DevBatch &b, const AlnDesc &d) 
     return b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi;
 }
 
+// ... and which of the fast alignments write direction words instead of score records (dir_plane.h): the narrow-band ones of a launch in dir_mode.
+// (Measured on MI355X: on 1 kb reads the words cost the row loop 5-8 % and save 36-42 % of the backtrack, a net 8-11 %; on 10 kb reads the all-chunks
+//  row loop loses 18-21 % -- more than the backtrack, a fifth of the time there, gains -- so wide-band alignments keep their records.)
+__device__ __forceinline__ bool takes_dir(const DevBatch &b, const AlnDesc &d) { return b.dir_mode && !takes_wide(b, d); }
+
 // kernel launch helper shared by the translation units (block = NT threads)
 template <typename K>
 static hipError_t launch_one(K kern, const DevBatch &b, hipStream_t stream, int lds_bytes, int block_threads = 64) {

@@ -272,15 +272,7 @@ int BatchStream::run() {
     while (!todo.empty()) {
         int64_t plane_bytes = 0;
         pass.resize(todo.size());
-        for (size_t t = 0; t < todo.size(); ++t) {
-            AlnDesc &d = desc_[todo[t]];
-            d.plane_cap = dir ? (first_pass ? dir_est_cells_[todo[t]] : dir_full_cells_[todo[t]]) : (first_pass ? est_cells_[todo[t]] : full_cells_[todo[t]]);
-            d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8) + 64 * 8 * 4);   // + 64 records of slack (fast loop stores whole 64-lane chunks)
-            pass[t] = d;
-        }
-        if ((rc = planes_.reserve((size_t)plane_bytes))) return rc;
-        memcpy(hi + o_desc_, pass.data(), sizeof(AlnDesc) * pass.size());
-
+        for (size_t t = 0; t < todo.size(); ++t) pass[t] = desc_[todo[t]];
         DevBatch b; memset(&b, 0, sizeof(b));
         b.n = (int)pass.size(); b.m = sc->m;
         {   // ---- LDS plan (engine.h LdsPlan): sized for the widest expected band / largest query of this pass
@@ -297,10 +289,20 @@ int BatchStream::run() {
             if (!any_wide) b.lds.wide_nw = 0;
             b.lds.narrow_off = (b.lds.wide_nw >= 1 && all_wide) ? 1 : 0;
         }
+        if (b.lds.wide_nw > 1) dir = false;
+        for (size_t t = 0; t < todo.size(); ++t) {
+            AlnDesc &d = desc_[todo[t]];
+            // direction-plane arenas for the narrow-band alignments of a dir pass; the wide-band ones keep score records (dp_common.h takes_dir / takes_wide)
+            const bool dir_a = dir && !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi);
+            d.plane_cap = dir_a ? (first_pass ? dir_est_cells_[todo[t]] : dir_full_cells_[todo[t]]) : (first_pass ? est_cells_[todo[t]] : full_cells_[todo[t]]);
+            d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8) + 64 * 8 * 4);   // + 64 records of slack (fast loop stores whole 64-lane chunks)
+            pass[t] = d;
+        }
+        if ((rc = planes_.reserve((size_t)plane_bytes))) return rc;
+        memcpy(hi + o_desc_, pass.data(), sizeof(AlnDesc) * pass.size());
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
-        if (b.lds.wide_nw > 1) dir = false;
         b.dir_mode = dir ? 1 : 0; b.row_sdist = di + o_sdist_; b.row_pd = (const uint32_t *)(di + o_pd_);
         b.want_lr = (trace || (flags_ & BS_WANT_BAND_STATE)) ? 1 : 0;
         { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
@@ -360,7 +362,7 @@ int BatchStream::run() {
             const int i = todo[t]; const AlnOut &r = got[t]; const AlnDesc &d = desc_[i];
             if (r.status == ABPOA_HIP_STATUS_NEED_SCORES && dir) { need_scores = true; again.push_back(i); stats_.n_need_scores += 1; __atomic_fetch_add(&g_dir_counts[1], 1, __ATOMIC_RELAXED); continue; }
             if (r.status == ABPOA_HIP_STATUS_OVERFLOW) {
-                if (d.plane_cap >= (dir ? dir_full_cells_[i] : full_cells_[i])) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
+                if (!first_pass) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
                 again.push_back(i); continue;
             }
             recs_[i] = r;

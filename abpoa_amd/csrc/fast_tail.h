@@ -22,7 +22,8 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = out_rec->seg[i_];
     ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
     WG_SYNC();
-    if constexpr (DIR) finish_alignment_dir<T, GAP>(b, d, out_rec, ts);
+    // (DIR: a launch in dir_mode -- its narrow-band alignments left direction words, its wide-band ones score records)
+    if constexpr (DIR) { if (takes_dir(b, d)) finish_alignment_dir<T, GAP>(b, d, out_rec, ts); else finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts); }
     else finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
 }
 

@@ -154,6 +154,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     std::vector<PoaSet> ps(n_sets);
     int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
+    int wide_lo = 1, wide_hi = 0;      // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off)
+    { LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
+      make_lds_plan(sc, max_qlen, mb, std::min<int64_t>((int64_t)((max_qlen + pn_) / pn_) * pn_, 2LL * w_max + 3 * pn_ + 32), n_sets, &pl);
+      if (pl.wide_nw >= 1) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; } }
     for (int s = 0; s < n_sets; ++s) {
         PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
         int64_t sum = 0; int mx = 0;
@@ -173,7 +177,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         const int64_t est = std::min<int64_t>(width, 2LL * w + 3 * pn + 32);
         // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
         //  global best will read from HBM; a set that needs more is flagged and redone like any other capacity miss)
-        const int64_t bytes = dir ? (int64_t)up((size_t)(width * (DB + CW * (bits / 8)) + (est * DB + est * CW * (bits / 8) / 4 + 32) * (cap - 1) + 64 * 8 * 4))
+        const bool dir_s = dir && !(w >= wide_lo && w <= wide_hi);      // (wide-band sets keep score records: dp_common.h takes_dir)
+        const int64_t bytes = dir_s ? (int64_t)up((size_t)(width * (DB + CW * (bits / 8)) + (est * DB + est * CW * (bits / 8) / 4 + 32) * (cap - 1) + 64 * 8 * 4))
                                   : (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
         S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
         max_node_cap = std::max(max_node_cap, (int)cap);

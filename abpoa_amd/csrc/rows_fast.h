@@ -250,7 +250,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             for (int k = 0; k < NPM; ++k) { const int dk = myrow - b1.p[k]; widerow = widerow && dk >= 1 && dk < ((WIDEB || !WPLAN) ? 64 : RR); }      // (single-wave loops: older ones come from HBM)
             tv_meta |= widerow ? (1 << 19) : 0;
         }
-        if constexpr (DIR) tv_meta |= a1.sd >= RR ? (1 << 21) : 0;      // bit 21: a successor beyond the score ring (or the sink) will read this row's H / E from HBM: it keeps its score records
+        if constexpr (DIR) {      // bit 21: a successor beyond the score ring (or the sink) will read this row's H / E from HBM: it keeps its score records.
+            // Such a row (2 % of them) leaves the tight loop -- whose copies of the straight-line body then carry no record code at all -- for the copy outside (bit 22)
+            const bool sp = a1.sd >= RR;
+            if (sp) { tv_meta |= 1 << 21; if (tv_meta & (1 << 17)) tv_meta = (tv_meta & ~(1 << 17)) | (1 << 22); }
+        }
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
         tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
@@ -352,7 +356,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             // from, with the reference's own tests on the stored neighbours (:260-300); the left neighbour of the chunk's first column is carried over
             Hrec = H - (long long)(end_sn - beg_sn + 1) * CW * PN;      // (a row that keeps its records has them in front of its words)
             const int Hm1 = wave_shr1(ct_pH, Hout), F1m1 = wave_shr1(ct_pF1, F1);
-            const unsigned u1 = Hout == E1v ? (unsigned)o1 : (E1out == wr(Hout - oe1) ? 0u : (o1 > 1 ? 1u : 0u));
+            const int en1_ = GAP == 1 ? imax(wr(E1v - e1), wr(Hout - oe1)) : E1out;      // (affine: E's maximum before the reference replaces it by "inf" where H is an F term, :880)
+            const unsigned u1 = Hout == E1v ? (unsigned)o1 : (en1_ == wr(Hout - oe1) ? 0u : (o1 > 1 ? 1u : 0u));
             const unsigned d1 = Hout == F1 ? 0u : (unsigned)CAPF1;
             unsigned l1 = rel >= 1 ? dir_literal<T>(Hm1, F1m1, F1, oe1, e1) : 0u, l2 = 0, u2 = 0, d2 = 0;
             if (GAP == 2) {
@@ -498,7 +503,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int key_c = (vvl == nvr - 1) ? kE : kN;
         const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * lane;                                       // LDS byte address of this lane's ring cell
         // arena byte offset of this lane's record -- DIR: of its direction word -- (cur = the row's offset once committed)
-        const unsigned rec_off = DIR ? (unsigned)((cur + (row_spill ? nvr * CW : 0)) * 32 + lane * DB) : (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));
+        const bool spill = DIR && SLOWV && row_spill;               // (the tight loop's copies never see a row that keeps its records: tile bit 22)
+        const unsigned rec_off = DIR ? (unsigned)((cur + (spill ? nvr * CW : 0)) * 32 + lane * DB) : (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));
         asm volatile("" :: "v"(key_c), "v"(qd_addr), "v"(rec_off));      // (materialised here, not sunk to their uses)
         __builtin_amdgcn_sched_barrier(0);
         if (I16) { Mv = (int)(short)raw0; E1v = raw1 >> 16; E2v = raw2; } else { Mv = raw0; E1v = raw1; E2v = raw2; }
@@ -510,9 +516,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (I16) { hm1 = (int)(short)r0_; ev1 = r1_ >> 16; ev2 = r2_; } else { hm1 = r0_; ev1 = r1_; ev2 = r2_; }
             const bool inH = (unsigned)x_ < (unsigned)(Wp_ + PN), inE = (unsigned)x_ < (unsigned)Wp_;
             if (NPC >= 4) kfirst = (inH && hm1 > Mv) ? kidx : kfirst;
-            if (DIR) { kE1 = (inE && ev1 > E1v) ? kidx : kE1; if (GAP == 2) kE2 = (inE && ev2 > E2v) ? kidx : kE2; }
+            if (DIR && NPC >= 4) { kE1 = (inE && ev1 > E1v) ? kidx : kE1; if (GAP == 2) kE2 = (inE && ev2 > E2v) ? kidx : kE2; }      // (two predecessors: read off E afterwards, below)
             Mv = inH ? imax(Mv, hm1) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v;
         };
+        const int E1v_first = E1v, E2v_first = E2v;
         if (NPC >= 2) {
             asm volatile("" : "+v"(rb0), "+v"(rb1));               // (the loads above stay unconditional)
             if (GAP == 2) asm volatile("" : "+v"(rb2));
@@ -561,7 +568,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         // ---- from here on the row is committed
         const int rec_pn = cur;                                    // (DIR, a row that keeps its records: they start here, the words follow)
-        off_pn = cur + ((DIR && row_spill) ? nvr * CW : 0); cur += row_units(nvr, row_spill);
+        off_pn = cur + (spill ? nvr * CW : 0); cur += row_units(nvr, spill);
         int Hout, E1out, E2out = inf, en1 = 0, t2a = 0, t2b = 0;
         if (GAP == 1) {
             const int tmp = imax(h, E1v);
@@ -588,6 +595,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             unsigned u2 = 0, d2 = 0;
             if (GAP == 2) { u2 = (unsigned)(E2out - t2b); d2 = umin_((unsigned)(Hout - F2), (unsigned)CAPF2); }
             // kM | kE1 << 4 (| kE2 << 8): one predecessor -- two constants
+            if (NPC == 2) { kE1 = E1v != E1v_first ? 2 : 1; if (GAP == 2) kE2 = E2v != E2v_first ? 2 : 1; }      // (the second predecessor holds the maximum iff it raised it: strictly greater)
             const unsigned kf = NPC == 1 ? ((h == Hout) ? (GAP == 1 ? 0x11u : 0x111u) : (GAP == 1 ? 0x10u : 0x110u))
                                          : (GAP == 1 ? ((unsigned)kE1 << 4) | (unsigned)mflag : ((((unsigned)kE2 << 4) | (unsigned)kE1) << 4) | (unsigned)mflag);
             unsigned wd = dir_word<GAP>(kf, u1, u2, d1, d2);
@@ -601,7 +609,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             char *const dp = (char *)io.planes + (size_t)rec_off;
             if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd;
         }
-        if (DIR && !row_spill) {}
+        if (DIR && !spill) {}
         else if (DIR && !in_band) {}      // (the row's words start right behind its last record)
         else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(H + lane * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2; rec.w = mflag; *(int4 *)(H + lane * CW) = rec; }
@@ -1180,7 +1188,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (!WPLAN && ((meta >> 20) & 1)) {                       // five to eight predecessors
                 if (turbo_body(std::integral_constant<int, 8>{}, std::true_type{}, row, ti) == 1) { commit_row(ti, true); CENSUS(2) ++row; continue; }
             }
-            if (!WPLAN && ((meta >> 17) & 1) && ok_ == 0) {                       // one or two predecessors and the tight loop declined: most often the row's band reaches one
+            if (!WPLAN && (((meta >> 17) & 1) ? ok_ == 0 : (DIR && ((meta >> 22) & 1)))) {                       // one or two predecessors and the tight loop declined: most often the row's band reaches one
                                                                       // vector beyond its predecessors' (every PN-th row of a chain) -- the copies that take those vectors
                 const int ok3 = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, std::true_type{}, row, ti) : turbo_body(std::integral_constant<int, 2>{}, std::true_type{}, row, ti);
                 if (ok3 == 1) { commit_row(ti, true); CENSUS(np == 1 ? 0 : 1) ++row; continue; }

@@ -186,6 +186,54 @@ def run_dir_model(case):
     return rc2, a, b, list(stats)
 
 
+def dir_words_mismatches(case, g):
+    """GPU: the direction words the row loops wrote (flat API in trace mode with ABPOA_HIP_DIRTRACE=1: plane 0 of the trace carries the words) against the
+    words oracle/dir_model.c derives from the oracle's scores, cell by cell, on the fields a walk decides with (kM, kE, H == Ein, E opened from H, H == F;
+    where F came from is compared through the walk itself: the cigar).  Returns None when the plane does not apply, else the list of differing rows."""
+    lib = oracle_lib(); case.reset()
+    res, tr = Result(), OracleTrace()
+    assert lib.abpoa_oracle_align(C.byref(case.sc), C.byref(case.pb), C.byref(res), C.byref(tr)) == 0
+    lib.abpoa_oracle_dir_words.argtypes = [C.POINTER(Scoring), C.POINTER(Problem), C.POINTER(OracleTrace), C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    mw = np.zeros((case.n_rows, tr.width), np.uint32)
+    rc = lib.abpoa_oracle_dir_words(C.byref(case.sc), C.byref(case.pb), C.byref(tr), res.best_row, res.best_col, mw.ctypes.data_as(C.POINTER(C.c_uint32)))
+    lib.abpoa_oracle_free_trace(C.byref(tr)); _libc.free(C.cast(res.cigar, C.c_void_p))
+    if rc != 0:
+        return None
+    old = os.environ.get("ABPOA_HIP_DIRTRACE")
+    os.environ["ABPOA_HIP_DIRTRACE"] = "1"
+    try:
+        h = run_hip([case], want_trace=True)[0]
+    finally:
+        if old is None:
+            del os.environ["ABPOA_HIP_DIRTRACE"]
+        else:
+            os.environ["ABPOA_HIP_DIRTRACE"] = old
+    convex = int(g["gap_mode"][0]) == 2
+    o1, o2 = int(g["gap_open1"][0]), int(g["gap_open2"][0])
+
+    def norm(w):
+        if not convex:
+            return np.stack([w & 15, (w >> 4) & 15, ((w >> 8) & 7) == o1, ((w >> 8) & 7) == 0, ((w >> 11) & 7) == 0], -1).astype(np.int32)
+        return np.stack([w & 15, (w >> 4) & 15, (w >> 8) & 15, ((w >> 12) & 7) == o1, ((w >> 12) & 7) == 0, ((w >> 15) & 31) == o2, ((w >> 15) & 31) == 0,
+                         ((w >> 20) & 7) == 0, ((w >> 23) & 31) == 0], -1).astype(np.int32)
+    pn = 16 if h.bits == 16 else 8
+    bad = []
+    for r in range(1, case.n_rows - 1):
+        if h.dp_beg_sn[r] < 0:
+            continue
+        W = (h.dp_end_sn[r] - h.dp_beg_sn[r] + 1) * pn
+        o = int(h.row_off[r])
+        gw = h.planes[o:o + W].astype(np.int64) & (0xffff if h.bits == 16 else 0xffffffff)
+        if convex and h.bits == 16:
+            gw = gw | ((h.planes[o + W:o + 2 * W].astype(np.int64) & 0xffff) << 16)
+        m = mw[r, h.dp_beg_sn[r] * pn: h.dp_beg_sn[r] * pn + W].astype(np.int64)
+        ncol = min(W, case.qlen + 1 - h.dp_beg_sn[r] * pn)          # (columns past the query are never read)
+        d = np.nonzero((norm(gw[:ncol]) != norm(m[:ncol])).any(-1))[0]
+        if len(d):
+            bad.append((r, len(d), int(d[0]), hex(int(gw[d[0]])), hex(int(m[d[0]]))))
+    return bad
+
+
 def mix64(x):
     x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
     x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)

@@ -35,8 +35,26 @@ def test_hip_matches_golden_and_oracle(engine, label, path):
     H.compare_with_golden(h2, g, check_planes=False, label="hip-dir-vs-golden " + label)
     assert np.array_equal(h2.cigar, o.cigar) and h2.best_score == o.best_score
     walked, redone = _dir_counts(engine)
-    if label.startswith(("s1k_", "s10k_", "s20k_", "seq_ag_gb", "heter_ag_gb", "heter_cg_gb")):      # global, banded, default penalties: the plane must have been used
+    if label.startswith(("s1k_", "seq_ag_gb", "heter_ag_gb", "heter_cg_gb")):      # global, narrow band, default penalties: the plane must have been used
         assert walked == 1 and redone == 0, (label, walked, redone)
+
+
+@pytest.mark.parametrize("env", [{}, {"ABPOA_HIP_NOWIDE": "1"}], ids=["default", "nowide"])
+def test_direction_words_match_the_model(engine, monkeypatch, env):
+    """Plane level: every direction word the row loops write (trace mode with ABPOA_HIP_DIRTRACE=1) carries the decisions oracle/dir_model.c derives from
+    the oracle's scores for that cell.  With ABPOA_HIP_NOWIDE=1 the 10 kb goldens run through the narrow kernel's chunk-by-chunk bodies, which write
+    the words too (their wide row loop keeps score records)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 0
+    for label, path in CASES:
+        if not label.startswith(("s1k_", "seq_ag_gb", "heter_ag_gb", "heter_cg_gb") + (("s10k_",) if env else ())):
+            continue
+        g = H.read_abpg(path)
+        bad = H.dir_words_mismatches(H.FlatCase(g), g)
+        assert bad is not None and bad == [], (label, bad[:5] if bad else bad)
+        n += 1
+    assert n >= 4
 
 
 def _dir_counts(lib):
@@ -104,7 +122,7 @@ def test_wide_band_variants(engine, monkeypatch, env):
         g = H.read_abpg(path)
         h = H.run_hip([H.FlatCase(g)])[0]
         H.compare_with_golden(h, g, label=f"{env} {label}")
-        h2 = H.run_hip([H.FlatCase(g)], want_trace=False)[0]      # direction-plane arenas (not with teams): with a 4-row ring most rows read a predecessor's kept score record from HBM
+        h2 = H.run_hip([H.FlatCase(g)], want_trace=False)[0]      # no trace: direction-plane arenas where the launch uses them (narrow-band row loop: the nowide variant)
         H.compare_with_golden(h2, g, check_planes=False, label=f"{env} dir {label}")
         n += 1
     assert n >= 3
