@@ -1,6 +1,6 @@
 # HBM traffic of the row-loop kernels on a bench workload: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (they do not fit one
 # pass; no tracing flag besides --kernel-trace), the same bench command each time.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts
-# 128-byte requests at 64 bytes -> x2; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Writes profiles/r2_pmc_traffic_<workload>.json,
+# 128-byte requests at 64 bytes -> x2; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Writes profiles/r3_pmc_traffic_<workload>.json,
 # which bench.py reports as roofline.traffic while the row-loop sources are unchanged (hash kept in the record).
 # usage (on the GPU box): bash tools/pmc_traffic.sh cfg2|cfg3|cfg4 [read-sets]
 cd /tmp && export TMPDIR=/tmp
@@ -30,10 +30,15 @@ all_rounds = "poa_rounds_kernel" in line["roofline"]["kernel"]
 rows = {k: v for k, v in per_kernel.items() if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_team_kernel", "dp_local_kernel"))}
 fetch_kb = sum(v["FETCH_SIZE"] for v in rows.values()); write_kb = sum(v["WRITE_SIZE"] for v in rows.values())
 hbm = (2 * fetch_kb + write_kb) * 1024 / max(1, rounds)
+steps = max(1, line["steps"])
 sys.path.insert(0, root)
 import bench
 rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "rounds": rounds,
        "hbm_bytes_per_launch": int(hbm), "algo_bytes_per_launch": line["roofline"]["algo_bytes_per_launch"],
+       # per STEP (one pass over the batch): what a bench run of the same workload can be compared with whatever its launch count
+       "hbm_bytes_per_step": int((2 * fetch_kb + write_kb) * 1024 / steps), "fetch_bytes_per_step": int(2 * fetch_kb * 1024 / steps), "write_bytes_per_step": int(write_kb * 1024 / steps),
+       "algo_bytes_per_step": int(line["roofline"]["algo_bytes_per_launch"] * rounds / steps),
+       "hbm_over_algorithmic": round((2 * fetch_kb + write_kb) * 1024 / max(1.0, line["roofline"]["algo_bytes_per_launch"] * rounds), 3),
        "FETCH_SIZE_KB_raw_per_launch": round(fetch_kb / max(1, rounds), 1), "WRITE_SIZE_KB_per_launch": round(write_kb / max(1, rounds), 1),
        "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies 128-B requests at 64 B)",
        "launch": ("one launch of abpoa_hip::poa_rounds_kernel = rounds 2..n of every read-set (graph phases, row loop and backtrack inside: its traffic includes the backtrack's re-read of the arenas)"
@@ -43,6 +48,6 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "rounds
        "all_kernels_MB_per_launch": {k: {"fetch_x2": round(2 * v["FETCH_SIZE"] / 1024 / max(1, rounds), 1), "write": round(v["WRITE_SIZE"] / 1024 / max(1, rounds), 1)} for k, v in per_kernel.items()},
        "how": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --workload %s --steps 1 --warmup 0`" % wl}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-json.dump(rec, open(os.path.join(root, "gpurun_out", f"r2_pmc_traffic_{wl}.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(root, "gpurun_out", f"r3_pmc_traffic_{wl}.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY
