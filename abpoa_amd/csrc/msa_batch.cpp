@@ -19,7 +19,20 @@
 #include "msa_batch.h"
 #include "poa_graph.h"
 
+#include <unordered_map>
 namespace abpoa_hip {
+
+namespace {
+std::mutex g_dig_mu; std::unordered_map<uint64_t, uint64_t> g_dig;
+uint64_t fnv64(const void *p, size_t n, uint64_t h = 1469598103934665603ull) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+}
+bool cigar_digest_on() { static const bool on = getenv("ABPOA_HIP_CIGAR_DIGEST") && atoi(getenv("ABPOA_HIP_CIGAR_DIGEST")); return on; }
+void cigar_digest_add(const uint8_t *seq0, int len0, int read_index, const uint64_t *cigar, int n_cigar) {
+    const uint64_t key = fnv64(seq0, (size_t)len0);
+    uint64_t h = fnv64(&read_index, sizeof(read_index)); h = fnv64(&n_cigar, sizeof(n_cigar), h); h = fnv64(cigar, 8 * (size_t)n_cigar, h);
+    std::lock_guard<std::mutex> lk(g_dig_mu);
+    uint64_t &d = g_dig[key]; d = (d * 0x9E3779B97F4A7C15ull) ^ h;      // (order-dependent within a set: reads are folded in order)
+}
 
 int effective_host_cores() {
     int n = (int)std::thread::hardware_concurrency(); if (n < 1) n = 1;
@@ -190,6 +203,7 @@ static int run_group(const abpoa_hip_scoring_t &scoring, const abpoa_hip_readset
             const int st = al->status(a);
             if (st != 0) { out[s].status = st; return; }
             out[s].n_cells += al->n_cells(a);
+            if (cigar_digest_on()) cigar_digest_add(sets[s].seqs[0], sets[s].lens[0], k, al->cigar(a), al->n_cigar(a));
             try { graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], al->cigar(a), al->n_cigar(a), k, weights_of(sets[s], k)); } catch (...) { fail.store(1); }
         });
         if (fail.load()) return ABPOA_HIP_EINVAL;
@@ -282,6 +296,15 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
 }  // namespace abpoa_hip
 
 extern "C" {
+// digest of the cigars folded so far for the read-set whose first read is seq0 (0: none); reset = 1 clears the table afterwards
+unsigned long long abpoa_hip__cigar_digest(const uint8_t *seq0, int len0, int reset) {
+    using namespace abpoa_hip;
+    std::lock_guard<std::mutex> lk(g_dig_mu);
+    const auto it = g_dig.find(fnv64(seq0, (size_t)len0));
+    const unsigned long long v = it == g_dig.end() ? 0ull : it->second;
+    if (reset) g_dig.clear();
+    return v;
+}
 void abpoa_hip_free_msa(abpoa_hip_msa_t *r) {
     if (!r) return;
     free(r->cons_base); free(r->cons_cov); free(r->cons_node_id); free(r->msa_base); free(r->is_rc);

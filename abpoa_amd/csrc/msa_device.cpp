@@ -18,6 +18,7 @@
 #include "poa_device.h"
 #include "poa_graph.h"
 #include "dir_plane.h"
+#include "msa_batch.h"
 
 namespace abpoa_hip {
 
@@ -300,7 +301,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
     //      per phase and round throughout (what the wide-band jobs use, and the per-round diagnostics below).
     const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
-    bool use_rounds = !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
+    bool use_rounds = !dbg_sync && !cigar_digest_on() && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
     DevBatch b_r = b; size_t rounds_lds = 0;
     if (use_rounds) {
         auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), std::max<size_t>((size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), (size_t)16 * 256)); };      // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
@@ -440,6 +441,17 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 fprintf(stderr, "[poa-device] round %d slowest row loop: set %d ticks %lld rows %d | all-chunk body %lld | not eligible %lld | ring-geometry %lld | > 5 chunks %lld | slow vectors straddle %lld | key window / wrap %lld\n", k, w_, (long long)o_.clk_dp, o_.n_rows_done, (long long)o_.seg[0], (long long)o_.seg[1], (long long)o_.seg[2], (long long)o_.seg[3], (long long)o_.seg[4], (long long)o_.seg[5]); }
             if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr, "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible (preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key window / wrap %.0f\n", k, sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);
             fprintf(stderr, "[poa-device] round %d tail means: steps %.0f  flag steps %.0f  slow steps %.0f  windows %.1f  window ticks %.0f (setup %.0f)  walk ticks %.0f\n", k, st_ / n_sets, sg[2] / n_sets / 1000, sg[3] / n_sets / 1000, sg[4] / n_sets / 1000, sg[5] / n_sets, sg[0] / n_sets, sg[1] / n_sets);
+        }
+        if (cigar_digest_on()) {      // (test hook: the graph cigar of every set's alignment of this round, folded into the per-set digests; synchronises the stream)
+            std::vector<AlnOut> ho(n_sets); HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
+            (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
+            std::vector<uint64_t> cgb;
+            for (int s_ = 0; s_ < n_sets; ++s_) {
+                if (k >= sets[s_].n_reads || ho[s_].status != 0) continue;
+                cgb.resize((size_t)std::max(1, ho[s_].n_cigar));
+                (void)hipMemcpy(cgb.data(), (uint8_t *)p.cigar + 8 * ps[s_].cigar_off, 8 * (size_t)ho[s_].n_cigar, hipMemcpyDeviceToHost);
+                cigar_digest_add(sets[s_].seqs[0], sets[s_].lens[0], k, cgb.data(), ho[s_].n_cigar);
+            }
         }
         HIP_OK(hipEventRecord(e[2], st), ABPOA_HIP_ELAUNCH);
         HIP_OK(launch_poa_fuse(p, st), ABPOA_HIP_ELAUNCH);

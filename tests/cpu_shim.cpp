@@ -46,7 +46,7 @@ class OracleGroupAligner : public GroupAligner {
             pb.out_off = p.ooff.data(); pb.out_row = p.out.data(); pb.max_pos_left = p.left.data(); pb.max_pos_right = p.right.data();
             // ABPOA_SHIM_DIR_CHECK=1: keep the trace and let oracle/dir_model.c build and walk the direction plane of this alignment;
             // its cigar and result fields must equal the value-comparing backtrack's (tests/test_dir_model.py)
-            static const bool dir_check = getenv("ABPOA_SHIM_DIR_CHECK") && atoi(getenv("ABPOA_SHIM_DIR_CHECK"));
+            const bool dir_check = getenv("ABPOA_SHIM_DIR_CHECK") && atoi(getenv("ABPOA_SHIM_DIR_CHECK"));      // (read per call: tests switch it on and off)
             abpoa_oracle_trace_t tr; memset(&tr, 0, sizeof(tr));
             int rc = abpoa_oracle_align(&sc_, &pb, &res_[i], dir_check ? &tr : 0);
             if (dir_check && rc == 0 && res_[i].status == 0) {

@@ -141,3 +141,38 @@ def test_device_driver_equals_oracle_backed_host_run(engine, monkeypatch, lockst
         for i, (a, b) in enumerate(zip(dev, ref)):
             assert a.status == 0 and b.status == 0
             assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{kw}: set {i} differs from the oracle-backed run"
+
+
+def test_device_driver_cigars_equal_the_oracle_backed_run(engine, monkeypatch):
+    """Direct cigar comparison (not only consensus / coverage): with ABPOA_HIP_CIGAR_DIGEST=1 both drivers fold the graph cigar of every alignment into
+    a digest per read-set -- the device-resident driver (one launch per phase and round in this mode; the cigars come off the device after every
+    backtrack) and the CPU build of the host driver, whose aligner is the oracle."""
+    import ctypes
+    import subprocess
+    import sys
+    code = ("import os, sys, ctypes; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+            "import helpers as H\n"
+            "from abpoa_amd import api, ffi, synth, seqio\n"
+            "import numpy as np\n"
+            "def digests(lib, sets, m):\n"
+            "    out = []\n"
+            "    lib.abpoa_hip__cigar_digest.restype = ctypes.c_ulonglong\n"
+            "    for s in sets:\n"
+            "        a = np.ascontiguousarray(seqio.encode(s[0], m), np.uint8)\n"
+            "        out.append(lib.abpoa_hip__cigar_digest(a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(a), 0))\n"
+            "    return out\n"
+            "for kw, shape in ((dict(gap_open1=4, gap_open2=0, gap_ext1=2), (8, 12, 700, 0.08)), (dict(), (6, 10, 900, 0.15))):\n"
+            "    sets = [synth.make_read_set(23, i, *shape[1:]) for i in range(shape[0])]\n"
+            "    p = api.Params(**kw)\n"
+            "    lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
+            "    dev = api.msa_batch(sets, p, n_threads=4); tm = api.msa_timing()\n"
+            "    assert all(r.status == 0 for r in dev) and tm['pad'] == 0, tm\n"
+            "    d_dev = digests(lib, sets, p.m); lib.abpoa_hip__cigar_digest(None, 0, 1)\n"
+            "    shim = H.cpu_shim_lib(); host = api.msa_batch(sets, p, lib=shim, n_threads=4)\n"
+            "    d_host = digests(shim, sets, p.m); shim.abpoa_hip__cigar_digest(None, 0, 1)\n"
+            "    assert all(d != 0 for d in d_dev) and d_dev == d_host, (d_dev, d_host)\n"
+            "    assert [r.cons_seq for r in dev] == [r.cons_seq for r in host]\n"
+            "print('CIGARS EQUAL')\n" % (ROOT, ROOT))
+    env = dict(os.environ, ABPOA_HIP_CIGAR_DIGEST="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "CIGARS EQUAL" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
