@@ -55,18 +55,28 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     GLOBAL_AS int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
     T *planes = (T *)(b.planes + d.plane_off);
     const unsigned char *arena = (const unsigned char *)planes;
-    const uint8_t *s_query = lds_raw + b.lds.q_off;
     int status = ts.status, best_score = ts.best_score, best_i = ts.best_i, best_j = ts.best_j, bt_steps = 0;
     WG_SYNC();       // all of this wave's arena / band stores have landed before the loads below
 
     // ------------------------------------------------------------------ global best, reference :1028-1041 (the sink's predecessors keep their score records)
     if (status == 0) {
-        for (int k = pred_off[gn - 1]; k < pred_off[gn]; ++k) {
-            const int in_row = pred_row[k];
-            const int pe = g_esn[in_row], pb = g_bsn[in_row];
-            const int dpe = (pe + 1) * PN - 1, end = qlen > dpe ? dpe : qlen;
-            const int score = (int)planes[g_coff[in_row] - (long long)(pe - pb + 1) * CW * PN + (long long)(end - pb * PN) * CW];      // (its records sit in front of its words)
-            if (score > best_score) { best_score = score; best_i = in_row; best_j = end; }
+        // a lane per in-edge of the sink, 64 at a time (the three dependent loads of an edge are in flight for all of them together); the first maximum in
+        // list order wins, as in the reference's loop with its strict ">"
+        const int k0 = __builtin_amdgcn_readfirstlane(pred_off[gn - 1]), k1 = __builtin_amdgcn_readfirstlane(pred_off[gn]);
+        for (int kb = k0; kb < k1; kb += 64) {
+            const int k = kb + lane; const bool v = k < k1;
+            int in_row = 0, end = 0, score = INT_MIN;
+            if (v) {
+                in_row = pred_row[k];
+                const int pe = g_esn[in_row], pb = g_bsn[in_row];
+                const int dpe = (pe + 1) * PN - 1; end = qlen > dpe ? dpe : qlen;
+                score = (int)planes[g_coff[in_row] - (long long)(pe - pb + 1) * CW * PN + (long long)(end - pb * PN) * CW];      // (its records sit in front of its words)
+            }
+            const int mx = wave_max_i32(score);
+            if (mx > best_score) {
+                const int first = __builtin_ctzll(__ballot(v && score == mx));
+                best_score = mx; best_i = __builtin_amdgcn_readlane(in_row, first); best_j = __builtin_amdgcn_readlane(end, first);
+            }
         }
     }
 
@@ -277,7 +287,9 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 if (dk != 255) { i -= dk; if (i >= w_lo) Ai = __builtin_amdgcn_readfirstlane(B.rowA[i - w_lo]); else restage = true; return true; }
                 const int po = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i)), po1 = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i + 1));
                 if (k >= po1 - po) return false;
-                i = __builtin_amdgcn_readfirstlane(gld_i32(pred_row + po + k)); restage = true; return true;
+                i = __builtin_amdgcn_readfirstlane(gld_i32(pred_row + po + k));
+                if (i >= w_lo && i <= w_hi) Ai = __builtin_amdgcn_readfirstlane(B.rowA[i - w_lo]); else restage = true;      // (usually still inside the window)
+                return true;
             };
             auto do_match = [&](int set_indel) __attribute__((always_inline)) {
                 if (kM == 0) return;
@@ -332,20 +344,23 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             if (have_pending) store_word(n_cigar - 1, last_word);
             WG_SYNC();
             // ---- final pass, a lane per word: row -> node id, matched bases, reversal (reference abpoa_reverse_cigar, abpoa_align.h:88-96)
-            const bool q_in_lds = qlen <= b.lds.q_cap;
             GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
             auto fix = [&](uint64_t wv, int &nm) __attribute__((always_inline)) -> uint64_t {
                 const int op = (int)(wv & 0xf);
                 if (op == ABPOA_HIP_CINS) return wv;
                 const int row_ = (int)(wv >> 34);
-                if (op == ABPOA_HIP_CMATCH) { const int q = (int)((wv >> 4) & 0x3fffffffu); nm += (int)row_base[row_] == (q_in_lds ? (int)s_query[q] : (int)g_query[q]) ? 1 : 0; }
+                if (op == ABPOA_HIP_CMATCH) { const int q = (int)((wv >> 4) & 0x3fffffffu); nm += (int)row_base[row_] == (int)g_query[q] ? 1 : 0; }      // (the query straight from HBM: this backtrack needs it nowhere else)
                 return (wv & 0x3ffffffffull) | ((uint64_t)(int64_t)row_node_id[row_] << 34);
             };
             int nm = 0;
             const int half = n_cigar >> 1;
-            for (int k = lane; k < half; k += 64) {
-                uint64_t a = fix(cg[k], nm), c_ = fix(cg[n_cigar - 1 - k], nm);
+            for (int k = lane; k < half; k += 128) {      // (two pairs of words per lane and turn: their loads -- the words, then node id and base by row -- overlap)
+                const int k2 = k + 64; const bool v2 = k2 < half;
+                uint64_t wa = cg[k], wc = cg[n_cigar - 1 - k], wa2 = v2 ? cg[k2] : 0, wc2 = v2 ? cg[n_cigar - 1 - k2] : 0;
+                const uint64_t a = fix(wa, nm), c_ = fix(wc, nm);
                 if (b.rev_cigar) { cg[k] = a; cg[n_cigar - 1 - k] = c_; } else { cg[k] = c_; cg[n_cigar - 1 - k] = a; }
+                if (v2) { const uint64_t a2 = fix(wa2, nm), c2 = fix(wc2, nm);
+                          if (b.rev_cigar) { cg[k2] = a2; cg[n_cigar - 1 - k2] = c2; } else { cg[k2] = c2; cg[n_cigar - 1 - k2] = a2; } }
             }
             if ((n_cigar & 1) && lane == 0) cg[half] = fix(cg[half], nm);
             n_match = __builtin_amdgcn_readlane(wave_scan_add_i32(nm), 63);

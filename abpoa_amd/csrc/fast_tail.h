@@ -13,8 +13,9 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     const int lane = threadIdx.x & 63;
     uint8_t *s_query = lds_raw + b.lds.q_off;
     int32_t *s_mat = (int32_t *)(lds_raw + b.lds.mat_off);
-    { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < b.m * b.m; i += 64) s_mat[i] = g_mat[i]; }
-    { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = lane; i < d.qlen; i += 64) s_query[i] = g_query[i]; }
+    const bool dir_a = DIR && takes_dir(b, d);      // (the direction-plane backtrack reads neither the score matrix nor -- but in its final pass, from HBM -- the query)
+    if (!dir_a) { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = lane; i < b.m * b.m; i += 64) s_mat[i] = g_mat[i]; }
+    if (!dir_a) { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = lane; i < d.qlen; i += 64) s_query[i] = g_query[i]; }
     TailState ts;
     ts.status = out_rec->status; ts.n_cells = out_rec->n_cells; ts.cursor = out_rec->cells_used; ts.rows_done = out_rec->n_rows_done;
     ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;

@@ -419,6 +419,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             sum_max += (double)ms_;
             if (k == max_reads - 1) { double mx_ = 0, mean_ = 0; for (double v_ : tot_set) { mx_ = std::max(mx_, v_); mean_ += v_; } fprintf(stderr, "[poa-device] rows+tail ticks over all rounds: sum of per-round maxima %.0f | slowest set alone %.0f | mean set %.0f\n", sum_max, mx_, mean_ / n_sets); }
             double sg[6] = {0, 0, 0, 0, 0, 0}, st_ = 0; for (const AlnOut &o_ : ho) { for (int q_ = 0; q_ < 6; ++q_) sg[q_] += o_.seg[q_]; st_ += o_.n_bt_steps; }
+            if (b.dir_mode) { double cu = 0, nc = 0, rd = 0; for (const AlnOut &o_ : ho) { cu += (double)o_.cells_used; nc += (double)o_.n_cells; rd += o_.n_rows_done; }      // (direction-plane arenas: how much of them is score records of rows kept for later readers)
+                              fprintf(stderr, "[poa-device] round %d arenas: %.0f rows, %.0f columns, %.0f units of 32 B per alignment; words alone would take %.0f (int16 affine) -> rows keeping their records: ~%.1f %%\n", k, rd / n_sets, nc / n_sets, cu / n_sets / 16, nc / n_sets / 16, 100.0 * (cu - nc) / (4.0 * nc + 1)); }
             if (b.dbg & 128) {      // placement report (row-loop seg[5] = HW_ID | XCC_ID << 32 survives the tail under dbg bit 7): how many alignments shared a SIMD, and how the sharers fared
                 std::vector<std::pair<unsigned long long, int>> pl; for (int s_ = 0; s_ < n_sets; ++s_) { const unsigned long long h_ = (unsigned long long)ho[s_].seg[5]; pl.push_back({((h_ >> 32) & 15) << 16 | (h_ & 0xff30) , s_}); }      // xcc | se, sh, cu | simd
                 std::sort(pl.begin(), pl.end()); double t_sh = 0, t_al = 0; int n_sh = 0, n_al = 0;
