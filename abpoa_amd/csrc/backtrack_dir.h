@@ -13,7 +13,7 @@ namespace abpoa_hip {
 // Window: rows [lo, hi] of words staged in LDS by LDS-DMA, up to DBTR rows, and per row
 //     rec  { p0, p1 }: for each of the first two predecessors its row distance (a byte; 255 = none / further than 254 rows / not in the window) and,
 //          above it, 16 bits, half the byte offset AB of its words in the window: the word of column c sits at window + AB + (c - cref) * DB;
-//     pd   the row distances to the first four predecessors, a byte each (DevBatch.row_pd, made once per alignment by the graph phase);
+//     pd   the row distances to the first eight predecessors, a byte each (DevBatch.row_pd, made once per alignment by the graph phase);
 //     stg  first staged column | left-cut flag << 15 | staged columns << 16;   rowA  the row's own AB
 //   so a match step -- 85-97 % of a walk -- needs ONE LDS round trip (the cell's word and its row's rec, both at addresses the previous step already
 //   knew) and a dozen scalar instructions: the word names the predecessor (kM), rec gives its row distance and where its words are.  Any other
@@ -30,7 +30,7 @@ namespace abpoa_hip {
 constexpr int DBTR = 256;     // most rows of a window
 constexpr int DIR_TRI_SLACK = 9;
 constexpr int DIR_NA = -32768;
-struct __attribute__((aligned(16))) DirBt { int2 rec[DBTR]; int32_t pd[DBTR], stg[DBTR], rowA[DBTR]; };      // the walk's LDS image; the words follow
+struct __attribute__((aligned(16))) DirBt { int2 rec[DBTR]; int2 pd[DBTR]; int32_t stg[DBTR], rowA[DBTR]; };      // the walk's LDS image; the words follow
 
 template <typename T, int GAP>
 __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts) {
@@ -49,7 +49,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     const int o1 = b.o1, o2 = b.o2;
     GLOBAL_AS const uint8_t *row_base = vgpr_ptr(b.row_base + d.row0);
     GLOBAL_AS const int32_t *row_node_id = vgpr_ptr(b.row_node_id + d.row0);
-    GLOBAL_AS const uint32_t *row_pd = vgpr_ptr(b.row_pd + d.row0);
+    GLOBAL_AS const uint32_t *row_pd = vgpr_ptr(b.row_pd + 2 * d.row0);      // (two dwords per row)
     GLOBAL_AS const int32_t *pred_off = vgpr_ptr(b.pred_off + d.poff0), *pred_row = vgpr_ptr(b.pred_row + d.pred0);
     GLOBAL_AS int32_t *g_bsn = vgpr_ptr(b.dp_beg_sn + d.row0), *g_esn = vgpr_ptr(b.dp_end_sn + d.row0);
     GLOBAL_AS int64_t *g_coff = vgpr_ptr(b.row_cell_off + d.row0);
@@ -96,11 +96,11 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             WG_SYNC();
             const int cref = jtop - 4096;                       // (below every staged column: A values stay in 16 bits)
             // candidates: lane l holds rows hi - l - 64 q (descending rows: cumulative sizes are plain prefix sums); every load of every candidate in flight together
-            int bs[NQ], es[NQ]; long long co[NQ]; unsigned pdv[NQ];
+            int bs[NQ], es[NQ]; long long co[NQ]; unsigned pdv[NQ], pdh[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int r = hi - 64 * q - lane, rc = imax(r, 1);
-                bs[q] = g_bsn[rc]; es[q] = g_esn[rc]; co[q] = g_coff[rc]; pdv[q] = row_pd[rc];
+                bs[q] = g_bsn[rc]; es[q] = g_esn[rc]; co[q] = g_coff[rc]; pdv[q] = row_pd[2 * rc]; pdh[q] = row_pd[2 * rc + 1];
             }
             int W[NQ], pc[NQ]; unsigned sa[NQ]; bool vq[NQ];
 #pragma unroll
@@ -161,7 +161,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             for (int q = 0; q < NQ; ++q) {
                 A[q] = off[q] - ((sl[q] - cref) << DBL);
                 const int li = hi - 64 * q - lane - lo;
-                if (vq[q] && li >= 0) { B.rowA[li] = A[q]; B.pd[li] = (int)pdv[q]; B.stg[li] = (sl[q] & 0x7fff) | ((sl[q] > pc[q] ? 1 : 0) << 15) | (ns[q] << 16); }
+                if (vq[q] && li >= 0) { B.rowA[li] = A[q]; B.pd[li] = make_int2((int)pdv[q], (int)pdh[q]); B.stg[li] = (sl[q] & 0x7fff) | ((sl[q] > pc[q] ? 1 : 0) << 15) | (ns[q] << 16); }
             }
             WG_SYNC();
 #pragma unroll
@@ -262,7 +262,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             // ---- full step: any state, the reference's priority order (:109-429) decided from the words (oracle/dir_model.c)
             flush_run(); ++n_general;
             if (status != 0) break;
-            const int stw = __builtin_amdgcn_readfirstlane(B.stg[i - w_lo]), pdw = __builtin_amdgcn_readfirstlane(B.pd[i - w_lo]);
+            const int stw = __builtin_amdgcn_readfirstlane(B.stg[i - w_lo]);
+            const int2 pd2 = uniform2(B.pd[i - w_lo]);
             const int sli = stw & 0x7fff, cut = (stw >> 15) & 1, nsi = (int)((unsigned)stw >> 16), si = j - sli;
             if ((unsigned)si >= (unsigned)nsi || (si == 0 && cut)) {      // the cell (or, possibly, its stored left neighbour) is not staged: re-centre the window on (i, j) once
                 if (reloaded) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 2; dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)stw << 32) | (unsigned)Ai; break; }      // ... it is not there: outside the row's band, no such cell
@@ -283,7 +284,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             int hit = 0;
             // move to predecessor k (0-based list index) of row i: from the record, else (more than four predecessors / a far one) from the CSR arrays
             auto go_pred = [&](int k) __attribute__((always_inline)) -> bool {
-                const int dk = k < 4 ? (int)(((unsigned)pdw >> (8 * k)) & 0xffu) : 255;
+                const int dk = k < 8 ? (int)(((unsigned)(k < 4 ? pd2.x : pd2.y) >> (8 * (k & 3))) & 0xffu) : 255;
                 if (dk != 255) { i -= dk; if (i >= w_lo) Ai = __builtin_amdgcn_readfirstlane(B.rowA[i - w_lo]); else restage = true; return true; }
                 const int po = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i)), po1 = __builtin_amdgcn_readfirstlane(gld_i32(pred_off + i + 1));
                 if (k >= po1 - po) return false;
@@ -335,7 +336,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 if (hit) { push(ABPOA_HIP_CINS, 1, i, j - 1); --j; ++n_aln; }
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
-            if (!hit && status == 0) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 3 | ((long long)cur_op << 8) | ((long long)indel_first << 16) | ((long long)n_general << 32); dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)w << 32) | (unsigned)pdw; }
+            if (!hit && status == 0) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 3 | ((long long)cur_op << 8) | ((long long)indel_first << 16) | ((long long)n_general << 32); dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)w << 32) | (unsigned)pd2.x; }
         }
         walk_ticks = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {

@@ -193,7 +193,7 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
     o_desc_ = take(sizeof(AlnDesc) * n); o_mat_ = take(sizeof(int32_t) * sc->m * sc->m); o_query_ = take(q_tot_ + 1);
-    o_base_ = take(rows_tot_); o_sdist_ = take(rows_tot_); o_pd_ = take(4 * rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
+    o_base_ = take(rows_tot_); o_sdist_ = take(rows_tot_); o_pd_ = take(8 * rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
     o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1) + 4 * 512);   // slack: tile prefetch over-reads up to TP entries
     in_bytes_ = o;
     o = 0;
@@ -252,19 +252,19 @@ int BatchStream::run() {
             AlnDesc &d = desc_[i];
             if (!(d.flags & ALN_FAST_OK)) continue;
             const int32_t *po = (const int32_t *)(hi + o_poff_) + d.poff0, *pr = (const int32_t *)(hi + o_pred_) + d.pred0; uint8_t *sd = hi + o_sdist_ + d.row0;
-            uint32_t *pdw = (uint32_t *)(hi + o_pd_) + d.row0;      // row distances to the first four predecessors (DevBatch.row_pd)
+            uint32_t *pdw = (uint32_t *)(hi + o_pd_) + 2 * d.row0;      // row distances to the first eight predecessors, two dwords per row (DevBatch.row_pd)
             memset(sd, 0, (size_t)d.n_rows);
             bool ok = true;
             for (int r = 0; r < d.n_rows && ok; ++r) {
                 const int np_ = po[r + 1] - po[r];
                 if (np_ > DIR_K_MAX && r < d.n_rows - 1) ok = false;
-                uint32_t pdv = np_ <= 4 ? 0u : 0xffffffffu;
+                uint64_t pdv = ~0ull;       // a byte per predecessor, 255 = none / too far
                 for (int k = po[r]; k < po[r + 1]; ++k) {
                     const int p_ = pr[k], dist = r == d.n_rows - 1 ? 255 : std::min(255, r - p_); if (dist > sd[p_]) sd[p_] = (uint8_t)dist;
-                    if (np_ <= 4) { if (r - p_ > 254) pdv = 0xffffffffu; else if (pdv != 0xffffffffu) pdv |= (uint32_t)(r - p_) << (8 * (k - po[r])); }
+                    const int t = k - po[r]; if (t < 8 && r - p_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((uint64_t)(r - p_) << (8 * t));
                 }
-                if (np_ <= 4 && pdv != 0xffffffffu) for (int k = np_; k < 4; ++k) pdv |= 255u << (8 * k);
-                pdw[r] = pdv;
+                (void)np_;
+                pdw[2 * r] = (uint32_t)pdv; pdw[2 * r + 1] = (uint32_t)(pdv >> 32);
             }
             if (!ok) d.flags = 0;
         }

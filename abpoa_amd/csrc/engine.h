@@ -97,8 +97,8 @@ struct DevBatch {
     const uint8_t *row_active;
     const uint8_t *row_sdist;    // dir_mode: per row min(255, largest row distance to a successor), 255 for a predecessor of the sink: rows whose H / E
                                  // some later row (beyond the LDS score ring) or the global best will read from HBM keep a score record besides the direction words
-    const uint32_t *row_pd;      // dir_mode: per row the row distances to its first four predecessors, a byte each (255: none / further than 254 rows), 0xffffffff for a
-                                 // row with more than four: what a step of the direction-plane backtrack needs to find the row it moves to (backtrack_dir.h)
+    const uint32_t *row_pd;      // dir_mode: per row TWO dwords: the row distances to its first eight predecessors, a byte each (255: none / further than 254 rows):
+                                 // what a step of the direction-plane backtrack needs to find the row it moves to (backtrack_dir.h); later ones come from the CSR arrays
     const int32_t *pred_off;     // (n_rows+1) per alignment
     const int32_t *pred_row;
     const int32_t *out_off;

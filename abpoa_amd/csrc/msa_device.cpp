@@ -201,7 +201,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     o = 0;
     L.o_ticket = take(4 * POA_CU_TICKETS);
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
-    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rpd = take(4 * node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
+    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rpd = take(8 * node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
     L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot); L.rows_bytes = o;
 

@@ -196,10 +196,9 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         if (r < n) p.pred_off[N0 + r] = off;
         if (off + np > S.pred_cap) overflow = true;
         else if (!in_lds) {
-            unsigned pdv = np <= 4 ? 0u : 0xffffffffu;
-            for (int t = 0; t < np; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u, t)]; p.pred_row[S.pred0 + off + t] = pr_; if (np <= 4) { if (r - pr_ > 254) pdv = 0xffffffffu; else pdv |= (unsigned)(r - pr_) << (8 * t); } }
-            if (np <= 4 && pdv != 0xffffffffu) for (int t = np; t < 4; ++t) pdv |= 255u << (8 * t);
-            if (r < n) p.row_pd[N0 + r] = pdv;
+            unsigned long long pdv = ~0ull;      // a byte per predecessor (the first eight), 255 = none / further than 254 rows
+            for (int t = 0; t < np; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u, t)]; p.pred_row[S.pred0 + off + t] = pr_; if (t < 8 && r - pr_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr_) << (8 * t)); }
+            if (r < n) { p.row_pd[2 * (N0 + r)] = (unsigned)pdv; p.row_pd[2 * (N0 + r) + 1] = (unsigned)(pdv >> 32); }
         }
         carry += all;
         __syncthreads();
@@ -221,14 +220,14 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
             for (int j = 0; j < 4; ++j) {
                 int32_t *dst = p.pred_row + S.pred0 + off[j];
                 const int r = r0 + j * GT; const int npr = r < n ? (int)np_lds[r < n ? r : 0] : 0;      // (np[j] is 0 for a row whose list does not fit: the set falls back anyway)
-                unsigned pdv = npr <= 4 ? 0u : 0xffffffffu;
+                unsigned long long pdv = ~0ull;      // a byte per predecessor (the first eight), 255 = none / further than 254 rows
+                (void)npr;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (t < np[j]) dst[t] = pr[j][t];
-                    if (npr <= 4) { const int dk = t < np[j] ? r - pr[j][t] : 255; if (dk > 254 && t < np[j]) pdv = 0xffffffffu; else if (pdv != 0xffffffffu) pdv |= (unsigned)(dk > 254 ? 255 : dk) << (8 * t); }
+                    if (t < np[j]) { dst[t] = pr[j][t]; if (r - pr[j][t] <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr[j][t]) << (8 * t)); }
                 }
-                if (r < n) p.row_pd[N0 + r] = pdv;
-                for (int t = POA_HOT; t < np[j]; ++t) dst[t] = p.nd_row[N0 + in_slot(p, N0 + u[j], t)];
+                for (int t = POA_HOT; t < np[j]; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u[j], t)]; dst[t] = pr_; if (t < 8 && r - pr_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr_) << (8 * t)); }
+                if (r < n) { p.row_pd[2 * (N0 + r)] = (unsigned)pdv; p.row_pd[2 * (N0 + r) + 1] = (unsigned)(pdv >> 32); }
             }
         }
     }

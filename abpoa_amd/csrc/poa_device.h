@@ -62,7 +62,7 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     // DP inputs produced by the prepare kernel (same arrays DevBatch points at)
     AlnDesc *aln; AlnOut *out;
     uint8_t *row_base; int32_t *row_node_id, *row_remain, *pred_off, *pred_row;
-    uint32_t *row_pd;              // per row: distances to the first four predecessors (DevBatch.row_pd)
+    uint32_t *row_pd;              // per row, two dwords: distances to the first eight predecessors (DevBatch.row_pd)
     uint8_t *row_sdist;            // per row: min(255, largest row distance to a successor), 255 for a predecessor of the sink (DevBatch.row_sdist)
     uint64_t *cigar;
     // consensus results (poa_consensus_kernel), indexed cons0 + position
