@@ -308,10 +308,12 @@ __device__ __forceinline__ bool takes_wide(const DevBatch &b, const AlnDesc &d) 
     return b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi;
 }
 
-// ... and which of the fast alignments write direction words instead of score records (dir_plane.h): the narrow-band ones of a launch in dir_mode.
+// ... and which of the fast alignments write direction words instead of score records (dir_plane.h): dir_mode 1 = the narrow-band ones of the launch,
+// dir_mode 2 = the wide-band ones too.
 // (Measured on MI355X: on 1 kb reads the words cost the row loop 5-8 % and save 36-42 % of the backtrack, a net 8-11 %; on 10 kb reads the all-chunks
-//  row loop loses 18-21 % -- more than the backtrack, a fifth of the time there, gains -- so wide-band alignments keep their records.)
-__device__ __forceinline__ bool takes_dir(const DevBatch &b, const AlnDesc &d) { return b.dir_mode && !takes_wide(b, d); }
+//  row loop loses 18-21 % -- more than the backtrack, a fifth of the time there, gains -- so wide-band alignments keep their records while the record
+//  arenas of the job fit the device; the host picks mode 2 when they do not: an eighth of the arena bytes, twice the read-sets in flight.)
+__device__ __forceinline__ bool takes_dir(const DevBatch &b, const AlnDesc &d) { return b.dir_mode == 2 || (b.dir_mode == 1 && !takes_wide(b, d)); }
 
 // kernel launch helper shared by the translation units (block = NT threads)
 template <typename K>

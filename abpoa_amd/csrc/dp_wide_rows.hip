@@ -36,7 +36,8 @@ static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
     return e;
 }
 hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream) {
-    // (wide-band alignments keep their score records also in dir_mode: dp_common.h takes_dir)
+    // (wide-band alignments keep their score records in dir_mode 1 and write direction words in dir_mode 2: dp_common.h takes_dir)
+    if (b.lds.wide_nw == 1 && b.dir_mode == 2) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, 1, true>(b, stream) : launch_wide_gap<2, 1, true>(b, stream);
     if (b.lds.wide_nw == 1) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, 1>(b, stream) : launch_wide_gap<2, 1>(b, stream);
     return launch_team_rows(b, stream);      // dp_team_rows.hip (score-record arenas only: the host does not set dir_mode with teams)
 }

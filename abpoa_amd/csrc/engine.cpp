@@ -143,18 +143,24 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           L.wide_nw = 1;
           if (mw_ && (atoi(mw_) == 1 || atoi(mw_) == 2 || atoi(mw_) == 4)) L.wide_nw = atoi(mw_);
           L.wfr_cols = WIDE_RING_COLS; L.wfr_rows = 16;
+          // ring words per column of the wide kernels: as the narrow loop's, but two instead of three for convex int32 (rows_fast.h EPACK: E as 16-bit
+          // differences to H, which needs gap-open + extend <= 65535)
+          const int fww = (P == 5 && max_bits == 32) ? 2 : fw;
+          if (P == 5 && (sc->gap_open1 + sc->gap_ext1 > 65535 || sc->gap_open2 + sc->gap_ext2 > 65535)) L.wide_nw = 0;
           L.wide_w_lo = 40; L.wide_w_hi = (L.wfr_cols - 2 * 8 - 1) / 2;
           { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");
           if (rr_env_ && atoi(rr_env_) >= 4) L.wfr_rows = atoi(rr_env_) >= 16 ? 16 : (atoi(rr_env_) >= 8 ? 8 : 4); else rr_env_ = nullptr;
-          // (up to 120 KB per wavefront: a convex int32 ring of 16 rows is 87 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
+          // (up to 120 KB per wavefront: a convex int32 ring of 16 rows is 58 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
           const int budget = 120 * 1024 - L.phase_off - 512;
-          while ((int64_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4 > budget && L.wfr_rows > 4) L.wfr_rows /= 2;
+          while ((int64_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4 > budget && L.wfr_rows > 4) L.wfr_rows /= 2;
           // one wavefront per alignment: LDS is what limits how many alignments a CU holds (160 KB, 256 CUs) -- a shallower ring when the
           // launch has more alignments than fit (rows with an older predecessor take the HBM gather: 1 % of rows at depth 8 on 5 % reads)
-          if (!(rr_env_)) while (L.wfr_rows > 8 && (int64_t)(160 * 1024 / (L.phase_off + (int64_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4 + 320)) * 256 < n_aln) L.wfr_rows /= 2;
-          L.wx_off = L.fr_off + (int)align_up((size_t)L.wfr_rows * fw * (L.wfr_cols + 4) * 4, 16);
-          L.total_wide = L.phase_off + L.wx_off + 16 * 16 + 64;
+          if (!(rr_env_)) while (L.wfr_rows > 8 && (int64_t)(128 / ((L.phase_off + (int64_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4 + 320 + 1279) / 1280)) * 256 < n_aln) L.wfr_rows /= 2;
+          L.wx_off = L.fr_off + (int)align_up((size_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4, 16);
+          // (exchange slots: teams only.  LDS is handed out in pieces of 1280 B on gfx950 -- 128 per CU, tools/probes/lds_granule.hip -- so three
+          //  workgroups per CU need <= 53760 B each, which a convex int32 ring of 8 rows plus a 10 kb query just meets without them)
+          L.total_wide = L.phase_off + L.wx_off + (L.wide_nw > 1 ? 16 * 16 + 64 : 0);
       } }
 }
 
@@ -290,10 +296,13 @@ int BatchStream::run() {
             b.lds.narrow_off = (b.lds.wide_nw >= 1 && all_wide) ? 1 : 0;
         }
         if (b.lds.wide_nw > 1) dir = false;
+        // (ABPOA_HIP_DIR_WIDE=1: words for the wide-band alignments too -- the device-resident driver does that by itself when the record arenas of a
+        //  job do not fit the device; here it is a test switch)
+        const bool dir_wide = dir && getenv("ABPOA_HIP_DIR_WIDE") && atoi(getenv("ABPOA_HIP_DIR_WIDE")) > 0;
         for (size_t t = 0; t < todo.size(); ++t) {
             AlnDesc &d = desc_[todo[t]];
             // direction-plane arenas for the narrow-band alignments of a dir pass; the wide-band ones keep score records (dp_common.h takes_dir / takes_wide)
-            const bool dir_a = dir && !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi);
+            const bool dir_a = dir && (dir_wide || !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi));
             d.plane_cap = dir_a ? (first_pass ? dir_est_cells_[todo[t]] : dir_full_cells_[todo[t]]) : (first_pass ? est_cells_[todo[t]] : full_cells_[todo[t]]);
             d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8) + 64 * 8 * 4);   // + 64 records of slack (fast loop stores whole 64-lane chunks)
             pass[t] = d;
@@ -303,7 +312,7 @@ int BatchStream::run() {
         b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
         b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = sc->ret_cigar; b.rev_cigar = sc->rev_cigar;
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
-        b.dir_mode = dir ? 1 : 0; b.row_sdist = di + o_sdist_; b.row_pd = (const uint32_t *)(di + o_pd_);
+        b.dir_mode = dir ? (dir_wide ? 2 : 1) : 0; b.row_sdist = di + o_sdist_; b.row_pd = (const uint32_t *)(di + o_pd_);
         b.want_lr = (trace || (flags_ & BS_WANT_BAND_STATE)) ? 1 : 0;
         { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
         b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);

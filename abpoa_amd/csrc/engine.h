@@ -84,7 +84,7 @@ struct DevBatch {
     int32_t fresh_band;          // max_pos_left/right start as (n_rows, 0): initialise them on the device
     int32_t want_lr;             // the caller reads max_pos_left/right back (the fast row loop derives them in a post-pass)
     int32_t bits_mask;           // score widths that may occur among the fast alignments: 1 = int16, 2 = int32, 3 = both (one kernel per width)
-    int32_t dir_mode;            // 1: the fast row loops write direction words (dir_plane.h) instead of score records, the tail walks those
+    int32_t dir_mode;            // 1: the narrow-band fast row loops write direction words (dir_plane.h) instead of score records, the tail walks those; 2: the wide-band ones too
     int32_t pad1;
     LdsPlan lds;
     const int32_t *mat;          // [m*m]

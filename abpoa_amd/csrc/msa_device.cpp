@@ -117,6 +117,19 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
            sc->m - 1 <= POA_ALN_CAP && sc->zdrop <= 0;
 }
 
+int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets) {
+    int max_qlen = 0; for (int s = 0; s < n_sets; ++s) for (int r = 0; r < sets[s].n_reads; ++r) max_qlen = std::max(max_qlen, sets[s].lens[r]);
+    if (max_qlen <= 0) return 0;
+    const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
+    LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
+    make_lds_plan(sc, max_qlen, mb, std::min<int64_t>((int64_t)((max_qlen + pn_) / pn_) * pn_, 2LL * w_max + 3 * pn_ + 32), n_sets, &pl);
+    if (pl.wide_nw != 1 || !(w_max >= pl.wide_w_lo && w_max <= pl.wide_w_hi) || pl.total_wide <= 0) return 0;
+    int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    // (LDS is handed out in pieces of 1280 B, 128 per CU: tools/probes/lds_granule.hip; 166-192 VGPRs: two wavefronts per SIMD at most)
+    const int per_cu = std::max(1, std::min(8, 128 / ((pl.total_wide + 1279) / 1280)));
+    return per_cu * cus;
+}
+
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
                    std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, int device, int slot) {
     if (slot < 0 || slot >= MSA_DEVICE_SLOTS) { set_err("bad device slot %d", slot); return ABPOA_HIP_EINVAL; }
@@ -155,10 +168,16 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     std::vector<PoaSet> ps(n_sets);
     int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
-    int wide_lo = 1, wide_hi = 0;      // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off)
+    int wide_lo = 1, wide_hi = 0, wide_ring_rows = 16;      // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off), depth of its score ring
     { LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
       make_lds_plan(sc, max_qlen, mb, std::min<int64_t>((int64_t)((max_qlen + pn_) / pn_) * pn_, 2LL * w_max + 3 * pn_ + 32), n_sets, &pl);
-      if (pl.wide_nw >= 1) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; } }
+      if (pl.wide_nw >= 1) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
+    // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
+    // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the
+    // read-sets are in flight instead of two passes with half the SIMDs idle.  ABPOA_HIP_DIR_WIDE=1 / 0: always / never.
+    bool dir_wide = false, any_wide_set = false;
+    { const char *e_ = getenv("ABPOA_HIP_DIR_WIDE"); if (dir && e_ && atoi(e_) > 0) dir_wide = true; }
+    const bool dir_wide_auto = dir && !getenv("ABPOA_HIP_DIR_WIDE");
     for (int s = 0; s < n_sets; ++s) {
         PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
         int64_t sum = 0; int mx = 0;
@@ -171,19 +190,32 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += S.cigar_cap;
         S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + cap + 1;
         S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
-        // arena: the widest score type the set can reach decides the cell size; columns per row as the band estimate of engine.cpp
-        int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
-        const int64_t width = (int64_t)((mx + pn) / pn) * pn;
         const int w = sc->wb + (int)(sc->wf * (float)mx);
-        const int64_t est = std::min<int64_t>(width, 2LL * w + 3 * pn + 32);
-        // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
-        //  global best will read from HBM; a set that needs more is flagged and redone like any other capacity miss)
-        const bool dir_s = dir && !(w >= wide_lo && w <= wide_hi);      // (wide-band sets keep score records: dp_common.h takes_dir)
-        const int64_t bytes = dir_s ? (int64_t)up((size_t)(width * (DB + CW * (bits / 8)) + (est * DB + est * CW * (bits / 8) / 4 + 32) * (cap - 1) + 64 * 8 * 4))
-                                  : (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
-        S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
         max_node_cap = std::max(max_node_cap, (int)cap);
+        any_wide_set |= (w >= wide_lo && w <= wide_hi);
     }
+    // arenas: the widest score type a set can reach decides the cell size; columns per row as the band estimate of engine.cpp
+    auto size_arenas = [&](bool dw) {
+        plane_tot = 0;
+        for (int s = 0; s < n_sets; ++s) {
+            PoaSet &S = ps[s]; int mx = 0; for (int r = 0; r < sets[s].n_reads; ++r) mx = std::max(mx, sets[s].lens[r]);
+            const int64_t cap = S.node_cap;
+            int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
+            const int64_t width = (int64_t)((mx + pn) / pn) * pn;
+            const int w = sc->wb + (int)(sc->wf * (float)mx);
+            const int64_t est = std::min<int64_t>(width, 2LL * w + 3 * pn + 32);
+            // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
+            //  global best will read from HBM; half of the rows where the wide loop's ring is only four rows deep; a set that needs more is flagged and
+            //  redone like any other capacity miss)
+            const bool wide_s = w >= wide_lo && w <= wide_hi;
+            const bool dir_s = dir && (dw || !wide_s);      // (dp_common.h takes_dir)
+            const int64_t rec_div = (wide_s && wide_ring_rows <= 4) ? 2 : 4;
+            const int64_t bytes = dir_s ? (int64_t)up((size_t)(width * (DB + CW * (bits / 8)) + (est * DB + est * CW * (bits / 8) / rec_div + 32) * (cap - 1) + 64 * 8 * 4))
+                                      : (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
+            S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
+        }
+    };
+    size_arenas(dir_wide);
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
     L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m); L.o_rargs = take(poa_rounds_args_bytes());      // (o_rargs: host-side staging only)
@@ -210,6 +242,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         const size_t want[4] = {L.in_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap, C.planes.dev_cap};
         size_t need = 0, given_back = 0;
         for (int i = 0; i < 4; ++i) if (want[i] > have[i]) { need += want[i]; given_back += have[i]; }      // a buffer that must grow is freed first
+        if (need > free_b + given_back && dir_wide_auto && any_wide_set && !dir_wide) {      // the record arenas of the wide-band sets do not fit: direction words for them too
+            dir_wide = true; size_arenas(true);
+            need = 0; given_back = 0;
+            const size_t want2[4] = {L.in_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot};
+            for (int i = 0; i < 4; ++i) if (want2[i] > have[i]) { need += want2[i]; given_back += have[i]; }
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device %d: %d sets: score-record arenas do not fit, direction words for the wide-band sets too (arenas %.1f GB)\n", device, n_sets, plane_tot / 1e9);
+        }
         if (need > free_b + given_back) {
             if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device %d: %d sets need %.1f GB in growing buffers (arenas %.1f GB), %.1f GB free + %.1f GB given back: splitting\n", device, n_sets, need / 1e9, plane_tot / 1e9, free_b / 1e9, given_back / 1e9);
             set_err("device-resident job needs %zu more bytes, %zu free", need, free_b + given_back); return ABPOA_HIP_ENOMEM;
@@ -290,7 +329,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
     { const char *dbg_ = getenv("ABPOA_HIP_DBG"); if (dbg_) b.dbg = atoi(dbg_); }      // (diagnostics: bit 7 keeps the row loop's counters in AlnOut.seg)
     b.mat = (const int32_t *)(di + L.o_mat); b.aln = p.aln; b.out = p.out;
-    b.dir_mode = (dir && b.lds.wide_nw <= 1) ? 1 : 0; b.row_sdist = p.row_sdist; b.row_pd = p.row_pd;
+    b.dir_mode = (dir && b.lds.wide_nw <= 1) ? (dir_wide ? 2 : 1) : 0; b.row_sdist = p.row_sdist; b.row_pd = p.row_pd;
     b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
     b.pred_off = p.pred_off; b.pred_row = p.pred_row; b.out_off = p.pred_off; b.out_row = p.pred_row;
     b.left = p.scratch; b.right = p.scratch;

@@ -28,6 +28,10 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 // device < 0: the device the engine was initialised on.  slot: which of the per-worker pool caches to use (one worker = one device queue of
 // the multi-GPU batch call; workers may share a device); a slot runs one job at a time.
 constexpr int MSA_DEVICE_SLOTS = 16;
+// Wide-band jobs (10 kb reads: one wavefront per alignment, tens of KB of LDS each): how many read-sets the device holds at once -- workgroups per CU by
+// the wide row loop's LDS x CUs.  A launch with more alignments than that runs its workgroups in turns, and because the alignments of a round take
+// about the same time the last, partly filled turn costs as much as a full one: the caller cuts such a job into passes of this size.  0: no preference.
+int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets);
 // frees every cached pool of every device queue (abpoa_hip_trim)
 void release_msa_device_caches();
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,

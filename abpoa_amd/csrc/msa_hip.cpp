@@ -67,6 +67,11 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
     for (int pass = first_pass; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
         size_t chunk = todo.size();
+        {   // wide-band jobs: passes of what the device holds at once (msa_device.h)
+            std::vector<abpoa_hip_readset_t> all_(todo.size()); for (size_t i = 0; i < todo.size(); ++i) all_[i] = sets[todo[i]];
+            const int res_ = msa_device_resident_sets(sc, (int)all_.size(), all_.data());
+            if (res_ > 0 && chunk > (size_t)res_) chunk = (size_t)res_;
+        }
         for (size_t at = 0; at < todo.size() && R.device_ok;) {
             const size_t nb = std::min(chunk, todo.size() - at);
             std::vector<abpoa_hip_readset_t> sub(nb); std::vector<abpoa_hip_msa_t> sub_out(nb);

@@ -131,7 +131,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto row_units = [&](int nv, bool spill) __attribute__((always_inline)) { return DIR ? dir_units(nv) + (spill ? nv * CW : 0) : nv * CW; };
     bool row_spill = false;                          // (DIR) the current row keeps its score records: set by the row loop before a body runs
     constexpr bool I16 = sizeof(T) == 2;
-    constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? 3 : 2);
+    constexpr bool WPLAN = NW > 1 || WIDEB;          // the wide kernels have their own score ring (LdsPlan wfr_*)
+    // Ring words per column.  int16: H | E1 << 16, E2.  int32: H, E1, E2 -- but in the wide kernels' convex ring (EPACK) H and ONE word of differences
+    // (H - E1) | (H - E2) << 16: E leaving a cell is max(Ein - e, H - oe) with Ein <= H, so H - E is in [e, oe] wherever H is a score, and 0 stands for
+    // "both inf" where H is inf (outside the band, padding).  Two words instead of three: a ring of 8 rows for a 10 kb convex alignment is 29 KB, and
+    // four workgroups share a CU (40 KB each) instead of three.  Row 0 -- E = inf beside real H -- stays out of such a ring: its successors read its records.
+    constexpr bool EPACK = WPLAN && !I16 && GAP == 2;
+    constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? (EPACK ? 2 : 3) : 2);
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
     constexpr int GEO_RING = 1 << 24;
     const int lane = threadIdx.x & 63, l = lane % PN, vvl = lane / PN;
@@ -141,7 +147,6 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int gn = d.n_rows, qlen = d.qlen, m = b.m, m1 = b.m + 1, w = d.w;
     const int inf = d.inf_min;
     const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
-    constexpr bool WPLAN = NW > 1 || WIDEB;          // the wide kernels have their own score ring (LdsPlan wfr_*)
     // (the single-wave wide kernel's ring width is a compile-time constant: address offsets and clamps fold into the instructions)
     const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WIDEB ? WIDE_RING_COLS : (WPLAN ? b.lds.wfr_cols : b.lds.fr_cols), RCS = RC + 4;
     int *fr = (int *)(lds_raw + b.lds.phase_off + b.lds.fr_off);
@@ -170,7 +175,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 
     // ---- LDS: extended score matrix (column m = 0) and the score ring, everything "inf"
     { GLOBAL_AS const int32_t *g_mat = vgpr_ptr(b.mat); for (int i = tid; i < m * m1; i += NT) { const int bb = i / m1, qc = i - bb * m1; s_mx[i] = qc < m ? g_mat[bb * m + qc] : 0; } }
-    for (int i = tid; i < RR * NPW * RCS; i += NT) { const int pl = (i / RCS) % NPW; fr[i] = (I16 && pl == 0) ? infw : inf; }
+    for (int i = tid; i < RR * NPW * RCS; i += NT) { const int pl = (i / RCS) % NPW; fr[i] = (I16 && pl == 0) ? infw : ((EPACK && pl == 1) ? 0 : inf); }
     if (NW > 1 && tid < 16) xch[tid] = make_int4(INT_MIN, INT_MIN, I16 ? 0 : INT_MIN, 0);      // entries of absent wavefronts stay neutral
     WG_SYNC();
     auto ring_put = [&](int slot, int x, int H, int E1, int E2) __attribute__((always_inline)) {
@@ -192,7 +197,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
         // (DIR: row 0 has no decisions to record; it keeps its score records because new branches anywhere in the graph start at the source)
         if ((long long)W0 * CW > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
-        const bool ring0 = W0 <= RC;
+        const bool ring0 = W0 <= RC && !EPACK;
         T *H = io.planes;
         for (int i = tid; i < W0; i += NT) {
             int h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
@@ -298,6 +303,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p), med3i(x - 1, -2, RC));
         int hm1, ev1, ev2 = inf;
         if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
+        else if (EPACK) { hm1 = src[0]; const int h0 = src[1]; const unsigned dd = (unsigned)src[RCS + 1]; ev1 = h0 - (int)(dd & 0xffffu); ev2 = h0 - (int)(dd >> 16); }
         else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
         if (k == 0) { Mv = hm1; E1v = ev1; E2v = ev2; kb = kidx; kE1 = kidx; kE2 = kidx; }
         else {
@@ -380,6 +386,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (to_ring && !ABL(2)) {
             int *qd = fr + my_slot + 2 + rel;
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
+            else if (EPACK) { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? (int)((unsigned)(Hout - E1out) | ((unsigned)(Hout - E2out) << 16)) : 0; }
             else { qd[0] = in_band ? Hout : inf; qd[RCS] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS] = in_band ? E2out : inf; }
         }
         if (!ABL(4)) {   // running arg-max candidate of this lane, reference :1043-1057
@@ -395,7 +402,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto pad_ring = [&](int nch, int my_slot) __attribute__((always_inline)) {        // "inf" after the band, up to the ring width
         if (!ABL(2)) for (int c = nch; c < (RC >> 6); ++c) {
             int *qd = fr + my_slot + 2 + c * 64 + lane;
-            qd[0] = infw; if (NPW > 1) qd[RCS] = inf; if (NPW > 2) qd[2 * RCS] = inf;
+            qd[0] = infw; if (NPW > 1) qd[RCS] = EPACK ? 0 : inf; if (NPW > 2) qd[2 * RCS] = inf;
         }
     };
     // reserve the row's arena cells; false = overflow
@@ -703,6 +710,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p), med3i(x - 1, -2, RC));
             ev2 = inf;
             if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
+            else if (EPACK) { hm1 = src[0]; const int h0 = src[1]; const unsigned dd = (unsigned)src[RCS + 1]; ev1 = h0 - (int)(dd & 0xffffu); ev2 = h0 - (int)(dd >> 16); }
             else { hm1 = src[0]; ev1 = src[RCS + 1]; if (GAP == 2) ev2 = src[2 * RCS + 1]; }
         };
         auto merge = [&](int g_, int c, int hm1, int ev1, int ev2, int kidx) __attribute__((always_inline)) {
@@ -946,13 +954,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             if (!TEAM || c < cnt) {
                 if (I16) { qd[c * 64] = in_band ? he : infw; if (GAP == 2) qd[RCS + c * 64] = in_band ? E2out : inf; }
+                else if (EPACK) { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? (int)((unsigned)(Hout - E1out) | ((unsigned)(Hout - E2out) << 16)) : 0; }
                 else { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS + c * 64] = in_band ? E2out : inf; }
             }
         }
-        if (!TEAM) { for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; } }      // "inf" up to the ring width
+        if (!TEAM) { for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = EPACK ? 0 : inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; } }      // "inf" up to the ring width
         else {                                                       // (teams: chunk c of the padding is written by wavefront c % NW)
             int *const qrow = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * lane, 0);
-            for (int c = nch; c < (RC >> 6); ++c) if (c % NW == wid) { qrow[c * 64] = infw; if (NPW > 1) qrow[RCS + c * 64] = inf; if (NPW > 2) qrow[2 * RCS + c * 64] = inf; }
+            for (int c = nch; c < (RC >> 6); ++c) if (c % NW == wid) { qrow[c * 64] = infw; if (NPW > 1) qrow[RCS + c * 64] = EPACK ? 0 : inf; if (NPW > 2) qrow[2 * RCS + c * 64] = inf; }
         }
         FSTAMP(4)
         // ---- row arg-max

@@ -39,11 +39,13 @@ def test_hip_matches_golden_and_oracle(engine, label, path):
         assert walked == 1 and redone == 0, (label, walked, redone)
 
 
-@pytest.mark.parametrize("env", [{}, {"ABPOA_HIP_NOWIDE": "1"}], ids=["default", "nowide"])
+@pytest.mark.parametrize("env", [{}, {"ABPOA_HIP_NOWIDE": "1"}, {"ABPOA_HIP_DIR_WIDE": "1"}, {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"}],
+                         ids=["default", "nowide", "dir_wide", "dir_wide_ring4"])
 def test_direction_words_match_the_model(engine, monkeypatch, env):
     """Plane level: every direction word the row loops write (trace mode with ABPOA_HIP_DIRTRACE=1) carries the decisions oracle/dir_model.c derives from
     the oracle's scores for that cell.  With ABPOA_HIP_NOWIDE=1 the 10 kb goldens run through the narrow kernel's chunk-by-chunk bodies, which write
-    the words too (their wide row loop keeps score records)."""
+    the words too (their wide row loop keeps score records); with ABPOA_HIP_DIR_WIDE=1 the all-chunks wide row loop writes them (what the device-resident
+    driver switches to when the record arenas of a 10 kb job do not fit the device), also with a 4-row score ring (every other row keeps its records for a reader in HBM)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = 0
@@ -108,11 +110,12 @@ def test_arena_overflow_retry_keeps_traces(engine, monkeypatch):
     assert n >= 2
 
 
-@pytest.mark.parametrize("env", [{"ABPOA_HIP_RING_ROWS": "4"}, {"ABPOA_HIP_TEAM": "2"}, {"ABPOA_HIP_TEAM": "4"}, {"ABPOA_HIP_NOWIDE": "1"}],
-                         ids=["ring4_hbm_gather", "team2", "team4", "nowide"])
+@pytest.mark.parametrize("env", [{"ABPOA_HIP_RING_ROWS": "4"}, {"ABPOA_HIP_TEAM": "2"}, {"ABPOA_HIP_TEAM": "4"}, {"ABPOA_HIP_NOWIDE": "1"}, {"ABPOA_HIP_DIR_WIDE": "1"},
+                                 {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"}],
+                         ids=["ring4_hbm_gather", "team2", "team4", "nowide", "dir_wide", "dir_wide_ring4"])
 def test_wide_band_variants(engine, monkeypatch, env):
     """The 10 kb goldens (4-5 chunks per row) through the other forms of the wide row loop: a 4-row score ring (every other row gathers a predecessor
-    from the HBM arena), teams of 2 / 4 wavefronts per alignment, and the chunk-by-chunk loop of the narrow kernel."""
+    from the HBM arena), teams of 2 / 4 wavefronts per alignment, the chunk-by-chunk loop of the narrow kernel, and the wide loop with direction words."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = 0

@@ -30,7 +30,7 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "kernel
        "wave_cycles_per_step": tot["SQ_WAVE_CYCLES"], "wait_any_per_step": tot["SQ_WAIT_ANY"], "active_inst_any_per_step": tot["SQ_ACTIVE_INST_ANY"],
        "all_kernels": {k: {c: v for c, v in d.items()} for k, d in acc.items() if k.startswith(("dp_", "poa_"))},
        "row_loop_sha": bench.row_loop_sha(),
-       "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("ABPOA_COMMIT", "working tree"),
+       "commit": (subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or (open(os.path.join(root, ".git_head")).read().strip() if os.path.exists(os.path.join(root, ".git_head")) else "") or os.environ.get("ABPOA_COMMIT") or "working tree"),
        "how": "tools/pmc_insts.sh: rocprofv3 --kernel-trace --pmc <4 counters>, two passes over `bench.py --workload %s --steps 1 --warmup 0`" % wl}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
 json.dump(rec, open(os.path.join(root, "gpurun_out", f"r3_pmc_insts_{wl}.json"), "w"), indent=1)

@@ -44,7 +44,7 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "rounds
        "launch": ("one launch of abpoa_hip::poa_rounds_kernel = rounds 2..n of every read-set (graph phases, row loop and backtrack inside: its traffic includes the backtrack's re-read of the arenas)"
                   if all_rounds else "one round of the progressive alignment = the row-loop kernels of that round (all score widths)"),
        "row_loop_sha": bench.row_loop_sha(),
-       "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("ABPOA_COMMIT", "working tree"),
+       "commit": (subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or (open(os.path.join(root, ".git_head")).read().strip() if os.path.exists(os.path.join(root, ".git_head")) else "") or os.environ.get("ABPOA_COMMIT") or "working tree"),
        "all_kernels_MB_per_launch": {k: {"fetch_x2": round(2 * v["FETCH_SIZE"] / 1024 / max(1, rounds), 1), "write": round(v["WRITE_SIZE"] / 1024 / max(1, rounds), 1)} for k, v in per_kernel.items()},
        "how": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --workload %s --steps 1 --warmup 0`" % wl}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
