@@ -1,4 +1,5 @@
 // Tail kernels of the fast path: global best + backtrack over the cell-record arenas the row loops left in HBM (backtrack.h).
+#include <algorithm>
 #include "fast_tail.h"
 
 namespace abpoa_hip {
@@ -23,6 +24,16 @@ static hipError_t launch_tail_gap(const DevBatch &b, hipStream_t stream) {
     return e;
 }
 hipError_t launch_fast_tail(const DevBatch &b, hipStream_t stream) {
+    if (b.dir_mode == 2) {
+        // every alignment of the launch walks direction words: no query, no score matrix in LDS -- the walk's image and its window start at byte 0 -- and the
+        // window is what lets the whole launch be resident (LDS comes in pieces of 1280 B, 128 per CU; at most eight workgroups per CU: a walk is a chain
+        // of dependent LDS reads, a second wavefront on the SIMD fills its waits)
+        DevBatch t = b;
+        const int per_cu = std::max(1, std::min(8, (b.n + 255) / 256));
+        const int total = std::min((128 / per_cu) * 1280, t.lds.bt_off + 56 * 1024) & ~15;
+        t.lds.phase_off = 0; t.lds.bt_bytes_tail = total - t.lds.bt_off; t.lds.total_tail = total;
+        return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_tail_gap<1, true>(t, stream) : launch_tail_gap<2, true>(t, stream);
+    }
     if (b.dir_mode) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_tail_gap<1, true>(b, stream) : launch_tail_gap<2, true>(b, stream);
     return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_tail_gap<1, false>(b, stream) : launch_tail_gap<2, false>(b, stream);
 }

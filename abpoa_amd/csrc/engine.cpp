@@ -134,7 +134,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (448 columns; depth by what fits:
     // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
     // the depth, ABPOA_HIP_TEAM=1|2|4 sets the wavefronts per alignment.
-    L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0; L.narrow_off = 0;
+    L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0; L.narrow_off = 0; L.w_mx_off = L.w_phase_off = 0;
     { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_TEAM");
       if (L.fr_cols && L.q_cap && !(nw_ && atoi(nw_))) {
           // wavefronts per alignment: 1.  Teams of 2 / 4 (ABPOA_HIP_TEAM=2|4, dp_team_rows.hip) give identical results but are slower on gfx950
@@ -143,6 +143,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           L.wide_nw = 1;
           if (mw_ && (atoi(mw_) == 1 || atoi(mw_) == 2 || atoi(mw_) == 4)) L.wide_nw = atoi(mw_);
           L.wfr_cols = WIDE_RING_COLS; L.wfr_rows = 16;
+          if (sc->m > 16) L.wide_nw = 0;      // (4-bit query codes)
+          L.w_mx_off = (int)align_up((size_t)(max_qlen + 2) / 2, 16); L.w_phase_off = L.w_mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
           // ring words per column of the wide kernels: as the narrow loop's, but two instead of three for convex int32 (rows_fast.h EPACK: E as 16-bit
           // differences to H, which needs gap-open + extend <= 65535)
           const int fww = (P == 5 && max_bits == 32) ? 2 : fw;
@@ -152,15 +154,26 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");
           if (rr_env_ && atoi(rr_env_) >= 4) L.wfr_rows = atoi(rr_env_) >= 16 ? 16 : (atoi(rr_env_) >= 8 ? 8 : 4); else rr_env_ = nullptr;
           // (up to 120 KB per wavefront: a convex int32 ring of 16 rows is 58 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
-          const int budget = 120 * 1024 - L.phase_off - 512;
+          const int budget = 120 * 1024 - L.w_phase_off - 512;
           while ((int64_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4 > budget && L.wfr_rows > 4) L.wfr_rows /= 2;
-          // one wavefront per alignment: LDS is what limits how many alignments a CU holds (160 KB, 256 CUs) -- a shallower ring when the
-          // launch has more alignments than fit (rows with an older predecessor take the HBM gather: 1 % of rows at depth 8 on 5 % reads)
-          if (!(rr_env_)) while (L.wfr_rows > 8 && (int64_t)(128 / ((L.phase_off + (int64_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4 + 320 + 1279) / 1280)) * 256 < n_aln) L.wfr_rows /= 2;
+          // One wavefront per alignment: LDS is what limits how many alignments a CU holds.  It is handed out in pieces of 1280 B, 128 per CU
+          // (tools/probes/lds_granule.hip: 3 x 53760 B fit a CU, 3 x 54080 B do not, whatever the occupancy query says).  The deepest ring with which
+          // the whole launch is resident, counting at most eight workgroups per CU -- two wavefronts per SIMD, which is what the registers allow and
+          // what pays: a SIMD with two alignments to issue from does 1.6x the rows of one with a single wavefront (tools/two_waves_probe.py).  A
+          // shallower ring sends more rows to the HBM gather (predecessor older than the ring: 0.5 % / 14 % / ~45 % of the rows of a 15 %-error
+          // graph at depth 16 / 8 / 4; rows +1.6 % / +6.5 %).
+          const int extra_ = L.wide_nw > 1 ? 16 * 16 + 64 : 0;      // (exchange slots: teams only)
+          auto per_cu_ = [&](int rows_) { return std::min<int64_t>(8, 128 / ((L.w_phase_off + (int64_t)rows_ * fww * (L.wfr_cols + 4) * 4 + extra_ + 1279) / 1280)); };
+          if (!(rr_env_)) {
+              const int top_ = L.wfr_rows; int best_ = top_;
+              for (int r_ = top_; r_ >= 4; r_ /= 2) {
+                  if (per_cu_(r_) > per_cu_(best_)) best_ = r_;
+                  if (per_cu_(r_) * 256 >= std::min(n_aln, 8 * 256)) { best_ = r_; break; }
+              }
+              L.wfr_rows = best_;
+          }
           L.wx_off = L.fr_off + (int)align_up((size_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4, 16);
-          // (exchange slots: teams only.  LDS is handed out in pieces of 1280 B on gfx950 -- 128 per CU, tools/probes/lds_granule.hip -- so three
-          //  workgroups per CU need <= 53760 B each, which a convex int32 ring of 8 rows plus a 10 kb query just meets without them)
-          L.total_wide = L.phase_off + L.wx_off + (L.wide_nw > 1 ? 16 * 16 + 64 : 0);
+          L.total_wide = L.w_phase_off + L.wx_off + extra_;
       } }
 }
 

@@ -66,6 +66,8 @@ struct LdsPlan {
     int32_t wide_w_lo, wide_w_hi; // an alignment takes the wide loop iff wide_w_lo <= its band half-width w <= wide_w_hi
     int32_t narrow_off;           // 1: every alignment of the launch takes the wide loop -- the narrow row-loop kernels are not launched
     int32_t total_wide;           // dynamic LDS bytes of the wide row-loop kernel
+    // (the wide kernels' own carve-up: query at q_off packed two 4-bit codes to a byte, then the extended matrix at w_mx_off, then -- w_phase_off -- ring and exchange slots)
+    int32_t w_mx_off, w_phase_off;
     // --- local row loop (rows_local.h): ring [loc_rows][words][loc_cols + 4] at phase_off + fr_off; loc_cols = 0: not used by this launch
     int32_t loc_rows, loc_cols, total_local;
     int32_t mx_off;               // int32 [m*(m+1)]: score matrix with an extra all-zero query column (code m = "no query base")

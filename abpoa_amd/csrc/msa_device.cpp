@@ -178,6 +178,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     bool dir_wide = false, any_wide_set = false;
     { const char *e_ = getenv("ABPOA_HIP_DIR_WIDE"); if (dir && e_ && atoi(e_) > 0) dir_wide = true; }
     const bool dir_wide_auto = dir && !getenv("ABPOA_HIP_DIR_WIDE");
+    // ... and whenever the pass is large enough for two wavefronts per SIMD (the LDS plan then takes a 4-row ring: eight workgroups per CU): the
+    // backtrack over words is 2.5x faster there than over records (configs[3] x 2048: 243 vs 609 ms per step), more than the row loop loses (1910 vs 1670 ms)
+    if (dir_wide_auto && wide_ring_rows <= 4 && wide_hi >= wide_lo) dir_wide = true;
     for (int s = 0; s < n_sets; ++s) {
         PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
         int64_t sum = 0; int mx = 0;

@@ -149,16 +149,23 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
     // (the single-wave wide kernel's ring width is a compile-time constant: address offsets and clamps fold into the instructions)
     const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WIDEB ? WIDE_RING_COLS : (WPLAN ? b.lds.wfr_cols : b.lds.fr_cols), RCS = RC + 4;
-    int *fr = (int *)(lds_raw + b.lds.phase_off + b.lds.fr_off);
+    // (the wide kernels have their own carve-up of the LDS: the query packed two codes to a byte -- LdsPlan.w_*)
+    const int ph_off = WPLAN ? b.lds.w_phase_off : b.lds.phase_off;
+    int *fr = (int *)(lds_raw + ph_off + b.lds.fr_off);
     // wide rows: exchange slots (two parities x 8 entries of 16 bytes) and the hand-over record of a row done by wavefront 0 alone
-    int4 *xch = (int4 *)(lds_raw + b.lds.phase_off + b.lds.wx_off);
+    int4 *xch = (int4 *)(lds_raw + ph_off + b.lds.wx_off);
     int *bcast = (int *)(xch + 16);
     // LDS byte address of ring row (r & (RR - 1)), column 0, held by lane r & 63: RR divides 64, so one lane-constant VGPR serves
     // every row -- a v_readlane replaces the and / mul / shift / add chain per predecessor and for the row's own slot
     typedef __attribute__((address_space(3))) int lds_int_t;
     const int vslot = (int)(unsigned)(size_t)(lds_int_t *)fr + 4 * ((threadIdx.x & 63 & (RR - 1)) * (NPW * RCS) + 2);
     auto ring_at = [&](int slot_addr, int col_idx) __attribute__((always_inline)) { return (const int *)(lds_int_t *)(size_t)(unsigned)(slot_addr + 4 * col_idx); };
-    int *s_mx = (int *)(lds_raw + b.lds.mx_off);
+    int *s_mx = (int *)(lds_raw + (WPLAN ? b.lds.w_mx_off : b.lds.mx_off));
+    // query code of base j (0-based): plain bytes, or -- wide kernels -- two 4-bit codes to a byte (ten thousand bases in 5 KB: with a 4-row ring an
+    // alignment then needs under 20 KB of LDS, eight workgroups share a CU and every SIMD has two wavefronts to issue from)
+    auto qat = [&](int j) __attribute__((always_inline)) -> int {
+        if constexpr (WPLAN) return ((int)s_query[j >> 1] >> ((j & 1) * 4)) & 15; else return (int)s_query[j];
+    };
     const int infw = I16 ? (int)(((unsigned)inf & 0xffffu) | ((unsigned)inf << 16)) : inf;
     const int qlen_sn = qlen / PN;
     auto wr = [](int x) __attribute__((always_inline)) { return (int)(T)x; };          // wrap to the score width
@@ -291,7 +298,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (beg_sn != qc_beg_sn) {                 // band start moved: refresh this lane's cached query codes
             qc_beg_sn = beg_sn;
             const int c0 = beg_sn * PN + lane, c1 = c0 + 64;
-            qoff0 = (c0 >= 1 && c0 <= qlen) ? (int)s_query[c0 - 1] : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? (int)s_query[c1 - 1] : m;
+            qoff0 = (c0 >= 1 && c0 <= qlen) ? qat(c0 - 1) : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? qat(c1 - 1) : m;
         }
     };
     // one predecessor's contribution from the score ring (k == 0: unmasked, see the header comment)
@@ -466,7 +473,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
             qc_beg_sn = beg_sn;
             const int c0 = beg_sn * PN + lane, c1 = c0 + 64;
-            qoff0 = (c0 >= 1 && c0 <= qlen) ? (int)s_query[c0 - 1] : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? (int)s_query[c1 - 1] : m;
+            qoff0 = (c0 >= 1 && c0 <= qlen) ? qat(c0 - 1) : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? qat(c1 - 1) : m;
         }
         const int q = *(const int *)((const char *)s_mx + (tb >> 16) + qoff0 * 4);
         const int colrel = beg_sn * PN + lane;                     // this lane's column
@@ -695,7 +702,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (__builtin_expect(beg_sn != qcx_beg_sn || (TEAM && c0 != qcx_c0), 0)) {
             qcx_beg_sn = beg_sn; qcx_c0 = c0;
 #pragma unroll
-            for (int c = 0; c < NCHX; ++c) { const int col = colb + 64 * c; qoffx[c] = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m; }
+            for (int c = 0; c < NCHX; ++c) { const int col = colb + 64 * c; qoffx[c] = (col >= 1 && col <= qlen) ? qat(col - 1) : m; }
         }
         FSTAMP(0)
         const int *mrow = s_mx + base * m1;
@@ -1007,7 +1014,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         for (int c = 0; c < nch; ++c) {
             const int col = beg_sn * PN + c * 64 + lane;
             int qc = c == 0 ? qoff0 : qoff1;
-            if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
+            if (c >= 2) qc = (col >= 1 && col <= qlen) ? qat(col - 1) : m;
             const int q = mrow[qc];
             int Mv = lane, E1v = inf, E2v = inf, kb = 0, kE1 = 1, kE2 = 1;
             if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v, kb, 1, kE1, kE2);
@@ -1046,7 +1053,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int rel = c * 64 + lane, col = beg_sn * PN + rel;
             const bool in_band = rel < Wr;
             int qc = c == 0 ? qoff0 : qoff1;
-            if (c >= 2) qc = (col >= 1 && col <= qlen) ? (int)s_query[col - 1] : m;
+            if (c >= 2) qc = (col >= 1 && col <= qlen) ? qat(col - 1) : m;
             const int q = mrow[qc];
             int Mv = inf, E1v = inf, E2v = inf, kb = 0, kE1 = 1, kE2 = 1;
             for (int k = 0; k < np; ++k) {
@@ -1291,7 +1298,10 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     io.g_left = vgpr_ptr(b.left + d.row0); io.g_right = vgpr_ptr(b.right + d.row0); io.g_coff = vgpr_ptr(b.row_cell_off + d.row0);
     io.planes = (T *)(b.planes + d.plane_off);
     uint8_t *s_query = lds_raw + b.lds.q_off;
-    { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off); for (int i = (NW > 1 ? (int)threadIdx.x : lane); i < d.qlen; i += NW * 64) s_query[i] = g_query[i]; }
+    { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
+      if constexpr (NW > 1 || WIDEB) {      // two codes to a byte (rows_fast: qat)
+          for (int i = (NW > 1 ? (int)threadIdx.x : lane); 2 * i < d.qlen; i += NW * 64) { const int lo_ = g_query[2 * i], hi_ = 2 * i + 1 < d.qlen ? (int)g_query[2 * i + 1] : 0; s_query[i] = (uint8_t)((lo_ & 15) | (hi_ << 4)); }
+      } else for (int i = (NW > 1 ? (int)threadIdx.x : lane); i < d.qlen; i += NW * 64) s_query[i] = g_query[i]; }
     WG_SYNC();
     long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
     const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
