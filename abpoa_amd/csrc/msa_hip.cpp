@@ -62,11 +62,12 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
     int key = 0; { int mx = 1, nr = 0; for (int i : idx) { nr = std::max(nr, sets[i].n_reads); for (int r = 0; r < sets[i].n_reads; ++r) mx = std::max(mx, sets[i].lens[r]); }
                    int lg = 0; while ((1 << lg) < mx) ++lg; key = lg * 1024 + std::min(nr, 1023); }
     int first_pass = 0;
+    { const char *fp_ = getenv("ABPOA_HIP_FIRST_PASS"); if (fp_ && atoi(fp_) == 1) first_pass = 1; }      // (profiling runs of one step: start at 6x as a warmed-up process would)
     if (!(getenv("ABPOA_HIP_NO_PASS_HINT") && atoi(getenv("ABPOA_HIP_NO_PASS_HINT")))) { std::lock_guard<std::mutex> lk(hint_mu); auto it = hint.find(key); if (it != hint.end()) first_pass = it->second; }
     bool most_outgrew = false; int n_small = 0, n_done = 0;      // (sets that finished / that would also have fitted the 3x estimate)
     for (int pass = first_pass; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
-        size_t chunk = todo.size();
+        size_t chunk = todo.size(); bool halved = false;      // (halved: the pass did not fit the device memory in the pieces first tried)
         {   // wide-band jobs: passes of what the device holds at once (msa_device.h)
             std::vector<abpoa_hip_readset_t> all_(todo.size()); for (size_t i = 0; i < todo.size(); ++i) all_[i] = sets[todo[i]];
             const int res_ = msa_device_resident_sets(sc, (int)all_.size(), all_.data());
@@ -78,7 +79,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             for (size_t i = 0; i < nb; ++i) sub[i] = sets[todo[at + i]];
             std::vector<int> fb; DeviceRunStats ds;
             const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], device, slot);
-            if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; continue; }           // split and retry this chunk
+            if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; halved = true; continue; }           // split and retry this chunk
             if (rc != ABPOA_HIP_OK) {
                 if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; }
                 // not a job for the device path (does not fit even alone / shape): what is still open -- the leftovers of the chunks already done in this
@@ -98,7 +99,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             at += nb;
         }
         if (R.device_ok && pass == 0) most_outgrew = left.size() * 2 >= todo.size();
-        if (R.device_ok && pass == 1 && most_outgrew && chunk == todo.size()) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = 1; }
+        if (R.device_ok && pass == 1 && most_outgrew && !halved) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = 1; }
         // the hint is dropped again when a job that started at 6x because of it turns out to fit 3x (a cleaner job of the same shape): twice the graph
         // and arena memory for nothing otherwise, for as long as the process lives
         if (R.device_ok && pass == 1 && first_pass == 1 && n_done > 0 && n_small * 2 > n_done) { std::lock_guard<std::mutex> lk(hint_mu); hint.erase(key); }
