@@ -72,6 +72,8 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             std::vector<abpoa_hip_readset_t> all_(todo.size()); for (size_t i = 0; i < todo.size(); ++i) all_[i] = sets[todo[i]];
             const int res_ = msa_device_resident_sets(sc, (int)all_.size(), all_.data());
             if (res_ > 0 && chunk > (size_t)res_) chunk = (size_t)res_;
+            const char *ps_ = getenv("ABPOA_HIP_PASS_SETS");      // (tests: several passes on a small job)
+            if (ps_ && atoi(ps_) > 0 && chunk > (size_t)atoi(ps_)) chunk = (size_t)atoi(ps_);
         }
         for (size_t at = 0; at < todo.size() && R.device_ok;) {
             const size_t nb = std::min(chunk, todo.size() - at);

@@ -59,6 +59,28 @@ def test_device_driver_equals_host_driver(engine, monkeypatch, name, kw, shape, 
         assert a.n_cells == b.n_cells, f"{name}: DP cell count of set {i} differs"
 
 
+@pytest.mark.parametrize("env", [{}, {"ABPOA_HIP_PASS_SETS": "3"}, {"ABPOA_HIP_DIR_WIDE": "1"}, {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"},
+                                 {"ABPOA_HIP_DIR_WIDE": "0", "ABPOA_HIP_RING_ROWS": "4"}],
+                         ids=["default", "three_passes", "direction_words", "direction_words_ring4", "records_ring4"])
+@pytest.mark.parametrize("kw", [dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2)], ids=["convex", "affine"])
+def test_wide_band_jobs_passes_and_arena_formats(engine, monkeypatch, env, kw):
+    """Wide-band read-sets (4.5 kb reads: band half-width 55, rows of 3 chunks) through the device-resident driver in the forms the driver picks by
+    job size and free memory on big jobs: one pass or several (passes of the resident number of sets), score-record or direction-word arenas, the
+    8-row or the 4-row score ring (packed E differences in the convex int32 ring, 4-bit query codes).  All equal to the host driver."""
+    from abpoa_amd import api, synth
+    sets = [synth.make_read_set(23, i, 6, 4500, 0.08) for i in range(8)]
+    host, dev, tm = _both(sets, api.Params(**kw))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev2 = api.msa_batch(sets, api.Params(**kw), n_threads=8)
+    assert api.msa_timing()["pad"] == 0
+    for i, (a, b, c) in enumerate(zip(dev, host, dev2)):
+        assert a.status == 0 and b.status == 0 and c.status == 0
+        assert a.cons_seq == b.cons_seq == c.cons_seq, f"{env}: consensus of set {i} differs"
+        assert a.cons_cov == b.cons_cov == c.cons_cov, f"{env}: coverage of set {i} differs"
+        assert a.n_cells == b.n_cells == c.n_cells, f"{env}: DP cell count of set {i} differs"
+
+
 def test_device_graph_equals_host_graph_after_every_read(engine):
     """Runs in a child process because the check mode is chosen by an environment variable at call time and prints to stderr."""
     code = ("import os,sys; sys.path.insert(0, %r)\n"
