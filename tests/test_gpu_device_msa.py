@@ -81,6 +81,28 @@ def test_wide_band_jobs_passes_and_arena_formats(engine, monkeypatch, env, kw):
         assert a.n_cells == b.n_cells == c.n_cells, f"{env}: DP cell count of set {i} differs"
 
 
+@pytest.mark.parametrize("env", [{}, {"ABPOA_HIP_DIR_WIDE": "1"}, {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"}, {"ABPOA_HIP_NODIR": "1"}],
+                         ids=["default", "direction_words", "direction_words_ring4", "records_only"])
+@pytest.mark.parametrize("kw", [dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2)], ids=["convex", "affine"])
+def test_mixed_band_widths_in_one_job(engine, monkeypatch, env, kw):
+    """One job whose read-sets take different row loops -- 1.5 kb reads (narrow band, one chunk), 3.9 kb (band half-width 49: the wide loop's
+    smallest), 7 kb (4 chunks), 11 kb with 12 % error (5-6 chunks, odd read lengths: the 4-bit query packing's last nibble) -- so that narrow and
+    wide kernels, both score widths and both arena formats meet in the same launches.  Equal to the host driver."""
+    from abpoa_amd import api, synth
+    shapes = [(5, 1500, 0.05), (4, 3901, 0.08), (4, 7003, 0.05), (3, 11001, 0.12), (6, 1203, 0.10), (3, 9999, 0.15)]
+    sets = [synth.make_read_set(29, i, *shapes[i % len(shapes)]) for i in range(9)]
+    host, dev, tm = _both(sets, api.Params(**kw))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev2 = api.msa_batch(sets, api.Params(**kw), n_threads=8)
+    assert api.msa_timing()["pad"] == 0
+    for i, (a, b, c) in enumerate(zip(dev, host, dev2)):
+        assert a.status == 0 and b.status == 0 and c.status == 0
+        assert a.cons_seq == b.cons_seq == c.cons_seq, f"{env}: consensus of set {i} differs"
+        assert a.cons_cov == b.cons_cov == c.cons_cov, f"{env}: coverage of set {i} differs"
+        assert a.n_cells == b.n_cells == c.n_cells, f"{env}: DP cell count of set {i} differs"
+
+
 def test_device_graph_equals_host_graph_after_every_read(engine):
     """Runs in a child process because the check mode is chosen by an environment variable at call time and prints to stderr."""
     code = ("import os,sys; sys.path.insert(0, %r)\n"
@@ -99,7 +121,9 @@ def test_device_graph_equals_host_graph_after_every_read(engine):
 def test_multi_queue_batch_call_matches_single_queue(engine):
     """abpoa_hip_msa_batch with ABPOA_GPU_DEVICES: cost-sorted batches dealt to per-device queues on worker threads, results in caller
     order.  One GPU here, so the list names device 0 twice (two queues, two pool caches, two streams): same records as the single queue.
-    The read-sets are ragged (different read counts and lengths) so that the cost sort really permutes them."""
+    The read-sets are ragged (different read counts and lengths) so that the cost sort really permutes them.
+    NOT covered here or anywhere: two DIFFERENT device ordinals (per-device __constant__ argument records of the all-rounds kernel, pool caches on
+    several devices) -- the test boxes of this pool have one GPU; the multi-GPU bench of the build driver is the first run of that path."""
     from abpoa_amd import api, synth
     sets = [synth.make_read_set(11, i, 4 + i % 7, 120 + 40 * (i % 5), 0.06) for i in range(600)]
     p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
