@@ -326,7 +326,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                         if (GAP == 1) { kMl = wl & 15; uEl0 = 0; uEl1 = 0; dFl = (wl >> DIRA_DF1_SH) & 7; }
                         else { kMl = wl & 15; uEl0 = (wl >> DIRC_UE1_SH) & 7; uEl1 = (wl >> DIRC_UE2_SH) & 31; dFl = x == 0 ? (wl >> DIRC_DF1_SH) & 7 : (wl >> DIRC_DF2_SH) & 31; }
                         const int h_is_hv = kMl != 0 || (GAP == 2 && (uEl0 == o1 || uEl1 == o2));
-                        if (!h_is_hv && dFl > ox) { status = ABPOA_HIP_STATUS_NEED_SCORES; break; }      // the plane cannot decide this one (dir_plane.h)
+                        if ((!h_is_hv && dFl > ox) || (b.dbg & 512)) { status = ABPOA_HIP_STATUS_NEED_SCORES; break; }      // the plane cannot decide this one (dir_plane.h); dbg bit 9: at the first insertion decided from the words (tests of the redo path)
                         lit = dir_f_origin(h_is_hv, dFl, ox);
                     }
                     if (lit == DIR_LIT_OPEN) { cur_op = OP_M | OP_E; hit = 1; }

@@ -59,6 +59,35 @@ def test_direction_words_match_the_model(engine, monkeypatch, env):
     assert n >= 4
 
 
+def test_need_scores_redo_path(engine, monkeypatch):
+    """The direction-plane walk gives up (ABPOA_HIP_STATUS_NEED_SCORES) where the words cannot decide where an F value came from -- never seen on real
+    data -- and the alignment is redone with score records.  ABPOA_HIP_DBG=512 makes the walk give up at the first insertion it would decide from
+    the words, so that the redo path runs: same results, and the counters say that alignments were redone."""
+    monkeypatch.setenv("ABPOA_HIP_DBG", "512")
+    engine.abpoa_hip_reset_stats()
+    _dir_counts(engine)
+    n = redone_total = 0
+    for label, path in CASES:
+        if not label.startswith(("s1k_", "heter_ag_gb", "heter_cg_gb")):
+            continue
+        g = H.read_abpg(path)
+        h = H.run_hip([H.FlatCase(g)], want_trace=False)[0]
+        H.compare_with_golden(h, g, check_planes=False, label=f"need-scores {label}")
+        walked, redone = _dir_counts(engine)
+        redone_total += redone
+        n += 1
+    assert n >= 3 and redone_total >= 1, (n, redone_total)
+    # the device-resident driver hands such a set to the host driver, which redoes the alignment with records
+    from abpoa_amd import api, synth
+    sets = [synth.make_read_set(31, i, 8, 600, 0.12) for i in range(6)]
+    p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
+    dev = api.msa_batch(sets, p, n_threads=4)
+    monkeypatch.setenv("ABPOA_HIP_DBG", "0")
+    ref = api.msa_batch(sets, p, n_threads=4)
+    for a, b_ in zip(dev, ref):
+        assert a.status == 0 and b_.status == 0 and a.cons_seq == b_.cons_seq and a.cons_cov == b_.cons_cov
+
+
 def _dir_counts(lib):
     import ctypes
     out = (ctypes.c_longlong * 2)()
