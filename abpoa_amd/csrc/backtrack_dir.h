@@ -59,6 +59,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     WG_SYNC();       // all of this wave's arena / band stores have landed before the loads below
 
     // ------------------------------------------------------------------ global best, reference :1028-1041 (the sink's predecessors keep their score records)
+    // (records of the wide kernel's spill rows are compact: rows_fast.h CWR)
+    const int cwr = takes_wide(b, d) ? (sizeof(T) == 2 ? (GAP == 2 ? 4 : 2) : 2) : CW;
     if (status == 0) {
         // a lane per in-edge of the sink, 64 at a time (the three dependent loads of an edge are in flight for all of them together); the first maximum in
         // list order wins, as in the reference's loop with its strict ">"
@@ -70,7 +72,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 in_row = pred_row[k];
                 const int pe = g_esn[in_row], pb = g_bsn[in_row];
                 const int dpe = (pe + 1) * PN - 1; end = qlen > dpe ? dpe : qlen;
-                score = (int)planes[g_coff[in_row] - (long long)(pe - pb + 1) * CW * PN + (long long)(end - pb * PN) * CW];      // (its records sit in front of its words)
+                score = (int)planes[g_coff[in_row] - (long long)(pe - pb + 1) * cwr * PN + (long long)(end - pb * PN) * cwr];      // (its records sit in front of its words)
             }
             const int mx = wave_max_i32(score);
             if (mx > best_score) {

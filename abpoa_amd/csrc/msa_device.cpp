@@ -213,7 +213,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             const bool wide_s = w >= wide_lo && w <= wide_hi;
             const bool dir_s = dir && (dw || !wide_s);      // (dp_common.h takes_dir)
             const int64_t rec_div = (wide_s && wide_ring_rows <= 4) ? 2 : 4;
-            const int64_t bytes = dir_s ? (int64_t)up((size_t)(width * (DB + CW * (bits / 8)) + (est * DB + est * CW * (bits / 8) / rec_div + 32) * (cap - 1) + 64 * 8 * 4))
+            // (bytes per cell record of a row that keeps its scores: CW values -- the wide kernel's compact records: 4 B int16 affine, else 8 B; rows_fast.h CWR)
+            const int64_t recb = wide_s ? ((bits == 16 && CW == 4) ? 4 : 8) : CW * (bits / 8);
+            const int64_t bytes = dir_s ? (int64_t)up((size_t)(width * (DB + recb) + (est * DB + est * recb / rec_div + 32) * (cap - 1) + 64 * 8 * 4))
                                       : (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
             S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
         }

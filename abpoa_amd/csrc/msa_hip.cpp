@@ -54,7 +54,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
                       int n_threads, int device, int slot) {
     PassOut R; memset(&R.tot, 0, sizeof(R.tot));
     std::vector<int> todo = idx, left;
-    const double factors[2] = {3.0, 6.0};
+    const double factors[3] = {3.0, 4.5, 6.0}; constexpr int NPASS = 3;
     // What the process learned about jobs of this shape (longest read by power of two, reads per set): when most sets of the last such job outgrew
     // the 3x pass and the 6x pass ran in one piece, the next one starts at 6x (noisy long reads: 50 x 10 kb at 15 % error grow to 3.9x; the doomed
     // first pass is ~3 % of such a job).  Results do not depend on it.  ABPOA_HIP_NO_PASS_HINT=1: always start at 3x.
@@ -62,10 +62,10 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
     int key = 0; { int mx = 1, nr = 0; for (int i : idx) { nr = std::max(nr, sets[i].n_reads); for (int r = 0; r < sets[i].n_reads; ++r) mx = std::max(mx, sets[i].lens[r]); }
                    int lg = 0; while ((1 << lg) < mx) ++lg; key = lg * 1024 + std::min(nr, 1023); }
     int first_pass = 0;
-    { const char *fp_ = getenv("ABPOA_HIP_FIRST_PASS"); if (fp_ && atoi(fp_) == 1) first_pass = 1; }      // (profiling runs of one step: start at 6x as a warmed-up process would)
+    { const char *fp_ = getenv("ABPOA_HIP_FIRST_PASS"); if (fp_ && atoi(fp_) >= 1 && atoi(fp_) < NPASS) first_pass = atoi(fp_); }      // (profiling runs of one step: start where a warmed-up process would)
     if (!(getenv("ABPOA_HIP_NO_PASS_HINT") && atoi(getenv("ABPOA_HIP_NO_PASS_HINT")))) { std::lock_guard<std::mutex> lk(hint_mu); auto it = hint.find(key); if (it != hint.end()) first_pass = it->second; }
     bool most_outgrew = false; int n_small = 0, n_done = 0;      // (sets that finished / that would also have fitted the 3x estimate)
-    for (int pass = first_pass; pass < 2 && R.device_ok && !todo.empty(); ++pass) {
+    for (int pass = first_pass; pass < NPASS && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
         size_t chunk = todo.size(); bool halved = false;      // (halved: the pass did not fit the device memory in the pieces first tried)
         {   // wide-band jobs: passes of what the device holds at once (msa_device.h)
@@ -95,16 +95,18 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             tot.total_s += ds.total_s; tot.n_cells += ds.n_cells; tot.algo_bytes += ds.algo_bytes; tot.n_alignments += ds.n_alignments; tot.n_rounds += ds.n_rounds;
             tot.rounds_ms += ds.rounds_ms; tot.rounds_launches += ds.rounds_launches; tot.rounds_algo_bytes += ds.rounds_algo_bytes;
             n_small += ds.n_fit_3x; n_done += (int)nb - (int)fb.size();
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %.0fx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %gx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
                                                      device, pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
             if (getenv("ABPOA_HIP_VERBOSE") && ds.rounds_launches) fprintf(stderr, "[abpoa-hip]   all-rounds kernel: %.1f ms (the phase times above are its duration split by the sets' clock ticks); mean set busy %.0f %% of it; mean set, 10^6 ticks: prepare %.1f, row loop %.1f, backtrack %.1f, fuse %.1f\n", ds.rounds_ms, 100.0 * ds.rounds_mean_over_max, ds.rounds_mticks[0], ds.rounds_mticks[1], ds.rounds_mticks[2], ds.rounds_mticks[3]);
             at += nb;
         }
-        if (R.device_ok && pass == 0) most_outgrew = left.size() * 2 >= todo.size();
-        if (R.device_ok && pass == 1 && most_outgrew && !halved) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = 1; }
-        // the hint is dropped again when a job that started at 6x because of it turns out to fit 3x (a cleaner job of the same shape): twice the graph
+        // most sets of the previous pass outgrew it and this one held most of them (in the pieces first tried): jobs of this shape start here next time
+        const bool outgrew_now = left.size() * 2 >= todo.size();
+        if (R.device_ok && pass > 0 && most_outgrew && !outgrew_now && !halved) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = pass; }
+        if (R.device_ok) most_outgrew = outgrew_now;
+        // the hint is dropped again when a job that started higher because of it turns out to fit 3x (a cleaner job of the same shape): more graph
         // and arena memory for nothing otherwise, for as long as the process lives
-        if (R.device_ok && pass == 1 && first_pass == 1 && n_done > 0 && n_small * 2 > n_done) { std::lock_guard<std::mutex> lk(hint_mu); hint.erase(key); }
+        if (R.device_ok && pass == first_pass && first_pass > 0 && n_done > 0 && n_small * 2 > n_done) { std::lock_guard<std::mutex> lk(hint_mu); hint.erase(key); }
         if (R.device_ok) todo.swap(left);
     }
     R.left = todo;

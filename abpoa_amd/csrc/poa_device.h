@@ -38,6 +38,7 @@ struct PoaSet {                    // immutable per read-set
 struct PoaState {                  // mutable per read-set
     int32_t n_nodes, status, order_buf, pad;     // order_buf: which row_node buffer is current; pad: fall-back reason
     int32_t cons_len, pad1;        // heaviest-bundling consensus length (poa_consensus_kernel)
+    int32_t grow_n2, grow_n6;      // nodes after 2 / 6 reads: the growth model of the doomed-pass test (poa_bodies.h)
     int64_t n_cells;               // DP cells over all alignments so far
     int64_t algo_bytes;            // cells * algorithmic bytes per cell (affine 5S, convex 8S; S = 2 | 4)
     int64_t algo_bytes_before;     // algo_bytes when the all-rounds kernel took the set over (what it computed itself = algo_bytes - this)

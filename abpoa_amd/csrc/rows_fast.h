@@ -124,13 +124,20 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #endif
     constexpr int PN = Width<T>::PN, NV = 64 / PN;
     constexpr int CW = FastFmt<T, GAP>::CW;          // values per arena cell record
+    constexpr bool I16 = sizeof(T) == 2;
+    // Records of the rows that keep their scores beside direction words in the WIDE kernel ("spill rows": read again from HBM by a far successor or by
+    // the global best -- H and E only) are compact, CWR values per cell instead of CW: int16 {H, E1} / {H, E1, E2, -}, int32 affine {H, E1}, int32 convex
+    // {H, (H - E1) | (H - E2) << 16} with 0xffff for "E is inf" (row 0).  8 bytes a cell instead of 16-32: with a 4-row ring almost half of the rows of a
+    // 15 %-error graph are such rows, and the arenas of 2 048 x 10 kb convex read-sets would not fit otherwise.
+    constexpr bool CSP = DIR && WIDEB;
+    constexpr int CWR = CSP ? (I16 ? (GAP == 2 ? 4 : 2) : 2) : CW;
+    constexpr bool CPK = CSP && !I16 && GAP == 2;
     static_assert(!(DIR && NW > 1), "teams of wavefronts keep the score-record arenas");
     constexpr int DB = DirFmt<T, GAP>::DB, CAPF1 = GAP == 1 ? DIRA_CAP1 : DIRC_CAP1, CAPF2 = DIRC_CAP2;
     auto dir_units = [](int nv) __attribute__((always_inline)) { return DirFmt<T, GAP>::units(nv); };
     // arena units of a row of nv vectors (spill: the row also keeps its score records)
-    auto row_units = [&](int nv, bool spill) __attribute__((always_inline)) { return DIR ? dir_units(nv) + (spill ? nv * CW : 0) : nv * CW; };
+    auto row_units = [&](int nv, bool spill) __attribute__((always_inline)) { return DIR ? dir_units(nv) + (spill ? nv * CWR : 0) : nv * CW; };
     bool row_spill = false;                          // (DIR) the current row keeps its score records: set by the row loop before a body runs
-    constexpr bool I16 = sizeof(T) == 2;
     constexpr bool WPLAN = NW > 1 || WIDEB;          // the wide kernels have their own score ring (LdsPlan wfr_*)
     // Ring words per column.  int16: H | E1 << 16, E2.  int32: H, E1, E2 -- but in the wide kernels' convex ring (EPACK) H and ONE word of differences
     // (H - E1) | (H - E2) << 16: E leaving a cell is max(Ein - e, H - oe) with Ein <= H, so H - E is in [e, oe] wherever H is a score, and 0 stands for
@@ -193,7 +200,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 
     int cur = 0, n_vec_lane = 0;                    // arena cursor in units of PN cells (one reference SIMD vector); cell count: per-lane sums of the flushed rows' vectors
     const int cap_pn = (int)(d.plane_cap / PN > 0x7fffffffLL ? 0x7fffffffLL : d.plane_cap / PN);
-    const int cap_turbo = cap_pn - (DIR ? dir_units(NV) + NV * CW : NV * CW);       // arena room test of the straight-line rows (at most NV vectors)
+    const int cap_turbo = cap_pn - (DIR ? dir_units(NV) + NV * CWR : NV * CW);       // arena room test of the straight-line rows (at most NV vectors)
     const int remain_end = __builtin_amdgcn_readfirstlane(io.row_remain[gn - 1]);
     // ------------------------------------------------------------------ row 0, reference :553-662
     int vg_geo = 0, vg_mi = 0, vg_off = 0;          // lane = row & 63: beg_sn | end_sn << 12 | in-ring << 24, arg-max column, arena offset / PN
@@ -203,7 +210,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int dp_end0 = imin(qlen, imax(0, qlen - r) + w);
         const int end_sn0 = dp_end0 / PN, W0 = (end_sn0 + 1) * PN;
         // (DIR: row 0 has no decisions to record; it keeps its score records because new branches anywhere in the graph start at the source)
-        if ((long long)W0 * CW > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
+        if ((long long)W0 * CWR > d.plane_cap) { status = ABPOA_HIP_STATUS_OVERFLOW; cursor_out = 0; n_cells_out = 0; rows_done_out = 0; return; }
         const bool ring0 = W0 <= RC && !EPACK;
         T *H = io.planes;
         for (int i = tid; i < W0; i += NT) {
@@ -213,12 +220,16 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int g1 = wr(-o1 - e1 * i), g2 = wr(-o2 - e2 * i);
                 h = i == 0 ? 0 : imax(g1, g2); x1 = i == 0 ? wr(-oe1) : inf; x2 = i == 0 ? wr(-oe2) : inf; f1 = i == 0 ? inf : g1; f2 = i == 0 ? inf : g2;
             }
-            T *cellp = H + (long long)i * CW;
-            cellp[0] = (T)h; cellp[PL_E1] = (T)x1; cellp[PL_F1] = (T)f1;
-            if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
+            T *cellp = H + (long long)i * CWR;
+            if constexpr (CPK) { cellp[0] = (T)h; cellp[1] = (T)(i == 0 ? (int)((unsigned)(h - x1) | ((unsigned)(h - x2) << 16)) : -1); }      // (E = inf beside a real H: 0xffff)
+            else if constexpr (CSP) { cellp[0] = (T)h; cellp[PL_E1] = (T)x1; if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[3] = (T)0; } }
+            else {
+                cellp[0] = (T)h; cellp[PL_E1] = (T)x1; cellp[PL_F1] = (T)f1;
+                if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
+            }
             if (ring0) ring_put(0, i, h, x1, x2);
         }
-        cur = (end_sn0 + 1) * CW;
+        cur = (end_sn0 + 1) * CWR;
         if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = DIR ? cur : 0; }      // (DIR: a row's offset is that of its -- here absent -- words, its records sit in front of them)     // source: successors get left = right = 1 (:556-561)
         if (NW > 1) WG_SYNC();               // ring row 0 was written by every wavefront
     }
@@ -367,7 +378,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if constexpr (DIR) {
             // the exact bodies record every comparison literally (dir_plane.h): H == Ein, E opened from H, H == F, and -- as the override -- where F came
             // from, with the reference's own tests on the stored neighbours (:260-300); the left neighbour of the chunk's first column is carried over
-            Hrec = H - (long long)(end_sn - beg_sn + 1) * CW * PN;      // (a row that keeps its records has them in front of its words)
+            Hrec = H - (long long)(end_sn - beg_sn + 1) * CWR * PN;      // (a row that keeps its records has them in front of its words)
             const int Hm1 = wave_shr1(ct_pH, Hout), F1m1 = wave_shr1(ct_pF1, F1);
             const int en1_ = GAP == 1 ? imax(wr(E1v - e1), wr(Hout - oe1)) : E1out;      // (affine: E's maximum before the reference replaces it by "inf" where H is an F term, :880)
             const unsigned u1 = Hout == E1v ? (unsigned)o1 : (en1_ == wr(Hout - oe1) ? 0u : (o1 > 1 ? 1u : 0u));
@@ -386,6 +397,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         // (DIR: only a row that keeps its records stores them, and only its in-band lanes do: the row's words start right behind its last record)
         if (ABL(1) || (DIR && !(row_spill && in_band))) {}
+        else if (CSP) {      // compact records (CWR): what a far successor and the global best read
+            if (I16 && GAP == 1) *(int *)(Hrec + (long long)rel * CWR) = he;
+            else if (I16) { int2 rec; rec.x = he; rec.y = E2out & 0xffff; *(int2 *)(Hrec + (long long)rel * CWR) = rec; }
+            else if (GAP == 1) { int2 rec; rec.x = Hout; rec.y = E1out; *(int2 *)(Hrec + (long long)rel * CWR) = rec; }
+            else { int2 rec; rec.x = Hout; rec.y = (int)((unsigned)(Hout - E1out) | ((unsigned)(Hout - E2out) << 16)); *(int2 *)(Hrec + (long long)rel * CWR) = rec; }
+        }
         else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(Hrec + (long long)rel * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
@@ -416,7 +433,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto reserve = [&]() __attribute__((always_inline)) {
         const int nvr = end_sn - beg_sn + 1;
         if (cur + row_units(nvr, row_spill) > cap_pn) return false;
-        off_pn = cur + ((DIR && row_spill) ? nvr * CW : 0); cur += row_units(nvr, row_spill);
+        off_pn = cur + ((DIR && row_spill) ? nvr * CWR : 0); cur += row_units(nvr, row_spill);
         return true;
     };
 
@@ -732,14 +749,17 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         auto hbm_read_all = [&](int p, int g_, int *hc, int *ec1, int *ec2) __attribute__((always_inline)) {
             const int pb = g_ & 0xfff, Wp = (((g_ >> 12) & 0xfff) - pb + 1) * PN;
             // (DIR: the predecessor kept its score records -- tile bit 21 / a row too wide for the ring -- in front of its direction words)
-            const T *Hp = io.planes + (long long)(uint32_t)(__builtin_amdgcn_readlane(vg_off, p & 63) - (DIR ? (((g_ >> 12) & 0xfff) - pb + 1) * CW : 0)) * PN;
+            const T *Hp = io.planes + (long long)(uint32_t)(__builtin_amdgcn_readlane(vg_off, p & 63) - (DIR ? (((g_ >> 12) & 0xfff) - pb + 1) * CWR : 0)) * PN;
             gld_wait();                                              // (earlier score-plane stores of this wave are complete)
             if (TEAM) lds_barrier();                                 // (... and of the other wavefronts of the team: the far flag is the same in all of them)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int x = colb + 64 * c - pb * PN, xh = med3i(x - 1, 0, Wp - 1), xe = med3i(x, 0, Wp - 1);
-                gld_async_cell(hc[c], Hp + (long long)xh * CW); gld_async_cell(ec1[c], Hp + (long long)xe * CW + PL_E1);
-                if (GAP == 2) gld_async_cell(ec2[c], Hp + (long long)xe * CW + PL_E2); else ec2[c] = inf;
+                if constexpr (CPK) { gld_async_cell(hc[c], Hp + (long long)xh * CWR); gld_async_cell(ec1[c], Hp + (long long)xe * CWR); gld_async_cell(ec2[c], Hp + (long long)xe * CWR + 1); }      // H[x-1]; H[x], differences
+                else {
+                    gld_async_cell(hc[c], Hp + (long long)xh * CWR); gld_async_cell(ec1[c], Hp + (long long)xe * CWR + PL_E1);
+                    if (GAP == 2) gld_async_cell(ec2[c], Hp + (long long)xe * CWR + PL_E2); else ec2[c] = inf;
+                }
             }
             // (the wait names the loaded registers: a register-only use must not be scheduled above it)
 #pragma unroll
@@ -747,6 +767,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int x = colb + 64 * c - pb * PN;
+                if constexpr (CPK) { const int h0 = ec1[c]; const unsigned d1_ = (unsigned)ec2[c] & 0xffffu, d2_ = (unsigned)ec2[c] >> 16; ec1[c] = d1_ == 0xffffu ? inf : h0 - (int)d1_; ec2[c] = d2_ == 0xffffu ? inf : h0 - (int)d2_; }
                 hc[c] = (unsigned)(x - 1) < (unsigned)Wp ? hc[c] : inf; ec1[c] = (unsigned)x < (unsigned)Wp ? ec1[c] : inf; if (GAP == 2) ec2[c] = (unsigned)x < (unsigned)Wp ? ec2[c] : inf;
             }
         };
@@ -885,8 +906,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         if (!I16) { const unsigned tv = kbst >> 11; if (__builtin_expect(tv == 0u || tv == 0x1FFFFFu, 0)) return 0; }
         FSTAMP(3)
         // ---- from here on the row is committed
-        T *const Hrow = io.planes + (long long)cur * PN + (long long)(lane + 64 * c0) * CW;
-        off_pn = cur + ((DIR && row_spill) ? (end_sn - beg_sn + 1) * CW : 0); cur += row_units(end_sn - beg_sn + 1, row_spill);
+        T *const Hrow = io.planes + (long long)cur * PN + (long long)(lane + 64 * c0) * CWR;
+        off_pn = cur + ((DIR && row_spill) ? (end_sn - beg_sn + 1) * CWR : 0); cur += row_units(end_sn - beg_sn + 1, row_spill);
         char *const Drow = (char *)io.planes + (size_t)off_pn * 32 + (size_t)(lane + 64 * c0) * DB;      // (DIR) this lane's direction word in the wavefront's first chunk
         int *const qd = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * (lane + 64 * c0), 0);
         // (nch is NCH - 1 or NCH: chunks 0 .. NCH - 3 are full, only the last two need band masks, only the last one a store guard)
@@ -953,8 +974,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (DIR && !row_spill) {}
             else if (DIR && !in_band) {}      // (the row's words start right behind its last record)
             else if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {      // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
-                T *H = Hrow + c * 64 * CW;
-                if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1[c], 0x05040100u); *(int2 *)H = rec; }
+                T *H = Hrow + c * 64 * CWR;
+                if (CSP) {      // compact records (CWR)
+                    if (I16 && GAP == 1) *(int *)H = he;
+                    else if (I16) { int2 rec; rec.x = he; rec.y = E2out & 0xffff; *(int2 *)H = rec; }
+                    else if (GAP == 1) { int2 rec; rec.x = Hout; rec.y = E1out; *(int2 *)H = rec; }
+                    else { int2 rec; rec.x = Hout; rec.y = (int)((unsigned)(Hout - E1out) | ((unsigned)(Hout - E2out) << 16)); *(int2 *)H = rec; }
+                }
+                else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1[c], 0x05040100u); *(int2 *)H = rec; }
                 else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1[c] << 16)); rec.z = F2[c] & 0xffff; rec.w = mflag; *(int4 *)H = rec; }
                 else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1[c]; rec.w = mflag; *(int4 *)H = rec; }
                 else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1[c]; r1.x = F2[c]; r1.y = mflag; r1.z = 0; r1.w = 0; ((int4 *)H)[0] = r0; ((int4 *)H)[1] = r1; }
@@ -1064,10 +1091,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
                     const int x = col - pb * PN;
                     const bool inH = in_band && (unsigned)x < (unsigned)(Wp + PN), inE = in_band && (unsigned)x < (unsigned)Wp;
-                    const T *Hp = io.planes + (long long)(uint32_t)(off_ - (DIR ? (pe - pb + 1) * CW : 0)) * PN;      // (DIR: its score records, in front of its direction words)
+                    const T *Hp = io.planes + (long long)(uint32_t)(off_ - (DIR ? (pe - pb + 1) * CWR : 0)) * PN;      // (DIR: its score records, in front of its direction words)
                     int hval = inf, ev1 = inf, ev2 = inf;
-                    if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CW));
-                    if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CW + PL_E2)); }
+                    if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CWR));
+                    if constexpr (CPK) { if (inE) { const int h0 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR)); const unsigned dd = (unsigned)gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + 1));
+                                                    ev1 = (dd & 0xffffu) == 0xffffu ? inf : h0 - (int)(dd & 0xffffu); ev2 = (dd >> 16) == 0xffffu ? inf : h0 - (int)(dd >> 16); } }
+                    else
+                    if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + PL_E2)); }
                     if (k == 0) { Mv = hval; E1v = ev1; E2v = ev2; kb = 1; kE1 = 1; kE2 = 1; }
                     else { kb = (inH && hval > Mv) ? k + 1 : kb; if (DIR) { kE1 = (inE && ev1 > E1v) ? k + 1 : kE1; if (GAP == 2) kE2 = (inE && ev2 > E2v) ? k + 1 : kE2; }
                            Mv = inH ? imax(Mv, hval) : Mv; E1v = inE ? imax(E1v, ev1) : E1v; if (GAP == 2) E2v = inE ? imax(E2v, ev2) : E2v; }

@@ -21,7 +21,7 @@ WORKLOADS = {
                  out_msa=True, desc="30 seqs x 500 aa, local convex BLOSUM62 (-m 1 -c -t BLOSUM62.mtx -r 1), MSA output"),
 }
 # sets (index 0 .. n-1, seed 1) with a committed reference digest
-DIGEST_SETS = {"cfg2": 8000, "cfg3": 1024, "cfg4": 2048, "cfg5": 1000}
+DIGEST_SETS = {"cfg2": 8000, "cfg3": 2048, "cfg4": 2048, "cfg5": 1000}
 
 
 def ref_options(wl, portable=False):

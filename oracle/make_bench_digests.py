@@ -46,8 +46,14 @@ def main():
     os.makedirs(OUT_DIR, exist_ok=True)
     for wl in names:
         n = DIGEST_SETS[wl]
+        have = []      # (a list that is being extended keeps the digests it has: set i's reads depend on (seed, i) only)
+        fn_old = os.path.join(OUT_DIR, wl + ".json")
+        if os.path.exists(fn_old):
+            old = json.load(open(fn_old))
+            if old.get("seed") == 1 and old.get("options") == ref_options(wl, portable=True):
+                have = old["sha256"][:n]
         with tempfile.TemporaryDirectory(prefix="abpoa_dig_") as tmp, ThreadPoolExecutor(max_workers=7) as ex:
-            shas = list(ex.map(lambda i: one(wl, i, tmp), range(n)))
+            shas = have + list(ex.map(lambda i: one(wl, i, tmp), range(len(have), n)))
         rec = {"workload": wl, "seed": 1, "options": ref_options(wl, portable=True), "n_sets": n,
                "generator": "oracle/make_bench_digests.py (abPOA v1.4.1, oracle/_ref/abpoa_ref)", "sha256": shas}
         with open(os.path.join(OUT_DIR, wl + ".json"), "w") as f:

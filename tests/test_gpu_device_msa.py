@@ -140,7 +140,7 @@ def test_multi_queue_batch_call_matches_single_queue(engine):
 
 
 def test_job_shape_hint_skips_the_doomed_pass(engine):
-    """Noisy reads outgrow the 3x node estimate of the first device pass; the second such job of the process starts at 6x.  Same results either
+    """Noisy reads outgrow the 3x node estimate of the first device pass; the second such job of the process starts at the factor that held them (4.5x or 6x).  Same results either
     way, equal to the host driver's.  (Child process: the hint is process-wide state and the passes are reported on stderr.)"""
     code = ("import os,sys; sys.path.insert(0, %r)\n"
             "from abpoa_amd import api, ffi, synth\n"
@@ -155,8 +155,8 @@ def test_job_shape_hint_skips_the_doomed_pass(engine):
     assert p.returncode == 0, p.stderr[-2000:]
     assert "OK True" in p.stdout, p.stdout
     first, second = p.stderr.split("SECOND CALL")
-    assert "pass 1, node slots 3x" in first and "pass 2, node slots 6x" in first, first[-1500:]
-    assert "node slots 3x" not in second and "node slots 6x" in second, second[-1500:]
+    assert "pass 1, node slots 3x" in first and ("pass 2, node slots 4.5x" in first), first[-1500:]
+    assert "node slots 3x" not in second and ("node slots 4.5x" in second or "node slots 6x" in second), second[-1500:]
 
 
 @pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
