@@ -177,23 +177,38 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         }
         for (int r = tid; r < n; r += GT) remain[r] = (int)(jump_lds[r] & 0xffffu) - 1;
     } else
-    // (graphs too large for the LDS records) reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping
-    if (wave == 0) for (int t0 = ((n - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
-        const int r = t0 + lane;
-        int tgt = r < n ? ld_fresh(nxt + r) : -1, dist = 1, val = 0; bool done = r >= n;
-        if (!done && tgt < 0) { val = -1; done = true; }                         // the sink (reference :247)
-        if (!done && tgt >= t0 + 64) { val = ld_fresh(remain + tgt) + 1; done = true; }
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int src = (!done) ? tgt - t0 : lane;
-            const int t_tgt = shfl(tgt, src), t_dist = shfl(dist, src), t_val = shfl(val, src), t_done = shfl((int)done, src);
-            if (!done) {
-                if (t_done) { val = t_val + dist; done = true; }
-                else { tgt = t_tgt; dist += t_dist; }
+    // (graphs too large for the LDS records) reverse sweep over 64-row blocks; inside a block the chains are resolved by pointer jumping.  The sweep is a
+    // chain over the blocks, so what a block costs is what counts (600 blocks for a 10 kb graph): the successor rows of the NEXT block are loaded while
+    // this one is resolved, and the values of the block above stay in a register -- a heaviest successor is almost always within the next few rows -- so
+    // that only a target further than 64 rows beyond the block goes to memory (and waits for this wave's stores).
+    if (wave == 0) {
+        int t0 = ((n - 1) >> 6) << 6;
+        int tgt_next = t0 + lane < n ? ld_fresh(nxt + t0 + lane) : -1, above = 0;      // above: values of block t0 + 64 (lane = row - t0 - 64)
+        for (; t0 >= 0; t0 -= 64) {
+            const int r = t0 + lane;
+            int tgt = tgt_next, dist = 1, val = 0; bool done = r >= n;
+            if (t0 >= 64) tgt_next = ld_fresh(nxt + t0 - 64 + lane);
+            if (!done && tgt < 0) { val = -1; done = true; }                         // the sink (reference :247)
+            const bool far = !done && tgt >= t0 + 128;
+            const int from_above = shfl(above, (tgt - t0 - 64) & 63);
+            if (!done && tgt >= t0 + 64 && !far) { val = from_above + 1; done = true; }
+            if (__any(far)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores are write-through: once acknowledged, later blocks read them from L2 (ld_fresh)
+                if (far) { val = ld_fresh(remain + tgt) + 1; done = true; }
             }
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int src = (!done) ? tgt - t0 : lane;
+                const int t_tgt = shfl(tgt, src), t_dist = shfl(dist, src), t_val = shfl(val, src), t_done = shfl((int)done, src);
+                if (!done) {
+                    if (t_done) { val = t_val + dist; done = true; }
+                    else { tgt = t_tgt; dist += t_dist; }
+                }
+            }
+            if (r < n) remain[r] = val;
+            above = val;
         }
-        if (r < n) remain[r] = val;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores are write-through: once acknowledged, later blocks read them from L2 (ld_fresh)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // (3) predecessor CSR in row order (in_id order kept, reference pre_index[][] :519-530)
     __shared__ int wtot[GW];
