@@ -103,9 +103,9 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
     extern __shared__ unsigned jump_lds[];                 // [n] remaining-length jump records (see (2)), when the launch provides them
     const bool in_lds = p.pad > 0 && n <= p.pad;
     uint8_t *np_lds = (uint8_t *)(jump_lds + p.pad);       // [n] in-degree per row (row 0: none), for (3)
-    if (in_lds) {
+    {
         // four rows per thread and pass, every load level issued for all four before the next one: the chain order -> node -> edge
-        // slots -> row of the successor is four dependent HBM/L2 round trips, and a thread owns ~10 rows
+        // slots -> row of the successor is four dependent HBM/L2 round trips, and a thread owns ~10 rows (150 on a 10 kb graph)
         for (int r0 = tid; r0 < n; r0 += 4 * GT) {
             int u[4], no[4], ni[4], bs[4], best[4], nx[4]; int4 w4[4], o4[4];
 #pragma unroll
@@ -147,21 +147,12 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
                 const int r = r0 + j * GT;
                 if (r < n) {
                     p.row_sdist[N0 + r] = (uint8_t)sd[j];
-                    jump_lds[r] = nx[j] >= 0 ? ((unsigned)nx[j] << 16) | 1u : ((unsigned)r << 16);
-                    np_lds[r] = (uint8_t)(r > 0 ? ni[j] : 0);
+                    if (in_lds) { jump_lds[r] = nx[j] >= 0 ? ((unsigned)nx[j] << 16) | 1u : ((unsigned)r << 16); np_lds[r] = (uint8_t)(r > 0 ? ni[j] : 0); }
+                    else nxt[r] = nx[j];
                     p.row_base[N0 + r] = (uint8_t)bs[j]; p.row_node_id[N0 + r] = u[j];
                 }
             }
         }
-    } else
-    for (int r = tid; r < n; r += GT) {
-        const int u = order[r];
-        const int no = p.nd_nout[N0 + u];
-        int best_w = -1, best = -1, far = 0;
-        for (int t = 0; t < no; ++t) { const int w = outw_slot(p, N0 + u, t), o = out_slot(p, N0 + u, t); if (w > best_w) { best_w = w; best = o; } far = imax_(far, p.nd_row[N0 + o]); }
-        p.row_sdist[N0 + r] = (uint8_t)(far >= n - 1 ? 255 : imin_(imax_(far - r, 0), 255));
-        nxt[r] = best >= 0 ? p.nd_row[N0 + best] : -1;
-        p.row_base[N0 + r] = p.nd_base[N0 + u]; p.row_node_id[N0 + r] = u;
     }
     __syncthreads();
     // (2) remaining length = (edges to the sink along heaviest successors) - 1, reference :233-274.
@@ -226,19 +217,15 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         const int off = carry + before + incl - np;
         if (r < n) p.pred_off[N0 + r] = off;
         if (off + np > S.pred_cap) overflow = true;
-        else if (!in_lds) {
-            unsigned long long pdv = ~0ull;      // a byte per predecessor (the first eight), 255 = none / further than 254 rows
-            for (int t = 0; t < np; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u, t)]; p.pred_row[S.pred0 + off + t] = pr_; if (t < 8 && r - pr_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr_) << (8 * t)); }
-            if (r < n) { p.row_pd[2 * (N0 + r)] = (unsigned)pdv; p.row_pd[2 * (N0 + r) + 1] = (unsigned)(pdv >> 32); }
-        }
         carry += all;
         __syncthreads();
     }
-    if (in_lds) {      // the lists themselves, four rows per thread and pass (see (1)); pred_off is read back by the thread that wrote it
+    {      // the lists themselves, four rows per thread and pass (see (1)); pred_off is read back by the thread that wrote it
         for (int r0 = tid; r0 < n; r0 += 4 * GT) {
             int u[4], np[4], off[4]; int4 i4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; const bool ok = r < n; u[j] = order[ok ? r : 0]; np[j] = ok ? (int)np_lds[r] : 0; off[j] = p.pred_off[N0 + (ok ? r : 0)]; }
+            for (int j = 0; j < 4; ++j) { const int r = r0 + j * GT; const bool ok = r < n; u[j] = order[ok ? r : 0]; off[j] = p.pred_off[N0 + (ok ? r : 0)];
+                                          np[j] = !ok ? 0 : (in_lds ? (int)np_lds[r] : (r > 0 ? (int)p.nd_nin[N0 + u[j]] : 0)); }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { if (off[j] + np[j] > S.pred_cap) np[j] = 0; i4[j] = *(const int4 *)(p.nd_in + (N0 + u[j]) * POA_HOT); }
             int pr[4][4];
@@ -250,9 +237,8 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int32_t *dst = p.pred_row + S.pred0 + off[j];
-                const int r = r0 + j * GT; const int npr = r < n ? (int)np_lds[r < n ? r : 0] : 0;      // (np[j] is 0 for a row whose list does not fit: the set falls back anyway)
+                const int r = r0 + j * GT;      // (np[j] is 0 for a row whose list does not fit: the set falls back anyway)
                 unsigned long long pdv = ~0ull;      // a byte per predecessor (the first eight), 255 = none / further than 254 rows
-                (void)npr;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (t < np[j]) { dst[t] = pr[j][t]; if (r - pr[j][t] <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr[j][t]) << (8 * t)); }
