@@ -494,6 +494,14 @@ void abpoa_hip_shutdown(void) {
 const char *abpoa_hip_last_error(void) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err_copy, g_err, sizeof(g_err)); return g_err_copy; }
 void abpoa_hip_get_stats(abpoa_hip_stats_t *out) { std::lock_guard<std::mutex> lk(g.stats_mu); *out = g.stats; }
 void abpoa_hip__dir_counts(long long *out) { out[0] = __atomic_exchange_n(&g_dir_counts[0], 0, __ATOMIC_RELAXED); out[1] = __atomic_exchange_n(&g_dir_counts[1], 0, __ATOMIC_RELAXED); }
+// (test hook, host only: the LDS carve-up of the wide row loop for a launch of n_aln alignments -- out: wide_nw, ring rows, LDS bytes per workgroup,
+//  workgroups per CU by the 1280-byte allocation granule of gfx950, the wide kernels' phase offset, the band half-widths [lo, hi] that take it)
+void abpoa_hip__wide_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int n_aln, int *out) {
+    abpoa_hip::LdsPlan L; const int pn = max_bits == 16 ? 16 : 8; const int w = sc->wb + (int)(sc->wf * (float)max_qlen);
+    abpoa_hip::make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>((int64_t)((max_qlen + pn) / pn) * pn, 2LL * w + 3 * pn + 32), n_aln, &L);
+    out[0] = L.wide_nw; out[1] = L.wfr_rows; out[2] = L.total_wide; out[3] = L.total_wide > 0 ? std::min(8, 128 / ((L.total_wide + 1279) / 1280)) : 0;
+    out[4] = L.w_phase_off; out[5] = L.wide_w_lo; out[6] = L.wide_w_hi;
+}
 void abpoa_hip__debug_clocks(long long *out) { for (int i = 0; i < 10; ++i) { out[i] = g_dbg[i]; g_dbg[i] = 0; } }
 void abpoa_hip_reset_stats(void) { std::lock_guard<std::mutex> lk(g.stats_mu); memset(&g.stats, 0, sizeof(g.stats)); }
 

@@ -55,6 +55,28 @@ def test_score_bits_matches_oracle_without_gpu():
         assert inf_a.value == inf_b.value
 
 
+def test_wide_loop_lds_plan_respects_the_allocation_granule():
+    """Host logic, no GPU: the LDS plan of the wide row loop.  gfx950 hands LDS out in pieces of 1280 bytes, 128 to a CU (tools/probes/lds_granule.hip), so
+    n workgroups share a CU only if each needs at most floor(128 / n) pieces; the plan takes the deepest score ring with which the whole launch is
+    resident, counting at most eight workgroups per CU, and the wide kernels' own carve-up packs the query two codes to a byte."""
+    lib = ffi.lib()
+    out = (C.c_int * 8)()
+    for kw in (dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2)):
+        sc = api.Params(**kw).scoring()
+        seen = {}
+        for bits in (16, 32):
+            for n_aln in (64, 256, 512, 768, 1024, 1100, 2048, 5000):
+                lib.abpoa_hip__wide_plan(C.byref(sc), 10100, bits, n_aln, out)
+                nw, rows, total, per_cu, wph, lo, hi = out[0], out[1], out[2], out[3], out[4], out[5], out[6]
+                assert nw == 1 and rows in (4, 8, 16) and lo <= 10 + 101 <= hi
+                assert per_cu >= 1 and ((total + 1279) // 1280) * per_cu <= 128, (kw, bits, n_aln, list(out))
+                assert per_cu * 256 >= min(n_aln, 2048) or rows == 4, (kw, bits, n_aln, list(out))      # resident, or the ring is as shallow as it gets
+                assert wph <= (10100 + 2) // 2 + 16 + 4 * sc.m * (sc.m + 1) + 32                               # 4-bit query codes
+                seen[(bits, n_aln)] = (rows, per_cu)
+        assert seen[(32, 1024)] == (8, 4) and seen[(32, 2048)] == (4, 8), seen      # 10 kb reads: four per CU with the 8-row ring, eight with the 4-row ring
+        assert seen[(32, 64)][0] == 16
+
+
 def test_no_device_fails_loudly():
     lib = ffi.lib()
     if lib.abpoa_hip_device_count() > 0:
