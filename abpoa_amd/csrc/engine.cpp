@@ -148,7 +148,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           // ring words per column of the wide kernels: as the narrow loop's, but two instead of three for convex int32 (rows_fast.h EPACK: E as 16-bit
           // differences to H, which needs gap-open + extend <= 65535)
           const int fww = (P == 5 && max_bits == 32) ? 2 : fw;
-          if (P == 5 && (sc->gap_open1 + sc->gap_ext1 > 65535 || sc->gap_open2 + sc->gap_ext2 > 65535)) L.wide_nw = 0;
+          if (P == 5 && (sc->gap_open1 + sc->gap_ext1 >= 65535 || sc->gap_open2 + sc->gap_ext2 >= 65535)) L.wide_nw = 0;      // (0xffff: "E is inf" in the compact spill records)
           L.wide_w_lo = 40; L.wide_w_hi = (L.wfr_cols - 2 * 8 - 1) / 2;
           { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
           const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");

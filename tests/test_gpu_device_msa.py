@@ -174,6 +174,9 @@ def test_device_driver_equals_oracle_backed_host_run(engine, monkeypatch, lockst
         (dict(), [(10 + i % 7, 300 + 130 * i, 0.12, (0.02, 0.08, 0.02) if i % 2 else (0.02, 0.02, 0.08)) for i in range(8)]),
         (dict(gap_open1=4, gap_open2=0, gap_ext1=2, extra_b=5, extra_f=0.02), [(16, 400 + 150 * i, 0.25, None) for i in range(6)]),
         (dict(gap_open1=6, gap_open2=30, gap_ext1=3, gap_ext2=1, extra_b=30, extra_f=0.03, match=3, mismatch=5), [(9 + i, 500 + 60 * i, 0.10, None) for i in range(6)]),
+        # penalties outside the direction words' range (o1 > 7): score-record arenas, on wide bands
+        (dict(gap_open1=20, gap_open2=60, gap_ext1=3, gap_ext2=1, extra_b=35, extra_f=0.02), [(7 + i, 600 + 90 * i, 0.12, None) for i in range(5)]),
+        (dict(gap_open1=9, gap_open2=0, gap_ext1=4, extra_b=40, extra_f=0.01), [(8, 700 + 50 * i, 0.08, (0.02, 0.03, 0.03)) for i in range(5)]),
     ]
     for kw, shapes in cases:
         sets = [synth.make_read_set(23, i, n, ln, err, rates=rt) for i, (n, ln, err, rt) in enumerate(shapes)]
