@@ -32,8 +32,19 @@ constexpr int DIR_TRI_SLACK = 9;
 constexpr int DIR_NA = -32768;
 struct __attribute__((aligned(16))) DirBt { int2 rec[DBTR]; int2 pd[DBTR]; int32_t stg[DBTR], rowA[DBTR]; };      // the walk's LDS image; the words follow
 
+// Two wavefronts on one walk (the all-rounds kernel, whose workgroups have three wavefronts idle during the backtrack): the MAIN wavefront (role 0) walks
+// from the best cell as always; a HELPER (role 1) starts at the same time from the arg-max cell of a row in the middle of the graph, in the state every
+// match step leaves behind (all operations allowed, indel_first 0), and walks to the end.  Backtracks that pass through the same cell in the same state
+// are identical from there on, and paths from neighbouring cells of a row run into each other within a few rows; both wavefronts note the cells of their
+// match runs in a table in LDS (row -> column | index of the cigar word), and when the main walk steps on a cell the helper has been on it stops:
+// the rest of its cigar is the helper's, from that word on.  No merge (the helper started on a branch the real path never touches): the main
+// wavefront simply walks to the end itself.  spec_ctl: eight ints of static LDS (hand-over flags and the helper's results); gen: the round, != 0.
+constexpr int SPEC_PM_ROWS = 512;      // rows below the helper's start row that the table covers
+// (what both wavefronts can tell before the row loop has finished: graphs of at least 768 rows; cigar indices and columns must fit the table's 16-bit fields)
+__device__ __forceinline__ bool dir_walk_pair(const DevBatch &b, const AlnDesc &d) { return d.n_rows >= 768 && d.cigar_cap < 65536 && d.qlen < 65536 && b.ret_cigar; }
 template <typename T, int GAP>
-__device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts) {
+__device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts, const int role = -1,
+                                                     int *spec_ctl = nullptr, const int gen = 0) {
     constexpr int PN = Width<T>::PN, CW = FastFmt<T, GAP>::CW, DB = DirFmt<T, GAP>::DB, S = (int)sizeof(T);
     constexpr int ALIGN = 16 / DB;                    // columns per 16-byte piece of a row of words
     constexpr int DBL = DB == 2 ? 1 : 2;
@@ -57,11 +68,26 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     const unsigned char *arena = (const unsigned char *)planes;
     int status = ts.status, best_score = ts.best_score, best_i = ts.best_i, best_j = ts.best_j, bt_steps = 0;
     WG_SYNC();       // all of this wave's arena / band stores have landed before the loads below
+    // ---- two wavefronts on the walk?
+    typedef __attribute__((address_space(3))) volatile int lds_vint_t;
+    const bool spec_static = role >= 0 && dir_walk_pair(b, d), spec = spec_static && status == 0;
+    const int R_g = spec ? (gn >> 1) : 0, R_lo = R_g - SPEC_PM_ROWS + 1;      // helper's start row (the middle: +-64 rows make no difference); the table covers rows [R_lo, R_g]
+    const int total_lds = b.lds.bt_off + b.lds.bt_bytes_tail;
+    const int half_lds = spec ? ((total_lds - SPEC_PM_ROWS * 4) >> 1) & ~15 : total_lds;      // each walk's share of the backtrack region; the table sits behind them
+    int *pm = (int *)(lds_raw + b.lds.phase_off + 2 * half_lds);
+    lds_vint_t *ctl = (lds_vint_t *)spec_ctl;
+    if (role == 1) {
+        // helper (it has waited for the main wavefront's "table is clear", which also says the row loop's stores have landed: fast_tail.h): the start cell
+        if (!spec) { if (spec_static) { if (lane == 0) ctl[2] = -1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ctl[1] = gen; } return; }
+        const int c_g = __builtin_amdgcn_readfirstlane(gld_i32(vgpr_ptr(b.row_max_i + d.row0) + R_g));
+        if (c_g < 1 || c_g > qlen) { if (lane == 0) ctl[2] = -1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ctl[1] = gen; return; }      // (no usable start: status -1 = "no helper")
+        best_i = R_g; best_j = c_g;
+    }
 
     // ------------------------------------------------------------------ global best, reference :1028-1041 (the sink's predecessors keep their score records)
     // (records of the wide kernel's spill rows are compact: rows_fast.h CWR)
     const int cwr = takes_wide(b, d) ? (sizeof(T) == 2 ? (GAP == 2 ? 4 : 2) : 2) : CW;
-    if (status == 0) {
+    if (status == 0 && role != 1) {
         // a lane per in-edge of the sink, 64 at a time (the three dependent loads of an edge are in flight for all of them together); the first maximum in
         // list order wins, as in the reference's loop with its strict ">"
         const int k0 = __builtin_amdgcn_readfirstlane(pred_off[gn - 1]), k1 = __builtin_amdgcn_readfirstlane(pred_off[gn]);
@@ -85,12 +111,21 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
     long long win_ticks = 0, walk_ticks = 0; int n_windows = 0, n_general = 0;
     long long dbg_why = 0, dbg_a = 0, dbg_b = 0;      // (dead end of the walk: where and on what, for AlnOut.seg under ABPOA_HIP_DBG bit 8)
+    if (spec_static && role == 0) {      // clear the table, then let the helper go (whatever the row loop's status: the helper waits for this)
+        for (int t = lane; t < SPEC_PM_ROWS; t += 64) pm[t] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) ctl[0] = gen;
+    }
     if (status == 0 && b.ret_cigar && d.cigar_cap < gn + qlen + 2) status = ABPOA_HIP_EBACKTRACK;      // (a walk emits at most one word per row or column it leaves: no per-step capacity test)
+    if (role == 1 && status != 0) { if (lane == 0) ctl[2] = -1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ctl[1] = gen; return; }
     if (status == 0 && b.ret_cigar) {
-        DirBt &B = *(DirBt *)(lds_raw + b.lds.phase_off);
-        unsigned char *win = lds_raw + b.lds.phase_off + (int)sizeof(DirBt);
-        const int win_bytes = b.lds.bt_off + b.lds.bt_bytes_tail - (int)sizeof(DirBt);
-        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off);
+        const int lds0 = b.lds.phase_off + (role == 1 ? half_lds : 0);
+        DirBt &B = *(DirBt *)(lds_raw + lds0);
+        unsigned char *win = lds_raw + lds0 + (int)sizeof(DirBt);
+        const int win_bytes = half_lds - (int)sizeof(DirBt);
+        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off + (role == 1 ? d.cigar_cap : 0));      // (the helper's words: the second half of the set's cigar slots)
+        GLOBAL_AS uint64_t *cg2 = vgpr_ptr(b.cigar + d.cigar_off + d.cigar_cap);
+        bool merged = false; int idx1 = 0;
         int w_lo = 1, w_hi = 0, w_cref = 0; bool w_tri = false;    // window = rows [w_lo, w_hi], empty at start; column origin of the AB values; column slices (not whole rows)?
         // ---- stage the window for a walk that stands at (hi, jtop); returns A of row hi
         auto load_window = [&](int hi, int jtop) __attribute__((always_inline)) -> int {
@@ -209,6 +244,16 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         auto flush_run = [&]() __attribute__((always_inline)) {
             if (run_n == 0) return;
             if (have_pending) { store_word(n_cigar - 1, last_word); have_pending = false; }
+            if (spec) {      // the cells of this run: noted (helper) or looked up (main)
+                const int row_ = lane < run_n ? runv : -1, col_ = run_j - lane, t_ = row_ - R_lo;
+                const bool inr = row_ >= 0 && (unsigned)t_ < (unsigned)SPEC_PM_ROWS;
+                if (role == 1) { if (inr) pm[t_] = col_ | ((n_cigar + lane) << 16); }
+                else {
+                    const int e_ = inr ? ((lds_vint_t *)pm)[t_] : 0;
+                    const unsigned long long hit_ = __ballot(inr && e_ != 0 && (e_ & 0xffff) == col_);
+                    if (hit_) { const int f_ = __builtin_ctzll(hit_); idx1 = (int)((unsigned)__builtin_amdgcn_readlane(e_, f_) >> 16); run_n = f_; merged = true; if (run_n == 0) return; }
+                }
+            }
             if (lane < run_n) cg[n_cigar + lane] = (uint64_t)(unsigned)runv << 34 | (uint64_t)(unsigned)(run_j - 1 - lane) << 4 | (uint64_t)ABPOA_HIP_CMATCH;
             // every cell a run passed must lie in its row's staged band (whole-row windows do not test it step by step; the rows of a run are all in the
             // current window: a run is flushed before the window changes): a cell outside is a dead end of the walk
@@ -218,8 +263,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             last_word = (uint64_t)ABPOA_HIP_CMATCH;            // (the last word so far is a match: the next insertion starts a word of its own)
         };
 
-        int i = sgpr(best_i), j = sgpr(best_j), start_i = i, start_j = j, cur_op = OP_ALL, indel_first = 1, pend = 0;
-        if (j < qlen) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
+        int i = sgpr(best_i), j = sgpr(best_j), start_i = i, start_j = j, cur_op = OP_ALL, indel_first = role == 1 ? 0 : 1, pend = 0;
+        if (j < qlen && role != 1) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
         const long long t_walk0 = (long long)__builtin_amdgcn_s_memtime();
         const int win_a = (int)(unsigned)(size_t)(lds_byte_t *)win, rec_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.rec;      // LDS byte addresses
         const int stg_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.stg;
@@ -228,10 +273,10 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         auto lds_r = [&](int addr) __attribute__((always_inline)) { const v2i_t v = *(const lds_i2_t *)(size_t)(unsigned)addr; return make_int2(v.x, v.y); };
         int Ai = 0; bool reloaded = false, restage = true;        // A of row i; restage: row i is not (known to be) in the window
         while (i > 0 && j > 0 && status == 0) {
-            if (restage || i > w_hi || i < w_lo) { flush_run(); Ai = load_window(i, j); restage = false; reloaded = true; }
+            if (restage || i > w_hi || i < w_lo) { flush_run(); if (merged) break; Ai = load_window(i, j); restage = false; reloaded = true; }
             // ---- match run: while a match is what the reference tries first (M allowed, indel_first == 0) and the word names one of the first two predecessors
             if ((cur_op & OP_M) && indel_first == 0 && pend == 0) {
-                if (run_n == 64) flush_run();
+                if (run_n == 64) { flush_run(); if (merged) break; }
                 if (run_n == 0) run_j = j;
                 int recp = rec_a + ((i - w_lo) << 3), wb = win_a + ((j - w_cref) << DBL), budget = imin(64 - run_n, j);
                 const int n0 = run_n;
@@ -263,7 +308,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             }
             // ---- full step: any state, the reference's priority order (:109-429) decided from the words (oracle/dir_model.c)
             flush_run(); ++n_general;
-            if (status != 0) break;
+            if (status != 0 || merged) break;
             const int stw = __builtin_amdgcn_readfirstlane(B.stg[i - w_lo]);
             const int2 pd2 = uniform2(B.pd[i - w_lo]);
             const int sli = stw & 0x7fff, cut = (stw >> 15) & 1, nsi = (int)((unsigned)stw >> 16), si = j - sli;
@@ -343,8 +388,24 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         walk_ticks = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {
             flush_run();
-            if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1);
-            if (have_pending) store_word(n_cigar - 1, last_word);
+            if (!merged) { if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1); if (have_pending) store_word(n_cigar - 1, last_word); }
+        }
+        if (role == 1) {      // helper: publish where its walk ended and leave (the main wavefront writes the result)
+            WG_SYNC();
+            if (lane == 0) { ctl[2] = status; ctl[3] = n_cigar; ctl[4] = j; ctl[5] = start_i; ctl[6] = start_j; ctl[7] = bt_steps; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) ctl[1] = gen;
+            return;
+        }
+        int n0 = n_cigar;      // words of this wavefront's own walk
+        if (status == 0 && merged) {      // the rest is the helper's: wait for it, take over its end state
+            while (ctl[1] != gen) __builtin_amdgcn_s_sleep(4);
+            const int hs = ctl[2];
+            if (hs != 0) status = hs;      // (the helper met it on the common path: so would this walk have)
+            else { n_cigar = n0 + ctl[3] - idx1; j = ctl[4]; start_i = ctl[5]; start_j = ctl[6]; bt_steps += ctl[7]; }
+        }
+        if (status == 0) {
+            n_aln = best_j - j;      // (every match and insertion step takes one query base, a deletion none)
             WG_SYNC();
             // ---- final pass, a lane per word: row -> node id, matched bases, reversal (reference abpoa_reverse_cigar, abpoa_align.h:88-96)
             GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
@@ -357,15 +418,16 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             };
             int nm = 0;
             const int half = n_cigar >> 1;
+            auto rd = [&](int k_) __attribute__((always_inline)) -> uint64_t { return k_ < n0 ? cg[k_] : cg2[idx1 + (k_ - n0)]; };      // (merged walks: the helper's words follow this wavefront's)
             for (int k = lane; k < half; k += 128) {      // (two pairs of words per lane and turn: their loads -- the words, then node id and base by row -- overlap)
                 const int k2 = k + 64; const bool v2 = k2 < half;
-                uint64_t wa = cg[k], wc = cg[n_cigar - 1 - k], wa2 = v2 ? cg[k2] : 0, wc2 = v2 ? cg[n_cigar - 1 - k2] : 0;
+                uint64_t wa = rd(k), wc = rd(n_cigar - 1 - k), wa2 = v2 ? rd(k2) : 0, wc2 = v2 ? rd(n_cigar - 1 - k2) : 0;
                 const uint64_t a = fix(wa, nm), c_ = fix(wc, nm);
                 if (b.rev_cigar) { cg[k] = a; cg[n_cigar - 1 - k] = c_; } else { cg[k] = c_; cg[n_cigar - 1 - k] = a; }
                 if (v2) { const uint64_t a2 = fix(wa2, nm), c2 = fix(wc2, nm);
                           if (b.rev_cigar) { cg[k2] = a2; cg[n_cigar - 1 - k2] = c2; } else { cg[k2] = c2; cg[n_cigar - 1 - k2] = a2; } }
             }
-            if ((n_cigar & 1) && lane == 0) cg[half] = fix(cg[half], nm);
+            if ((n_cigar & 1) && lane == 0) cg[half] = fix(rd(half), nm);
             n_match = __builtin_amdgcn_readlane(wave_scan_add_i32(nm), 63);
             node_e = row_node_id[best_i]; query_e = best_j - 1;
             node_s = row_node_id[start_i]; query_s = start_j - 1;

@@ -44,11 +44,13 @@ __device__ __noinline__ long long rounds_rows(const int slot, const int s_) {
     align_fast_rows<T, GAP, 1, false, DIR>(b, d, b.out + s);
     return (long long)__builtin_amdgcn_s_memtime();
 }
+// role 0: the wavefront that ran the row loop; role 1: a second wavefront of the workgroup that walks the lower half of the graph at the same time
+// (backtrack_dir.h); ctl: eight ints of static LDS; gen: the round
 template <typename T, int GAP, bool DIR>
-__device__ __noinline__ void rounds_tail(const int slot, const int s_) {
+__device__ __noinline__ void rounds_tail(const int slot, const int s_, const int role_, int *ctl, const int gen_) {
     const DevBatch &b = g_rounds[UNI(slot)].b; const int s = UNI(s_);
     const AlnDesc d = uniform_desc(b.aln + s);
-    align_fast_tail<T, GAP, DIR>(b, d, b.out + s);
+    align_fast_tail<T, GAP, DIR>(b, d, b.out + s, UNI(role_), ctl, UNI(gen_));
 }
 
 template <int GAP>
@@ -62,7 +64,8 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
     // Which wavefront runs the one-wave phases.  A workgroup's four wavefronts sit on the four SIMDs of its CU; if it were always wavefront 0, the
     // four workgroups of a CU would run their row loops on the same SIMD while the other three idle.  Each workgroup draws a ticket from a per-CU
     // counter and the wavefront on SIMD (ticket mod 4) does the work.
-    __shared__ int sh_simd[GW], sh_target;
+    __shared__ int sh_simd[GW], sh_target, sh_walk[8];      // sh_walk: hand-over between the two wavefronts of a backtrack
+    if (tid < 8) sh_walk[tid] = 0;
     {
         const unsigned hwid = __builtin_amdgcn_s_getreg(63492);      // HW_REG_HW_ID: simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]
         if ((tid & 63) == 0) sh_simd[tid >> 6] = (int)((hwid >> 4) & 3);
@@ -73,6 +76,8 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
     int worker = 0;
 #pragma unroll
     for (int w_ = GW - 1; w_ >= 0; --w_) if (sh_simd[w_] == sh_target) worker = w_;
+    const int helper = (worker + 2) & (GW - 1);      // the backtrack's second wavefront (another SIMD of the CU)
+    const bool pair = !(b.dbg & 1024);               // (ABPOA_HIP_DBG bit 10: one wavefront per backtrack, for comparison)
     for (int k = k_lo; k < n_reads; ++k) {
         const long long c0 = (long long)__builtin_amdgcn_s_memtime();
         rounds_prepare(slot, s, k);
@@ -84,11 +89,16 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
             const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags;
             if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {      // (the host launches this kernel only for jobs whose reads all take the narrow loop)
                 if (b.dir_mode) {
-                    if (bits == 16) { c2 = rounds_rows<int16_t, GAP, true>(slot, s); rounds_tail<int16_t, GAP, true>(slot, s); }
-                    else { c2 = rounds_rows<int32_t, GAP, true>(slot, s); rounds_tail<int32_t, GAP, true>(slot, s); }
-                } else if (bits == 16) { c2 = rounds_rows<int16_t, GAP, false>(slot, s); rounds_tail<int16_t, GAP, false>(slot, s); }
-                else { c2 = rounds_rows<int32_t, GAP, false>(slot, s); rounds_tail<int32_t, GAP, false>(slot, s); }
+                    if (bits == 16) { c2 = rounds_rows<int16_t, GAP, true>(slot, s); rounds_tail<int16_t, GAP, true>(slot, s, pair ? 0 : -1, sh_walk, k); }
+                    else { c2 = rounds_rows<int32_t, GAP, true>(slot, s); rounds_tail<int32_t, GAP, true>(slot, s, pair ? 0 : -1, sh_walk, k); }
+                } else if (bits == 16) { c2 = rounds_rows<int16_t, GAP, false>(slot, s); rounds_tail<int16_t, GAP, false>(slot, s, -1, sh_walk, k); }
+                else { c2 = rounds_rows<int32_t, GAP, false>(slot, s); rounds_tail<int32_t, GAP, false>(slot, s, -1, sh_walk, k); }
             } else if ((tid & 63) == 0) b.out[s].status = ABPOA_HIP_EINVAL;       // -> poa_fuse_body marks the set for the fall-back
+        } else if ((tid >> 6) == helper && b.dir_mode && pair) {
+            const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags;
+            if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {
+                if (bits == 16) rounds_tail<int16_t, GAP, true>(slot, s, 1, sh_walk, k); else rounds_tail<int32_t, GAP, true>(slot, s, 1, sh_walk, k);
+            }
         }
         __syncthreads();                                    // graph cigar and result record are complete
         const long long c3 = (long long)__builtin_amdgcn_s_memtime();

@@ -39,6 +39,9 @@ def engine():
     ("affine_15pct", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (24, 20, 300, 0.15)),
     ("convex_default", dict(), (24, 12, 500, 0.10)),
     ("ragged_tiny", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (16, 5, 40, 0.05)),
+    # graphs of 1000+ rows: in the all-rounds kernel two wavefronts share the backtrack (backtrack_dir.h)
+    ("affine_1kb", dict(gap_open1=4, gap_open2=0, gap_ext1=2), (24, 14, 1000, 0.06)),
+    ("convex_1kb_noisy", dict(), (16, 12, 1100, 0.14)),
 ])
 @pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
 def test_device_driver_equals_host_driver(engine, monkeypatch, name, kw, shape, lockstep):
