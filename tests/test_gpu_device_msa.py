@@ -106,6 +106,25 @@ def test_mixed_band_widths_in_one_job(engine, monkeypatch, env, kw):
         assert a.n_cells == b.n_cells == c.n_cells, f"{env}: DP cell count of set {i} differs"
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2)], ids=["convex", "affine"])
+def test_two_wavefronts_on_a_backtrack_change_nothing(engine, monkeypatch, kw):
+    """All-rounds kernel, graphs of 800-3000 rows: the backtrack shared by two wavefronts (the helper starts mid-graph and the main walk takes over its
+    cigar where the two meet, backtrack_dir.h) against one wavefront per backtrack (ABPOA_HIP_DBG bit 10) and against the host driver: consensus,
+    coverage and DP cell counts of 64 read-sets with 3-20 % errors, deletion- and insertion-heavy mixes, 8-25 reads."""
+    from abpoa_amd import api, ffi, synth
+    shapes = [(8 + (7 * i) % 18, 800 + 137 * (i % 13), 0.03 + 0.017 * (i % 11), None if i % 3 == 0 else ((0.02, 0.09, 0.02) if i % 3 == 1 else (0.02, 0.02, 0.09))) for i in range(64)]
+    sets = [synth.make_read_set(41, i, n, ln, err, rates=rt) for i, (n, ln, err, rt) in enumerate(shapes)]
+    p = api.Params(**kw)
+    engine.abpoa_hip_reset_stats()
+    host, two, tm = _both(sets, p)
+    assert tm["pad"] == 0 and ffi.stats()["rounds_launches"] > 0
+    monkeypatch.setenv("ABPOA_HIP_DBG", "1024")
+    one = api.msa_batch(sets, p, n_threads=8)
+    for i, (a, b, c) in enumerate(zip(two, one, host)):
+        assert a.status == 0 and b.status == 0 and c.status == 0
+        assert a.cons_seq == b.cons_seq == c.cons_seq and a.cons_cov == b.cons_cov == c.cons_cov and a.n_cells == b.n_cells == c.n_cells, f"set {i} {shapes[i]}"
+
+
 def test_device_graph_equals_host_graph_after_every_read(engine):
     """Runs in a child process because the check mode is chosen by an environment variable at call time and prints to stderr."""
     code = ("import os,sys; sys.path.insert(0, %r)\n"
