@@ -30,7 +30,8 @@ namespace abpoa_hip {
 constexpr int DBTR = 256;     // most rows of a window
 constexpr int DIR_TRI_SLACK = 9;
 constexpr int DIR_NA = -32768;
-struct __attribute__((aligned(16))) DirBt { int2 rec[DBTR]; int2 pd[DBTR]; int32_t stg[DBTR], rowA[DBTR]; };      // the walk's LDS image; the words follow
+template <int R> struct __attribute__((aligned(16))) DirBtT { int2 rec[R]; int2 pd[R]; int32_t stg[R], rowA[R]; };      // the walk's LDS image (R rows at most in a window); the words follow
+typedef DirBtT<DBTR> DirBt;
 
 // Two wavefronts on one walk (the all-rounds kernel, whose workgroups have three wavefronts idle during the backtrack): the MAIN wavefront (role 0) walks
 // from the best cell as always; a HELPER (role 1) starts at the same time from the arg-max cell of a row in the middle of the graph, in the state every
@@ -39,16 +40,22 @@ struct __attribute__((aligned(16))) DirBt { int2 rec[DBTR]; int2 pd[DBTR]; int32
 // match runs in a table in LDS (row -> column | index of the cigar word), and when the main walk steps on a cell the helper has been on it stops:
 // the rest of its cigar is the helper's, from that word on.  No merge (the helper started on a branch the real path never touches): the main
 // wavefront simply walks to the end itself.  spec_ctl: eight ints of static LDS (hand-over flags and the helper's results); gen: the round, != 0.
-constexpr int SPEC_PM_ROWS = 512;      // rows below the helper's start row that the table covers
+constexpr int SPEC_PM_ROWS = 256;      // rows below a helper's start row that its table covers
+constexpr int SPEC_WK = 4;             // wavefronts on a walk: the main one and three helpers, which start at 3/4, 1/2 and 1/4 of the graph
 // (what both wavefronts can tell before the row loop has finished: graphs of at least 768 rows; cigar indices and columns must fit the table's 16-bit fields)
 __device__ __forceinline__ bool dir_walk_pair(const DevBatch &b, const AlnDesc &d) { return d.n_rows >= 768 && d.cigar_cap < 65536 && d.qlen < 65536 && b.ret_cigar; }
-template <typename T, int GAP>
+// More than one helper: helper r notes its cells in table r and looks the cells of its own runs up in the table of the next wavefront down whose rows it has
+// reached, exactly as the main wavefront does; the cigar is then a chain -- main, then from the word where main met helper a on, then from where a met b ...
+// spec_ctl: 8 ints per wavefront (ints 0..7: [0] = "tables are clear", set by the main wavefront; helper r: [8r] done, status, words, j, start_i, start_j,
+// steps, met << 16 | index -- -1: walked to the end).  DBR: rows a window holds at most (64 per wavefront when four share the backtrack's LDS).
+template <typename T, int GAP, int DBR = DBTR>
 __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const TailState &ts, const int role = -1,
                                                      int *spec_ctl = nullptr, const int gen = 0) {
     constexpr int PN = Width<T>::PN, CW = FastFmt<T, GAP>::CW, DB = DirFmt<T, GAP>::DB, S = (int)sizeof(T);
     constexpr int ALIGN = 16 / DB;                    // columns per 16-byte piece of a row of words
     constexpr int DBL = DB == 2 ? 1 : 2;
-    constexpr int NQ = DBTR / 64;
+    constexpr int NQ = DBR / 64;
+    typedef DirBtT<DBR> DirBt;
     typedef typename std::conditional<GAP == 1, uint16_t, uint32_t>::type DW;
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     typedef __attribute__((address_space(3))) DW lds_dw_t;
@@ -71,23 +78,26 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     // ---- two wavefronts on the walk?
     typedef __attribute__((address_space(3))) volatile int lds_vint_t;
     const bool spec_static = role >= 0 && dir_walk_pair(b, d), spec = spec_static && status == 0;
-    const int R_g = spec ? (gn >> 1) : 0, R_lo = R_g - SPEC_PM_ROWS + 1;      // helper's start row (the middle: +-64 rows make no difference); the table covers rows [R_lo, R_g]
+    auto start_row = [&](int r_) __attribute__((always_inline)) { return (int)(((long long)gn * (SPEC_WK - r_)) / SPEC_WK); };      // helper r starts at row gn (4 - r) / 4; its table covers the 256 rows below
+    const int R_g = spec && role >= 1 ? start_row(role) : 0, R_lo = R_g - SPEC_PM_ROWS + 1;
     const int total_lds = b.lds.bt_off + b.lds.bt_bytes_tail;
-    const int half_lds = spec ? ((total_lds - SPEC_PM_ROWS * 4) >> 1) & ~15 : total_lds;      // each walk's share of the backtrack region; the table sits behind them
-    int *pm = (int *)(lds_raw + b.lds.phase_off + 2 * half_lds);
-    lds_vint_t *ctl = (lds_vint_t *)spec_ctl;
-    if (role == 1) {
-        // helper (it has waited for the main wavefront's "table is clear", which also says the row loop's stores have landed: fast_tail.h): the start cell
-        if (!spec) { if (spec_static) { if (lane == 0) ctl[2] = -1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ctl[1] = gen; } return; }
+    const int half_lds = spec_static ? ((total_lds - (SPEC_WK - 1) * SPEC_PM_ROWS * 4) / SPEC_WK) & ~15 : total_lds;      // each walk's share of the backtrack region; the tables sit behind them
+    int *pm_all = (int *)(lds_raw + b.lds.phase_off + SPEC_WK * half_lds);      // table of helper r: pm_all + (r - 1) * SPEC_PM_ROWS
+    int *pm = pm_all + (role >= 1 ? role - 1 : 0) * SPEC_PM_ROWS;
+    lds_vint_t *ctl = (lds_vint_t *)spec_ctl, *my = ctl + 8 * (role > 0 ? role : 0);
+    auto helper_out = [&](int st_) __attribute__((always_inline)) { if (lane == 0) my[1] = st_; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) my[0] = gen; };
+    if (role >= 1) {
+        // helper (it has waited for the main wavefront's "tables are clear", which also says the row loop's stores have landed: fast_tail.h): the start cell
+        if (!spec) { if (spec_static) helper_out(-1); return; }
         const int c_g = __builtin_amdgcn_readfirstlane(gld_i32(vgpr_ptr(b.row_max_i + d.row0) + R_g));
-        if (c_g < 1 || c_g > qlen) { if (lane == 0) ctl[2] = -1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ctl[1] = gen; return; }      // (no usable start: status -1 = "no helper")
+        if (c_g < 1 || c_g > qlen) { helper_out(-1); return; }      // (no usable start: status -1 = "no helper")
         best_i = R_g; best_j = c_g;
     }
 
     // ------------------------------------------------------------------ global best, reference :1028-1041 (the sink's predecessors keep their score records)
     // (records of the wide kernel's spill rows are compact: rows_fast.h CWR)
     const int cwr = takes_wide(b, d) ? (sizeof(T) == 2 ? (GAP == 2 ? 4 : 2) : 2) : CW;
-    if (status == 0 && role != 1) {
+    if (status == 0 && role < 1) {
         // a lane per in-edge of the sink, 64 at a time (the three dependent loads of an edge are in flight for all of them together); the first maximum in
         // list order wins, as in the reference's loop with its strict ">"
         const int k0 = __builtin_amdgcn_readfirstlane(pred_off[gn - 1]), k1 = __builtin_amdgcn_readfirstlane(pred_off[gn]);
@@ -111,21 +121,21 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     int n_cigar = 0, node_s = 0, node_e = 0, query_s = 0, query_e = 0, n_aln = 0, n_match = 0;
     long long win_ticks = 0, walk_ticks = 0; int n_windows = 0, n_general = 0;
     long long dbg_why = 0, dbg_a = 0, dbg_b = 0;      // (dead end of the walk: where and on what, for AlnOut.seg under ABPOA_HIP_DBG bit 8)
-    if (spec_static && role == 0) {      // clear the table, then let the helper go (whatever the row loop's status: the helper waits for this)
-        for (int t = lane; t < SPEC_PM_ROWS; t += 64) pm[t] = 0;
+    if (spec_static && role == 0) {      // clear the tables, then let the helpers go (whatever the row loop's status: they wait for this)
+        for (int t = lane; t < (SPEC_WK - 1) * SPEC_PM_ROWS; t += 64) pm_all[t] = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) ctl[0] = gen;
     }
     if (status == 0 && b.ret_cigar && d.cigar_cap < gn + qlen + 2) status = ABPOA_HIP_EBACKTRACK;      // (a walk emits at most one word per row or column it leaves: no per-step capacity test)
-    if (role == 1 && status != 0) { if (lane == 0) ctl[2] = -1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) ctl[1] = gen; return; }
+    if (role >= 1 && status != 0) { helper_out(-1); return; }
     if (status == 0 && b.ret_cigar) {
-        const int lds0 = b.lds.phase_off + (role == 1 ? half_lds : 0);
+        const int lds0 = b.lds.phase_off + (role >= 1 ? role * half_lds : 0);
         DirBt &B = *(DirBt *)(lds_raw + lds0);
         unsigned char *win = lds_raw + lds0 + (int)sizeof(DirBt);
         const int win_bytes = half_lds - (int)sizeof(DirBt);
-        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off + (role == 1 ? d.cigar_cap : 0));      // (the helper's words: the second half of the set's cigar slots)
-        GLOBAL_AS uint64_t *cg2 = vgpr_ptr(b.cigar + d.cigar_off + d.cigar_cap);
-        bool merged = false; int idx1 = 0;
+        GLOBAL_AS uint64_t *cg = vgpr_ptr(b.cigar + d.cigar_off + (role >= 1 ? (long long)role * d.cigar_cap : 0));      // (helper r's words: part r of the set's cigar slots)
+        bool merged = false; int idx1 = 0, met = 0;      // met: the helper whose path this walk ran into; idx1: index of the cigar word of the cell where
+        int t_next = (role > 0 ? role : 0) + 1;        // the next helper down whose table this walk may look its cells up in
         int w_lo = 1, w_hi = 0, w_cref = 0; bool w_tri = false;    // window = rows [w_lo, w_hi], empty at start; column origin of the AB values; column slices (not whole rows)?
         // ---- stage the window for a walk that stands at (hi, jtop); returns A of row hi
         auto load_window = [&](int hi, int jtop) __attribute__((always_inline)) -> int {
@@ -244,15 +254,18 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         auto flush_run = [&]() __attribute__((always_inline)) {
             if (run_n == 0) return;
             if (have_pending) { store_word(n_cigar - 1, last_word); have_pending = false; }
-            if (spec) {      // the cells of this run: noted (helper) or looked up (main)
-                const int row_ = lane < run_n ? runv : -1, col_ = run_j - lane, t_ = row_ - R_lo;
-                const bool inr = row_ >= 0 && (unsigned)t_ < (unsigned)SPEC_PM_ROWS;
-                if (role == 1) { if (inr) pm[t_] = col_ | ((n_cigar + lane) << 16); }
-                else {
-                    const int e_ = inr ? ((lds_vint_t *)pm)[t_] : 0;
-                    const unsigned long long hit_ = __ballot(inr && e_ != 0 && (e_ & 0xffff) == col_);
-                    if (hit_) { const int f_ = __builtin_ctzll(hit_); idx1 = (int)((unsigned)__builtin_amdgcn_readlane(e_, f_) >> 16); run_n = f_; merged = true; if (run_n == 0) return; }
+            if (spec) {      // the cells of this run: looked up in the table of the next helper down, noted in this helper's own
+                const int row_ = lane < run_n ? runv : -1, col_ = run_j - lane;
+                const int row_first = __builtin_amdgcn_readlane(runv, 0);      // (the highest row of the run)
+                while (t_next < SPEC_WK && row_first < start_row(t_next) - SPEC_PM_ROWS + 1) ++t_next;      // (the whole run is below that table)
+                if (t_next < SPEC_WK) {
+                    const int tl_ = row_ - (start_row(t_next) - SPEC_PM_ROWS + 1);
+                    const bool in2 = row_ >= 0 && (unsigned)tl_ < (unsigned)SPEC_PM_ROWS;
+                    const int e_ = in2 ? ((lds_vint_t *)(pm_all + (t_next - 1) * SPEC_PM_ROWS))[tl_] : 0;
+                    const unsigned long long hit_ = __ballot(in2 && e_ != 0 && (e_ & 0xffff) == col_);
+                    if (hit_) { const int f_ = __builtin_ctzll(hit_); idx1 = (int)((unsigned)__builtin_amdgcn_readlane(e_, f_) >> 16); met = t_next; run_n = f_; merged = true; if (run_n == 0) return; }
                 }
+                if (role >= 1) { const int t_ = row_ - R_lo; if (lane < run_n && (unsigned)t_ < (unsigned)SPEC_PM_ROWS) pm[t_] = col_ | ((n_cigar + lane) << 16); }
             }
             if (lane < run_n) cg[n_cigar + lane] = (uint64_t)(unsigned)runv << 34 | (uint64_t)(unsigned)(run_j - 1 - lane) << 4 | (uint64_t)ABPOA_HIP_CMATCH;
             // every cell a run passed must lie in its row's staged band (whole-row windows do not test it step by step; the rows of a run are all in the
@@ -263,8 +276,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             last_word = (uint64_t)ABPOA_HIP_CMATCH;            // (the last word so far is a match: the next insertion starts a word of its own)
         };
 
-        int i = sgpr(best_i), j = sgpr(best_j), start_i = i, start_j = j, cur_op = OP_ALL, indel_first = role == 1 ? 0 : 1, pend = 0;
-        if (j < qlen && role != 1) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
+        int i = sgpr(best_i), j = sgpr(best_j), start_i = i, start_j = j, cur_op = OP_ALL, indel_first = role >= 1 ? 0 : 1, pend = 0;
+        if (j < qlen && role < 1) push(ABPOA_HIP_CINS, qlen - j, -1, qlen - 1);
         const long long t_walk0 = (long long)__builtin_amdgcn_s_memtime();
         const int win_a = (int)(unsigned)(size_t)(lds_byte_t *)win, rec_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.rec;      // LDS byte addresses
         const int stg_a = (int)(unsigned)(size_t)(lds_byte_t *)(unsigned char *)B.stg;
@@ -390,19 +403,34 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             flush_run();
             if (!merged) { if (j > 0) push(ABPOA_HIP_CINS, j, -1, j - 1); if (have_pending) store_word(n_cigar - 1, last_word); }
         }
-        if (role == 1) {      // helper: publish where its walk ended and leave (the main wavefront writes the result)
+        if (role >= 1) {      // helper: publish where its walk ended (or whom it met) and leave (the main wavefront writes the result)
             WG_SYNC();
-            if (lane == 0) { ctl[2] = status; ctl[3] = n_cigar; ctl[4] = j; ctl[5] = start_i; ctl[6] = start_j; ctl[7] = bt_steps; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) ctl[1] = gen;
+            if (lane == 0) { my[2] = n_cigar; my[3] = j; my[4] = start_i; my[5] = start_j; my[6] = bt_steps; my[7] = (status == 0 && merged) ? ((met << 16) | idx1) : -1; }
+            helper_out(status);
             return;
         }
-        int n0 = n_cigar;      // words of this wavefront's own walk
-        if (status == 0 && merged) {      // the rest is the helper's: wait for it, take over its end state
-            while (ctl[1] != gen) __builtin_amdgcn_s_sleep(4);
-            const int hs = ctl[2];
-            if (hs != 0) status = hs;      // (the helper met it on the common path: so would this walk have)
-            else { n_cigar = n0 + ctl[3] - idx1; j = ctl[4]; start_i = ctl[5]; start_j = ctl[6]; bt_steps += ctl[7]; }
+        // the chain of walks: segment q = words [seg_off[q], seg_off[q] + seg_len[q]) of wavefront seg_wk[q]
+        int seg_wk[SPEC_WK], seg_off[SPEC_WK], seg_len[SPEC_WK], n_seg = 1;
+        seg_wk[0] = 0; seg_off[0] = 0; seg_len[0] = n_cigar;
+#pragma unroll
+        for (int q = 1; q < SPEC_WK; ++q) { seg_wk[q] = 0; seg_off[q] = 0; seg_len[q] = 0; }
+        if (status == 0 && merged) {      // the rest is the helpers': wait for each in turn, take over the end state of the last
+            int nxt = met, from = idx1;
+#pragma unroll
+            for (int q = 1; q < SPEC_WK; ++q) {
+                if (nxt <= 0 || status != 0) continue;
+                lds_vint_t *h = ctl + 8 * nxt;
+                while (h[0] != gen) __builtin_amdgcn_s_sleep(4);
+                const int hs = h[1];
+                if (hs != 0) { status = hs; continue; }      // (the helper met it on the common path: so would this walk have)
+                seg_wk[q] = nxt; seg_off[q] = from; seg_len[q] = h[2] - from; n_seg = q + 1;
+                j = h[3]; start_i = h[4]; start_j = h[5]; bt_steps += h[6];
+                const int mm = h[7];
+                if (mm >= 0) { nxt = mm >> 16; from = mm & 0xffff; } else nxt = 0;
+            }
+            if (status == 0) { n_cigar = 0;
+#pragma unroll
+                for (int q = 0; q < SPEC_WK; ++q) n_cigar += seg_len[q]; }
         }
         if (status == 0) {
             n_aln = best_j - j;      // (every match and insertion step takes one query base, a deletion none)
@@ -418,7 +446,13 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             };
             int nm = 0;
             const int half = n_cigar >> 1;
-            auto rd = [&](int k_) __attribute__((always_inline)) -> uint64_t { return k_ < n0 ? cg[k_] : cg2[idx1 + (k_ - n0)]; };      // (merged walks: the helper's words follow this wavefront's)
+            static_assert(SPEC_WK == 4, "the chain below is written out for four segments");
+            const int c0_ = seg_len[0], c1_ = c0_ + seg_len[1], c2_ = c1_ + seg_len[2];      // (segments that do not exist are empty)
+            const long long p1_ = (long long)seg_wk[1] * d.cigar_cap + seg_off[1] - c0_, p2_ = (long long)seg_wk[2] * d.cigar_cap + seg_off[2] - c1_, p3_ = (long long)seg_wk[3] * d.cigar_cap + seg_off[3] - c2_;
+            auto rd = [&](int k_) __attribute__((always_inline)) -> uint64_t {      // (a chain of walks: the words of the helpers follow this wavefront's)
+                const long long at_ = k_ < c0_ ? (long long)k_ : (k_ < c1_ ? p1_ + k_ : (k_ < c2_ ? p2_ + k_ : p3_ + k_));
+                return cg[at_];
+            };
             for (int k = lane; k < half; k += 128) {      // (two pairs of words per lane and turn: their loads -- the words, then node id and base by row -- overlap)
                 const int k2 = k + 64; const bool v2 = k2 < half;
                 uint64_t wa = rd(k), wc = rd(n_cigar - 1 - k), wa2 = v2 ? rd(k2) : 0, wc2 = v2 ? rd(n_cigar - 1 - k2) : 0;

@@ -12,7 +12,7 @@ namespace abpoa_hip {
 template <typename T, int GAP, bool DIR = false>
 __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec, const int role = -1, int *spec_ctl = nullptr, const int gen = 0) {
     const int lane = threadIdx.x & 63;
-    if (role == 1) {      // helper: only where a pair walks, and not before the main wavefront has finished the row loop and cleared the table
+    if (role >= 1) {      // helper: only where several wavefronts walk, and not before the main wavefront has finished the row loop and cleared the table
         if (!(DIR && takes_dir(b, d) && dir_walk_pair(b, d))) return;
         typedef __attribute__((address_space(3))) volatile int lds_vint_t;
         while (((lds_vint_t *)spec_ctl)[0] != gen) __builtin_amdgcn_s_sleep(4);
@@ -30,7 +30,11 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
     WG_SYNC();
     // (DIR: a launch in dir_mode -- its narrow-band alignments left direction words, its wide-band ones score records)
-    if constexpr (DIR) { if (takes_dir(b, d)) finish_alignment_dir<T, GAP>(b, d, out_rec, ts, role, spec_ctl, gen); else finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts); }
+    if constexpr (DIR) {
+        if (!takes_dir(b, d)) finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
+        else if (role >= 0 && dir_walk_pair(b, d)) finish_alignment_dir<T, GAP, 64>(b, d, out_rec, ts, role, spec_ctl, gen);      // (several wavefronts on the walk: windows of 64 rows each)
+        else if (role <= 0) finish_alignment_dir<T, GAP>(b, d, out_rec, ts);
+    }
     else finish_alignment<T, GAP, FastFmt<T, GAP>::CW>(b, d, out_rec, ts);
 }
 

@@ -190,7 +190,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         S.read0 = read_i; read_i += sets[s].n_reads;
         S.node0 = node_tot; node_tot += cap + 1;
         S.pred0 = pred_tot; pred_tot += S.pred_cap;
-        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += 2 * (int64_t)S.cigar_cap;      // (twice: the second half takes the words of the backtrack's second wavefront, backtrack_dir.h)
+        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += 4 * (int64_t)S.cigar_cap;      // (four times: parts 1-3 take the words of the backtrack's helper wavefronts, backtrack_dir.h SPEC_WK)
         S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + cap + 1;
         S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
         const int w = sc->wb + (int)(sc->wf * (float)mx);

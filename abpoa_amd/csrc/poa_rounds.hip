@@ -64,8 +64,8 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
     // Which wavefront runs the one-wave phases.  A workgroup's four wavefronts sit on the four SIMDs of its CU; if it were always wavefront 0, the
     // four workgroups of a CU would run their row loops on the same SIMD while the other three idle.  Each workgroup draws a ticket from a per-CU
     // counter and the wavefront on SIMD (ticket mod 4) does the work.
-    __shared__ int sh_simd[GW], sh_target, sh_walk[8];      // sh_walk: hand-over between the two wavefronts of a backtrack
-    if (tid < 8) sh_walk[tid] = 0;
+    __shared__ int sh_simd[GW], sh_target, sh_walk[8 * SPEC_WK];      // sh_walk: hand-over between the wavefronts of a backtrack
+    if (tid < 8 * SPEC_WK) sh_walk[tid] = 0;
     {
         const unsigned hwid = __builtin_amdgcn_s_getreg(63492);      // HW_REG_HW_ID: simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]
         if ((tid & 63) == 0) sh_simd[tid >> 6] = (int)((hwid >> 4) & 3);
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
     int worker = 0;
 #pragma unroll
     for (int w_ = GW - 1; w_ >= 0; --w_) if (sh_simd[w_] == sh_target) worker = w_;
-    const int helper = (worker + 2) & (GW - 1);      // the backtrack's second wavefront (another SIMD of the CU)
+    static_assert(GW == SPEC_WK, "one wavefront of the workgroup per walk of a backtrack");
     const bool pair = !(b.dbg & 1024);               // (ABPOA_HIP_DBG bit 10: one wavefront per backtrack, for comparison)
     for (int k = k_lo; k < n_reads; ++k) {
         const long long c0 = (long long)__builtin_amdgcn_s_memtime();
@@ -94,10 +94,10 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
                 } else if (bits == 16) { c2 = rounds_rows<int16_t, GAP, false>(slot, s); rounds_tail<int16_t, GAP, false>(slot, s, -1, sh_walk, k); }
                 else { c2 = rounds_rows<int32_t, GAP, false>(slot, s); rounds_tail<int32_t, GAP, false>(slot, s, -1, sh_walk, k); }
             } else if ((tid & 63) == 0) b.out[s].status = ABPOA_HIP_EINVAL;       // -> poa_fuse_body marks the set for the fall-back
-        } else if ((tid >> 6) == helper && b.dir_mode && pair) {
-            const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags;
+        } else if (b.dir_mode && pair) {      // the other three wavefronts: helpers of the backtrack (backtrack_dir.h)
+            const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags, hr = (((int)(tid >> 6) - worker) & (GW - 1));
             if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {
-                if (bits == 16) rounds_tail<int16_t, GAP, true>(slot, s, 1, sh_walk, k); else rounds_tail<int32_t, GAP, true>(slot, s, 1, sh_walk, k);
+                if (bits == 16) rounds_tail<int16_t, GAP, true>(slot, s, hr, sh_walk, k); else rounds_tail<int32_t, GAP, true>(slot, s, hr, sh_walk, k);
             }
         }
         __syncthreads();                                    // graph cigar and result record are complete
