@@ -138,9 +138,23 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         int t_next = (role > 0 ? role : 0) + 1;        // the next helper down whose table this walk may look its cells up in
         int w_lo = 1, w_hi = 0, w_cref = 0; bool w_tri = false;    // window = rows [w_lo, w_hi], empty at start; column origin of the AB values; column slices (not whole rows)?
         // ---- stage the window for a walk that stands at (hi, jtop); returns A of row hi
+        unsigned nx_end = 0; bool nx_ok = false;      // whole-row windows: where the window below this one ends in the arena (= where this one starts)
         auto load_window = [&](int hi, int jtop) __attribute__((always_inline)) -> int {
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime(); ++n_windows;
             WG_SYNC();
+            // The walk usually leaves a whole-row window through its lowest row: the next window then ends exactly where this one started, and its copy --
+            // the win_bytes in front of that point, rows are adjacent in the arena -- can go out BEFORE the rows' geometry is known (which only says
+            // which of the copied rows are complete): one memory round trip per window instead of two.
+            const bool early = nx_ok && hi == w_lo - 1;
+            const unsigned e_lo = nx_end > (unsigned)win_bytes ? nx_end - (unsigned)win_bytes : 0u;
+            if (early) {
+                const int n16 = (int)((nx_end - e_lo) >> 4);
+                const int4 *src = (const int4 *)(arena + e_lo); int4 *dst = (int4 *)win;
+                for (int i0 = 0; i0 < n16; i0 += 64) {
+                    const int idx = i0 + lane;
+                    if (idx < n16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx), (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
+                }
+            }
             const int cref = jtop - 4096;                       // (below every staged column: A values stay in 16 bits)
             // candidates: lane l holds rows hi - l - 64 q (descending rows: cumulative sizes are plain prefix sums); every load of every candidate in flight together
             int bs[NQ], es[NQ]; long long co[NQ]; unsigned pdv[NQ], pdh[NQ];
@@ -156,8 +170,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             // whole rows: rows are adjacent in the arena, [start of row r, end of row hi) must fit
             int r_full = 0;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) r_full += __builtin_popcountll(__ballot(vq[q] && end_hi - sa[q] <= (unsigned)win_bytes));
-            const bool narrow = r_full >= imin(16, hi);
+            for (int q = 0; q < NQ; ++q) r_full += __builtin_popcountll(__ballot(vq[q] && (early ? sa[q] >= e_lo : end_hi - sa[q] <= (unsigned)win_bytes)));
+            const bool narrow = early || r_full >= imin(16, hi);
             int sl[NQ], ns[NQ], off[NQ], R;
             unsigned s_lo = 0;
             if (narrow) {
@@ -165,6 +179,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 const int ql = (R - 1) >> 6, ll = (R - 1) & 63;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) if (q == ql) s_lo = (unsigned)__builtin_amdgcn_readlane((int)sa[q], ll);
+                nx_end = s_lo;                       // (the start of the lowest complete row)
+                if (early) s_lo = e_lo;              // (the copy started in front of it)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) { sl[q] = pc[q]; ns[q] = W[q]; off[q] = (int)(sa[q] - s_lo); }
             } else {
@@ -181,7 +197,9 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             }
             const int lo = hi - R + 1;
             // ---- the words: LDS-DMA, issued now, waited for at the end (the records are built meanwhile)
-            if (narrow) {
+            nx_ok = narrow;
+            if (narrow && early) {}
+            else if (narrow) {
                 const int n16 = (int)((end_hi - s_lo) >> 4);
                 const int4 *src = (const int4 *)(arena + s_lo); int4 *dst = (int4 *)win;
                 for (int i0 = 0; i0 < n16; i0 += 64) {
