@@ -55,15 +55,15 @@ struct Arena {                 // grow-only device / pinned-host buffers kept ac
         HIP_OK(hipHostMalloc((void **)&host, n, hipHostMallocDefault), ABPOA_HIP_ENOMEM); host_cap = n; return 0;
     }
 };
-struct Cache { Arena in, graph, rows, planes, out; hipStream_t stream = nullptr, copy_stream = nullptr; hipEvent_t ev_copy = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
+struct Cache { Arena in, graph, rows, planes, out, msa; hipStream_t stream = nullptr, copy_stream = nullptr; hipEvent_t ev_copy = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
 Cache g_cache[MSA_DEVICE_SLOTS]; std::mutex g_cache_mu[MSA_DEVICE_SLOTS];      // one per worker of the multi-device batch call
 
 struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
-    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, in_bytes;
+    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, in_bytes;
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
     size_t o_cnode, o_ccov, o_cbase;
-    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, graph_bytes;
+    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, o_rid, o_mrank, o_msaoff, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
     size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
 };
@@ -105,16 +105,19 @@ void release_msa_device_caches() {
         if (C.device < 0) continue;
         (void)hipSetDevice(C.device);
         if (C.stream) (void)hipStreamSynchronize(C.stream);
-        for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
+        for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out, &C.msa}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
     }
     if (cur >= 0) (void)hipSetDevice(cur);
 }
 
+// What the device-resident driver takes: affine / convex gaps, any alphabet of up to 27 codes, consensus and / or MSA output; global alignment with the
+// adaptive band, or local alignment (no band, abpoa_align.c:150) of reads the local row loop holds (checked per job in run_msa_device: EINVAL -> host driver).
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;
-    return sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0 && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && !(flags & (ABPOA_HIP_OUT_MSA | ABPOA_HIP_AMB_STRAND)) &&
-           sc->m - 1 <= POA_ALN_CAP && sc->zdrop <= 0;
+    if (sc->gap_mode == ABPOA_HIP_LINEAR_GAP || (flags & ABPOA_HIP_AMB_STRAND) || sc->m - 1 > POA_ALN_MAX || sc->m < 2 || sc->zdrop > 0) return false;
+    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE) return !(getenv("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_LOCAL")));
+    return sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0;
 }
 
 int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets) {
@@ -130,8 +133,12 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
     return per_cu * cus;
 }
 
-int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, int device, int slot) {
+int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot) {
+    abpoa_hip_scoring_t sc_norm = *sc_in; const bool local = sc_in->align_mode == ABPOA_HIP_LOCAL_MODE;
+    if (local) sc_norm.wb = -1;                                  // reference abpoa_post_set_para, src/abpoa_align.c:150
+    const abpoa_hip_scoring_t *sc = &sc_norm;
+    const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
     if (slot < 0 || slot >= MSA_DEVICE_SLOTS) { set_err("bad device slot %d", slot); return ABPOA_HIP_EINVAL; }
     std::lock_guard<std::mutex> lk(g_cache_mu[slot]);
     Cache &C = g_cache[slot];
@@ -141,7 +148,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     if (C.device != device) {
         if (C.device >= 0) {      // the slot served another device before: its pools and stream live there
             (void)hipSetDevice(C.device);
-            for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
+            for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out, &C.msa}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
             if (C.stream) (void)hipStreamDestroy(C.stream); if (C.copy_stream) (void)hipStreamDestroy(C.copy_stream); if (C.ev_copy) (void)hipEventDestroy(C.ev_copy);
             for (hipEvent_t e : C.ev) (void)hipEventDestroy(e);
             C = Cache();
@@ -155,7 +162,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     const double t_begin = now_s();
     const int P = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5, CW = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8;
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
-    const bool dir = dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
+    const bool dir = !local && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
                      !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
 
@@ -168,10 +175,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     std::vector<PoaSet> ps(n_sets);
     int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
+    const int aln_cap = std::max(1, sc->m - 1), rid_words = want_msa ? std::max(1, (max_reads + 63) / 64) : 0;
+    auto est_cols = [&](int64_t width, int w, int pn) { return local ? width : std::min<int64_t>(width, 2LL * w + 3 * pn + 32); };      // columns per row: the whole query in local mode
     int wide_lo = 1, wide_hi = 0, wide_ring_rows = 16;      // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off), depth of its score ring
     { LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
-      make_lds_plan(sc, max_qlen, mb, std::min<int64_t>((int64_t)((max_qlen + pn_) / pn_) * pn_, 2LL * w_max + 3 * pn_ + 32), n_sets, &pl);
-      if (pl.wide_nw >= 1) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
+      make_lds_plan(sc, max_qlen, mb, est_cols((int64_t)((max_qlen + pn_) / pn_) * pn_, w_max, pn_), n_sets, &pl);
+      if (pl.wide_nw >= 1 && !local) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
+    // cigar slots: four times the words of a backtrack where the all-rounds kernel's helper wavefronts write their parts (backtrack_dir.h SPEC_WK, dir_walk_pair)
+    const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo);
     // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
     // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the
     // read-sets are in flight instead of two passes with half the SIMDs idle.  ABPOA_HIP_DIR_WIDE=1 / 0: always / never.
@@ -190,8 +201,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         S.read0 = read_i; read_i += sets[s].n_reads;
         S.node0 = node_tot; node_tot += cap + 1;
         S.pred0 = pred_tot; pred_tot += S.pred_cap;
-        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += 4 * (int64_t)S.cigar_cap;      // (four times: parts 1-3 take the words of the backtrack's helper wavefronts, backtrack_dir.h SPEC_WK)
-        S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + cap + 1;
+        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += ((rounds_possible && S.cigar_cap < 65536) ? 4 : 1) * (int64_t)S.cigar_cap;      // (four times: parts 1-3 take the words of the helper wavefronts)
+        S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + 4 * cap + 8;      // (fuse: 3 x qlen + nodes; order / rank passes: up to four tables of one int per node)
         S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
         const int w = sc->wb + (int)(sc->wf * (float)mx);
         max_node_cap = std::max(max_node_cap, (int)cap);
@@ -206,16 +217,18 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
             const int64_t width = (int64_t)((mx + pn) / pn) * pn;
             const int w = sc->wb + (int)(sc->wf * (float)mx);
-            const int64_t est = std::min<int64_t>(width, 2LL * w + 3 * pn + 32);
+            const int64_t est = est_cols(width, w, pn);
             // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
             //  global best will read from HBM; half of the rows where the wide loop's ring is only four rows deep; a set that needs more is flagged and
             //  redone like any other capacity miss)
-            const bool wide_s = w >= wide_lo && w <= wide_hi;
+            const bool wide_s = !local && w >= wide_lo && w <= wide_hi;
             const bool dir_s = dir && (dw || !wide_s);      // (dp_common.h takes_dir)
             const int64_t rec_div = (wide_s && wide_ring_rows <= 4) ? 2 : 4;
             // (bytes per cell record of a row that keeps its scores: CW values -- the wide kernel's compact records: 4 B int16 affine, else 8 B; rows_fast.h CWR)
             const int64_t recb = wide_s ? ((bits == 16 && CW == 4) ? 4 : 8) : CW * (bits / 8);
-            const int64_t bytes = dir_s ? (int64_t)up((size_t)(width * (DB + recb) + (est * DB + est * recb / rec_div + 32) * (cap - 1) + 64 * 8 * 4))
+            // (local row loop, rows_local.h: every row the whole query wide, cell records, 64 records of slack behind the last row)
+            const int64_t bytes = local ? (int64_t)up((size_t)((width * cap + 64) * CW * (bits / 8) + 64 * 8 * 4))
+                                : dir_s ? (int64_t)up((size_t)(width * (DB + recb) + (est * DB + est * recb / rec_div + 32) * (cap - 1) + 64 * 8 * 4))
                                       : (int64_t)up((size_t)((width + est * (cap - 1)) * CW * (bits / 8) + 64 * 8 * 4));
             S.plane_off = plane_tot; S.plane_cap = bytes - 64 * 8 * 4; plane_tot += bytes;
         }
@@ -223,7 +236,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     size_arenas(dir_wide);
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
-    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m); L.o_rargs = take(poa_rounds_args_bytes());      // (o_rargs: host-side staging only)
+    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m); L.o_rargs = take(poa_rounds_args_bytes()); L.o_msaoff_h = take(want_msa ? 8 * (size_t)n_sets : 0);      // (o_rargs, o_msaoff_h: host-side staging only)
     L.o_reads = take(tot_bases + 64); L.in_bytes = o;      // reads last: they go up in two parts
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
@@ -233,7 +246,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
     L.o_out = take(4 * node_tot * POA_HOT); L.o_outw = take(4 * node_tot * POA_HOT); L.o_nread = take(4 * node_tot);
     L.o_outx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_outwx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_inx = take(4 * node_tot * (POA_IN_CAP - POA_HOT));
-    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * POA_ALN_CAP); L.o_row = take(4 * node_tot);
+    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * (size_t)aln_cap); L.o_row = take(4 * node_tot);
+    L.o_rid = take(8 * node_tot * POA_OUT_CAP * (size_t)rid_words); L.o_mrank = take(want_msa ? 4 * node_tot : 0); L.o_msaoff = take(want_msa ? 8 * (size_t)n_sets : 0);
     L.graph_bytes = o;
     o = 0;
     L.o_ticket = take(4 * POA_CU_TICKETS);
@@ -298,6 +312,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     PoaDev p; memset(&p, 0, sizeof(p));
     p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2; p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
+    p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = local ? 1 : 0; p.banded = sc->wb >= 0 ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
+    // LDS tables of the order / rank kernels (two ints per node; the rank pass packs four tables into the same space): up to 6000 nodes = 52 KB, three workgroups per CU
+    p.order_lds = (local || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
     p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;      // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
     p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
     p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;
@@ -305,6 +322,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     p.nd_in = (int32_t *)(dg + L.o_in); p.nd_out = (int32_t *)(dg + L.o_out); p.nd_outw = (int32_t *)(dg + L.o_outw); p.nd_aln = (int32_t *)(dg + L.o_aln);
     p.nd_inx = (int32_t *)(dg + L.o_inx); p.nd_outx = (int32_t *)(dg + L.o_outx); p.nd_outwx = (int32_t *)(dg + L.o_outwx);
     p.nd_nread = (int32_t *)(dg + L.o_nread); p.nd_row = (int32_t *)(dg + L.o_row);
+    p.nd_rid = (uint64_t *)(dg + L.o_rid); p.msa_rank = (int32_t *)(dg + L.o_mrank); p.msa_off = (const int64_t *)(dg + L.o_msaoff); p.msa_out = nullptr;
     p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
     p.scratch = (int32_t *)(dr + L.o_scratch);
     p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
@@ -317,7 +335,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     {
         int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
-        make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(width, 2LL * w_max + 3 * pn + 32), n_sets, &b.lds);
+        make_lds_plan(sc, max_qlen, max_bits, est_cols(width, w_max, pn), n_sets, &b.lds);
+        if (local) {      // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the host driver's (general kernel)
+            b.lds.wide_nw = 0;
+            if (max_bits != 16 || b.lds.loc_cols <= 0 || (max_qlen / 16 + 1) * 16 > b.lds.loc_cols || max_qlen > b.lds.q_cap) { set_err("local alignment outside the device row loop's range"); return ABPOA_HIP_EINVAL; }
+        }
         // score widths the rounds can meet (the width grows with graph and read size): launch only the kernels that can have work
         int min_qlen = max_qlen;
         for (int s = 0; s < n_sets; ++s) for (int r = 1; r < sets[s].n_reads; ++r) min_qlen = std::min(min_qlen, sets[s].lens[r]);
@@ -328,7 +350,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         if (w_max < b.lds.wide_w_lo || w_min > b.lds.wide_w_hi) b.lds.wide_nw = 0;                       // no read takes the wide loop
         b.lds.narrow_off = (b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_max <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
     }
-    if (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
+    if (!local && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
     b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
@@ -345,7 +367,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
     //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
     //      per phase and round throughout (what the wide-band jobs use, and the per-round diagnostics below).
     const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
-    bool use_rounds = !dbg_sync && !cigar_digest_on() && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
+    bool use_rounds = !local && rounds_possible && !dbg_sync && !cigar_digest_on() && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
     DevBatch b_r = b; size_t rounds_lds = 0;
     if (use_rounds) {
         auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), std::max<size_t>((size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), (size_t)16 * 256)); };      // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
@@ -376,7 +398,25 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         return e_ == hipSuccess ? 0 : 1;
     };
     // debug (ABPOA_HIP_DEVSYNC=1): after every fuse, check set 0..3 structurally and against the host graph fed with the same cigars
-    std::vector<PoaGraph> dbg_graphs; if (dbg_sync) { dbg_graphs.resize(std::min(n_sets, 4)); for (auto &g_ : dbg_graphs) g_.reset(0, false); }
+    std::vector<PoaGraph> dbg_graphs; if (dbg_sync) { dbg_graphs.resize(std::min(n_sets, 4)); for (size_t i_ = 0; i_ < dbg_graphs.size(); ++i_) dbg_graphs[i_].reset(sets[i_].n_reads, want_msa); }
+    // debug (ABPOA_HIP_DEVSYNC=1, order_mode 1): the row order the order kernel left against the host graph's Kahn walk (poa_graph.cpp topological_sort)
+    auto dbg_order_check = [&](int k) {
+        if (!dbg_sync) return;
+        for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
+            if (k >= sets[s].n_reads) continue;
+            PoaState hst; (void)hipMemcpy(&hst, (uint8_t *)p.state + sizeof(PoaState) * s, sizeof(hst), hipMemcpyDeviceToHost);
+            if (hst.status != POA_ST_OK) { fprintf(stderr, "[poa-device]   set %d round %d: row order: set not ok (status %d reason %d)\n", s, k, hst.status, hst.pad); continue; }
+            const int n = hst.n_nodes; std::vector<int32_t> order(n), row(n);
+            (void)hipMemcpy(order.data(), p.row_node[hst.order_buf] + ps[s].node0, 4 * (size_t)n, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(row.data(), p.nd_row + ps[s].node0, 4 * (size_t)n, hipMemcpyDeviceToHost);
+            PoaGraph &G = dbg_graphs[s]; int bad = 0;
+            try { G.topological_sort(false); } catch (...) { fprintf(stderr, "[poa-device]   set %d round %d: host sort failed\n", s, k); continue; }
+            if (G.n_nodes() != n) { fprintf(stderr, "[poa-device]   set %d round %d: row order check FAILED: node count %d vs host %d\n", s, k, n, G.n_nodes()); continue; }
+            for (int r = 0; r < n; ++r) { if (order[r] != G.index_to_node()[r] && bad++ < 6) fprintf(stderr, "[poa-device]   set %d round %d: row %d: device node %d, host node %d\n", s, k, r, order[r], G.index_to_node()[r]);
+                                          if (order[r] >= 0 && order[r] < n && row[order[r]] != r && bad++ < 6) fprintf(stderr, "[poa-device]   set %d round %d: nd_row / order mismatch at row %d\n", s, k, r); }
+            fprintf(stderr, "[poa-device]   set %d round %d: row order check %s (%d rows)\n", s, k, bad ? "FAILED" : "ok", n);
+        }
+    };
     auto dbg_check = [&](int k) {
         if (!dbg_sync) return;
         for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
@@ -393,7 +433,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 dbg_graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], cg.data(), ao.n_cigar, k);
             }
             if (hst.status != POA_ST_OK) continue;
-            std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln(n * POA_ALN_CAP), nread(n), row(n), order(n);
+            std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln((size_t)n * aln_cap), nread(n), row(n), order(n);
             auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
             dl(base.data(), p.nd_base, 1, 1); dl(nin.data(), p.nd_nin, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl(naln.data(), p.nd_naln, 1, 1);
             // edge lists come back as hot + cold halves and are merged into [node][CAP] arrays
@@ -403,7 +443,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 (void)hipMemcpy(c_.data(), cold + (size_t)S.node0 * (cap_ - POA_HOT), c_.size() * 4, hipMemcpyDeviceToHost);
                 for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_] : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
             };
-            dl_list(in.data(), p.nd_in, p.nd_inx, POA_IN_CAP); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx, POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, POA_ALN_CAP);
+            dl_list(in.data(), p.nd_in, p.nd_inx, POA_IN_CAP); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx, POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, aln_cap);
             dl(nread.data(), p.nd_nread, 4, 1); dl(row.data(), p.nd_row, 4, 1); dl(order.data(), p.row_node[hst.order_buf], 4, 1);
             int bad = 0;
             auto complain = [&](const char *what, int a, int b_) { if (bad++ < 8) fprintf(stderr, "[poa-device]   set %d round %d: %s (%d, %d)\n", s, k, what, a, b_); };
@@ -418,7 +458,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
                 if (h.out_id.size() != nout[u]) complain("out-degree differs", u, nout[u]);
                 else for (int t = 0; t < nout[u]; ++t) { if (h.out_id[t] != outv[u * POA_OUT_CAP + t]) complain("out edge differs", u, t); if (h.out_w[t] != outw[u * POA_OUT_CAP + t]) complain("out weight differs", u, t); }
                 if (h.aligned.size() != naln[u]) complain("aligned count differs", u, naln[u]);
-                else for (int t = 0; t < naln[u]; ++t) if (h.aligned[t] != aln[u * POA_ALN_CAP + t]) complain("aligned node differs", u, t);
+                else for (int t = 0; t < naln[u]; ++t) if (h.aligned[t] != aln[(size_t)u * aln_cap + t]) complain("aligned node differs", u, t);
                 if (h.n_read != nread[u]) complain("n_read differs", u, nread[u]);
             }
             fprintf(stderr, "[poa-device]   set %d round %d: graph check %s (%d nodes)\n", s, k, bad ? "FAILED" : "ok", n);
@@ -447,6 +487,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         }
         p.round = k;
         hipEvent_t *e = C.ev.data() + 4 * k;
+        if (p.order_mode) { HIP_OK(launch_poa_order(p, st), ABPOA_HIP_ELAUNCH); if (stage("row order", k)) return ABPOA_HIP_ELAUNCH; dbg_order_check(k); }
         HIP_OK(launch_poa_prepare(p, st), ABPOA_HIP_ELAUNCH);
         if (stage("prepare", k)) return ABPOA_HIP_ELAUNCH;
         HIP_OK(hipEventRecord(e[0], st), ABPOA_HIP_ELAUNCH);
@@ -506,11 +547,29 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
         HIP_OK(hipEventRecord(e[3], st), ABPOA_HIP_ELAUNCH);
     }
     // ---- consensus on the device, then one small download: per-set state + consensus (node ids, bases, coverage)
-    HIP_OK(launch_poa_consensus(p, st), ABPOA_HIP_ELAUNCH);
-    if (stage("consensus", max_reads)) return ABPOA_HIP_ELAUNCH;
+    if (want_cons) { HIP_OK(launch_poa_consensus(p, st), ABPOA_HIP_ELAUNCH); if (stage("consensus", max_reads)) return ABPOA_HIP_ELAUNCH; }
+    if (want_msa) { HIP_OK(launch_poa_msa_rank(p, st), ABPOA_HIP_ELAUNCH); if (stage("msa rank", max_reads)) return ABPOA_HIP_ELAUNCH; }
     uint8_t *hg = C.graph.host;
     HIP_OK(hipMemcpyAsync(hg, dg, dl_bytes, hipMemcpyDeviceToHost, st), ABPOA_HIP_ELAUNCH);
     HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
+    // ---- MSA rows (reference abpoa_generate_rc_msa, src/abpoa_output.c:123-166): the rank pass left the column count of every set in its state; the results are
+    //      laid out back to back (rows x columns bytes per set), filled on the device and downloaded in one piece
+    std::vector<int64_t> msa_off; int64_t msa_total = 0;
+    if (want_msa) {
+        const PoaState *hs_ = (const PoaState *)(hg + L.o_state);
+        msa_off.resize(n_sets);
+        for (int s = 0; s < n_sets; ++s) { msa_off[s] = msa_total; if (hs_[s].status == POA_ST_OK && hs_[s].n_nodes > 2) msa_total += (int64_t)(sets[s].n_reads + (want_cons ? 1 : 0)) * std::max(0, hs_[s].msa_len); }
+        if (msa_total > 0) {
+            if ((rc = C.msa.need_dev((size_t)msa_total)) || (rc = C.msa.need_host((size_t)msa_total))) return rc;
+            memcpy(hi + L.o_msaoff_h, msa_off.data(), 8 * (size_t)n_sets);
+            HIP_OK(hipMemcpyAsync(dg + L.o_msaoff, hi + L.o_msaoff_h, 8 * (size_t)n_sets, hipMemcpyHostToDevice, st), ABPOA_HIP_ELAUNCH);
+            p.msa_out = C.msa.dev;
+            HIP_OK(launch_poa_msa_fill(p, st), ABPOA_HIP_ELAUNCH);
+            if (stage("msa fill", max_reads)) return ABPOA_HIP_ELAUNCH;
+            HIP_OK(hipMemcpyAsync(C.msa.host, C.msa.dev, (size_t)msa_total, hipMemcpyDeviceToHost, st), ABPOA_HIP_ELAUNCH);
+            HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
+        }
+    }
     const double t_done = now_s();
     if (stats) {
         float ms = 0;
@@ -543,13 +602,32 @@ int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_re
             abpoa_hip_msa_t &o_ = out[s];
             memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
             if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
-            const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
-            o_.n_cells = hs[s].n_cells; o_.cons_len = len;
-            o_.cons_base = (uint8_t *)malloc(len + 1); o_.cons_cov = (int32_t *)malloc(4 * (len + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (len + 1));
-            memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len); memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
+            o_.n_cells = hs[s].n_cells;
+            if (want_cons && hs[s].n_nodes > 2) {
+                const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
+                o_.cons_len = len;
+                o_.cons_base = (uint8_t *)malloc(len + 1); o_.cons_cov = (int32_t *)malloc(4 * (len + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (len + 1));
+                memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len); memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
+            }
+            if (want_msa && hs[s].n_nodes > 2) {      // (an empty graph has no MSA: the host driver leaves the record zeroed too)
+                const int len = std::max(0, hs[s].msa_len);
+                o_.msa_len = len; o_.msa_rows = sets[s].n_reads + (want_cons ? 1 : 0);
+                o_.msa_base = (uint8_t *)malloc((size_t)o_.msa_rows * (len > 0 ? len : 1));
+                if (len > 0) memcpy(o_.msa_base, C.msa.host + msa_off[s], (size_t)o_.msa_rows * len);
+            }
         }
     });
-    if (dbg_sync) {      // cross-check the device consensus of the first sets against the host routine on the downloaded graph
+    if (dbg_sync && want_msa) {      // cross-check the device MSA of the first sets against the host routine on the host graph that was fed the same cigars
+        for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
+            if (hs[s].status != POA_ST_OK || hs[s].n_nodes <= 2) continue;
+            int ml = 0; std::vector<std::vector<uint8_t>> rows; std::vector<int> col;
+            try { dbg_graphs[s].rc_msa(sc->m, &ml, &rows, &col); } catch (...) { fprintf(stderr, "[poa-device]   set %d: host rc_msa failed\n", s); continue; }
+            bool same = ml == out[s].msa_len;
+            for (int r = 0; same && r < sets[s].n_reads; ++r) same = memcmp(rows[r].data(), out[s].msa_base + (size_t)r * ml, (size_t)ml) == 0;
+            fprintf(stderr, "[poa-device]   set %d: msa check %s (device %d columns, host %d)\n", s, same ? "ok" : "FAILED", out[s].msa_len, ml);
+        }
+    }
+    if (dbg_sync && want_cons) {      // cross-check the device consensus of the first sets against the host routine on the downloaded graph
         for (int s = 0; s < std::min(n_sets, 4); ++s) {
             if (hs[s].status != POA_ST_OK) continue;
             const PoaSet &S = ps[s]; const int n = hs[s].n_nodes;

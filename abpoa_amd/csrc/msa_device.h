@@ -18,8 +18,8 @@ struct DeviceRunStats {
     double rounds_mticks[4];      // mean per set: 10^6 shader-clock ticks in prepare / row loop / backtrack / fuse
 };
 
-// true when the scoring / output options can run on the device-resident path (global, banded, affine or convex gaps,
-// consensus only, nucleotide-sized alphabet); env ABPOA_HIP_HOSTGRAPH=1 forces the host driver
+// true when the scoring / output options can run on the device-resident path (affine or convex gaps; global mode with the adaptive band or local
+// mode; consensus and / or MSA output; alphabets of up to 27 codes); env ABPOA_HIP_HOSTGRAPH=1 forces the host driver
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 
 // Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
@@ -35,6 +35,6 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
 // frees every cached pool of every device queue (abpoa_hip_trim)
 void release_msa_device_caches();
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, int device = -1, int slot = 0);
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device = -1, int slot = 0);
 
 }  // namespace abpoa_hip

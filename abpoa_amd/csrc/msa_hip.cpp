@@ -51,7 +51,7 @@ namespace {
 // the host driver.  A pass that does not fit the device memory is split in halves.
 struct PassOut { int rc = ABPOA_HIP_OK; bool device_ok = true; DeviceRunStats tot; std::vector<int> left; };
 PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, const std::vector<int> &idx,
-                      int n_threads, int device, int slot) {
+                      int n_threads, int device, int slot, unsigned flags) {
     PassOut R; memset(&R.tot, 0, sizeof(R.tot));
     std::vector<int> todo = idx, left;
     const double factors[3] = {3.0, 4.5, 6.0}; constexpr int NPASS = 3;
@@ -80,7 +80,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             std::vector<abpoa_hip_readset_t> sub(nb); std::vector<abpoa_hip_msa_t> sub_out(nb);
             for (size_t i = 0; i < nb; ++i) sub[i] = sets[todo[at + i]];
             std::vector<int> fb; DeviceRunStats ds;
-            const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], device, slot);
+            const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], flags, device, slot);
             if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; halved = true; continue; }           // split and retry this chunk
             if (rc != ABPOA_HIP_OK) {
                 if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; }
@@ -131,10 +131,12 @@ std::vector<int> device_list() {
 }  // namespace abpoa_hip
 
 extern "C" {
-int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
+int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets,
                         abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
     using namespace abpoa_hip;
     if (engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
+    abpoa_hip_scoring_t sc_norm; const abpoa_hip_scoring_t *sc = sc_in;
+    if (sc_in && sc_in->align_mode == ABPOA_HIP_LOCAL_MODE) { sc_norm = *sc_in; sc_norm.wb = -1; sc = &sc_norm; }      // reference abpoa_post_set_para, src/abpoa_align.c:150: local mode has no band
     bool plain = true;      // per-base weights and the strand retry are host-driver features
     for (int s = 0; plain && sets && s < n_sets; ++s) plain = sets[s].weights == nullptr;
     if (n_sets > 0 && sc && sets && out && plain && msa_device_eligible(sc, flags)) {
@@ -169,7 +171,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_h
             const int thr = std::max(1, n_threads / n_q);
             for (int b_; (b_ = next.fetch_add(1)) < (int)batches.size();) {
                 const auto t0 = std::chrono::steady_clock::now();
-                results[b_] = device_passes(sc, sets, out, batches[b_], thr, devs[q], q);
+                results[b_] = device_passes(sc, sets, out, batches[b_], thr, devs[q], q, flags);
                 q_busy[q] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (results[b_].rc != ABPOA_HIP_OK) break;
             }

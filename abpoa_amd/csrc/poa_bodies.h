@@ -155,8 +155,9 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         }
     }
     __syncthreads();
-    // (2) remaining length = (edges to the sink along heaviest successors) - 1, reference :233-274.
-    if (in_lds) {
+    // (2) remaining length = (edges to the sink along heaviest successors) - 1, reference :233-274 (only the adaptive band reads it: abpoa_graph.c:303-311)
+    if (!p.banded) { for (int r = tid; r < n; r += GT) remain[r] = 0; }
+    else if (in_lds) {
         // Pointer jumping over all rows at once in LDS.  A record "row of a later node on the chain << 16 | edges up to it" is one
         // 32-bit word, so a row may read a neighbour's record while that neighbour is being advanced: either version is a valid jump.
         for (int span = 1; span < n; span <<= 1) {
@@ -311,7 +312,11 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
             if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; return; }
             out_slot(p, F, no) = to; outw_slot(p, F, no) = 1; p.nd_nout[F] = (uint8_t)(no + 1);
             in_slot(p, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
+            hit = no;
+            for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + w_] = 0;      // (a new edge: no read went through it yet)
         }
+        // read k went through this edge (reference :453-472; a node is the tail of at most one edge per read, so no other lane touches these words)
+        if (p.rid_words) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + (k >> 6)] |= 1ull << (k & 63);
         p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
     };
     // all wavefronts walk the query together, GT positions per pass: per-position work (node lookup, new node, edge) is private to
@@ -328,7 +333,7 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
             if ((int)p.nd_base[N0 + c] == b) { node = c; isnew = false; }
             else {                                                              // reference abpoa_get_aligned_id :377-386
                 const int na = p.nd_naln[N0 + c];
-                for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + c) * POA_ALN_CAP + t]; if ((int)p.nd_base[N0 + a] == b) { node = a; isnew = false; break; } }
+                for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + c) * p.aln_cap + t]; if ((int)p.nd_base[N0 + a] == b) { node = a; isnew = false; break; } }
             }
         }
         // group-end row of the aligned group that places this position in the row order (see the bookkeeping below); read before
@@ -338,7 +343,7 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
             const int ref = isnew ? c : node;
             gv = p.nd_row[N0 + ref];
             const int na = p.nd_naln[N0 + ref];
-            for (int t = 0; t < na; ++t) gv = imax_(gv, p.nd_row[N0 + p.nd_aln[(N0 + ref) * POA_ALN_CAP + t]]);
+            for (int t = 0; t < na; ++t) gv = imax_(gv, p.nd_row[N0 + p.nd_aln[(N0 + ref) * p.aln_cap + t]]);
         }
         // exchange 1: ids of the new nodes (path order) and the running maximum AR
         const unsigned long long newmask = __ballot(isnew);
@@ -356,16 +361,16 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
             p.nd_base[Y] = (uint8_t)b; p.nd_nin[Y] = 0; p.nd_nout[Y] = 0; p.nd_naln[Y] = 0; p.nd_nread[Y] = 0;
             if (c >= 0) {                                                       // mismatch: new node joins c's aligned group, reference :393-401
                 const int na = p.nd_naln[N0 + c];
-                if (na + 1 > POA_ALN_CAP) fail = true;
+                if (na + 1 > p.aln_cap) fail = true;
                 else {
                     for (int t = 0; t < na; ++t) {
-                        const int other = p.nd_aln[(N0 + c) * POA_ALN_CAP + t];
+                        const int other = p.nd_aln[(N0 + c) * p.aln_cap + t];
                         const int no_ = p.nd_naln[N0 + other];                   // == na for every member of the group
-                        p.nd_aln[(N0 + other) * POA_ALN_CAP + no_] = node; p.nd_naln[N0 + other] = (uint8_t)(no_ + 1);
-                        p.nd_aln[Y * POA_ALN_CAP + t] = other;
+                        p.nd_aln[(N0 + other) * p.aln_cap + no_] = node; p.nd_naln[N0 + other] = (uint8_t)(no_ + 1);
+                        p.nd_aln[Y * p.aln_cap + t] = other;
                     }
-                    p.nd_aln[(N0 + c) * POA_ALN_CAP + na] = node; p.nd_naln[N0 + c] = (uint8_t)(na + 1);
-                    p.nd_aln[Y * POA_ALN_CAP + na] = c; p.nd_naln[Y] = (uint8_t)(na + 1);
+                    p.nd_aln[(N0 + c) * p.aln_cap + na] = node; p.nd_naln[N0 + c] = (uint8_t)(na + 1);
+                    p.nd_aln[Y * p.aln_cap + na] = c; p.nd_naln[Y] = (uint8_t)(na + 1);
                 }
             }
         }

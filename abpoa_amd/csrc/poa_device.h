@@ -18,7 +18,8 @@ constexpr int POA_IN_CAP = 15;     // in-edges per node kept on the device (more
 constexpr int POA_OUT_CAP = 16;    // out-edges per node
 constexpr int POA_HOT = 4;         // slots of every edge list in the hot arrays (16-byte records: most nodes have 1-2 edges, and the graph
                                    // kernels stream the whole graph every round); the other slots live in the cold arrays
-constexpr int POA_ALN_CAP = 4;     // aligned (mismatch-alternative) nodes per node: enough for nucleotides (m = 5)
+constexpr int POA_ALN_MAX = 26;    // aligned (mismatch-alternative) nodes per node: at most m - 1 (every member of a group has its own base); the stride of
+                                   // nd_aln is PoaDev.aln_cap = m - 1 (4 for nucleotides, 26 for the 27-code amino-acid alphabet)
 
 #define POA_ST_OK        0
 #define POA_ST_FALLBACK  100       // capacity exceeded somewhere (nodes, edges, arena, cigar): redo this set on the host driver
@@ -37,7 +38,7 @@ struct PoaSet {                    // immutable per read-set
 
 struct PoaState {                  // mutable per read-set
     int32_t n_nodes, status, order_buf, pad;     // order_buf: which row_node buffer is current; pad: fall-back reason
-    int32_t cons_len, pad1;        // heaviest-bundling consensus length (poa_consensus_kernel)
+    int32_t cons_len, msa_len;     // heaviest-bundling consensus length (poa_consensus_kernel); MSA columns (poa_msa_rank_kernel)
     int32_t grow_n2, grow_n6;      // nodes after 2 / 6 reads: the growth model of the doomed-pass test (poa_bodies.h)
     int64_t n_cells;               // DP cells over all alignments so far
     int64_t algo_bytes;            // cells * algorithmic bytes per cell (affine 5S, convex 8S; S = 2 | 4)
@@ -50,13 +51,21 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     int32_t max_mat, min_mis, o1, e1, o2, e2, wb; float wf;
     int32_t gap_mode, round;       // round k: read k of every set is aligned / fused
     int32_t max_qlen, pad;         // pad: node capacity of the prepare kernel's LDS jump records (4 bytes each; 0 = use the global-memory sweep)
+    int32_t aln_cap;               // slots per node in nd_aln (m - 1)
+    int32_t rid_words;             // read-id bitsets per out-edge (abpoa_para_t.use_read_ids: MSA output): 64-bit words per edge, 0 = not kept
+    int32_t order_mode;            // 0: the row order is maintained incrementally by the fuse phase (global mode: any topological order gives the same result);
+                                   // 1: the reference's own order, rebuilt before every alignment (poa_order_kernel: local mode breaks score ties by row index)
+    int32_t banded;                // 0: no adaptive band (local mode): the remaining length is not computed
+    int32_t msa_rows, msa_cons;    // rows of a set's MSA = its reads (+ 1 when msa_cons: the consensus row, abpoa_output.c:151-164)
+    int32_t order_lds, pad_b;      // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice)
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
     // graph, indexed node0 + node id
     uint8_t *nd_base, *nd_nin, *nd_nout, *nd_naln;
     int32_t *nd_in, *nd_out, *nd_outw;              // hot slots  [node][POA_HOT]: in ids, out ids, out weights
     int32_t *nd_inx, *nd_outx, *nd_outwx;           // cold slots [node][CAP - POA_HOT]
-    int32_t *nd_aln;                                // [node][POA_ALN_CAP]
+    int32_t *nd_aln;                                // [node][aln_cap]
+    uint64_t *nd_rid;                               // [node][POA_OUT_CAP][rid_words]: reads that went through the out-edge (reference abpoa_node_t.read_ids)
     int32_t *nd_nread, *nd_row;
     int32_t *row_node[2];          // row order (double buffered), indexed node0 + row
     int32_t *scratch;
@@ -68,12 +77,20 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     uint64_t *cigar;
     // consensus results (poa_consensus_kernel), indexed cons0 + position
     int32_t *cons_node, *cons_cov; uint8_t *cons_base;
+    // MSA output (poa_msa_rank_kernel / poa_msa_fill_kernel): per node its MSA column + 1 (node0 + node id), the row-major result pool
+    int32_t *msa_rank; uint8_t *msa_out; const int64_t *msa_off;      // msa_off[set]: first byte of the set's rows in msa_out (host prefix sum over rows x msa_len)
 };
 
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s);
+// the reference's row order (abpoa_BFS_set_node_index, src/abpoa_graph.c:186-231) rebuilt on the device: order_mode 1, before every prepare
+hipError_t launch_poa_order(const PoaDev &p, hipStream_t s);
+// MSA output: rank pass (abpoa_DFS_set_msa_rank, src/abpoa_graph.c:315-362) -> PoaState.msa_len, msa_rank; fill pass (abpoa_output.c:103-166) -> msa_out
+hipError_t launch_poa_msa_rank(const PoaDev &p, hipStream_t s);
+hipError_t launch_poa_msa_fill(const PoaDev &p, hipStream_t s);
+size_t poa_order_lds_bytes(int node_cap);      // dynamic LDS of the order / rank kernels for a table capacity of node_cap nodes
 // poa_rounds.hip: rounds k_lo .. n_reads - 1 of every set in one launch (narrow-band jobs), and how many of its workgroups a CU holds
 constexpr int POA_CU_TICKETS = 4096;      // per-CU ticket counters of the all-rounds kernel (index: XCC id, SE, SH, CU), zeroed by the launch
 // host_args: poa_rounds_args_bytes() of pinned host memory that stays valid until the stream has passed the launch (8-byte aligned)

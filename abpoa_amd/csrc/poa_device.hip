@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
-    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0; st->algo_bytes_before = 0; }
+    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; st->cons_len = 0; st->msa_len = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0; st->algo_bytes_before = 0; }
     if (S.n_reads <= 0) { if (lane == 0) { st->n_nodes = 2; st->status = POA_ST_OK; } return; }
     const int L = p.read_len[S.read0];
     const uint8_t *seq = p.reads + p.read_off[S.read0];
@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
         p.nd_nin[N0 + u] = (uint8_t)nin; p.nd_nout[N0 + u] = (uint8_t)nout;
         in_slot(p, N0 + u, 0) = in0; out_slot(p, N0 + u, 0) = out0; outw_slot(p, N0 + u, 0) = 1;
         p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
+        if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * POA_OUT_CAP) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }      // read 0 went through the node's one edge
         // row order: source, the chain, sink
         const int row = u == 0 ? 0 : (u == 1 ? n - 1 : u - 1);
         p.nd_row[N0 + u] = row; p.row_node[0][N0 + row] = u;
@@ -153,6 +154,169 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
     if (lane == 0) { st->cons_len = len; if (overflow) { st->status = POA_ST_FALLBACK; st->pad = 5; } }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference's row order, rebuilt before every alignment (order_mode 1): abpoa_BFS_set_node_index, src/abpoa_graph.c:186-231 -- a Kahn walk with a
+// FIFO queue in which a node is enqueued only when it AND every node aligned to it have no unvisited predecessor, followed at once by those aligned
+// nodes.  Local mode needs exactly this order: the best cell of a local alignment is the first row that reaches the maximum (reference :1012-1016).
+//
+// One wavefront per read-set.  The queue IS the order array; up to 64 queue entries are processed per pass, a lane each, and the pass reproduces what the
+// sequential walk would have done with them.  Every in-degree decrement has a time stamp  key = 16 * (queue position of the node popped) + (index of
+// the out-edge)  -- the order in which the reference performs them.  zt[v] = the largest key that touched v, so once v's count is zero zt[v] is the moment it
+// became zero.  The reference enqueues a group at the moment its LAST member reaches zero, that member first and then its aligned list in list order
+// (a member that reaches zero earlier fails the check at :212-215 and is not looked at again): so the edge (lane, k) whose key equals zt[v], with every
+// aligned node of v at zero and none of them later than v, pushes the group, and the groups of a pass are pushed in key order (prefix sum over the lanes,
+// edges in order inside a lane).  A chain graph degenerates to one node per pass: a pass costs one round trip to the node's edge record plus LDS work.
+constexpr int ORD_RING = 1024;                 // the most recent queue entries, in LDS (the frontier of a POA graph is a few nodes wide)
+extern __shared__ int ord_lds[];               // [ORD_RING] ring, then -- LDS tables -- [cap] in-degree counters, [cap] zero times (rank pass: + [cap] rank, [cap] stack)
+// table `which`, entry i; n: the stride between tables (LDS: the launch's table capacity; global: the node count)
+template <bool L> __device__ __forceinline__ int &tbl(const PoaDev &p, int32_t *g, int which, int n, int i) { return L ? ord_lds[ORD_RING + which * n + i] : g[(int64_t)which * n + i]; }
+template <bool L> __device__ __forceinline__ int tbl_ld(const PoaDev &p, int32_t *g, int which, int n, int i) { return L ? ord_lds[ORD_RING + which * n + i] : ld_fresh(g + (int64_t)which * n + i); }
+
+template <bool L>
+__device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S, const int n, int32_t *order) {
+    const int lane = threadIdx.x;
+    const int64_t N0 = S.node0;
+    int32_t *g = p.scratch + S.scratch0;           // (global tables when the graph is larger than the LDS tables: [n] counters, [n] zero times)
+    for (int u = lane; u < n; u += 64) { tbl<L>(p, g, 0, n, u) = p.nd_nin[N0 + u]; tbl<L>(p, g, 1, n, u) = -1; }
+    if (lane == 0) { order[0] = 0; p.nd_row[N0] = 0; ord_lds[0] = 0; }
+    __syncthreads();
+    int head = 0, tail = 1;
+    while (head < tail) {
+        const int cnt = imin_(64, tail - head), pos = head + lane; const bool act = lane < cnt;
+        int u = 1, no = 0; int4 o4 = make_int4(0, 0, 0, 0);
+        if (act) u = (tail - head <= ORD_RING) ? ord_lds[pos & (ORD_RING - 1)] : ld_fresh(order + pos);
+        if (act) { no = p.nd_nout[N0 + u]; o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
+        auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))); };
+        for (int k = 0; k < no; ++k) { const int v = target(k); atomicSub(&tbl<L>(p, g, 0, n, v), 1); atomicMax(&tbl<L>(p, g, 1, n, v), pos * 16 + k); }
+        __syncthreads();
+        unsigned trig = 0; int total = 0;
+        for (int k = 0; k < no; ++k) {
+            const int v = target(k), key = pos * 16 + k;
+            if (tbl_ld<L>(p, g, 0, n, v) != 0 || tbl_ld<L>(p, g, 1, n, v) != key) continue;
+            const int na = p.nd_naln[N0 + v]; bool ready = true;
+            for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
+            if (ready) { trig |= 1u << k; total += 1 + na; }
+        }
+        const int incl = wave_scan_add(total), all = __builtin_amdgcn_readlane(incl, 63);
+        if (tail + all > n) return false;                                          // (more entries than nodes: not a graph this walk understands)
+        int at = tail + incl - total;
+        for (int k = 0; k < no; ++k) if (trig >> k & 1) {
+            const int v = target(k), na = p.nd_naln[N0 + v];
+            order[at] = v; p.nd_row[N0 + v] = at; ord_lds[at & (ORD_RING - 1)] = v; ++at;
+            for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; order[at] = a; p.nd_row[N0 + a] = at; ord_lds[at & (ORD_RING - 1)] = a; ++at; }
+        }
+        tail += all; head += cnt;
+        __syncthreads();
+    }
+    return head == n;
+}
+
+__global__ void __launch_bounds__(64) poa_order_kernel(const PoaDev p) {
+    const int s = blockIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    PoaState *st = p.state + s;
+    if (uni(st->status) != POA_ST_OK || p.round >= S.n_reads) return;
+    const int n = uni(st->n_nodes);
+    if (n <= 2) return;
+    int32_t *order = p.row_node[uni(st->order_buf)] + S.node0;
+    const bool ok = n <= p.order_lds ? poa_order_body<true>(p, S, n, order) : poa_order_body<false>(p, S, n, order);
+    // (the sink is the last node the walk reaches, reference :203-206; anything else means the graph is not what the fuse phase should have left)
+    if (threadIdx.x == 0 && (!ok || ld_fresh(order + n - 1) != 1)) { st->status = POA_ST_FALLBACK; st->pad = 7; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MSA output, pass 1: one column per aligned group, numbered by the reference's depth-first variant of the same walk (abpoa_DFS_set_msa_rank,
+// src/abpoa_graph.c:315-362: a LIFO stack instead of the queue; a node takes the next rank when it is popped, together with its aligned nodes, unless
+// one of them was popped before).  A stack walk is sequential in the nodes; the out-edges of the popped node are handled a lane each, with the same
+// time-stamp rule as above for which edge pushes a group (two out-edges of one node may lead to two members of one group: the later edge pushes).
+template <bool L>
+__device__ __forceinline__ int poa_msa_rank_body(const PoaDev &p, const PoaSet &S, const int n) {
+    const int lane = threadIdx.x;
+    const int64_t N0 = S.node0;
+    int32_t *g = p.scratch + S.scratch0;           // tables: 0 counters, 1 zero times, 2 rank, 3 stack
+    for (int u = lane; u < n; u += 64) { tbl<L>(p, g, 0, n, u) = p.nd_nin[N0 + u]; tbl<L>(p, g, 1, n, u) = -1; tbl<L>(p, g, 2, n, u) = 0; }
+    if (lane == 0) { tbl<L>(p, g, 3, n, 0) = 0; tbl<L>(p, g, 2, n, 0) = -1; }
+    __syncthreads();
+    int sp = 1, msa_rank = 0, pops = 0; bool done = false;
+    while (sp > 0 && !done) {
+        const int cur = uni(tbl_ld<L>(p, g, 3, n, sp - 1)); --sp;
+        const int na_c = p.nd_naln[N0 + cur], no = cur == 1 ? 0 : (int)p.nd_nout[N0 + cur];
+        if (uni(tbl_ld<L>(p, g, 2, n, cur)) < 0) {
+            if (lane == 0) tbl<L>(p, g, 2, n, cur) = msa_rank;
+            if (lane < na_c) tbl<L>(p, g, 2, n, p.nd_aln[(N0 + cur) * p.aln_cap + lane]) = msa_rank;      // (aln_cap <= 26 < 64: a lane each)
+            ++msa_rank;
+        }
+        if (cur == 1) { done = true; break; }
+        const int key = pops * 16 + lane; ++pops;
+        int v = -1;
+        if (lane < no) { v = out_slot(p, N0 + cur, lane); atomicSub(&tbl<L>(p, g, 0, n, v), 1); atomicMax(&tbl<L>(p, g, 1, n, v), key); }
+        __syncthreads();
+        int total = 0, na = 0;
+        if (lane < no && tbl_ld<L>(p, g, 0, n, v) == 0) {
+            na = p.nd_naln[N0 + v]; bool ready = true;
+            for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
+            if (ready) total = 1 + na;
+        }
+        const int incl = wave_scan_add(total), all = __builtin_amdgcn_readlane(incl, 63);
+        if (sp + all > n) return -1;
+        if (total) {
+            int at = sp + incl - total;
+            tbl<L>(p, g, 3, n, at) = v; tbl<L>(p, g, 2, n, v) = -1; ++at;
+            for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; tbl<L>(p, g, 3, n, at) = a; tbl<L>(p, g, 2, n, a) = -1; ++at; }
+        }
+        sp += all;
+        __syncthreads();
+    }
+    if (!done) return -1;
+    __syncthreads();
+    // the column of a node: the largest rank in its group (abpoa_output.c:141-147; the members of a group share their rank)
+    for (int u = lane; u < n; u += 64) {
+        int rk = tbl_ld<L>(p, g, 2, n, u); const int na = p.nd_naln[N0 + u];
+        for (int t = 0; t < na; ++t) rk = imax_(rk, tbl_ld<L>(p, g, 2, n, p.nd_aln[(N0 + u) * p.aln_cap + t]));
+        p.msa_rank[N0 + u] = rk;
+    }
+    return uni(tbl_ld<L>(p, g, 2, n, 1)) - 1;                                       // msa_len = rank of the sink - 1 (abpoa_output.c:130)
+}
+
+__global__ void __launch_bounds__(64) poa_msa_rank_kernel(const PoaDev p) {
+    const int s = blockIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    PoaState *st = p.state + s;
+    if (uni(st->status) != POA_ST_OK) return;
+    const int n = uni(st->n_nodes);
+    if (n <= 2) { if (threadIdx.x == 0) st->msa_len = 0; return; }
+    const int len = 4 * n <= 2 * p.order_lds ? poa_msa_rank_body<true>(p, S, n) : poa_msa_rank_body<false>(p, S, n);      // (four tables in the space of the order kernel's two)
+    if (threadIdx.x == 0) { if (len < 0) { st->status = POA_ST_FALLBACK; st->pad = 8; st->msa_len = 0; } else st->msa_len = len; }
+}
+
+// MSA output, pass 2 (after the host has laid the sets' results out back to back: msa_off): rows of gap codes, then every node writes its base into the
+// column of its group for each read that left it through one of its out-edges (abpoa_set_msa_seq, abpoa_output.c:103-120); the consensus row likewise
+// from the consensus path (:151-164).  Two nodes of one column belong to one aligned group and a read passes through one of them: no two writers per cell.
+__global__ void __launch_bounds__(GT) poa_msa_fill_kernel(const PoaDev p) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    const PoaState *st = p.state + s;
+    if (st->status != POA_ST_OK) return;
+    const int n = st->n_nodes, len = st->msa_len, rows = S.n_reads + (p.msa_cons ? 1 : 0);
+    if (n <= 2 || len <= 0) return;
+    uint8_t *out = p.msa_out + p.msa_off[s];
+    const int64_t N0 = S.node0, cells = (int64_t)rows * len;
+    for (int64_t i = tid; i < cells; i += GT) out[i] = (uint8_t)p.m;
+    __syncthreads();
+    for (int u = 2 + tid; u < n; u += GT) {
+        const int col = p.msa_rank[N0 + u] - 1, no = p.nd_nout[N0 + u]; const uint8_t b = p.nd_base[N0 + u];
+        for (int e = 0; e < no; ++e) for (int w_ = 0; w_ < p.rid_words; ++w_) {
+            unsigned long long num = p.nd_rid[((N0 + u) * POA_OUT_CAP + e) * p.rid_words + w_];
+            while (num) { const int r = w_ * 64 + __builtin_ctzll(num); num &= num - 1; if (r < S.n_reads) out[(int64_t)r * len + col] = b; }
+        }
+    }
+    if (p.msa_cons) for (int i = tid; i < st->cons_len; i += GT) out[(int64_t)S.n_reads * len + p.msa_rank[N0 + p.cons_node[S.cons0 + i]] - 1] = p.cons_base[S.cons0 + i];
+}
+
 static hipError_t launch_k(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.n_sets), dim3(64), 0, s, p);
@@ -170,5 +334,20 @@ hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
+size_t poa_order_lds_bytes(int node_cap) { return 4 * (size_t)ORD_RING + 8 * (size_t)(node_cap > 0 ? node_cap : 0); }
+static hipError_t launch_ord(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    const size_t lds = poa_order_lds_bytes(p.order_lds);
+    if (lds > 65536) { hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kern, dim3(p.n_sets), dim3(64), lds, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_poa_order(const PoaDev &p, hipStream_t s) { return launch_ord(poa_order_kernel, p, s); }
+hipError_t launch_poa_msa_rank(const PoaDev &p, hipStream_t s) { return launch_ord(poa_msa_rank_kernel, p, s); }
+hipError_t launch_poa_msa_fill(const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(poa_msa_fill_kernel, dim3(p.n_sets), dim3(GT), 0, s, p);
+    return hipGetLastError();
+}
 
 }  // namespace abpoa_hip

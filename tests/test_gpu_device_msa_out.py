@@ -1,0 +1,133 @@
+"""GPU (-m gpu): the device-resident read-set driver on the jobs it did not take before round 4 -- MSA output (read-id bitsets per edge,
+MSA rank walk and row fill on the device), amino-acid alphabets (aligned groups of up to 26 nodes) and LOCAL alignment (the reference's own
+Kahn row order rebuilt on the device before every read: local mode breaks score ties by row index).  Every result is compared with the
+CPU build of the host layer whose aligner is the plain-C oracle (tests/cpu_shim.cpp): MSA rows byte for byte, consensus, coverage.
+Reference code these follow: src/abpoa_graph.c:186-231 (row order), :315-375 (MSA rank), :418-484 (read ids), src/abpoa_output.c:103-166 (RC-MSA)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from abpoa_amd import ffi
+    lib = ffi.lib()
+    assert lib.abpoa_hip_device_count() >= 1
+    ffi.check(lib.abpoa_hip_init(0))
+    return lib
+
+
+def _same(dev, ref, what, cons=True, msa=True):
+    for i, (a, b) in enumerate(zip(dev, ref)):
+        assert a.status == 0 and b.status == 0, f"{what}: set {i} status {a.status} / {b.status}"
+        if msa:
+            assert a.msa_len == b.msa_len, f"{what}: set {i}: {a.msa_len} MSA columns, oracle-backed run {b.msa_len}"
+            assert a.msa_seq == b.msa_seq, f"{what}: MSA rows of set {i} differ"
+        if cons:
+            assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{what}: consensus of set {i} differs"
+
+
+@pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
+@pytest.mark.parametrize("out_cons", [False, True], ids=["msa_only", "msa_and_consensus"])
+def test_global_msa_output_on_the_device(engine, monkeypatch, lockstep, out_cons):
+    """Nucleotide reads, global banded alignment, MSA output (-r 1 / -r 2): ragged sets (3-40 reads: one and -- at 70 reads -- two words of read ids per
+    edge), 2-18 % errors, affine and convex gaps.  The all-rounds kernel and the lock-step launches share the fuse body that keeps the read ids."""
+    import helpers as H
+    from abpoa_amd import api, synth
+    monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", str(lockstep))
+    shim = H.cpu_shim_lib()
+    for kw, shapes in ((dict(gap_open1=4, gap_open2=0, gap_ext1=2), [(3 + (5 * i) % 38, 120 + 61 * i, 0.02 + 0.02 * (i % 8)) for i in range(12)] + [(70, 150, 0.08)]),
+                       (dict(), [(6 + i, 300 + 90 * i, 0.12) for i in range(6)])):
+        sets = [synth.make_read_set(31, i, n, ln, err) for i, (n, ln, err) in enumerate(shapes)]
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4)
+        assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+        ref = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"{kw} out_cons={out_cons}", cons=out_cons)
+
+
+def test_protein_global_msa_and_consensus_on_the_device(engine):
+    """27-code alphabet, BLOSUM62, global convex gaps: aligned groups of more than four nodes (substitution-heavy reads), consensus + MSA."""
+    import helpers as H
+    from abpoa_amd import api, synth, workloads
+    shim = H.cpu_shim_lib()
+    p = api.Params(is_aa=True, score_matrix=workloads.BLOSUM62)
+    sets = [synth.make_read_set(37, i, 12 + i % 9, 150 + 40 * i, alphabet=synth.AA, rates=(0.10 + 0.02 * (i % 4), 0.02, 0.02)) for i in range(10)]
+    dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+    _same(dev, ref, "protein global")
+
+
+@pytest.mark.parametrize("name,kw,mk", [
+    ("aa_blosum_convex", dict(aln_mode=1, is_aa=True, score_matrix="BLOSUM62"), lambda i: dict(n_reads=8 + i % 23, length=60 + 37 * i, alphabet="AA", rates=(0.05 + 0.01 * (i % 5), 0.03, 0.03))),
+    ("aa_blosum_affine", dict(aln_mode=1, is_aa=True, score_matrix="BLOSUM62", gap_open1=11, gap_open2=0, gap_ext1=1), lambda i: dict(n_reads=10 + i % 7, length=100 + 38 * i, alphabet="AA", rates=(0.08, 0.02, 0.04))),
+    ("nt_local_convex", dict(aln_mode=1), lambda i: dict(n_reads=6 + i % 11, length=90 + 43 * i, err=0.04 + 0.02 * (i % 6))),
+    ("nt_local_affine", dict(aln_mode=1, gap_open1=4, gap_open2=0, gap_ext1=2), lambda i: dict(n_reads=12, length=200 + 28 * i, err=0.10)),
+])
+def test_local_mode_msa_on_the_device(engine, name, kw, mk):
+    """Local alignment (-m 1: no band), MSA output, ragged read-sets of 60-540 residues: the shape of BASELINE.json configs[4] and around it.  The row
+    order is the reference's Kahn walk rebuilt on the device before every read (poa_order_kernel)."""
+    import helpers as H
+    from abpoa_amd import api, synth, workloads
+    shim = H.cpu_shim_lib()
+    kw = dict(kw)
+    if kw.get("score_matrix") == "BLOSUM62":
+        kw["score_matrix"] = workloads.BLOSUM62
+    p = api.Params(**kw)
+    sets = []
+    for i in range(12):
+        a = mk(i)
+        if a.get("alphabet") == "AA":
+            a["alphabet"] = synth.AA
+        sets.append(synth.make_read_set(43, i, **a))
+    for out_cons in (False, True):
+        dev = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4)
+        assert api.msa_timing()["pad"] == 0, f"{name}: device driver not used for every set"
+        ref = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"{name} out_cons={out_cons}", cons=out_cons)
+    dev = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4)      # consensus only, local mode
+    assert api.msa_timing()["pad"] == 0
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
+    _same(dev, ref, f"{name} consensus only", msa=False)
+
+
+def test_config5_sample_on_the_device_against_reference_digests(engine):
+    """BASELINE.json configs[4]: the first 48 sets (30 x 500 aa, local convex BLOSUM62, MSA output) through the device driver against the committed
+    digests of the reference's own output for those sets."""
+    from abpoa_amd import api, synth, workloads
+    wl = workloads.WORKLOADS["cfg5"]
+    dig = workloads.load_digests("cfg5")
+    assert dig is not None
+    sets = [synth.make_read_set(1, i, **synth.CONFIGS[5]) for i in range(48)]
+    p = api.Params(**wl["params"])
+    res = api.msa_batch(sets, p, out_cons=False, out_msa=True, n_threads=8)
+    assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+    for i, r in enumerate(res):
+        assert r.status == 0
+        assert workloads.output_sha(api.format_output(r, [f"r{j}" for j in range(len(sets[i]))], False, True)) == dig[i], f"set {i}: output differs from the reference's"
+
+
+def test_device_row_order_graph_and_msa_checks_after_every_read(engine):
+    """ABPOA_HIP_DEVSYNC=1 (child process: the mode is read from the environment and reports on stderr): after every read the library compares the row
+    order the order kernel wrote with the host graph's Kahn walk, the device graph with the host graph fed the same cigars, and at the end the device
+    MSA with the host routine."""
+    code = ("import os,sys; sys.path.insert(0, %r)\n"
+            "from abpoa_amd import api, ffi, synth, workloads\n"
+            "lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
+            "sets = [synth.make_read_set(3, i, 9, 120 + 30 * i, alphabet=synth.AA, rates=(0.08, 0.03, 0.03)) for i in range(5)]\n"
+            "p = api.Params(aln_mode=1, is_aa=True, score_matrix=workloads.BLOSUM62)\n"
+            "r = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)\n"
+            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['pad'])\n" % ROOT)
+    env = dict(os.environ, ABPOA_HIP_DEVSYNC="1", ABPOA_HIP_HOSTGRAPH="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "OK True 0" in p.stdout, (p.stdout, p.stderr[-3000:])
+    for what in ("row order check ok", "graph check ok", "msa check ok", "consensus check ok"):
+        assert what in p.stderr, (what, p.stderr[-3000:])
+    assert "FAILED" not in p.stderr, p.stderr[-3000:]
