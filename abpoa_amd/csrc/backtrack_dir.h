@@ -145,7 +145,7 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             // The walk usually leaves a whole-row window through its lowest row: the next window then ends exactly where this one started, and its copy --
             // the win_bytes in front of that point, rows are adjacent in the arena -- can go out BEFORE the rows' geometry is known (which only says
             // which of the copied rows are complete): one memory round trip per window instead of two.
-            const bool early = nx_ok && hi == w_lo - 1;
+            bool early = nx_ok && hi == w_lo - 1;
             const unsigned e_lo = nx_end > (unsigned)win_bytes ? nx_end - (unsigned)win_bytes : 0u;
             if (early) {
                 const int n16 = (int)((nx_end - e_lo) >> 4);
@@ -171,6 +171,15 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             int r_full = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) r_full += __builtin_popcountll(__ballot(vq[q] && (early ? sa[q] >= e_lo : end_hi - sa[q] <= (unsigned)win_bytes)));
+            if (early && r_full == 0) {
+                // the speculative copy holds no complete row (row hi -- its words plus, behind them, the score records of the row below when that one keeps
+                // them -- is larger than the window: a spill row after a band blow-up, or the 64-row windows of four wavefronts on one walk): let the copy
+                // drain, forget it, and size the window for (hi, jtop) as if nothing had been copied
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                early = false; nx_ok = false;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) r_full += __builtin_popcountll(__ballot(vq[q] && end_hi - sa[q] <= (unsigned)win_bytes));
+            }
             const bool narrow = early || r_full >= imin(16, hi);
             int sl[NQ], ns[NQ], off[NQ], R;
             unsigned s_lo = 0;

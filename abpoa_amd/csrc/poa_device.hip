@@ -13,6 +13,10 @@
 // which topological order is used (predecessor lists keep their in_id order, band and remaining length are functions of
 // the graph), and the batch driver's tests check the consensus of every set against the host driver, which keeps the
 // reference's order.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "poa_bodies.h"      // helpers, poa_prepare_body, poa_fuse_body
 
 namespace abpoa_hip {
@@ -173,28 +177,65 @@ extern __shared__ int ord_lds[];               // [ORD_RING] ring, then -- LDS t
 template <bool L> __device__ __forceinline__ int &tbl(const PoaDev &p, int32_t *g, int which, int n, int i) { return L ? ord_lds[ORD_RING + which * n + i] : g[(int64_t)which * n + i]; }
 template <bool L> __device__ __forceinline__ int tbl_ld(const PoaDev &p, int32_t *g, int which, int n, int i) { return L ? ord_lds[ORD_RING + which * n + i] : ld_fresh(g + (int64_t)which * n + i); }
 
+// (Measured and dropped: the adjacency staged in LDS too -- 26 bytes a node.  A walk's wavefront then waits 24 % less, but 70 KB of LDS leave one
+//  workgroup per CU instead of six and the launch runs in four turns: 4.1 ms instead of 1.5 ms per launch on configs[4].)
+// orders this wavefront's table accesses (one wavefront per read-set: no barrier): LDS tables need the LDS queue drained, global ones the stores acknowledged.
+// (Not __syncthreads(): its vmcnt(0) would also wait, every pass, for the stores of the row order -- a memory round trip the walk does not depend on.)
+template <bool L> __device__ __forceinline__ void tbl_fence() {
+    if (L) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 template <bool L>
 __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S, const int n, int32_t *order) {
     const int lane = threadIdx.x;
     const int64_t N0 = S.node0;
     int32_t *g = p.scratch + S.scratch0;           // (global tables when the graph is larger than the LDS tables: [n] counters, [n] zero times)
-    for (int u = lane; u < n; u += 64) { tbl<L>(p, g, 0, n, u) = p.nd_nin[N0 + u]; tbl<L>(p, g, 1, n, u) = -1; }
+    for (int u = lane; u < n; u += 64) {
+        tbl<L>(p, g, 0, n, u) = p.nd_nin[N0 + u]; tbl<L>(p, g, 1, n, u) = -1;
+    }
     if (lane == 0) { order[0] = 0; p.nd_row[N0] = 0; ord_lds[0] = 0; }
-    __syncthreads();
+    tbl_fence<L>();
     int head = 0, tail = 1;
     while (head < tail) {
+        if (tail - head == 1) {
+            // ONE node in the queue (most passes: a POA graph is chains with short bubbles): the reference's own sequential step, executed by every lane
+            // with the same values (wave-uniform control flow, broadcast LDS reads; lane 0 stores) -- no atomics, no time-stamp comparison, no scan:
+            // a third of the LDS round trips of the parallel pass below.  zt is kept up to date for the passes that compare it.
+            const int u = uni(ord_lds[head & (ORD_RING - 1)]);
+            int no; int4 o4;
+            no = uni((int)p.nd_nout[N0 + u]); o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT);
+            int at = tail;
+            for (int k = 0; k < no; ++k) {
+                const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))));
+                const int d = uni(tbl_ld<L>(p, g, 0, n, v)) - 1;
+                if (lane == 0) { tbl<L>(p, g, 0, n, v) = d; tbl<L>(p, g, 1, n, v) = head * 16 + k; }
+                if (d != 0) continue;
+                const int na = uni((int)p.nd_naln[N0 + v]);
+                bool ready = true;
+                if (na > 0) { tbl_fence<L>(); for (int t = 0; t < na && ready; ++t) ready = uni(tbl_ld<L>(p, g, 0, n, p.nd_aln[(N0 + v) * p.aln_cap + t])) == 0; }      // (fence: lane 0's store above may be what an aligned node's entry holds)
+                if (!ready) continue;
+                if (at + 1 + na > n) return false;
+                if (lane == 0) { order[at] = v; p.nd_row[N0 + v] = at; ord_lds[at & (ORD_RING - 1)] = v; }
+                if (lane < na) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + lane]; order[at + 1 + lane] = a; p.nd_row[N0 + a] = at + 1 + lane; ord_lds[(at + 1 + lane) & (ORD_RING - 1)] = a; }
+                at += 1 + na;
+            }
+            tail = at; ++head;
+            tbl_fence<L>();
+            continue;
+        }
         const int cnt = imin_(64, tail - head), pos = head + lane; const bool act = lane < cnt;
         int u = 1, no = 0; int4 o4 = make_int4(0, 0, 0, 0);
-        if (act) u = (tail - head <= ORD_RING) ? ord_lds[pos & (ORD_RING - 1)] : ld_fresh(order + pos);
+        if (tail - head <= ORD_RING) { if (act) u = ord_lds[pos & (ORD_RING - 1)]; }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (act) u = ld_fresh(order + pos); }      // (a frontier wider than the ring: from the order array, once its stores are acknowledged)
         if (act) { no = p.nd_nout[N0 + u]; o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
         auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))); };
         for (int k = 0; k < no; ++k) { const int v = target(k); atomicSub(&tbl<L>(p, g, 0, n, v), 1); atomicMax(&tbl<L>(p, g, 1, n, v), pos * 16 + k); }
-        __syncthreads();
+        tbl_fence<L>();
         unsigned trig = 0; int total = 0;
         for (int k = 0; k < no; ++k) {
             const int v = target(k), key = pos * 16 + k;
             if (tbl_ld<L>(p, g, 0, n, v) != 0 || tbl_ld<L>(p, g, 1, n, v) != key) continue;
-            const int na = p.nd_naln[N0 + v]; bool ready = true;
+            const int na = (int)p.nd_naln[N0 + v]; bool ready = true;
             for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
             if (ready) { trig |= 1u << k; total += 1 + na; }
         }
@@ -202,12 +243,12 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
         if (tail + all > n) return false;                                          // (more entries than nodes: not a graph this walk understands)
         int at = tail + incl - total;
         for (int k = 0; k < no; ++k) if (trig >> k & 1) {
-            const int v = target(k), na = p.nd_naln[N0 + v];
+            const int v = target(k), na = (int)p.nd_naln[N0 + v];
             order[at] = v; p.nd_row[N0 + v] = at; ord_lds[at & (ORD_RING - 1)] = v; ++at;
             for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; order[at] = a; p.nd_row[N0 + a] = at; ord_lds[at & (ORD_RING - 1)] = a; ++at; }
         }
         tail += all; head += cnt;
-        __syncthreads();
+        tbl_fence<L>();
     }
     return head == n;
 }
@@ -223,6 +264,7 @@ __global__ void __launch_bounds__(64) poa_order_kernel(const PoaDev p) {
     int32_t *order = p.row_node[uni(st->order_buf)] + S.node0;
     const bool ok = n <= p.order_lds ? poa_order_body<true>(p, S, n, order) : poa_order_body<false>(p, S, n, order);
     // (the sink is the last node the walk reaches, reference :203-206; anything else means the graph is not what the fuse phase should have left)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && (!ok || ld_fresh(order + n - 1) != 1)) { st->status = POA_ST_FALLBACK; st->pad = 7; }
 }
 
@@ -338,7 +380,15 @@ size_t poa_order_lds_bytes(int node_cap) { return 4 * (size_t)ORD_RING + 8 * (si
 static hipError_t launch_ord(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
     const size_t lds = poa_order_lds_bytes(p.order_lds);
-    if (lds > 65536) { hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    // (above 64 KB the kernel's dynamic-LDS limit has to be raised: once per kernel, device and size -- the call is slow enough to stall a queue of
+    //  back-to-back launches when repeated every round)
+    if (lds > 65536) {
+        static std::mutex mu; static std::map<std::pair<const void *, int>, size_t> raised;
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        size_t &have = raised[{(const void *)kern, dev}];
+        if (have < lds) { hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; have = lds; }
+    }
     hipLaunchKernelGGL(kern, dim3(p.n_sets), dim3(64), lds, s, p);
     return hipGetLastError();
 }

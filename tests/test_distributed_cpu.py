@@ -6,6 +6,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -63,6 +64,30 @@ def test_two_rank_shards_equal_single_process(tmp_path):
     assert int(lines[0][0].split()[1]) == sum(r.n_cells for r in single)
 
 
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abpoa_amd.shard import gather_records
+    first, n = shard_range(21, world, rank)                      # ragged shards (21 sets over 8 ranks: 3,3,3,3,3,2,2,2) and ragged records, one rank may be empty
+    recs = gather_records([b"set%d-" % (first + i) + b"ACGT" * ((first + i) % 5) for i in range(n)], dist)
+    if rank == 0:
+        with open(os.path.join(out_dir, "gathered.txt"), "wb") as f:
+            f.write(b"\n".join(recs))
+    else:
+        assert recs is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_result_gather_over_gloo(tmp_path, world):
+    """The one collective of the multi-GPU job -- every rank's consensus records on rank 0, in rank order (abpoa_amd.shard.gather_records: one padded
+    all_gather) -- at world 2 and at the 8 ranks of the scaling run, over gloo."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = open(tmp_path / "gathered.txt", "rb").read().split(b"\n")
+    assert got == [b"set%d-" % k + b"ACGT" * (k % 5) for k in range(21)]
+
+
 def test_shard_rules():
     for total in (0, 1, 7, 8, 1000, 8000):
         for world in (1, 2, 3, 8):
@@ -94,6 +119,7 @@ def test_bench_self_launch_over_gloo():
     rec = json.loads(line)
     assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["max_rank_plus_1"] == 2.0
     assert rec["sets_all_ranks"] == rec["total_sets"] == 40 and rec["sum_of_first_indices"] == shard_range(40, 2, 1)[0]
+    assert rec["records_gathered"] == 40          # the result gather: every record on rank 0, in order (asserted inside the run)
     if torch.cuda.device_count() < 2:
         q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sets", "8"], capture_output=True, text=True, env=env, timeout=300)
         assert q.returncode == 2 and "nothing was launched" in q.stderr and "Traceback" not in q.stderr

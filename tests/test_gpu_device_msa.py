@@ -125,6 +125,25 @@ def test_two_wavefronts_on_a_backtrack_change_nothing(engine, monkeypatch, kw):
         assert a.cons_seq == b.cons_seq == c.cons_seq and a.cons_cov == b.cons_cov == c.cons_cov and a.n_cells == b.n_cells == c.n_cells, f"set {i} {shapes[i]}"
 
 
+@pytest.mark.parametrize("bt_bytes", ["4096", "6144"])
+def test_small_backtrack_windows_with_wide_rows(engine, monkeypatch, bt_bytes):
+    """The backtrack's LDS window at its smallest (ABPOA_HIP_BT_BYTES; in the all-rounds kernel four wavefronts share it: about 1 KB each) against noisy
+    reads whose bands open to 100+ columns and whose rows keep score records beside their direction words: the window that was copied ahead of the geometry
+    loads can then hold no complete row, and the walk has to drop that copy and size the window anew (backtrack_dir.h load_window).  Both forms of the
+    driver, equal to the host driver."""
+    from abpoa_amd import api, synth
+    monkeypatch.setenv("ABPOA_HIP_BT_BYTES", bt_bytes)
+    shapes = [(10 + i % 6, 700 + 90 * i, 0.20 + 0.02 * (i % 4), (0.05, 0.10, 0.05) if i % 2 else (0.05, 0.05, 0.10)) for i in range(12)]
+    sets = [synth.make_read_set(47, i, n, ln, err, rates=rt) for i, (n, ln, err, rt) in enumerate(shapes)]
+    for kw in (dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict()):
+        for lockstep in ("0", "1"):
+            monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", lockstep)
+            host, dev, tm = _both(sets, api.Params(**kw))
+            for i, (a, b) in enumerate(zip(dev, host)):
+                assert a.status == 0 and b.status == 0, (kw, lockstep, i, a.status, b.status)
+                assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov and a.n_cells == b.n_cells, f"{kw} lockstep={lockstep}: set {i} differs"
+
+
 def test_device_graph_equals_host_graph_after_every_read(engine):
     """Runs in a child process because the check mode is chosen by an environment variable at call time and prints to stderr."""
     code = ("import os,sys; sys.path.insert(0, %r)\n"

@@ -1,6 +1,6 @@
 # Instruction counts of the dominant kernel of a bench workload (rocprofv3 PMC, one pass): SQ_INSTS_VALU / SALU / LDS and wave cycles, as a JSON record
 # under gpurun_out/ that bench.py reads (copied to profiles/) for its integer-VALU roofline while the row-loop sources are unchanged.
-# usage (GPU box): bash tools/pmc_insts.sh cfg2|cfg3|cfg4 [read-sets]
+# usage (GPU box): bash tools/pmc_insts.sh cfg2|cfg3|cfg4|cfg5 [read-sets]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 WL=${1:-cfg2}; N=${2:-0}
@@ -18,7 +18,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for d in ("/tmp/pmc_out_i", "/tmp/pmc_out_w"):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0].replace("void abpoa_hip::", "")][r["Counter_Name"]] += float(r["Counter_Value"])
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("abpoa_hip::", "")][r["Counter_Name"]] += float(r["Counter_Value"])
 line = json.loads(open("/tmp/pmc_log_i.txt").read().strip().split("\n")[-1])
 all_rounds = "poa_rounds_kernel" in line["roofline"]["kernel"]
 keys = [k for k in acc if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_local_kernel"))]
@@ -35,6 +35,6 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "kernel
        "commit": (subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or (open(os.path.join(root, ".git_head")).read().strip() if os.path.exists(os.path.join(root, ".git_head")) else "") or os.environ.get("ABPOA_COMMIT") or "working tree"),
        "how": "tools/pmc_insts.sh: rocprofv3 --kernel-trace --pmc <4 counters>, two passes over `bench.py --workload %s --steps 1 --warmup 0`" % wl}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-json.dump(rec, open(os.path.join(root, "gpurun_out", f"r3_pmc_insts_{wl}.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(root, "gpurun_out", f"r4_pmc_insts_{wl}.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in rec.items() if k != "all_kernels"}, indent=1))
 PY
