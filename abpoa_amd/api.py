@@ -28,7 +28,7 @@ class Msa(C.Structure):              # abpoa_hip_msa_t
 
 class MsaTiming(C.Structure):        # abpoa_hip_msa_timing_t
     _fields_ = [("host_sort_s", C.c_double), ("host_fuse_s", C.c_double), ("engine_s", C.c_double), ("cons_s", C.c_double),
-                ("total_s", C.c_double), ("n_rounds", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32), ("pad", C.c_int32)]
+                ("total_s", C.c_double), ("n_rounds", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32), ("n_host_sets", C.c_int32)]
 
 
 class Params:
@@ -195,7 +195,9 @@ def msa_timing(lib=None):
     _bind_msa(lib)
     t = MsaTiming()
     lib.abpoa_hip_get_msa_timing(C.byref(t))
-    return {k: getattr(t, k) for k, _ in MsaTiming._fields_}
+    d = {k: getattr(t, k) for k, _ in MsaTiming._fields_}
+    d["pad"] = d["n_host_sets"]          # (the field's name before round 4)
+    return d
 
 
 def format_output(result, names=None, out_cons=True, out_msa=False):

@@ -54,8 +54,14 @@ def main(argv=None, lib=None, out=None):
                         gap_open1=o1, gap_open2=o2, gap_ext1=e1, gap_ext2=e2, extra_b=a.extra_b, extra_f=a.extra_f)
     files = [ln.strip() for ln in open(a.input) if ln.strip()] if a.in_list else [a.input]
     names, sets, weights = [], [], []
+    sticky = {}      # a nameless record shows the last name seen at its position in an earlier file of the list (the reference's abpoa_seq_t lives across the files: src/abpoa_seq.c:123-130)
     for fn in files:
         n, s, q = seqio.read_fastx(fn)
+        for i, nm in enumerate(n):
+            if nm:
+                sticky[i] = nm
+            elif i in sticky:
+                n[i] = sticky[i]
         names.append(n)
         sets.append(s)
         weights.append([seqio.qv_weights(x, y) for x, y in zip(s, q)])

@@ -9,6 +9,7 @@ namespace abpoa_hip {
 // first read, so that a test can compare the device-resident driver's cigars with the oracle-backed host run directly (abpoa_hip__cigar_digest).
 bool cigar_digest_on();
 void cigar_digest_add(const uint8_t *seq0, int len0, int read_index, const uint64_t *cigar, int n_cigar);
+void cigar_digest_set(const uint8_t *seq0, int len0, uint64_t value);      // (the device-resident driver keeps the digest on the device: poa_device.h)
 int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out,
                   unsigned flags, int n_threads, int n_groups, AlignerFactory make, abpoa_hip_msa_timing_t *timing);
 }

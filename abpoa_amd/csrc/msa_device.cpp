@@ -312,6 +312,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     PoaDev p; memset(&p, 0, sizeof(p));
     p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2; p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
+    p.dig_on = cigar_digest_on() ? 1 : 0;      // (tests: the fuse phase folds every graph cigar into PoaState.cigar_dig)
     p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = local ? 1 : 0; p.banded = sc->wb >= 0 ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
     // LDS tables of the order / rank kernels (two ints per node; the rank pass packs four tables into the same space): up to 6000 nodes = 52 KB, three workgroups per CU
     p.order_lds = (local || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
@@ -367,7 +368,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
     //      per phase and round throughout (what the wide-band jobs use, and the per-round diagnostics below).
     const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
-    bool use_rounds = !local && rounds_possible && !dbg_sync && !cigar_digest_on() && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
+    bool use_rounds = !local && rounds_possible && !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
     DevBatch b_r = b; size_t rounds_lds = 0;
     if (use_rounds) {
         auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), std::max<size_t>((size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), (size_t)16 * 256)); };      // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
@@ -529,17 +530,6 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr, "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible (preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key window / wrap %.0f\n", k, sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);
             fprintf(stderr, "[poa-device] round %d tail means: steps %.0f  flag steps %.0f  slow steps %.0f  windows %.1f  window ticks %.0f (setup %.0f)  walk ticks %.0f\n", k, st_ / n_sets, sg[2] / n_sets / 1000, sg[3] / n_sets / 1000, sg[4] / n_sets / 1000, sg[5] / n_sets, sg[0] / n_sets, sg[1] / n_sets);
         }
-        if (cigar_digest_on()) {      // (test hook: the graph cigar of every set's alignment of this round, folded into the per-set digests; synchronises the stream)
-            std::vector<AlnOut> ho(n_sets); HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
-            (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
-            std::vector<uint64_t> cgb;
-            for (int s_ = 0; s_ < n_sets; ++s_) {
-                if (k >= sets[s_].n_reads || ho[s_].status != 0) continue;
-                cgb.resize((size_t)std::max(1, ho[s_].n_cigar));
-                (void)hipMemcpy(cgb.data(), (uint8_t *)p.cigar + 8 * ps[s_].cigar_off, 8 * (size_t)ho[s_].n_cigar, hipMemcpyDeviceToHost);
-                cigar_digest_add(sets[s_].seqs[0], sets[s_].lens[0], k, cgb.data(), ho[s_].n_cigar);
-            }
-        }
         HIP_OK(hipEventRecord(e[2], st), ABPOA_HIP_ELAUNCH);
         HIP_OK(launch_poa_fuse(p, st), ABPOA_HIP_ELAUNCH);
         if (stage("fuse", k)) return ABPOA_HIP_ELAUNCH;
@@ -603,6 +593,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
             if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
             o_.n_cells = hs[s].n_cells;
+            if (p.dig_on && sets[s].n_reads > 0) cigar_digest_set(sets[s].seqs[0], sets[s].lens[0], hs[s].cigar_dig);
             if (want_cons && hs[s].n_nodes > 2) {
                 const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
                 o_.cons_len = len;

@@ -115,6 +115,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
 
 // ABPOA_GPU_DEVICES: "all", or a comma list of device ordinals (a repeated ordinal = two queues on that
 // device); unset = the device the engine was initialised on.
+bool strict_mode() { const char *e = getenv("ABPOA_HIP_STRICT"); return e && atoi(e) != 0; }
 std::vector<int> device_list() {
     std::vector<int> d;
     const char *e = getenv("ABPOA_GPU_DEVICES");
@@ -205,8 +206,10 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpo
             memset(&g_timing, 0, sizeof(g_timing));
             g_timing.engine_s = tot.device_s; g_timing.cons_s = tot.cons_s; g_timing.total_s = tot.total_s; g_timing.n_rounds = tot.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = n_q;
             g_timing.host_sort_s = tot.prepare_ms / 1e3; g_timing.host_fuse_s = tot.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
-            g_timing.pad = (int32_t)todo.size();             // how many sets take the host driver
+            g_timing.n_host_sets = (int32_t)todo.size();             // how many sets take the host driver
             if (todo.empty()) return ABPOA_HIP_OK;
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] %zu of %d read-sets outgrew a device capacity: host driver for those\n", todo.size(), n_sets);
+            if (strict_mode()) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); set_err("ABPOA_HIP_STRICT: %zu of %d read-sets would take the host driver (device capacities: node / edge / aligned slots, arena)", todo.size(), n_sets); return ABPOA_HIP_ESTRICT; }
             std::vector<abpoa_hip_readset_t> sub(todo.size()); std::vector<abpoa_hip_msa_t> sub_out(todo.size());
             for (size_t i = 0; i < todo.size(); ++i) sub[i] = sets[todo[i]];
             abpoa_hip_msa_timing_t t2;
@@ -217,7 +220,12 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpo
         }
         for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]);
     }
-    return run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &g_timing);
+    // the whole job on the host driver: its options are not the device-resident driver's (linear gaps, extension mode, -s, per-base weights, no band in
+    // global mode, local reads beyond the local row loop), or it does not fit the device even alone
+    if (strict_mode() && n_sets > 0) { set_err("ABPOA_HIP_STRICT: this job's options are the host driver's (see msa_device_eligible)"); return ABPOA_HIP_ESTRICT; }
+    const int rc_host = run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &g_timing);
+    g_timing.n_host_sets = n_sets;
+    return rc_host;
 }
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
 void abpoa_hip_trim(void) { abpoa_hip::release_msa_device_caches(); }

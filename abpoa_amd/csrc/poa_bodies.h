@@ -285,6 +285,16 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     const int cur = uni(st->order_buf);
     const int32_t *order_old = p.row_node[cur] + N0; int32_t *order_new = p.row_node[cur ^ 1] + N0;
     int32_t *cand = p.scratch + S.scratch0, *n_anchor = cand + p.max_qlen, *n_j = n_anchor + p.max_qlen, *addcnt = n_j + p.max_qlen;
+    if (p.dig_on) {      // (tests) this alignment's cigar into the set's digest -- before the early return: an empty cigar is a cigar too
+        __shared__ unsigned long long sh_dig;
+        if (tid == 0) sh_dig = 0;
+        __syncthreads();
+        unsigned long long part = 0;
+        for (int i = tid; i < n_cigar; i += GT) part += poa_cigar_word_mix(cg[i], i);
+        if (part) atomicAdd(&sh_dig, part);
+        __syncthreads();
+        if (tid == 0) st->cigar_dig = poa_cigar_digest_round(st->cigar_dig, k, n_cigar, sh_dig);
+    }
     if (n_cigar == 0) return;                                                   // reference :614-616
     // F0/F1: node every query base is aligned to (-1: inserted base)
     for (int q = tid; q < qlen; q += GT) cand[q] = -1;

@@ -44,7 +44,16 @@ struct PoaState {                  // mutable per read-set
     int64_t algo_bytes;            // cells * algorithmic bytes per cell (affine 5S, convex 8S; S = 2 | 4)
     int64_t algo_bytes_before;     // algo_bytes when the all-rounds kernel took the set over (what it computed itself = algo_bytes - this)
     int64_t t_phase[4];            // all-rounds kernel (poa_rounds.hip): shader-clock ticks this set spent in prepare / row loop / backtrack / fuse
+    uint64_t cigar_dig;            // (PoaDev.dig_on, tests) digest of every graph cigar fused into this set so far, folded in read order: poa_cigar_digest_round
 };
+// Test hook (ABPOA_HIP_CIGAR_DIGEST=1): one 64-bit digest per read-set over the graph cigars of all its alignments, computed the same way by the fuse phase on
+// the device (all lanes: a sum of per-word mixes) and by the host driver (msa_batch.cpp), so that the cigars of BOTH forms of the device driver -- the all-rounds
+// kernel with its four-wavefront backtrack included -- can be compared with the oracle-backed host run word for word without leaving the device.
+__host__ __device__ inline uint64_t poa_mix64(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+__host__ __device__ inline uint64_t poa_cigar_word_mix(uint64_t word, int i) { return poa_mix64(word + 0xD6E8FEB86659FD93ull * (uint64_t)(i + 1)); }
+__host__ __device__ inline uint64_t poa_cigar_digest_round(uint64_t before, int read_index, int n_cigar, uint64_t sum_of_word_mixes) {
+    return (before * 0x9E3779B97F4A7C15ull) ^ (sum_of_word_mixes + poa_mix64(((uint64_t)(uint32_t)read_index << 32) | (uint32_t)n_cigar));
+}
 
 struct PoaDev {                    // everything the poa_* kernels need; passed by value
     int32_t n_sets, m;
@@ -57,7 +66,7 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
                                    // 1: the reference's own order, rebuilt before every alignment (poa_order_kernel: local mode breaks score ties by row index)
     int32_t banded;                // 0: no adaptive band (local mode): the remaining length is not computed
     int32_t msa_rows, msa_cons;    // rows of a set's MSA = its reads (+ 1 when msa_cons: the consensus row, abpoa_output.c:151-164)
-    int32_t order_lds, pad_b;      // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice)
+    int32_t order_lds, dig_on;     // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice); dig_on: PoaState.cigar_dig is kept
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
     // graph, indexed node0 + node id

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
-    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; st->cons_len = 0; st->msa_len = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0; st->algo_bytes_before = 0; }
+    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; st->cons_len = 0; st->msa_len = 0; st->cigar_dig = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0; st->algo_bytes_before = 0; }
     if (S.n_reads <= 0) { if (lane == 0) { st->n_nodes = 2; st->status = POA_ST_OK; } return; }
     const int L = p.read_len[S.read0];
     const uint8_t *seq = p.reads + p.read_off[S.read0];

@@ -1,0 +1,248 @@
+/*
+ * abpoa_batch -- C front end of the MI355X engine's read-set batch entry (include/abpoa_hip.h, abpoa_hip_msa_batch).
+ *
+ * Same command line as the reference's `abpoa` for what the engine covers (option letters and defaults of
+ * src/abpoa.c:22-59, :148-214 and abpoa_init_para, src/abpoa_align.c:93-141), same output text
+ * (abpoa_output_fx_consensus, src/abpoa_output.c:495-512; abpoa_output_rc_msa, :70-101).  The one difference is the
+ * reason it exists: with -l the reference runs the files of the list one after the other through one abpoa_t
+ * (src/abpoa.c:131-141); here every file of the list is one read-set and ALL of them go to the GPU in ONE call.
+ *
+ *   abpoa_batch [options] <in.fa|in.fq|list.txt>      (plain or gzip'ed; FASTA / FASTQ)
+ *     -m INT   0 global, 1 local, 2 extension          -M INT match [2]      -X INT mismatch [4]      -t FILE score matrix
+ *     -O INT[,INT] gap open [4,24]   -E INT[,INT] gap extension [2,1]   -b INT [10] / -f FLOAT [0.01] adaptive band (b < 0: off)
+ *     -c amino acids   -l the input is a list of files   -o FILE output [stdout]   -r INT 0 consensus, 1 MSA, 2 both
+ *     -s ambiguous strand   -Q base qualities as edge weights   -T INT host threads [all]   -v version
+ * Options of the reference that the engine does not cover (-S -k -w -n -p -i -g -d -q -z -e, -r 3/4/5) are refused, not ignored.
+ *
+ * Plain C99 + zlib; links against libabpoa_hip.so only.  Own code throughout: no klib / kseq.
+ */
+#include <getopt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include "abpoa_hip.h"
+
+#define DIE(...) do { fprintf(stderr, "abpoa_batch: " __VA_ARGS__); fputc('\n', stderr); exit(1); } while (0)
+
+/* ---- alphabets: codes and letters of the reference's tables (src/abpoa_seq.c:15-95) */
+static uint8_t nt_code[256], aa_code[256];
+static const char nt_letter[] = "ACGTN-", aa_letter[] = "ACGTNBDEFHIJKLMOPQRSUVWXYZ*-";
+static void init_tables(void) {
+    memset(nt_code, 4, sizeof nt_code); memset(aa_code, 26, sizeof aa_code);
+    const char *nt = "ACGT";
+    for (int i = 0; i < 4; ++i) { nt_code[(uint8_t)nt[i]] = (uint8_t)i; nt_code[(uint8_t)(nt[i] + 32)] = (uint8_t)i; nt_code[i] = (uint8_t)i; }
+    nt_code['U'] = nt_code['u'] = 3;
+    for (int i = 0; i < 26; ++i) { aa_code[(uint8_t)aa_letter[i]] = (uint8_t)i; if (aa_letter[i] >= 'A' && aa_letter[i] <= 'Z') aa_code[(uint8_t)(aa_letter[i] + 32)] = (uint8_t)i; }
+    for (int i = 0; i < 27; ++i) aa_code[i] = (uint8_t)i;
+}
+
+/* ---- growable byte / pointer arrays */
+typedef struct { char *s; size_t n, cap; } str_t;
+static void str_push(str_t *a, const char *p, size_t k) {
+    if (a->n + k + 1 > a->cap) { a->cap = (a->n + k + 1) * 2 + 64; a->s = (char *)realloc(a->s, a->cap); if (!a->s) DIE("out of memory"); }
+    memcpy(a->s + a->n, p, k); a->n += k; a->s[a->n] = 0;
+}
+
+/* one input file = one read-set */
+typedef struct {
+    int n, cap;
+    char **name; uint8_t **code; int32_t *len; int32_t **weight;      /* weight: NULL unless -Q */
+} readset_t;
+static void rs_add(readset_t *r, const char *name, const str_t *seq, const str_t *qual, const uint8_t *tbl, int use_qv) {
+    if (r->n == r->cap) {
+        r->cap = r->cap ? 2 * r->cap : 64;
+        r->name = (char **)realloc(r->name, sizeof(char *) * r->cap); r->code = (uint8_t **)realloc(r->code, sizeof(uint8_t *) * r->cap);
+        r->len = (int32_t *)realloc(r->len, sizeof(int32_t) * r->cap); r->weight = (int32_t **)realloc(r->weight, sizeof(int32_t *) * r->cap);
+        if (!r->name || !r->code || !r->len || !r->weight) DIE("out of memory");
+    }
+    const int i = r->n++, L = (int)seq->n;
+    r->name[i] = strdup(name); r->len[i] = L;
+    r->code[i] = (uint8_t *)malloc(L > 0 ? L : 1);
+    for (int j = 0; j < L; ++j) r->code[i][j] = tbl[(uint8_t)seq->s[j]];
+    r->weight[i] = NULL;
+    if (use_qv) {      /* reference src/abpoa_align.c:462-467: quality - 32 where the record has as many qualities as bases, else 1 */
+        r->weight[i] = (int32_t *)malloc(sizeof(int32_t) * (L > 0 ? L : 1));
+        const int has_q = qual->n == seq->n && L > 0;
+        for (int j = 0; j < L; ++j) r->weight[i][j] = has_q ? (int32_t)(uint8_t)qual->s[j] - 32 : 1;
+    }
+}
+
+/* FASTA / FASTQ records of a (possibly gzip'ed) file: header line '>' or '@' (name = text up to the first blank), sequence lines up to the next
+ * header or a '+' line, then -- FASTQ -- quality lines until as many characters as bases */
+static void read_file(const char *fn, readset_t *r, const uint8_t *tbl, int use_qv) {
+    gzFile fp = gzopen(fn, "r");
+    if (!fp) DIE("cannot open %s", fn);
+    static char line[1 << 16];
+    str_t seq = {0, 0, 0}, qual = {0, 0, 0}, name = {0, 0, 0};
+    int have = 0, in_qual = 0, cont = 0;                             /* cont: the previous piece did not end its line */
+    str_push(&seq, "", 0); str_push(&qual, "", 0); str_push(&name, "", 0);
+    for (;;) {
+        char *got = gzgets(fp, line, sizeof line);
+        size_t k = got ? strlen(line) : 0;
+        const int whole = got && k > 0 && line[k - 1] == '\n';      /* (a line longer than the buffer comes in pieces) */
+        while (k > 0 && (line[k - 1] == '\n' || line[k - 1] == '\r')) line[--k] = 0;
+        const int is_head = got && !cont && !in_qual && (line[0] == '>' || line[0] == '@');
+        if (!got || is_head) {
+            if (have) rs_add(r, name.s, &seq, &qual, tbl, use_qv);
+            if (!got) break;
+            size_t e = 1; while (e < k && line[e] != ' ' && line[e] != '\t') ++e;
+            name.n = 0; str_push(&name, line + 1, e - 1);
+            seq.n = 0; seq.s[0] = 0; qual.n = 0; qual.s[0] = 0; have = 1; in_qual = 0;
+        } else if (have && !cont && !in_qual && line[0] == '+') in_qual = 1;
+        else if (have && in_qual) { str_push(&qual, line, k); if (qual.n >= seq.n) in_qual = 0; }
+        else if (have) { for (size_t j = 0; j < k; ++j) if (line[j] != ' ' && line[j] != '\t') str_push(&seq, line + j, 1); }
+        cont = !whole;
+    }
+    gzclose(fp); free(seq.s); free(qual.s); free(name.s);
+}
+
+/* ---- score matrix: abpoa_set_mat_from_file (src/abpoa_align.c:34-85) / gen_simple_mat (:12-25) */
+static void simple_matrix(int m, int match, int mismatch, int32_t *mat, int *max_mat, int *min_mis) {
+    match = abs(match); mismatch = -abs(mismatch);
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) mat[i * m + j] = (i == m - 1 || j == m - 1) ? 0 : (i == j ? match : mismatch);
+    *max_mat = match; *min_mis = -mismatch;
+}
+static void matrix_from_file(const char *fn, int m, const uint8_t *tbl, int32_t *mat, int *max_mat, int *min_mis) {
+    FILE *f = fopen(fn, "r");
+    if (!f) DIE("cannot open matrix file %s", fn);
+    char line[4096]; int order[64], n_order = -1;
+    memset(mat, 0, sizeof(int32_t) * m * m);
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '#') continue;
+        if (n_order < 0) { n_order = 0; for (char *p = line; *p; ++p) if (*p != ' ' && *p != '\t' && *p != '\n' && *p != '\r' && n_order < 64) order[n_order++] = tbl[(uint8_t)*p]; continue; }
+        char *p = line; while (*p == ' ' || *p == '\t') ++p;
+        if (!*p || *p == '\n' || *p == '\r') continue;
+        const int row = tbl[(uint8_t)*p];
+        if (row >= m) DIE("unknown residue '%c' in %s", *p, fn);
+        while (*p && *p != ' ' && *p != '\t') ++p;
+        for (int n = 0;; ++n) {
+            char *e; const long v = strtol(p, &e, 10);
+            if (e == p) break;
+            if (n >= m || n >= n_order) DIE("too many scores in a row of %s", fn);
+            mat[row * m + order[n]] = (int32_t)v; p = e;
+        }
+    }
+    fclose(f);
+    int mx = 0, mn = 0;
+    for (int i = 0; i < m * m; ++i) { if (mat[i] > mx) mx = mat[i]; if (-mat[i] > mn) mn = -mat[i]; }
+    *max_mat = mx; *min_mis = mn;
+}
+
+static const struct option long_opt[] = {
+    {"aln-mode", 1, NULL, 'm'}, {"match", 1, NULL, 'M'}, {"mismatch", 1, NULL, 'X'}, {"matrix", 1, NULL, 't'}, {"gap-open", 1, NULL, 'O'}, {"gap-ext", 1, NULL, 'E'},
+    {"extra-b", 1, NULL, 'b'}, {"extra-f", 1, NULL, 'f'}, {"zdrop", 1, NULL, 'z'}, {"bonus", 1, NULL, 'e'}, {"seeding", 0, NULL, 'S'}, {"k-mer", 1, NULL, 'k'},
+    {"window", 1, NULL, 'w'}, {"min-poa-win", 1, NULL, 'n'}, {"progressive", 0, NULL, 'p'}, {"use-qual-weight", 0, NULL, 'Q'}, {"amino-acid", 0, NULL, 'c'},
+    {"in-list", 0, NULL, 'l'}, {"increment", 1, NULL, 'i'}, {"amb-strand", 0, NULL, 's'}, {"output", 1, NULL, 'o'}, {"result", 1, NULL, 'r'}, {"out-pog", 1, NULL, 'g'},
+    {"max-num-cons", 1, NULL, 'd'}, {"min-freq", 1, NULL, 'q'}, {"threads", 1, NULL, 'T'}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {0, 0, 0, 0}};
+
+int main(int argc, char **argv) {
+    int mode = 0, match = 2, mismatch = 4, o1 = 4, o2 = 24, e1 = 2, e2 = 1, wb = 10, m = 5, in_list = 0, out_cons = 1, out_msa = 0, amb = 0, use_qv = 0, threads = 0, c;
+    float wf = 0.01f; const char *mat_fn = NULL; char *s;
+    while ((c = getopt_long(argc, argv, "m:M:X:t:O:E:b:f:z:e:QSk:w:n:i:clpso:r:g:d:q:T:hvV:", long_opt, NULL)) >= 0) {
+        switch (c) {
+            case 'm': mode = atoi(optarg); if (mode < 0 || mode > 2) DIE("unknown alignment mode: %d", mode); break;
+            case 'M': match = atoi(optarg); break;
+            case 'X': mismatch = atoi(optarg); break;
+            case 't': mat_fn = optarg; break;
+            case 'O': o1 = (int)strtol(optarg, &s, 10); if (*s == ',') o2 = (int)strtol(s + 1, &s, 10); break;
+            case 'E': e1 = (int)strtol(optarg, &s, 10); if (*s == ',') e2 = (int)strtol(s + 1, &s, 10); break;
+            case 'b': wb = atoi(optarg); break;
+            case 'f': wf = (float)atof(optarg); break;
+            case 'Q': use_qv = 1; break;
+            case 'c': m = 27; break;
+            case 'l': in_list = 1; break;
+            case 's': amb = 1; break;
+            case 'T': threads = atoi(optarg); break;
+            case 'o': if (strcmp(optarg, "-") != 0 && freopen(optarg, "wb", stdout) == NULL) DIE("failed to open the output file %s", optarg); break;
+            case 'r': { const int r = atoi(optarg); if (r == 0) { out_cons = 1; out_msa = 0; } else if (r == 1) { out_cons = 0; out_msa = 1; } else if (r == 2) { out_cons = out_msa = 1; }
+                        else { fprintf(stderr, "abpoa_batch: -r %d (GFA / FASTQ output) is outside this engine\n", r); return 2; } } break;
+            case 'v': printf("abpoa_batch (MI355X engine; output of abPOA 1.4.1)\n"); return 0;
+            case 'V': break;
+            case 'h': fprintf(stderr, "usage: abpoa_batch [-m -M -X -t -O -E -b -f -c -l -o -r -s -Q -T] <in.fa|in.fq|list.txt>   (see the head of abpoa_batch.c)\n"); return 1;
+            default: fprintf(stderr, "abpoa_batch: option -%c is outside this engine (seeding, guide tree, incremental graphs, plots, multiple consensus, z-drop)\n", c); return 2;
+        }
+    }
+    if (argc - optind != 1) { fprintf(stderr, "usage: abpoa_batch [options] <in.fa|in.fq|list.txt>\n"); return 1; }
+    init_tables();
+    const uint8_t *tbl = m > 5 ? aa_code : nt_code; const char *letter = m > 5 ? aa_letter : nt_letter;
+
+    /* ---- the read-sets */
+    int n_sets = 0, cap_sets = 0; readset_t *rs = NULL;
+    char fn[4096];
+    FILE *lf = in_list ? fopen(argv[optind], "r") : NULL;
+    if (in_list && !lf) DIE("cannot open list %s", argv[optind]);
+    for (;;) {
+        if (in_list) { if (!fgets(fn, sizeof fn, lf)) break; size_t k = strlen(fn); while (k > 0 && (fn[k - 1] == '\n' || fn[k - 1] == '\r')) fn[--k] = 0; if (k == 0) continue; }
+        else { if (n_sets == 1) break; snprintf(fn, sizeof fn, "%s", argv[optind]); }
+        if (n_sets == cap_sets) { cap_sets = cap_sets ? 2 * cap_sets : 256; rs = (readset_t *)realloc(rs, sizeof(readset_t) * cap_sets); if (!rs) DIE("out of memory"); }
+        memset(&rs[n_sets], 0, sizeof(readset_t));
+        read_file(fn, &rs[n_sets], tbl, use_qv);
+        ++n_sets;
+    }
+    if (lf) fclose(lf);
+
+    /* ---- parameters: abpoa_post_set_para (src/abpoa_align.c:143-168) */
+    abpoa_hip_scoring_t sc; memset(&sc, 0, sizeof sc);
+    int32_t *mat = (int32_t *)malloc(sizeof(int32_t) * m * m); int max_mat, min_mis;
+    if (mat_fn) matrix_from_file(mat_fn, m, tbl, mat, &max_mat, &min_mis); else simple_matrix(m, match, mismatch, mat, &max_mat, &min_mis);
+    sc.m = m; sc.mat = mat; sc.max_mat = max_mat; sc.min_mis = min_mis;
+    sc.gap_open1 = o1; sc.gap_ext1 = e1; sc.gap_open2 = o2; sc.gap_ext2 = e2;
+    sc.align_mode = mode; sc.gap_mode = o1 == 0 ? ABPOA_HIP_LINEAR_GAP : ((o1 > 0 && o2 == 0) ? ABPOA_HIP_AFFINE_GAP : ABPOA_HIP_CONVEX_GAP);
+    sc.wb = mode == ABPOA_HIP_LOCAL_MODE ? -1 : wb; sc.wf = wf; sc.zdrop = -1; sc.ret_cigar = 1; sc.rev_cigar = 0;
+
+    abpoa_hip_readset_t *sets = (abpoa_hip_readset_t *)calloc(n_sets > 0 ? n_sets : 1, sizeof *sets);
+    abpoa_hip_msa_t *out = (abpoa_hip_msa_t *)calloc(n_sets > 0 ? n_sets : 1, sizeof *out);
+    for (int i = 0; i < n_sets; ++i) {
+        sets[i].n_reads = rs[i].n; sets[i].seqs = (const uint8_t *const *)rs[i].code; sets[i].lens = rs[i].len;
+        sets[i].weights = use_qv ? (const int32_t *const *)rs[i].weight : NULL;
+    }
+    int rc = abpoa_hip_init(0);
+    if (rc != ABPOA_HIP_OK) DIE("no usable GPU (%d): %s", rc, abpoa_hip_last_error());
+    const unsigned flags = (out_cons ? ABPOA_HIP_OUT_CONS : 0u) | (out_msa ? ABPOA_HIP_OUT_MSA : 0u) | (amb ? ABPOA_HIP_AMB_STRAND : 0u);
+    rc = abpoa_hip_msa_batch(&sc, n_sets, sets, out, flags, threads);
+    if (rc != ABPOA_HIP_OK) DIE("abpoa_hip_msa_batch failed (%d): %s", rc, abpoa_hip_last_error());
+
+    /* A record without a name: the reference prints ">Seq_<i>" -- unless an earlier file of the list had a named record at the same position: its abpoa_seq_t
+     * lives across the files of a list and abpoa_cpy_str leaves a string alone when the new one is empty (src/abpoa_seq.c:123-130), so the old name shows
+     * (src/abpoa_output.c:75-81).  Reproduced here: the last non-empty name seen at each record position. */
+    int sticky_n = 0; char **sticky = NULL;
+    for (int i = 0; i < n_sets; ++i) {
+        if (rs[i].n > sticky_n) { sticky = (char **)realloc(sticky, sizeof(char *) * rs[i].n); for (int r = sticky_n; r < rs[i].n; ++r) sticky[r] = NULL; sticky_n = rs[i].n; }
+        for (int r = 0; r < rs[i].n; ++r) {
+            if (rs[i].name[r][0]) sticky[r] = rs[i].name[r];
+            else if (sticky[r]) { free(rs[i].name[r]); rs[i].name[r] = strdup(sticky[r]); }
+        }
+    }
+    free(sticky);
+
+    /* ---- output, file by file as the reference prints it (src/abpoa_align.c:346-371: MSA when asked for -- with the consensus row if both --, else consensus) */
+    for (int i = 0; i < n_sets; ++i) {
+        const abpoa_hip_msa_t *o = &out[i];
+        if (o->status != ABPOA_HIP_OK) DIE("alignment failed for input %d (status %d)", i + 1, o->status);
+        if (out_msa) {
+            if (o->msa_len <= 0) continue;
+            for (int r = 0; r < rs[i].n; ++r) {
+                if (rs[i].name[r][0]) printf(">%s%s\n", rs[i].name[r], (o->is_rc && o->is_rc[r]) ? "_reverse_complement" : ""); else printf(">Seq_%d\n", r + 1);
+                const uint8_t *row = o->msa_base + (size_t)r * o->msa_len;
+                for (int j = 0; j < o->msa_len; ++j) putchar(letter[row[j]]);
+                putchar('\n');
+            }
+            if (out_cons) {
+                printf(">Consensus_sequence\n");
+                const uint8_t *row = o->msa_base + (size_t)rs[i].n * o->msa_len;
+                for (int j = 0; j < o->msa_len; ++j) putchar(letter[row[j]]);
+                putchar('\n');
+            }
+        } else if (out_cons) {
+            printf(">Consensus_sequence\n");
+            for (int j = 0; j < o->cons_len; ++j) putchar(letter[o->cons_base[j]]);
+            putchar('\n');
+        }
+    }
+    for (int i = 0; i < n_sets; ++i) abpoa_hip_free_msa(&out[i]);
+    fflush(stdout);
+    abpoa_hip_shutdown();
+    return 0;
+}

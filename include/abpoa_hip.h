@@ -53,6 +53,7 @@ extern "C" {
 #define ABPOA_HIP_ENOMEM   -3   /* device or host allocation failed                     */
 #define ABPOA_HIP_ELAUNCH  -4   /* kernel launch / execution error                      */
 #define ABPOA_HIP_EBACKTRACK -5 /* dead end in backtrack (reference: err_fatal "Error in *_backtrack") */
+#define ABPOA_HIP_ESTRICT  -6   /* ABPOA_HIP_STRICT=1 and some read-set would have left the device-resident driver for the host driver */
 
 /* The scoring / mode fields the DP reads from abpoa_para_t (src/abpoa.h:62-81). */
 typedef struct abpoa_hip_scoring_t {
@@ -210,7 +211,10 @@ void abpoa_hip_free_msa(abpoa_hip_msa_t *r);
 /* Phase timers of the last abpoa_hip_msa_batch call (seconds): host graph work, engine calls. */
 typedef struct abpoa_hip_msa_timing_t {
     double host_sort_s, host_fuse_s, engine_s, cons_s, total_s;   /* per-group averages for the first three */
-    int32_t n_rounds, n_threads, n_groups, pad;                   /* n_groups = read-set groups run concurrently (one stream each) */
+    int32_t n_rounds, n_threads, n_groups;                        /* n_groups = read-set groups run concurrently (one stream each) */
+    int32_t n_host_sets;          /* read-sets of the call that took the HOST driver (host graph, one H2D / launch / D2H per round) instead of the device-resident
+                                     one: the whole job when its options are not the device driver's, else the sets that outgrew a device capacity.
+                                     With ABPOA_HIP_STRICT=1 in the environment such a call fails with ABPOA_HIP_ESTRICT instead of slowing down silently. */
 } abpoa_hip_msa_timing_t;
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out);
 

@@ -89,4 +89,7 @@ void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = g_timing; }
 void abpoa_shim_dir_counts(long long *o) { o[0] = n_dir_steps.exchange(0); o[1] = n_dir_ambig.exchange(0); o[2] = n_dir_lit.exchange(0); }
 long long abpoa_shim_dir_checked(void) { return n_dir_checked.exchange(0); }      // alignments the direction-plane model confirmed since the last call
 const char *abpoa_hip_last_error(void) { return "cpu shim"; }
+// (life-cycle entries so that host programs written against include/abpoa_hip.h -- abpoa_amd/host/abpoa_batch.c -- link against this test build too)
+int abpoa_hip_init(int) { return 0; }
+void abpoa_hip_shutdown(void) {}
 }

@@ -1,0 +1,155 @@
+"""The C front end of the batch entry (abpoa_amd/host/abpoa_batch.c: the reference's command line, every file of a `-l` list in ONE
+abpoa_hip_msa_batch call).  CPU: its own host logic -- option parsing, FASTA / FASTQ / gzip reading, alphabets, matrix files, quality weights,
+output text -- linked against the oracle-backed build of the host layer (tests/_build/libcpu_shim.so), compared byte for byte with the
+reference's printed outputs under tests/golden/out_* and, where the compiled reference is present (oracle/_ref/abpoa_ref), with a run of it on
+the same `-l` list.  GPU (-m gpu): the shipped binary (abpoa_amd/abpoa_batch, linked to libabpoa_hip.so) against the same."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import helpers as H
+from abpoa_amd import synth
+
+D = H.GOLDEN_DIR
+ROOT = H.ROOT
+REF = os.path.join(ROOT, "oracle", "_ref", "abpoa_ref")
+BLOSUM = os.path.join(D, "data", "BLOSUM62.mtx")
+
+
+def _golden(name):
+    return open(os.path.join(D, name, "output.txt")).read()
+
+
+def _cpu_binary():
+    H.cpu_shim_lib()
+    bdir = os.path.join(ROOT, "tests", "_build")
+    exe, src = os.path.join(bdir, "abpoa_batch_cpu"), os.path.join(ROOT, "abpoa_amd", "host", "abpoa_batch.c")
+    shim = os.path.join(bdir, "libcpu_shim.so")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(shim)):
+        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-L" + bdir, "-lcpu_shim", "-lz",
+                               "-Wl,-rpath," + bdir])
+    return exe
+
+
+def _run(exe, args, expect_rc=0):
+    p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+    assert p.returncode == expect_rc, (p.returncode, p.stderr[-1500:])
+    return p.stdout
+
+
+CASES = [
+    (["-O", "4,0", "-E", "2", os.path.join(D, "data", "seq.fa")], "out_seq_cons"),                    # BASELINE.json configs[0]
+    (["-r", "1", os.path.join(D, "data", "test.fa")], "out_test_msa"),
+    (["-r", "2", os.path.join(D, "data", "test.fa")], "out_test_cons_msa"),
+    ([os.path.join(D, "data", "heter.fa")], "out_heter_cons"),
+    (["-m", "1", "-c", "-t", BLOSUM, "-r", "1", os.path.join(D, "aa_blosum_loc", "input.fa")], "aa_blosum_loc"),
+    (["-O", "4,0", "-E", "2", "-Q", os.path.join(D, "out_qv_cons", "input.fq")], "out_qv_cons"),
+    (["-O", "4,0", "-E", "2", "-Q", "-r", "2", os.path.join(D, "out_qv_msa", "input.fq")], "out_qv_msa"),
+    (["-s", "-r", "2", os.path.join(D, "out_rc_msa", "input.fa")], "out_rc_msa"),
+    (["-s", "-r", "2", os.path.join(D, "out_rc_long_msa", "input.fa")], "out_rc_long_msa"),
+]
+
+
+def _check_cases(exe):
+    for args, name in CASES:
+        cmd = open(os.path.join(D, name, "cmd.txt")).read() if os.path.exists(os.path.join(D, name, "cmd.txt")) else ""
+        assert _run(exe, args) == _golden(name), f"{name}: {' '.join(args)} (golden made with: {cmd.strip()})"
+
+
+def _list_job(tmp_path, n=6):
+    """a `-l` list of ragged read-sets: FASTA with wrapped lines, one gzip'ed file, nameless records"""
+    files = []
+    for i in range(n):
+        reads = synth.make_read_set(9, i, 4 + i, 150 + 40 * i, 0.06)
+        fn = str(tmp_path / f"s{i}.fa")
+        with open(fn, "w") as f:
+            for j, r in enumerate(reads):
+                f.write(f">r{j} some comment\n" if (i + j) % 4 else ">\n")
+                for k in range(0, len(r), 60):
+                    f.write(r[k:k + 60] + "\n")
+        if i == 2:
+            with open(fn, "rb") as f, gzip.open(fn + ".gz", "wb") as g:
+                g.write(f.read())
+            fn += ".gz"
+        files.append(fn)
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("\n".join(files) + "\n")
+    return lst
+
+
+def test_c_front_end_matches_the_reference_outputs():
+    _check_cases(_cpu_binary())
+
+
+def test_c_front_end_list_is_one_batch_and_equals_the_reference_cli(tmp_path):
+    exe = _cpu_binary()
+    seq = os.path.join(D, "data", "seq.fa"); s1k = os.path.join(D, "out_s1k_cons", "input.fa")
+    lst = tmp_path / "two.txt"; lst.write_text(seq + "\n" + s1k + "\n")
+    assert _run(exe, ["-O", "4,0", "-E", "2", "-l", str(lst)]) == _golden("out_seq_cons") + _golden("out_s1k_cons")
+    if not os.path.exists(REF):
+        pytest.skip("compiled reference not present: the golden outputs above are the check")
+    job = _list_job(tmp_path)
+    for opts in (["-O", "4,0", "-E", "2"], ["-r", "2"], ["-r", "1", "-b", "20", "-f", "0.05"]):
+        ref = subprocess.run([REF] + opts + ["-l", job], capture_output=True, text=True, timeout=600)
+        assert ref.returncode == 0
+        assert _run(exe, opts + ["-l", job]) == ref.stdout, opts
+
+
+def test_c_front_end_refuses_what_the_engine_does_not_build():
+    exe = _cpu_binary()
+    seq = os.path.join(D, "data", "seq.fa")
+    for bad in (["-r", "3"], ["-S"], ["-d", "2"], ["-p"]):
+        p = subprocess.run([exe] + bad + [seq], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 2 and "outside this engine" in p.stderr and p.stdout == ""
+
+
+@pytest.mark.gpu
+def test_shipped_binary_on_the_gpu(tmp_path):
+    """abpoa_amd/abpoa_batch (C, linked to libabpoa_hip.so only): golden outputs, and a `-l` list of 40 read-sets against the compiled reference
+    (oracle/_ref/abpoa_ref travels to the GPU box prebuilt), consensus and MSA."""
+    exe = os.path.join(ROOT, "abpoa_amd", "abpoa_batch")
+    assert os.path.exists(exe), "abpoa_amd/abpoa_batch not built (make -C abpoa_amd/csrc)"
+    _check_cases(exe)
+    if os.path.exists(REF):
+        job = _list_job(tmp_path, 40)
+        for opts in (["-O", "4,0", "-E", "2"], ["-r", "2"], ["-O", "4,0", "-E", "2", "-r", "1"]):
+            ref = subprocess.run([REF] + opts + ["-l", job], capture_output=True, text=True, timeout=600)
+            assert ref.returncode == 0
+            assert _run(exe, opts + ["-l", job]) == ref.stdout, opts
+
+
+def test_host_layer_under_address_and_ub_sanitizers(tmp_path):
+    """the host layer (graph fusion, Kahn order, consensus, RC-MSA in poa_graph.cpp; the threaded batch driver msa_batch.cpp; the C front
+    end) built with -fsanitize=address,undefined together with the oracle and run on golden inputs and on a threaded `-l` job (two groups of read-sets
+    advancing on their own threads): same outputs, no report.  (CPU build only: GPU sanitizers are not available on this pool.)"""
+    bdir = os.path.join(ROOT, "tests", "_build", "asan")
+    os.makedirs(bdir, exist_ok=True)
+    exe = os.path.join(bdir, "abpoa_batch_asan")
+    csrc, odir = os.path.join(ROOT, "abpoa_amd", "csrc"), os.path.join(ROOT, "oracle")
+    srcs_cpp = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(csrc, "poa_graph.cpp"), os.path.join(csrc, "msa_batch.cpp")]
+    srcs_c = [os.path.join(odir, "abpoa_dp_oracle.c"), os.path.join(odir, "dir_model.c"), os.path.join(ROOT, "abpoa_amd", "host", "abpoa_batch.c")]
+    deps = srcs_cpp + srcs_c + [os.path.join(csrc, "poa_graph.h"), os.path.join(csrc, "msa_batch.h"), os.path.join(ROOT, "include", "abpoa_hip.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+        objs = []
+        for f in srcs_c:
+            objs.append(os.path.join(bdir, os.path.basename(f) + ".o"))
+            subprocess.check_call(["gcc", "-std=gnu99"] + san + ["-c", "-I" + os.path.join(ROOT, "include"), "-o", objs[-1], f])
+        for f in srcs_cpp:
+            objs.append(os.path.join(bdir, os.path.basename(f) + ".o"))
+            subprocess.check_call(["g++", "-std=c++17"] + san + ["-c", "-I" + os.path.join(ROOT, "include"), "-o", objs[-1], f])
+        subprocess.check_call(["g++"] + san + ["-pthread", "-o", exe] + objs + ["-lz"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    job = _list_job(tmp_path, 8)
+    runs = [(["-O", "4,0", "-E", "2", os.path.join(D, "data", "seq.fa")], _golden("out_seq_cons")),
+            (["-r", "2", os.path.join(D, "data", "test.fa")], _golden("out_test_cons_msa")),
+            (["-m", "1", "-c", "-t", BLOSUM, "-r", "1", os.path.join(D, "aa_blosum_loc", "input.fa")], _golden("aa_blosum_loc")),
+            (["-s", "-r", "2", os.path.join(D, "out_rc_msa", "input.fa")], _golden("out_rc_msa")),
+            (["-r", "2", "-T", "4", "-l", job], None)]
+    plain = _cpu_binary()
+    for args, want in runs:
+        p = subprocess.run([exe] + args, capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0 and "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, (args, p.stderr[-3000:])
+        assert p.stdout == (want if want is not None else _run(plain, args)), args

@@ -53,7 +53,7 @@ def test_device_driver_equals_host_driver(engine, monkeypatch, name, kw, shape, 
     sets = [synth.make_read_set(11, i, n_reads if i % 5 else max(2, n_reads // 2), ln, err) for i in range(n_sets)]
     engine.abpoa_hip_reset_stats()
     host, dev, tm = _both(sets, api.Params(**kw))
-    assert tm["n_groups"] == 1 and tm["pad"] == 0, f"device driver not used for every set: {tm}"
+    assert tm["n_groups"] == 1 and tm["n_host_sets"] == 0, f"device driver not used for every set: {tm}"
     assert (ffi.stats()["rounds_launches"] > 0) == (lockstep == 0), ffi.stats()
     for i, (a, b) in enumerate(zip(dev, host)):
         assert a.status == 0 and b.status == 0
@@ -76,7 +76,7 @@ def test_wide_band_jobs_passes_and_arena_formats(engine, monkeypatch, env, kw):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     dev2 = api.msa_batch(sets, api.Params(**kw), n_threads=8)
-    assert api.msa_timing()["pad"] == 0
+    assert api.msa_timing()["n_host_sets"] == 0
     for i, (a, b, c) in enumerate(zip(dev, host, dev2)):
         assert a.status == 0 and b.status == 0 and c.status == 0
         assert a.cons_seq == b.cons_seq == c.cons_seq, f"{env}: consensus of set {i} differs"
@@ -98,7 +98,7 @@ def test_mixed_band_widths_in_one_job(engine, monkeypatch, env, kw):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     dev2 = api.msa_batch(sets, api.Params(**kw), n_threads=8)
-    assert api.msa_timing()["pad"] == 0
+    assert api.msa_timing()["n_host_sets"] == 0
     for i, (a, b, c) in enumerate(zip(dev, host, dev2)):
         assert a.status == 0 and b.status == 0 and c.status == 0
         assert a.cons_seq == b.cons_seq == c.cons_seq, f"{env}: consensus of set {i} differs"
@@ -117,7 +117,7 @@ def test_two_wavefronts_on_a_backtrack_change_nothing(engine, monkeypatch, kw):
     p = api.Params(**kw)
     engine.abpoa_hip_reset_stats()
     host, two, tm = _both(sets, p)
-    assert tm["pad"] == 0 and ffi.stats()["rounds_launches"] > 0
+    assert tm["n_host_sets"] == 0 and ffi.stats()["rounds_launches"] > 0
     monkeypatch.setenv("ABPOA_HIP_DBG", "1024")
     one = api.msa_batch(sets, p, n_threads=8)
     for i, (a, b, c) in enumerate(zip(two, one, host)):
@@ -151,7 +151,7 @@ def test_device_graph_equals_host_graph_after_every_read(engine):
             "lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
             "sets = [synth.make_read_set(3, i, 10, 250, 0.08) for i in range(6)]\n"
             "r = api.msa_batch(sets, api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), n_threads=4)\n"
-            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['pad'])\n" % ROOT)
+            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['n_host_sets'])\n" % ROOT)
     env = dict(os.environ, ABPOA_HIP_DEVSYNC="1", ABPOA_HIP_HOSTGRAPH="0")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -224,7 +224,7 @@ def test_device_driver_equals_oracle_backed_host_run(engine, monkeypatch, lockst
         p = api.Params(**kw)
         engine.abpoa_hip_reset_stats()
         dev = api.msa_batch(sets, p, n_threads=4)
-        assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+        assert api.msa_timing()["n_host_sets"] == 0, "device driver not used for every set"
         w_max = p.wb + int(p.wf * max(ln for _, ln, _, _ in shapes))      # (a band half-width of 40 or more takes the wide row loop: one launch per phase and round)
         assert (ffi.stats()["rounds_launches"] > 0) == (lockstep == 0 and w_max < 40)
         ref = api.msa_batch(sets, p, n_threads=4, lib=shim)
@@ -233,13 +233,31 @@ def test_device_driver_equals_oracle_backed_host_run(engine, monkeypatch, lockst
             assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{kw}: set {i} differs from the oracle-backed run"
 
 
-def test_device_driver_cigars_equal_the_oracle_backed_run(engine, monkeypatch):
-    """Direct cigar comparison (not only consensus / coverage): with ABPOA_HIP_CIGAR_DIGEST=1 both drivers fold the graph cigar of every alignment into
-    a digest per read-set -- the device-resident driver (one launch per phase and round in this mode; the cigars come off the device after every
-    backtrack) and the CPU build of the host driver, whose aligner is the oracle."""
-    import ctypes
+CIGAR_JOBS = {
+    # narrow bands, graphs of 700-2500 rows: in the all-rounds kernel four wavefronts share every backtrack (helper parts, merged cigars)
+    "narrow_affine": (dict(gap_open1=4, gap_open2=0, gap_ext1=2), [(12, 700 + 60 * i, 0.08) for i in range(8)]),
+    "narrow_convex_noisy": (dict(), [(10, 900 + 90 * i, 0.15) for i in range(6)]),
+    "narrow_1500": (dict(gap_open1=4, gap_open2=0, gap_ext1=2), [(9, 1500 + 100 * i, 0.05 + 0.02 * i) for i in range(5)]),
+    # wide bands (10 kb reads: the all-chunks row loop, column-slice backtrack windows), 5 % and 15 % errors
+    "wide_affine_5": (dict(gap_open1=4, gap_open2=0, gap_ext1=2), [(8, 10000 + 17 * i, 0.05) for i in range(4)]),
+    "wide_convex_15": (dict(), [(8, 10000 - 23 * i, 0.15) for i in range(4)]),
+}
+
+
+@pytest.mark.parametrize("job,env", [("narrow_affine", {}), ("narrow_affine", {"ABPOA_HIP_LOCKSTEP": "1"}), ("narrow_convex_noisy", {}), ("narrow_convex_noisy", {"ABPOA_HIP_LOCKSTEP": "1"}),
+                                     ("narrow_1500", {}), ("narrow_1500", {"ABPOA_HIP_DBG": "1024"}),
+                                     ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "0"}), ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "1"}), ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"}),
+                                     ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "0"}), ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "1"}), ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"})],
+                         ids=lambda v: v if isinstance(v, str) else ("default" if not v else "_".join(f"{k[10:].lower()}{x}" for k, x in v.items())))
+def test_device_driver_cigars_equal_the_oracle_backed_run(engine, job, env):
+    """Direct cigar comparison (not only consensus / coverage).  With ABPOA_HIP_CIGAR_DIGEST=1 the fuse phase of the device-resident driver folds the graph
+    cigar of every alignment into a 64-bit digest per read-set ON THE DEVICE (poa_bodies.h, poa_device.h poa_cigar_digest_round) -- so both of its forms are
+    covered: the all-rounds kernel, whose backtrack is shared by four wavefronts (helper cigar parts, merged at the cells where the walks meet), and the
+    lock-step launches; narrow bands and 10 kb wide bands in both arena formats (score records / direction words, 8- and 4-row score ring).  The CPU build of
+    the host driver, whose aligner is the plain-C oracle, folds the same function over its cigars (msa_batch.cpp): equal digests = equal cigars, word for word."""
     import subprocess
     import sys
+    kw, shapes = CIGAR_JOBS[job]
     code = ("import os, sys, ctypes; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
             "import helpers as H\n"
             "from abpoa_amd import api, ffi, synth, seqio\n"
@@ -251,18 +269,21 @@ def test_device_driver_cigars_equal_the_oracle_backed_run(engine, monkeypatch):
             "        a = np.ascontiguousarray(seqio.encode(s[0], m), np.uint8)\n"
             "        out.append(lib.abpoa_hip__cigar_digest(a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(a), 0))\n"
             "    return out\n"
-            "for kw, shape in ((dict(gap_open1=4, gap_open2=0, gap_ext1=2), (8, 12, 700, 0.08)), (dict(), (6, 10, 900, 0.15))):\n"
-            "    sets = [synth.make_read_set(23, i, *shape[1:]) for i in range(shape[0])]\n"
-            "    p = api.Params(**kw)\n"
-            "    lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
-            "    dev = api.msa_batch(sets, p, n_threads=4); tm = api.msa_timing()\n"
-            "    assert all(r.status == 0 for r in dev) and tm['pad'] == 0, tm\n"
-            "    d_dev = digests(lib, sets, p.m); lib.abpoa_hip__cigar_digest(None, 0, 1)\n"
-            "    shim = H.cpu_shim_lib(); host = api.msa_batch(sets, p, lib=shim, n_threads=4)\n"
-            "    d_host = digests(shim, sets, p.m); shim.abpoa_hip__cigar_digest(None, 0, 1)\n"
-            "    assert all(d != 0 for d in d_dev) and d_dev == d_host, (d_dev, d_host)\n"
-            "    assert [r.cons_seq for r in dev] == [r.cons_seq for r in host]\n"
-            "print('CIGARS EQUAL')\n" % (ROOT, ROOT))
-    env = dict(os.environ, ABPOA_HIP_CIGAR_DIGEST="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+            "kw, shapes = %r, %r\n"
+            "sets = [synth.make_read_set(23, i, n, ln, err) for i, (n, ln, err) in enumerate(shapes)]\n"
+            "p = api.Params(**kw)\n"
+            "lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0)); lib.abpoa_hip_reset_stats()\n"
+            "dev = api.msa_batch(sets, p, n_threads=4); tm = api.msa_timing()\n"
+            "assert all(r.status == 0 for r in dev) and tm['n_host_sets'] == 0, tm\n"
+            "print('ROUNDS_LAUNCHES', ffi.stats()['rounds_launches'])\n"
+            "d_dev = digests(lib, sets, p.m); lib.abpoa_hip__cigar_digest(None, 0, 1)\n"
+            "shim = H.cpu_shim_lib(); host = api.msa_batch(sets, p, lib=shim, n_threads=8)\n"
+            "d_host = digests(shim, sets, p.m); shim.abpoa_hip__cigar_digest(None, 0, 1)\n"
+            "assert all(d != 0 for d in d_dev) and d_dev == d_host, (d_dev, d_host)\n"
+            "assert [r.cons_seq for r in dev] == [r.cons_seq for r in host]\n"
+            "print('CIGARS EQUAL')\n" % (ROOT, ROOT, kw, shapes))
+    e = dict(os.environ, ABPOA_HIP_CIGAR_DIGEST="1", **env)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=900)
     assert r.returncode == 0 and "CIGARS EQUAL" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    narrow_all_rounds = job.startswith("narrow") and "ABPOA_HIP_LOCKSTEP" not in env
+    assert ("ROUNDS_LAUNCHES 0" not in r.stdout) == narrow_all_rounds, r.stdout

@@ -46,7 +46,7 @@ def test_global_msa_output_on_the_device(engine, monkeypatch, lockstep, out_cons
         sets = [synth.make_read_set(31, i, n, ln, err) for i, (n, ln, err) in enumerate(shapes)]
         p = api.Params(**kw)
         dev = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4)
-        assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+        assert api.msa_timing()["n_host_sets"] == 0, "device driver not used for every set"
         ref = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4, lib=shim)
         _same(dev, ref, f"{kw} out_cons={out_cons}", cons=out_cons)
 
@@ -59,7 +59,7 @@ def test_protein_global_msa_and_consensus_on_the_device(engine):
     p = api.Params(is_aa=True, score_matrix=workloads.BLOSUM62)
     sets = [synth.make_read_set(37, i, 12 + i % 9, 150 + 40 * i, alphabet=synth.AA, rates=(0.10 + 0.02 * (i % 4), 0.02, 0.02)) for i in range(10)]
     dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
-    assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+    assert api.msa_timing()["n_host_sets"] == 0, "device driver not used for every set"
     ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
     _same(dev, ref, "protein global")
 
@@ -88,11 +88,11 @@ def test_local_mode_msa_on_the_device(engine, name, kw, mk):
         sets.append(synth.make_read_set(43, i, **a))
     for out_cons in (False, True):
         dev = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4)
-        assert api.msa_timing()["pad"] == 0, f"{name}: device driver not used for every set"
+        assert api.msa_timing()["n_host_sets"] == 0, f"{name}: device driver not used for every set"
         ref = api.msa_batch(sets, p, out_cons=out_cons, out_msa=True, n_threads=4, lib=shim)
         _same(dev, ref, f"{name} out_cons={out_cons}", cons=out_cons)
     dev = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4)      # consensus only, local mode
-    assert api.msa_timing()["pad"] == 0
+    assert api.msa_timing()["n_host_sets"] == 0
     ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
     _same(dev, ref, f"{name} consensus only", msa=False)
 
@@ -107,7 +107,7 @@ def test_config5_sample_on_the_device_against_reference_digests(engine):
     sets = [synth.make_read_set(1, i, **synth.CONFIGS[5]) for i in range(48)]
     p = api.Params(**wl["params"])
     res = api.msa_batch(sets, p, out_cons=False, out_msa=True, n_threads=8)
-    assert api.msa_timing()["pad"] == 0, "device driver not used for every set"
+    assert api.msa_timing()["n_host_sets"] == 0, "device driver not used for every set"
     for i, r in enumerate(res):
         assert r.status == 0
         assert workloads.output_sha(api.format_output(r, [f"r{j}" for j in range(len(sets[i]))], False, True)) == dig[i], f"set {i}: output differs from the reference's"
@@ -123,7 +123,7 @@ def test_device_row_order_graph_and_msa_checks_after_every_read(engine):
             "sets = [synth.make_read_set(3, i, 9, 120 + 30 * i, alphabet=synth.AA, rates=(0.08, 0.03, 0.03)) for i in range(5)]\n"
             "p = api.Params(aln_mode=1, is_aa=True, score_matrix=workloads.BLOSUM62)\n"
             "r = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)\n"
-            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['pad'])\n" % ROOT)
+            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['n_host_sets'])\n" % ROOT)
     env = dict(os.environ, ABPOA_HIP_DEVSYNC="1", ABPOA_HIP_HOSTGRAPH="0")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -131,3 +131,19 @@ def test_device_row_order_graph_and_msa_checks_after_every_read(engine):
     for what in ("row order check ok", "graph check ok", "msa check ok", "consensus check ok"):
         assert what in p.stderr, (what, p.stderr[-3000:])
     assert "FAILED" not in p.stderr, p.stderr[-3000:]
+
+
+def test_strict_mode_reports_instead_of_slowing_down(engine, monkeypatch):
+    """ABPOA_HIP_STRICT=1: a job whose options are the host driver's (here: linear gaps) fails with ABPOA_HIP_ESTRICT instead of running at host-driver
+    speed unnoticed; without the switch it runs and reports every set in abpoa_hip_msa_timing_t.n_host_sets.  A device-driver job is unaffected."""
+    from abpoa_amd import api, ffi, synth
+    sets = [synth.make_read_set(53, i, 6, 200, 0.05) for i in range(4)]
+    lin = api.Params(gap_open1=0, gap_open2=0, gap_ext1=2)
+    r = api.msa_batch(sets, lin, n_threads=4)
+    assert all(x.status == 0 for x in r) and api.msa_timing()["n_host_sets"] == len(sets)
+    monkeypatch.setenv("ABPOA_HIP_STRICT", "1")
+    with pytest.raises(ffi.EngineError) as ei:
+        api.msa_batch(sets, lin, n_threads=4)
+    assert "(-6)" in str(ei.value) and "ABPOA_HIP_STRICT" in str(ei.value)
+    ok = api.msa_batch(sets, api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), n_threads=4)
+    assert all(x.status == 0 for x in ok) and api.msa_timing()["n_host_sets"] == 0
