@@ -60,7 +60,7 @@ Cache g_cache[MSA_DEVICE_SLOTS]; std::mutex g_cache_mu[MSA_DEVICE_SLOTS];      /
 
 struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
-    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, in_bytes;
+    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, o_wts, in_bytes;
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
     size_t o_cnode, o_ccov, o_cbase;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, o_rid, o_mrank, o_msaoff, graph_bytes;
@@ -237,6 +237,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
     L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m); L.o_rargs = take(poa_rounds_args_bytes()); L.o_msaoff_h = take(want_msa ? 8 * (size_t)n_sets : 0);      // (o_rargs, o_msaoff_h: host-side staging only)
+    bool any_w = false; for (int s = 0; s < n_sets && !any_w; ++s) any_w = sets[s].weights != nullptr;
+    L.o_wts = take(any_w ? 4 * (size_t)(tot_bases + 64) : 0);      // (per-base weights, -Q: in front of the reads, so that they go up with the first part)
     L.o_reads = take(tot_bases + 64); L.in_bytes = o;      // reads last: they go up in two parts
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
@@ -301,6 +303,15 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         });
     };
     stage_reads(0, 2);
+    if (any_w) {      // weights of every read, same offsets as the bases; a read (or a set) without weights counts 1 per base
+        int32_t *wd = (int32_t *)(hi + L.o_wts);
+        parallel_ranges(std::min(n_threads, 16), n_sets, [&](int lo, int hi_) {
+            for (int s = lo; s < hi_; ++s) for (int r = 0; r < sets[s].n_reads; ++r) {
+                int32_t *dst = wd + roff[ps[s].read0 + r]; const int32_t *src = sets[s].weights ? sets[s].weights[r] : nullptr;
+                if (src) memcpy(dst, src, 4 * (size_t)sets[s].lens[r]); else for (int j = 0; j < sets[s].lens[r]; ++j) dst[j] = 1;
+            }
+        });
+    }
     memcpy(hi + L.o_mat, sc->mat, 4 * sc->m * sc->m);
     hipStream_t st = C.stream;
     if (!C.copy_stream) { HIP_OK(hipStreamCreateWithFlags(&C.copy_stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV); HIP_OK(hipEventCreateWithFlags(&C.ev_copy, hipEventDisableTiming), ABPOA_HIP_ENODEV); }
@@ -319,6 +330,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;      // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
     p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
     p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;
+    p.wts = any_w ? (const int32_t *)(di + L.o_wts) : nullptr;
     p.nd_base = dg + L.o_base; p.nd_nin = dg + L.o_nin; p.nd_nout = dg + L.o_nout; p.nd_naln = dg + L.o_naln;
     p.nd_in = (int32_t *)(dg + L.o_in); p.nd_out = (int32_t *)(dg + L.o_out); p.nd_outw = (int32_t *)(dg + L.o_outw); p.nd_aln = (int32_t *)(dg + L.o_aln);
     p.nd_inx = (int32_t *)(dg + L.o_inx); p.nd_outx = (int32_t *)(dg + L.o_outx); p.nd_outwx = (int32_t *)(dg + L.o_outwx);
@@ -425,13 +437,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             PoaState hst; (void)hipMemcpy(&hst, (uint8_t *)p.state + sizeof(PoaState) * s, sizeof(hst), hipMemcpyDeviceToHost);
             const PoaSet &S = ps[s]; const int n = hst.n_nodes;
             // host graph: same cigar
-            if (k == 0) dbg_graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0);
+            if (k == 0) dbg_graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0, sets[s].weights ? sets[s].weights[0] : nullptr);
             else {
                 AlnOut ao; (void)hipMemcpy(&ao, (uint8_t *)p.out + sizeof(AlnOut) * s, sizeof(ao), hipMemcpyDeviceToHost);
                 std::vector<uint64_t> cg(std::max(1, ao.n_cigar)); (void)hipMemcpy(cg.data(), (uint8_t *)p.cigar + 8 * S.cigar_off, 8 * (size_t)ao.n_cigar, hipMemcpyDeviceToHost);
                 fprintf(stderr, "[poa-device]   set %d round %d: dp status %d score %d n_cigar %d rows %d; device state status %d reason %d nodes %d\n", s, k, ao.status, ao.best_score, ao.n_cigar, ao.n_rows_done, hst.status, hst.pad, n);
                 if (ao.status != 0) continue;
-                dbg_graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], cg.data(), ao.n_cigar, k);
+                dbg_graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], cg.data(), ao.n_cigar, k, sets[s].weights ? sets[s].weights[k] : nullptr);
             }
             if (hst.status != POA_ST_OK) continue;
             std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln((size_t)n * aln_cap), nread(n), row(n), order(n);

@@ -138,9 +138,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpo
     if (engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
     abpoa_hip_scoring_t sc_norm; const abpoa_hip_scoring_t *sc = sc_in;
     if (sc_in && sc_in->align_mode == ABPOA_HIP_LOCAL_MODE) { sc_norm = *sc_in; sc_norm.wb = -1; sc = &sc_norm; }      // reference abpoa_post_set_para, src/abpoa_align.c:150: local mode has no band
-    bool plain = true;      // per-base weights and the strand retry are host-driver features
-    for (int s = 0; plain && sets && s < n_sets; ++s) plain = sets[s].weights == nullptr;
-    if (n_sets > 0 && sc && sets && out && plain && msa_device_eligible(sc, flags)) {
+    if (n_sets > 0 && sc && sets && out && msa_device_eligible(sc, flags)) {
         // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
         if (n_threads <= 0) n_threads = effective_host_cores();
         for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL; }

@@ -310,17 +310,18 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     bool fail = false;
     // adds edge from -> to (both lane-private; `from_new` / `to_new`: the node was created by this read, its lists are still empty
     // apart from what this very walk put there, which is known without a load)
-    auto add_edge = [&](bool act, int from, bool from_new, int to, bool to_new) {
+    const int32_t *wq = p.wts ? p.wts + p.read_off[S.read0 + k] : nullptr;      // per-base weights of this read (-Q), reference :634-667: an edge takes the weight of the base it leads to
+    auto add_edge = [&](bool act, int from, bool from_new, int to, bool to_new, int w) {
         if (!act) return;
         const int64_t F = N0 + from, T = N0 + to;
         int no = from_new ? 0 : (int)p.nd_nout[F];
         int hit = -1;
         if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (out_slot(p, F, t) == to) { hit = t; break; }
-        if (hit >= 0) outw_slot(p, F, hit) += 1;
+        if (hit >= 0) outw_slot(p, F, hit) += w;
         else {
             const int ni = to_new ? 0 : (int)p.nd_nin[T];
             if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; return; }
-            out_slot(p, F, no) = to; outw_slot(p, F, no) = 1; p.nd_nout[F] = (uint8_t)(no + 1);
+            out_slot(p, F, no) = to; outw_slot(p, F, no) = w; p.nd_nout[F] = (uint8_t)(no + 1);
             in_slot(p, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
             hit = no;
             for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + w_] = 0;      // (a new edge: no read went through it yet)
@@ -395,7 +396,7 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
         sNode[tid] = node; sIsNew[tid] = (int)isnew; sAR[tid] = AR;
         __syncthreads();
         const int prev = tid > 0 ? sNode[tid - 1] : prev_c, prev_new = tid > 0 ? sIsNew[tid - 1] : prev_new_c, prevAR = tid > 0 ? sAR[tid - 1] : carry_ar;
-        add_edge(act, prev, prev_new != 0, node, isnew);
+        add_edge(act, prev, prev_new != 0, node, isnew, (wq && act) ? wq[q] : 1);
         const bool start = isnew && (prev_new == 0 || prevAR != AR);
         const int sq_w = wave_scan_max(start ? q : -1);
         if (lane == 63) sSqm[wave] = sq_w;
@@ -413,7 +414,7 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     }
     // F3: last node -> sink (reference :667)
     bool any_fail = __syncthreads_or(fail);
-    if (!any_fail) { add_edge(tid == 0, prev_c, prev_new_c != 0, 1, false); any_fail = __syncthreads_or(fail); }
+    if (!any_fail) { add_edge(tid == 0, prev_c, prev_new_c != 0, 1, false, wq ? wq[qlen - 1] : 1); any_fail = __syncthreads_or(fail); }      // reference :667: the last base's weight
     if (tid == 0) { sh_fail = any_fail ? 1 : 0; sh_nodes = n_nodes; }
     __syncthreads();
     if (sh_fail) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }

@@ -69,6 +69,7 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     int32_t order_lds, dig_on;     // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice); dig_on: PoaState.cigar_dig is kept
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
+    const int32_t *wts;            // per-base edge weights, parallel to `reads` (the reference's -Q: abpoa_msa1 src/abpoa_align.c:462-467); NULL: every weight 1
     // graph, indexed node0 + node id
     uint8_t *nd_base, *nd_nin, *nd_nout, *nd_naln;
     int32_t *nd_in, *nd_out, *nd_outw;              // hot slots  [node][POA_HOT]: in ids, out ids, out weights

@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
         else if (u == 1) { nin = 1; in0 = L + 1; }
         else { nin = 1; in0 = i == 0 ? 0 : u - 1; nout = 1; out0 = i == L - 1 ? 1 : u + 1; }
         p.nd_nin[N0 + u] = (uint8_t)nin; p.nd_nout[N0 + u] = (uint8_t)nout;
-        in_slot(p, N0 + u, 0) = in0; out_slot(p, N0 + u, 0) = out0; outw_slot(p, N0 + u, 0) = 1;
+        // (edge weight = weight of the base the edge leads to; the edge into the sink takes the last base's: reference abpoa_add_graph_sequence :486-499)
+        const int32_t *wq = p.wts ? p.wts + p.read_off[S.read0] : nullptr;
+        in_slot(p, N0 + u, 0) = in0; out_slot(p, N0 + u, 0) = out0; outw_slot(p, N0 + u, 0) = !wq ? 1 : (u == 0 ? wq[0] : (u == 1 ? 0 : wq[i == L - 1 ? L - 1 : i + 1]));
         p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
         if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * POA_OUT_CAP) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }      // read 0 went through the node's one edge
         // row order: source, the chain, sink

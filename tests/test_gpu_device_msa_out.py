@@ -147,3 +147,32 @@ def test_strict_mode_reports_instead_of_slowing_down(engine, monkeypatch):
     assert "(-6)" in str(ei.value) and "ABPOA_HIP_STRICT" in str(ei.value)
     ok = api.msa_batch(sets, api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), n_threads=4)
     assert all(x.status == 0 for x in ok) and api.msa_timing()["n_host_sets"] == 0
+
+
+@pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
+def test_per_base_weights_on_the_device(engine, monkeypatch, lockstep):
+    """The reference's -Q (base qualities as edge weights, src/abpoa_align.c:462-467; abpoa_graph.c:486-499, :634-667): the device fuse phase adds the weight of
+    the base an edge leads to.  Ragged sets, some reads (and one whole set) without weights, consensus + coverage + MSA against the oracle-backed run; and the
+    reference CLI's own -Q outputs (goldens out_qv_*) through the device driver."""
+    import numpy as np
+    import helpers as H
+    from abpoa_amd import api, seqio, synth
+    monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", str(lockstep))
+    shim = H.cpu_shim_lib()
+    rng = np.random.default_rng(7)
+    sets = [synth.make_read_set(59, i, 5 + i % 9, 180 + 50 * i, 0.04 + 0.02 * (i % 5)) for i in range(10)]
+    weights = [[rng.integers(1, 41, len(r)).astype(np.int32) for r in s] for s in sets]
+    weights[3] = None
+    for kw in (dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict()):
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, weights=weights)
+        assert api.msa_timing()["n_host_sets"] == 0, "device driver not used for every set"
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, weights=weights, lib=shim)
+        _same(dev, ref, f"weights {kw}")
+    D = H.GOLDEN_DIR
+    for name, out_msa in (("out_qv_cons", False), ("out_qv_msa", True)):
+        names, seqs, quals = seqio.read_fastx(os.path.join(D, name, "input.fq"))
+        w = [[seqio.qv_weights(s, q) for s, q in zip(seqs, quals)]]
+        r = api.msa_batch([seqs], api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), out_cons=True, out_msa=out_msa, weights=w)
+        assert api.msa_timing()["n_host_sets"] == 0
+        assert api.format_output(r[0], names, True, out_msa) == open(os.path.join(D, name, "output.txt")).read(), name
