@@ -190,6 +190,47 @@ def msa_batch(read_sets, params, out_cons=True, out_msa=False, n_threads=0, lib=
     return res
 
 
+class BatchContext:
+    """abpoa_hip_ctx_t: the batch entry with per-caller state (own device queue, timing, last error): one host thread per context may call while others do."""
+
+    def __init__(self, device=-1, lib=None):
+        self.lib = lib or ffi.lib()
+        _bind_msa(self.lib)
+        self.lib.abpoa_hip_ctx_create.restype = C.c_void_p
+        self.lib.abpoa_hip_ctx_create.argtypes = [C.c_int]
+        self.lib.abpoa_hip_ctx_destroy.argtypes = [C.c_void_p]
+        self.lib.abpoa_hip_msa_batch_ctx.argtypes = [C.c_void_p, C.POINTER(ffi.Scoring), C.c_int, C.POINTER(ReadSet), C.POINTER(Msa), C.c_uint, C.c_int]
+        self.lib.abpoa_hip_msa_batch_ctx.restype = C.c_int
+        self.lib.abpoa_hip_ctx_get_msa_timing.argtypes = [C.c_void_p, C.POINTER(MsaTiming)]
+        self.lib.abpoa_hip_ctx_last_error.restype = C.c_char_p
+        self.lib.abpoa_hip_ctx_last_error.argtypes = [C.c_void_p]
+        self.h = self.lib.abpoa_hip_ctx_create(device)
+        if not self.h:
+            raise ffi.EngineError("abpoa_hip_ctx_create failed: " + self.lib.abpoa_hip_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.abpoa_hip_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def msa_batch(self, read_sets, params, out_cons=True, out_msa=False, n_threads=0, encoded=None, weights=None):
+        enc = encoded or EncodedSets(read_sets, params.m, weights)
+        out = (Msa * enc.n)()
+        sc = params.scoring()
+        flags = (OUT_CONS if out_cons else 0) | (OUT_MSA if out_msa else 0)
+        rc = self.lib.abpoa_hip_msa_batch_ctx(self.h, C.byref(sc), enc.n, enc.sets, out, flags, n_threads)
+        if rc != 0:
+            raise ffi.EngineError(f"abpoa_hip_msa_batch_ctx failed ({rc}): {self.lib.abpoa_hip_ctx_last_error(self.h).decode()}")
+        return BatchResults(_BatchOut(self.lib, out, enc.n), params.m)
+
+    def timing(self):
+        t = MsaTiming()
+        self.lib.abpoa_hip_ctx_get_msa_timing(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in MsaTiming._fields_}
+
+
 def msa_timing(lib=None):
     lib = lib or ffi.lib()
     _bind_msa(lib)

@@ -63,6 +63,8 @@ class BatchStream {
 };
 
 void set_err(const char *fmt, ...);
+const char *thread_last_error();      // the last message set_err formatted on the calling thread ("" if none since clear_thread_error)
+void clear_thread_error();
 void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, int n_aln, LdsPlan *L);
 int engine_device();            // device the process is bound to, or -1
 void add_global_stats(const StreamStats &s);

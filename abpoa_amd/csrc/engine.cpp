@@ -23,10 +23,14 @@ namespace abpoa_hip {
 // per-thread copy taken under the lock.
 static char g_err[512] = ""; static std::mutex g_err_mu;
 static thread_local char g_err_copy[512] = "";
+static thread_local char tl_err[512] = "";      // last error raised on THIS thread (a context's call copies it: abpoa_hip_ctx_last_error)
 void set_err(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(tl_err, sizeof(tl_err), fmt, ap); va_end(ap);
     std::lock_guard<std::mutex> lk(g_err_mu);
-    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    memcpy(g_err, tl_err, sizeof(g_err));
 }
+const char *thread_last_error() { return tl_err; }
+void clear_thread_error() { tl_err[0] = 0; }
 #define HIP_TRY(expr, code)                                                                          \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                             \
         set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return code; } } while (0)

@@ -131,19 +131,27 @@ std::vector<int> device_list() {
 }  // namespace
 }  // namespace abpoa_hip
 
-extern "C" {
-int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets,
-                        abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
-    using namespace abpoa_hip;
-    if (engine_device() < 0) { int rc = abpoa_hip_init(0); if (rc) return rc; }
+// A context (include/abpoa_hip.h abpoa_hip_ctx_t): the per-caller state of the batch entry -- device, device queue (pool cache, stream, the
+// all-rounds kernel's argument record), timing and last error of its own calls -- so that several host threads can run batches side by side.
+struct abpoa_hip_ctx { int device; int slot; abpoa_hip_msa_timing_t timing; char err[512]; };
+namespace abpoa_hip {
+namespace {
+std::mutex g_ctx_mu; bool g_ctx_slot_used[MSA_DEVICE_SLOTS] = {false};
+constexpr int CTX_SLOT_LO = MSA_DEVICE_SLOTS / 2;      // the upper half of the device queues belongs to contexts, the lower half to the process-wide entry
+// the batch entry proper: `tm` receives the call's timing record; ctx_device / ctx_slot >= 0: one device queue, the context's
+int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads,
+                   abpoa_hip_msa_timing_t &g_timing, int ctx_device, int ctx_slot) {
+    if (engine_device() < 0) { int rc = abpoa_hip_init(ctx_device >= 0 ? ctx_device : 0); if (rc) return rc; }
     abpoa_hip_scoring_t sc_norm; const abpoa_hip_scoring_t *sc = sc_in;
     if (sc_in && sc_in->align_mode == ABPOA_HIP_LOCAL_MODE) { sc_norm = *sc_in; sc_norm.wb = -1; sc = &sc_norm; }      // reference abpoa_post_set_para, src/abpoa_align.c:150: local mode has no band
     if (n_sets > 0 && sc && sets && out && msa_device_eligible(sc, flags)) {
         // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
         if (n_threads <= 0) n_threads = effective_host_cores();
-        for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) return ABPOA_HIP_EINVAL; }
+        for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) { set_err("read-set %d: read %d is empty", s, r); return ABPOA_HIP_EINVAL; } }
         for (int s = 0; s < n_sets; ++s) memset(&out[s], 0, sizeof(out[s]));
-        const std::vector<int> devs = device_list();
+        std::vector<int> devs = device_list();
+        if ((int)devs.size() > CTX_SLOT_LO) devs.resize(CTX_SLOT_LO);
+        if (ctx_slot >= 0) devs.assign(1, ctx_device);      // a context: its own device, its own queue
         const int n_q = (int)devs.size();
         // ---- batches: sets sorted by estimated DP cost (sum of read lengths x reads), heaviest first, dealt round-robin so that every batch
         //      holds the same mix; device queues pull batches from one shared counter (a fast device simply takes more of them)
@@ -170,7 +178,7 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpo
             const int thr = std::max(1, n_threads / n_q);
             for (int b_; (b_ = next.fetch_add(1)) < (int)batches.size();) {
                 const auto t0 = std::chrono::steady_clock::now();
-                results[b_] = device_passes(sc, sets, out, batches[b_], thr, devs[q], q, flags);
+                results[b_] = device_passes(sc, sets, out, batches[b_], thr, devs[q], ctx_slot >= 0 ? ctx_slot : q, flags);
                 q_busy[q] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (results[b_].rc != ABPOA_HIP_OK) break;
             }
@@ -225,6 +233,43 @@ int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpo
     g_timing.n_host_sets = n_sets;
     return rc_host;
 }
+}  // namespace
+}  // namespace abpoa_hip
+
+extern "C" {
+int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
+    return abpoa_hip::msa_batch_impl(sc, n_sets, sets, out, flags, n_threads, abpoa_hip::g_timing, -1, -1);
+}
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
+// ---- contexts
+abpoa_hip_ctx_t *abpoa_hip_ctx_create(int device) {
+    using namespace abpoa_hip;
+    if (engine_device() < 0) { if (abpoa_hip_init(device >= 0 ? device : 0) != ABPOA_HIP_OK) return nullptr; }
+    int n = 0; (void)hipGetDeviceCount(&n);
+    if (device < 0) device = engine_device();
+    if (device >= n) { set_err("device %d out of range (0..%d)", device, n - 1); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (int s = MSA_DEVICE_SLOTS - 1; s >= CTX_SLOT_LO; --s) if (!g_ctx_slot_used[s]) {
+        g_ctx_slot_used[s] = true;
+        abpoa_hip_ctx *c = new abpoa_hip_ctx(); c->device = device; c->slot = s; memset(&c->timing, 0, sizeof(c->timing)); c->err[0] = 0;
+        return c;
+    }
+    set_err("all %d batch contexts are in use", MSA_DEVICE_SLOTS - CTX_SLOT_LO);
+    return nullptr;
+}
+void abpoa_hip_ctx_destroy(abpoa_hip_ctx_t *c) {
+    if (!c) return;
+    { std::lock_guard<std::mutex> lk(abpoa_hip::g_ctx_mu); abpoa_hip::g_ctx_slot_used[c->slot] = false; }
+    delete c;      // (the queue's pools stay cached for the next context that takes the slot; abpoa_hip_trim releases them)
+}
+int abpoa_hip_msa_batch_ctx(abpoa_hip_ctx_t *c, const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
+    if (!c) return ABPOA_HIP_EINVAL;
+    abpoa_hip::clear_thread_error();
+    const int rc = abpoa_hip::msa_batch_impl(sc, n_sets, sets, out, flags, n_threads, c->timing, c->device, c->slot);
+    if (rc != ABPOA_HIP_OK) { const char *m = abpoa_hip::thread_last_error(); snprintf(c->err, sizeof(c->err), "%s", m[0] ? m : abpoa_hip_last_error()); } else c->err[0] = 0;
+    return rc;
+}
+void abpoa_hip_ctx_get_msa_timing(const abpoa_hip_ctx_t *c, abpoa_hip_msa_timing_t *out) { if (c && out) *out = c->timing; }
+const char *abpoa_hip_ctx_last_error(const abpoa_hip_ctx_t *c) { return c ? c->err : "null context"; }
 void abpoa_hip_trim(void) { abpoa_hip::release_msa_device_caches(); }
 }

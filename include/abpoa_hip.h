@@ -218,6 +218,19 @@ typedef struct abpoa_hip_msa_timing_t {
 } abpoa_hip_msa_timing_t;
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out);
 
+/* ---- contexts (additive; SURVEY.md 8b: "the replacement should be re-entrant per abpoa_t") --------------------------------------------------
+ * abpoa_hip_msa_batch keeps its timing record and last error per PROCESS and drives the device queues named by ABPOA_GPU_DEVICES: one caller at a
+ * time.  A context is the same entry with the per-caller state in a handle: its own device queue (stream, pool cache, argument record), timing and
+ * last error -- one host thread per context may call at the same time as others (the reference's abpoa_t plays this role: one graph, one caller).
+ * Up to 8 contexts; a context may name any device.  Results are those of abpoa_hip_msa_batch. */
+typedef struct abpoa_hip_ctx abpoa_hip_ctx_t;
+abpoa_hip_ctx_t *abpoa_hip_ctx_create(int device);          /* device < 0: the device of abpoa_hip_init; NULL on failure (abpoa_hip_last_error) */
+void abpoa_hip_ctx_destroy(abpoa_hip_ctx_t *ctx);
+int  abpoa_hip_msa_batch_ctx(abpoa_hip_ctx_t *ctx, const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
+                             abpoa_hip_msa_t *out, unsigned flags, int n_threads);
+void abpoa_hip_ctx_get_msa_timing(const abpoa_hip_ctx_t *ctx, abpoa_hip_msa_timing_t *out);
+const char *abpoa_hip_ctx_last_error(const abpoa_hip_ctx_t *ctx);
+
 #ifdef __cplusplus
 }
 #endif

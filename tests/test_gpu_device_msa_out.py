@@ -176,3 +176,37 @@ def test_per_base_weights_on_the_device(engine, monkeypatch, lockstep):
         r = api.msa_batch([seqs], api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), out_cons=True, out_msa=out_msa, weights=w)
         assert api.msa_timing()["n_host_sets"] == 0
         assert api.format_output(r[0], names, True, out_msa) == open(os.path.join(D, name, "output.txt")).read(), name
+
+
+def test_two_contexts_on_two_host_threads(engine):
+    """abpoa_hip_ctx_t: two host threads, a context each (own device queue, timing and last error), different jobs at the same time -- one narrow-band
+    job that takes the all-rounds kernel (per-queue __constant__ argument records) and one local amino-acid MSA job -- three calls each; results equal
+    those of the process-wide entry, each context's timing describes its own job, and a failing call leaves its message in its own context only."""
+    import threading
+    from abpoa_amd import api, ffi, synth, workloads
+    jobs = [(api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), [synth.make_read_set(61, i, 12, 600, 0.06) for i in range(24)], dict(out_cons=True, out_msa=False)),
+            (api.Params(aln_mode=1, is_aa=True, score_matrix=workloads.BLOSUM62), [synth.make_read_set(67, i, 10, 200, alphabet=synth.AA, rates=(0.06, 0.03, 0.03)) for i in range(16)], dict(out_cons=False, out_msa=True))]
+    want = [api.msa_batch(sets, p, n_threads=4, **kw) for p, sets, kw in jobs]
+    ctxs = [api.BatchContext() for _ in jobs]
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            p, sets, kw = jobs[i]
+            for _ in range(3):
+                got[i] = ctxs[i].msa_batch(sets, p, n_threads=4, **kw)
+        except Exception as ex:      # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    for i, (p, sets, kw) in enumerate(jobs):
+        for a, b in zip(got[i], want[i]):
+            assert a.status == 0 and a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov and a.msa_seq == b.msa_seq
+        tm = ctxs[i].timing()
+        assert tm["n_host_sets"] == 0 and tm["n_rounds"] == max(len(s) for s in sets) - 1, tm
+    with pytest.raises(ffi.EngineError):      # a malformed job: the message stays with the context that made the call
+        ctxs[0].msa_batch([[""]], jobs[0][0])
+    assert ctxs[0].lib.abpoa_hip_ctx_last_error(ctxs[0].h) != b"" and ctxs[1].lib.abpoa_hip_ctx_last_error(ctxs[1].h) == b""
+    [c.close() for c in ctxs]
