@@ -132,7 +132,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
         const int lw = P == 3 ? 1 : 2;                 // ring words per column (int16: H | E1 packed, E2)
         L.loc_cols = 9 * 64; L.loc_rows = 16;
         while ((int64_t)L.loc_rows * lw * (L.loc_cols + 4) * 4 > 60 * 1024 - L.phase_off && L.loc_rows > 4) L.loc_rows /= 2;
-        L.total_local = L.phase_off + L.fr_off + (int)align_up((size_t)L.loc_rows * lw * (L.loc_cols + 4) * 4, 16) + 64;
+        L.total_local = L.phase_off + L.fr_off + (int)align_up((size_t)L.loc_rows * lw * (L.loc_cols + 4) * 4, 16) + 256;      // (+ the team kernel's exchange slots: 2 x 4 x 16 bytes)
     }
     // wide row loop (dp_wide_rows.hip): alignments whose band half-width w is in [wide_w_lo, wide_w_hi] -- rows of 2..7 chunks of 64 columns --
     // go to the kernel that keeps every chunk of a row in registers; it has its own score ring (448 columns; depth by what fits:

@@ -59,6 +59,37 @@ def test_direction_words_match_the_model(engine, monkeypatch, env):
     assert n >= 4
 
 
+@pytest.mark.parametrize("team", ["0", "1"], ids=["one_wavefront", "team_of_four"])
+def test_local_row_loops_plane_level(engine, monkeypatch, team):
+    """Both forms of the local row loop (rows_local.h) -- one wavefront with every chunk of a row in registers, and the team of four wavefronts that split
+    the chunks (one LDS exchange of carry-chain results and arg-max keys per row) -- on the local goldens (nucleotides, affine / convex; amino acids with
+    BLOSUM62) and on synthetic local alignments of 3-9 chunks with ragged chunk shares (reads of 150-560 residues; graphs with 1-6 predecessors per row,
+    predecessors older than the score ring): every plane cell, best cell, cigar against the golden vectors and the oracle."""
+    import os
+    from abpoa_amd import api, synth, workloads
+    monkeypatch.setenv("ABPOA_HIP_LOCAL_TEAM", team)
+    n = 0
+    for label, path in CASES:
+        if "_loc" not in label:
+            continue
+        g = H.read_abpg(path)
+        case = H.FlatCase(g)
+        h = H.run_hip([case])[0]
+        H.compare_with_golden(h, g, label=f"local team={team} {label}")
+        H.compare_outs(h, H.run_oracle(case), label=f"local team={team} vs oracle {label}")
+        n += 1
+    assert n >= 3
+    # whole MSAs (30 rounds of growing graphs) through the device driver: 150 .. 560 residues = 3 .. 9 chunks, 1 / 2 / 3 chunks per wavefront with uneven shares
+    shim = H.cpu_shim_lib()
+    p = api.Params(aln_mode=1, is_aa=True, score_matrix=workloads.BLOSUM62)
+    sets = [synth.make_read_set(71, i, 14, ln, alphabet=synth.AA, rates=(0.07, 0.03, 0.03)) for i, ln in enumerate((150, 200, 260, 330, 390, 450, 515, 560))]
+    dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 0
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+    for i, (a, b) in enumerate(zip(dev, ref)):
+        assert a.status == 0 and a.msa_seq == b.msa_seq and a.cons_seq == b.cons_seq and a.n_cells == b.n_cells, f"team={team}: set {i}"
+
+
 def test_need_scores_redo_path(engine, monkeypatch):
     """The direction-plane walk gives up (ABPOA_HIP_STATUS_NEED_SCORES) where the words cannot decide where an F value came from -- never seen on real
     data -- and the alignment is redone with score records.  ABPOA_HIP_DBG=512 makes the walk give up at the first insertion it would decide from
