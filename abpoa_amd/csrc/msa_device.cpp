@@ -573,6 +573,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         }
     }
     const double t_done = now_s();
+    if (getenv("ABPOA_HIP_ORDER_PROF") && p.order_mode) {      // (library built with -DABPOA_HIP_ORDER_PROF: the order walk's passes and ticks per kind, mean per set)
+        const PoaState *hs_ = (const PoaState *)(C.graph.host + L.o_state); double a_[4] = {0, 0, 0, 0};
+        for (int s = 0; s < n_sets; ++s) for (int i = 0; i < 4; ++i) a_[i] += (double)hs_[s].t_phase[i];
+        fprintf(stderr, "[abpoa-hip] order walk per set: %.0f single-node passes x %.0f ticks, %.0f parallel passes x %.0f ticks\n", a_[2] / n_sets, a_[2] > 0 ? a_[0] / a_[2] : 0.0, a_[3] / n_sets, a_[3] > 0 ? a_[1] / a_[3] : 0.0);
+    }
     if (stats) {
         float ms = 0;
         hipEvent_t prev = C.ev[1];

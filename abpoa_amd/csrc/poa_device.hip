@@ -176,8 +176,15 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
 constexpr int ORD_RING = 1024;                 // the most recent queue entries, in LDS (the frontier of a POA graph is a few nodes wide)
 extern __shared__ int ord_lds[];               // [ORD_RING] ring, then -- LDS tables -- [cap] in-degree counters, [cap] zero times (rank pass: + [cap] rank, [cap] stack)
 // table `which`, entry i; n: the stride between tables (LDS: the launch's table capacity; global: the node count)
-template <bool L> __device__ __forceinline__ int &tbl(const PoaDev &p, int32_t *g, int which, int n, int i) { return L ? ord_lds[ORD_RING + which * n + i] : g[(int64_t)which * n + i]; }
-template <bool L> __device__ __forceinline__ int tbl_ld(const PoaDev &p, int32_t *g, int which, int n, int i) { return L ? ord_lds[ORD_RING + which * n + i] : ld_fresh(g + (int64_t)which * n + i); }
+// (one function per operation, the address space chosen at compile time: a reference picked by `L ? lds : global` is a GENERIC pointer, and every access
+//  through it a FLAT instruction -- which counts on both memory counters, so that waiting for a table entry in LDS also waited for the row-order stores of
+//  the pass before to be acknowledged by memory, ~1 us per pass)
+template <bool L> __device__ __forceinline__ int tbl_ld(const PoaDev &p, int32_t *g, int which, int n, int i) { if constexpr (L) return ord_lds[ORD_RING + which * n + i]; else return ld_fresh(g + (int64_t)which * n + i); }
+template <bool L> __device__ __forceinline__ void tbl_st(const PoaDev &p, int32_t *g, int which, int n, int i, int v) { if constexpr (L) ord_lds[ORD_RING + which * n + i] = v; else g[(int64_t)which * n + i] = v; }
+template <bool L> __device__ __forceinline__ void tbl_dec_max(const PoaDev &p, int32_t *g, int n, int i, int key) {      // counter (table 0) - 1, zero time (table 1) = max(., key)
+    if constexpr (L) { atomicSub(&ord_lds[ORD_RING + i], 1); atomicMax(&ord_lds[ORD_RING + n + i], key); }
+    else { atomicSub(g + i, 1); atomicMax(g + (int64_t)n + i, key); }
+}
 
 // (Measured and dropped: the adjacency staged in LDS too -- 26 bytes a node.  A walk's wavefront then waits 24 % less, but 70 KB of LDS leave one
 //  workgroup per CU instead of six and the launch runs in four turns: 4.1 ms instead of 1.5 ms per launch on configs[4].)
@@ -192,66 +199,137 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
     const int lane = threadIdx.x;
     const int64_t N0 = S.node0;
     int32_t *g = p.scratch + S.scratch0;           // (global tables when the graph is larger than the LDS tables: [n] counters, [n] zero times)
+    // (LDS tables: the size of every node's aligned group as a byte table behind them -- the group size of a TARGET was the second dependent memory round
+    //  trip of a pass, after the popped node's out-edge record)
+    // ... and, 16 bits a node, the target of a node's ONLY out-edge (0xffff: none or several, or a graph of 65535+ nodes: the edge record comes from memory):
+    // most nodes of a POA graph are links of a chain, and the out-edge record of the node just popped was the one memory round trip (~1 us) left in a pass
+    uint8_t *const s_naln = (uint8_t *)(ord_lds + ORD_RING + 2 * n);
+    uint16_t *const s_next = (uint16_t *)(ord_lds + ORD_RING + 2 * n + ((n + 3) >> 2));
+    // ... and the QUEUE itself, 16 bits an entry, for graphs of fewer than 65535 nodes: the row order and nd_row go to memory in one coalesced sweep after
+    // the walk.  (Stored pass by pass they kept a store in flight at every wait for a load: vmcnt counts loads and stores alike, and a store takes ~1 us to be
+    // acknowledged -- measured: 3000 cycles per single-node pass, 5600 per parallel pass, nearly all of it that.)
+    uint16_t *const s_q = s_next + ((n + 1) & ~1);
+    const bool QL = L && n < 65535;
+    auto qget = [&](int pos_, int head_, int tail_) __attribute__((always_inline)) -> int {
+        if (QL) return (int)s_q[pos_];
+        if (tail_ - head_ <= ORD_RING) return ord_lds[pos_ & (ORD_RING - 1)];
+        return ld_fresh(order + pos_);
+    };
+    auto qput = [&](int at_, int node_) __attribute__((always_inline)) {
+        if (QL) s_q[at_] = (uint16_t)node_;
+        else { order[at_] = node_; p.nd_row[N0 + node_] = at_; ord_lds[at_ & (ORD_RING - 1)] = node_; }
+    };
     for (int u = lane; u < n; u += 64) {
-        tbl<L>(p, g, 0, n, u) = p.nd_nin[N0 + u]; tbl<L>(p, g, 1, n, u) = -1;
+        tbl_st<L>(p, g, 0, n, u, p.nd_nin[N0 + u]); tbl_st<L>(p, g, 1, n, u, -1);
+        if (L) { s_naln[u] = p.nd_naln[N0 + u]; s_next[u] = (p.nd_nout[N0 + u] == 1 && n < 65535) ? (uint16_t)p.nd_out[(N0 + u) * POA_HOT] : (uint16_t)0xffff; }
     }
-    if (lane == 0) { order[0] = 0; p.nd_row[N0] = 0; ord_lds[0] = 0; }
+    auto naln_of = [&](int v) __attribute__((always_inline)) -> int { return L ? (int)s_naln[v] : (int)p.nd_naln[N0 + v]; };
+    if (lane == 0) qput(0, 0);
     tbl_fence<L>();
     int head = 0, tail = 1;
+#ifdef ABPOA_HIP_ORDER_PROF
+    long long t_seq = 0, t_par = 0, n_seq = 0, n_par = 0, t_last = (long long)__builtin_amdgcn_s_memtime();
+#define ORD_PROF(T, N) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); T += t_ - t_last; t_last = t_; ++N; }
+#else
+#define ORD_PROF(T, N)
+#endif
     while (head < tail) {
         if (tail - head == 1) {
             // ONE node in the queue (most passes: a POA graph is chains with short bubbles): the reference's own sequential step, executed by every lane
             // with the same values (wave-uniform control flow, broadcast LDS reads; lane 0 stores) -- no atomics, no time-stamp comparison, no scan:
             // a third of the LDS round trips of the parallel pass below.  zt is kept up to date for the passes that compare it.
-            const int u = uni(ord_lds[head & (ORD_RING - 1)]);
+            if (!QL && tail - head > ORD_RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int u = uni(qget(head, head, tail));
             int no; int4 o4;
-            no = uni((int)p.nd_nout[N0 + u]); o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT);
+            const int nx = L ? uni((int)s_next[u]) : 0xffff;
+            if (nx != 0xffff) { no = 1; o4 = make_int4(nx, 0, 0, 0); }
+            else { no = uni((int)p.nd_nout[N0 + u]); o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
             int at = tail;
             for (int k = 0; k < no; ++k) {
                 const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))));
                 const int d = uni(tbl_ld<L>(p, g, 0, n, v)) - 1;
-                if (lane == 0) { tbl<L>(p, g, 0, n, v) = d; tbl<L>(p, g, 1, n, v) = head * 16 + k; }
+                if (lane == 0) { tbl_st<L>(p, g, 0, n, v, d); tbl_st<L>(p, g, 1, n, v, head * 16 + k); }
                 if (d != 0) continue;
-                const int na = uni((int)p.nd_naln[N0 + v]);
+                const int na = uni(naln_of(v));
                 bool ready = true;
                 if (na > 0) { tbl_fence<L>(); for (int t = 0; t < na && ready; ++t) ready = uni(tbl_ld<L>(p, g, 0, n, p.nd_aln[(N0 + v) * p.aln_cap + t])) == 0; }      // (fence: lane 0's store above may be what an aligned node's entry holds)
                 if (!ready) continue;
                 if (at + 1 + na > n) return false;
-                if (lane == 0) { order[at] = v; p.nd_row[N0 + v] = at; ord_lds[at & (ORD_RING - 1)] = v; }
-                if (lane < na) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + lane]; order[at + 1 + lane] = a; p.nd_row[N0 + a] = at + 1 + lane; ord_lds[(at + 1 + lane) & (ORD_RING - 1)] = a; }
+                if (lane == 0) qput(at, v);
+                if (lane < na) qput(at + 1 + lane, p.nd_aln[(N0 + v) * p.aln_cap + lane]);
                 at += 1 + na;
             }
             tail = at; ++head;
             tbl_fence<L>();
+            ORD_PROF(t_seq, n_seq)
             continue;
         }
         const int cnt = imin_(64, tail - head), pos = head + lane; const bool act = lane < cnt;
         int u = 1, no = 0; int4 o4 = make_int4(0, 0, 0, 0);
-        if (tail - head <= ORD_RING) { if (act) u = ord_lds[pos & (ORD_RING - 1)]; }
-        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (act) u = ld_fresh(order + pos); }      // (a frontier wider than the ring: from the order array, once its stores are acknowledged)
+        if (!QL && tail - head > ORD_RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a frontier wider than the ring: from the order array, once its stores are acknowledged)
+        if (act) u = qget(pos, head, tail);
         if (act) { no = p.nd_nout[N0 + u]; o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
         auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))); };
-        for (int k = 0; k < no; ++k) { const int v = target(k); atomicSub(&tbl<L>(p, g, 0, n, v), 1); atomicMax(&tbl<L>(p, g, 1, n, v), pos * 16 + k); }
+        for (int k = 0; k < no; ++k) tbl_dec_max<L>(p, g, n, target(k), pos * 16 + k);
         tbl_fence<L>();
+        // Which edges push a group.  The first four edges of a lane and the first four aligned nodes of their targets are looked at together, so that the
+        // memory loads of this half of the pass -- the aligned lists -- are all in flight at once (as a loop with an early exit they were one dependent
+        // round trip per aligned node: 78 % of the columns of a 30-sequence protein MSA hold a group); longer lists take the loop.
+        constexpr int KQ = 4, TQ = 4;
         unsigned trig = 0; int total = 0;
-        for (int k = 0; k < no; ++k) {
+        int vq[KQ], naq[KQ], aq[KQ][TQ]; bool cq[KQ];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            vq[k] = k < no ? target(k) : 0;
+            cq[k] = k < no && tbl_ld<L>(p, g, 0, n, vq[k]) == 0 && tbl_ld<L>(p, g, 1, n, vq[k]) == pos * 16 + k;
+            naq[k] = cq[k] ? naln_of(vq[k]) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) aq[k][t] = (cq[k] && t < naq[k]) ? p.nd_aln[(N0 + vq[k]) * p.aln_cap + t] : 0;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) if (cq[k]) {
+            const int key = pos * 16 + k; bool ready = true;
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) if (t < naq[k]) ready = ready && tbl_ld<L>(p, g, 0, n, aq[k][t]) == 0 && tbl_ld<L>(p, g, 1, n, aq[k][t]) < key;
+            for (int t = TQ; t < naq[k] && ready; ++t) { const int a = p.nd_aln[(N0 + vq[k]) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
+            if (ready) { trig |= 1u << k; total += 1 + naq[k]; }
+        }
+        for (int k = KQ; k < no; ++k) {
             const int v = target(k), key = pos * 16 + k;
             if (tbl_ld<L>(p, g, 0, n, v) != 0 || tbl_ld<L>(p, g, 1, n, v) != key) continue;
-            const int na = (int)p.nd_naln[N0 + v]; bool ready = true;
+            const int na = naln_of(v); bool ready = true;
             for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
             if (ready) { trig |= 1u << k; total += 1 + na; }
         }
         const int incl = wave_scan_add(total), all = __builtin_amdgcn_readlane(incl, 63);
         if (tail + all > n) return false;                                          // (more entries than nodes: not a graph this walk understands)
         int at = tail + incl - total;
-        for (int k = 0; k < no; ++k) if (trig >> k & 1) {
-            const int v = target(k), na = (int)p.nd_naln[N0 + v];
-            order[at] = v; p.nd_row[N0 + v] = at; ord_lds[at & (ORD_RING - 1)] = v; ++at;
-            for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; order[at] = a; p.nd_row[N0 + a] = at; ord_lds[at & (ORD_RING - 1)] = a; ++at; }
+        auto put = [&](int node_) __attribute__((always_inline)) { qput(at, node_); ++at; };
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) if (trig >> k & 1) {
+            put(vq[k]);
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) if (t < naq[k]) put(aq[k][t]);
+            for (int t = TQ; t < naq[k]; ++t) put(p.nd_aln[(N0 + vq[k]) * p.aln_cap + t]);
+        }
+        for (int k = KQ; k < no; ++k) if (trig >> k & 1) {
+            const int v = target(k), na = naln_of(v);
+            put(v);
+            for (int t = 0; t < na; ++t) put(p.nd_aln[(N0 + v) * p.aln_cap + t]);
         }
         tail += all; head += cnt;
         tbl_fence<L>();
+        ORD_PROF(t_par, n_par)
     }
+    if (QL) {      // the order and every node's row, in one sweep
+        if (head != n || s_q[n - 1] != 1) return false;
+        for (int r = lane; r < n; r += 64) { const int u_ = s_q[r]; order[r] = u_; p.nd_row[N0 + u_] = r; }
+    }
+#ifdef ABPOA_HIP_ORDER_PROF
+    if (lane == 0) { PoaState *st_ = p.state + (int)blockIdx.x; st_->t_phase[0] += t_seq; st_->t_phase[1] += t_par; st_->t_phase[2] += n_seq; st_->t_phase[3] += n_par; }
+#endif
     return head == n;
 }
 
@@ -280,22 +358,22 @@ __device__ __forceinline__ int poa_msa_rank_body(const PoaDev &p, const PoaSet &
     const int lane = threadIdx.x;
     const int64_t N0 = S.node0;
     int32_t *g = p.scratch + S.scratch0;           // tables: 0 counters, 1 zero times, 2 rank, 3 stack
-    for (int u = lane; u < n; u += 64) { tbl<L>(p, g, 0, n, u) = p.nd_nin[N0 + u]; tbl<L>(p, g, 1, n, u) = -1; tbl<L>(p, g, 2, n, u) = 0; }
-    if (lane == 0) { tbl<L>(p, g, 3, n, 0) = 0; tbl<L>(p, g, 2, n, 0) = -1; }
+    for (int u = lane; u < n; u += 64) { tbl_st<L>(p, g, 0, n, u, p.nd_nin[N0 + u]); tbl_st<L>(p, g, 1, n, u, -1); tbl_st<L>(p, g, 2, n, u, 0); }
+    if (lane == 0) { tbl_st<L>(p, g, 3, n, 0, 0); tbl_st<L>(p, g, 2, n, 0, -1); }
     __syncthreads();
     int sp = 1, msa_rank = 0, pops = 0; bool done = false;
     while (sp > 0 && !done) {
         const int cur = uni(tbl_ld<L>(p, g, 3, n, sp - 1)); --sp;
         const int na_c = p.nd_naln[N0 + cur], no = cur == 1 ? 0 : (int)p.nd_nout[N0 + cur];
         if (uni(tbl_ld<L>(p, g, 2, n, cur)) < 0) {
-            if (lane == 0) tbl<L>(p, g, 2, n, cur) = msa_rank;
-            if (lane < na_c) tbl<L>(p, g, 2, n, p.nd_aln[(N0 + cur) * p.aln_cap + lane]) = msa_rank;      // (aln_cap <= 26 < 64: a lane each)
+            if (lane == 0) tbl_st<L>(p, g, 2, n, cur, msa_rank);
+            if (lane < na_c) tbl_st<L>(p, g, 2, n, p.nd_aln[(N0 + cur) * p.aln_cap + lane], msa_rank);      // (aln_cap <= 26 < 64: a lane each)
             ++msa_rank;
         }
         if (cur == 1) { done = true; break; }
         const int key = pops * 16 + lane; ++pops;
         int v = -1;
-        if (lane < no) { v = out_slot(p, N0 + cur, lane); atomicSub(&tbl<L>(p, g, 0, n, v), 1); atomicMax(&tbl<L>(p, g, 1, n, v), key); }
+        if (lane < no) { v = out_slot(p, N0 + cur, lane); tbl_dec_max<L>(p, g, n, v, key); }
         __syncthreads();
         int total = 0, na = 0;
         if (lane < no && tbl_ld<L>(p, g, 0, n, v) == 0) {
@@ -307,8 +385,8 @@ __device__ __forceinline__ int poa_msa_rank_body(const PoaDev &p, const PoaSet &
         if (sp + all > n) return -1;
         if (total) {
             int at = sp + incl - total;
-            tbl<L>(p, g, 3, n, at) = v; tbl<L>(p, g, 2, n, v) = -1; ++at;
-            for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; tbl<L>(p, g, 3, n, at) = a; tbl<L>(p, g, 2, n, a) = -1; ++at; }
+            tbl_st<L>(p, g, 3, n, at, v); tbl_st<L>(p, g, 2, n, v, -1); ++at;
+            for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; tbl_st<L>(p, g, 3, n, at, a); tbl_st<L>(p, g, 2, n, a, -1); ++at; }
         }
         sp += all;
         __syncthreads();
@@ -378,7 +456,7 @@ hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
-size_t poa_order_lds_bytes(int node_cap) { return 4 * (size_t)ORD_RING + 8 * (size_t)(node_cap > 0 ? node_cap : 0); }
+size_t poa_order_lds_bytes(int node_cap) { return 4 * (size_t)ORD_RING + 13 * (size_t)(node_cap > 0 ? node_cap : 0) + 32; }      // two int tables + the order walk's group-size bytes, 16-bit chain links and 16-bit queue
 static hipError_t launch_ord(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
     const size_t lds = poa_order_lds_bytes(p.order_lds);
