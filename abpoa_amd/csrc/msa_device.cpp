@@ -327,6 +327,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = local ? 1 : 0; p.banded = sc->wb >= 0 ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
     // LDS tables of the order / rank kernels (two ints per node; the rank pass packs four tables into the same space): up to 6000 nodes = 52 KB, three workgroups per CU
     p.order_lds = (local || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
+    // (the all-in-LDS order walk: what is left of 40 KB -- four workgroups per CU -- after 13 bytes a node goes to aligned-list entries, 2 bytes each)
+    p.order_ecap = local ? std::max(1024, std::min(65535, (40 * 1024 - 128 - 13 * p.order_lds) / 2)) : 0;
+    { const char *e_ = getenv("ABPOA_HIP_ORDER_LDS"); if (e_ && !atoi(e_)) p.order_ecap = 0; }      // (ABPOA_HIP_ORDER_LDS=0: the general walk everywhere)
     p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;      // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
     p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
     p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;

@@ -66,6 +66,7 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
                                    // 1: the reference's own order, rebuilt before every alignment (poa_order_kernel: local mode breaks score ties by row index)
     int32_t banded;                // 0: no adaptive band (local mode): the remaining length is not computed
     int32_t msa_rows, msa_cons;    // rows of a set's MSA = its reads (+ 1 when msa_cons: the consensus row, abpoa_output.c:151-164)
+    int32_t order_ecap, pad_e;     // aligned-list entries (16 bits each) the order kernel's all-in-LDS walk holds
     int32_t order_lds, dig_on;     // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice); dig_on: PoaState.cigar_dig is kept
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
@@ -100,7 +101,7 @@ hipError_t launch_poa_order(const PoaDev &p, hipStream_t s);
 // MSA output: rank pass (abpoa_DFS_set_msa_rank, src/abpoa_graph.c:315-362) -> PoaState.msa_len, msa_rank; fill pass (abpoa_output.c:103-166) -> msa_out
 hipError_t launch_poa_msa_rank(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_msa_fill(const PoaDev &p, hipStream_t s);
-size_t poa_order_lds_bytes(int node_cap);      // dynamic LDS of the order / rank kernels for a table capacity of node_cap nodes
+size_t poa_order_lds_bytes(int node_cap, int ecap);      // dynamic LDS of the order / rank kernels for a table capacity of node_cap nodes
 // poa_rounds.hip: rounds k_lo .. n_reads - 1 of every set in one launch (narrow-band jobs), and how many of its workgroups a CU holds
 constexpr int POA_CU_TICKETS = 4096;      // per-CU ticket counters of the all-rounds kernel (index: XCC id, SE, SH, CU), zeroed by the launch
 // host_args: poa_rounds_args_bytes() of pinned host memory that stays valid until the stream has passed the launch (8-byte aligned)

@@ -333,6 +333,107 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
     return head == n;
 }
 
+
+// ---- the same walk with EVERYTHING it touches in LDS (graphs of up to PoaDev.order_lds nodes whose aligned lists hold at most PoaDev.order_ecap entries:
+//      what BASELINE.json configs[4] and every short-read MSA look like).  Measured on the version above: a pass costs 3000 (one node) to 5600 (several)
+//      cycles, nearly all of it memory round trips -- the popped node's out-edge record, the aligned lists of every candidate, and, through vmcnt, the
+//      acknowledgement of the order stores of the pass before.  Here:
+//   * ONE counter per aligned GROUP instead of one per node: cnt[rep] = sum of the members' in-degrees (rep = the member with the smallest id).  The
+//     reference enqueues a group when the decrement that zeroes a member finds every other member at zero (abpoa_graph.c:210-221) -- that is the LAST
+//     decrement over all in-edges of the group, i.e. the one that brings the sum to zero; its target is the member pushed first.  No list is read to decide;
+//   * among the edges of one pass that hit a group whose sum is now zero the latest in the reference's order (key = 16 x queue position + edge index) wins:
+//     the counter word, free once it is zero, takes the maximum of key + 1;
+//   * aligned lists as a CSR of 16-bit ids (list order kept: it is the order in which the members follow the trigger into the queue), the only out-edge of
+//     a chain node, the group sizes and the queue itself: all LDS; the out-edge record of a node with several edges is the one memory read left.
+//   The row order and nd_row are written in one coalesced sweep at the end.
+__device__ __forceinline__ int poa_order_body_lds(const PoaDev &p, const PoaSet &S, const int n, int32_t *order) {      // 1 done, 0 failed, -1: does not fit (the caller takes the general body)
+    const int lane = threadIdx.x;
+    const int64_t N0 = S.node0;
+    int *const cnt = ord_lds;                                            // [n]
+    uint16_t *const s_rep = (uint16_t *)(cnt + n), *const s_next = s_rep + n, *const s_q = s_next + n, *const s_aoff = s_q + n;      // [n] each, s_aoff [n + 1]
+    uint16_t *const s_alist = s_aoff + n + 1 + (n & 1 ? 0 : 1);         // [order_ecap]
+    uint8_t *const s_naln = (uint8_t *)(s_alist + p.order_ecap);         // [n]
+    // ---- tables: group sizes and CSR offsets (prefix sum in node order), then representatives, counters, lists, chain links
+    int carry = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int u = t0 + lane, na = u < n ? (int)p.nd_naln[N0 + u] : 0;
+        const int incl = wave_scan_add(na);
+        if (u < n) { s_naln[u] = (uint8_t)na; s_aoff[u] = (uint16_t)imin_(carry + incl - na, 65535); cnt[u] = 0; }
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (carry > p.order_ecap || carry > 65535) return -1;
+    if (lane == 0) s_aoff[n] = (uint16_t)carry;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+    for (int u = lane; u < n; u += 64) {
+        const int na = s_naln[u], off = s_aoff[u]; int r = u;
+        for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + u) * p.aln_cap + t]; s_alist[off + t] = (uint16_t)a; r = imin_(r, a); }
+        s_rep[u] = (uint16_t)r;
+        atomicAdd(&cnt[r], (int)p.nd_nin[N0 + u]);
+        s_next[u] = p.nd_nout[N0 + u] == 1 ? (uint16_t)p.nd_out[(N0 + u) * POA_HOT] : (uint16_t)0xffff;
+    }
+    if (lane == 0) s_q[0] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+    auto fence = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    int head = 0, tail = 1;
+    while (head < tail) {
+        if (tail - head == 1) {      // one node in the queue: the reference's own step on wave-uniform values (lane 0 stores; a pushed group's members a lane each)
+            const int u = uni((int)s_q[head]);
+            int no; int4 o4;
+            const int nx = uni((int)s_next[u]);
+            if (nx != 0xffff) { no = 1; o4 = make_int4(nx, 0, 0, 0); }
+            else { no = uni((int)p.nd_nout[N0 + u]); o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
+            int at = tail;
+            for (int k = 0; k < no; ++k) {
+                const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))));
+                const int r = uni((int)s_rep[v]);
+                const int d = uni(cnt[r]) - 1;
+                if (lane == 0) cnt[r] = d != 0 ? d : 0x7fffffff;          // (a group that was pushed keeps a value no decrement reaches)
+                if (d != 0) { fence(); continue; }                        // (the next edge may hit the same group)
+                const int na = uni((int)s_naln[v]), off = uni((int)s_aoff[v]);
+                if (at + 1 + na > n) return 0;
+                if (lane == 0) s_q[at] = (uint16_t)v;
+                if (lane < na) s_q[at + 1 + lane] = s_alist[off + lane];
+                at += 1 + na;
+                fence();
+            }
+            tail = at; ++head;
+            fence();
+            continue;
+        }
+        const int cnt_ = imin_(64, tail - head), pos = head + lane; const bool act = lane < cnt_;
+        int u = 1, no = 0; int4 o4 = make_int4(0, 0, 0, 0);
+        if (act) {
+            u = s_q[pos];
+            const int nx = s_next[u];
+            if (nx != 0xffff) { no = 1; o4.x = nx; } else { no = p.nd_nout[N0 + u]; o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
+        }
+        auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))); };
+        for (int k = 0; k < no; ++k) atomicSub(&cnt[s_rep[target(k)]], 1);
+        fence();
+        unsigned zero = 0;                                               // edges whose group's sum is zero now
+        for (int k = 0; k < no; ++k) if (cnt[s_rep[target(k)]] == 0) zero |= 1u << k;
+        fence();
+        for (int k = 0; k < no; ++k) if (zero >> k & 1) atomicMax(&cnt[s_rep[target(k)]], pos * 16 + k + 1);
+        fence();
+        unsigned trig = 0; int total = 0;
+        for (int k = 0; k < no; ++k) if ((zero >> k & 1) && cnt[s_rep[target(k)]] == pos * 16 + k + 1) { trig |= 1u << k; total += 1 + s_naln[target(k)]; }
+        const int incl = wave_scan_add(total), all = __builtin_amdgcn_readlane(incl, 63);
+        if (tail + all > n) return 0;
+        int at = tail + incl - total;
+        for (int k = 0; k < no; ++k) if (trig >> k & 1) {
+            const int v = target(k), na = s_naln[v], off = s_aoff[v];
+            s_q[at++] = (uint16_t)v;
+            for (int t = 0; t < na; ++t) s_q[at++] = s_alist[off + t];
+            cnt[s_rep[v]] = 0x7fffffff;
+        }
+        tail += all; head += cnt_;
+        fence();
+    }
+    if (head != n || s_q[n - 1] != 1) return 0;
+    for (int r = lane; r < n; r += 64) { const int u_ = s_q[r]; order[r] = u_; p.nd_row[N0 + u_] = r; }
+    return 1;
+}
+
 __global__ void __launch_bounds__(64) poa_order_kernel(const PoaDev p) {
     const int s = blockIdx.x;
     if (s >= p.n_sets) return;
@@ -342,7 +443,9 @@ __global__ void __launch_bounds__(64) poa_order_kernel(const PoaDev p) {
     const int n = uni(st->n_nodes);
     if (n <= 2) return;
     int32_t *order = p.row_node[uni(st->order_buf)] + S.node0;
-    const bool ok = n <= p.order_lds ? poa_order_body<true>(p, S, n, order) : poa_order_body<false>(p, S, n, order);
+    int done = -1;
+    if (n <= p.order_lds && n < 65535 && p.order_ecap > 0) done = poa_order_body_lds(p, S, n, order);
+    const bool ok = done >= 0 ? done == 1 : (n <= p.order_lds ? poa_order_body<true>(p, S, n, order) : poa_order_body<false>(p, S, n, order));
     // (the sink is the last node the walk reaches, reference :203-206; anything else means the graph is not what the fuse phase should have left)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && (!ok || ld_fresh(order + n - 1) != 1)) { st->status = POA_ST_FALLBACK; st->pad = 7; }
@@ -456,10 +559,14 @@ hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }
-size_t poa_order_lds_bytes(int node_cap) { return 4 * (size_t)ORD_RING + 13 * (size_t)(node_cap > 0 ? node_cap : 0) + 32; }      // two int tables + the order walk's group-size bytes, 16-bit chain links and 16-bit queue
+// the larger of the two layouts: the general walk's ring + two int tables + byte and 16-bit tables; the all-in-LDS walk's 13 bytes a node + 2 per aligned-list entry
+size_t poa_order_lds_bytes(int node_cap, int ecap) {
+    const size_t nc = (size_t)(node_cap > 0 ? node_cap : 0);
+    return std::max(4 * (size_t)ORD_RING + 13 * nc + 32, 13 * nc + 2 * (size_t)(ecap > 0 ? ecap : 0) + 64);
+}
 static hipError_t launch_ord(void (*kern)(const PoaDev), const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
-    const size_t lds = poa_order_lds_bytes(p.order_lds);
+    const size_t lds = poa_order_lds_bytes(p.order_lds, p.order_ecap);
     // (above 64 KB the kernel's dynamic-LDS limit has to be raised: once per kernel, device and size -- the call is slow enough to stall a queue of
     //  back-to-back launches when repeated every round)
     if (lds > 65536) {
