@@ -21,7 +21,7 @@ for d in ("/tmp/pmc_out_i", "/tmp/pmc_out_w"):
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("abpoa_hip::", "")][r["Counter_Name"]] += float(r["Counter_Value"])
 line = json.loads(open("/tmp/pmc_log_i.txt").read().strip().split("\n")[-1])
 all_rounds = "poa_rounds_kernel" in line["roofline"]["kernel"]
-keys = [k for k in acc if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_local_kernel"))]
+keys = [k for k in acc if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_local_kernel", "dp_local_team_kernel"))]
 tot = collections.defaultdict(float)
 for k in keys:
     for c, v in acc[k].items(): tot[c] += v

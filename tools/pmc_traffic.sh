@@ -29,7 +29,7 @@ line = json.loads(open("/tmp/pmc_log_WRITE_SIZE.txt").read().strip().split("\n")
 rounds = line["roofline"]["launches"]
 # the kernel the bench line's roofline is about: the all-rounds kernel where the job took it (narrow bands), else the row-loop kernels of a round
 all_rounds = "poa_rounds_kernel" in line["roofline"]["kernel"]
-rows = {k: v for k, v in per_kernel.items() if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_team_kernel", "dp_local_kernel"))}
+rows = {k: v for k, v in per_kernel.items() if k.startswith(("poa_rounds_kernel",) if all_rounds else ("dp_fast_kernel", "dp_wide_kernel", "dp_team_kernel", "dp_local_kernel", "dp_local_team_kernel"))}
 fetch_kb = sum(v["FETCH_SIZE"] for v in rows.values()); write_kb = sum(v["WRITE_SIZE"] for v in rows.values())
 hbm = (2 * fetch_kb + write_kb) * 1024 / max(1, rounds)
 steps = max(1, line["steps"])
