@@ -210,3 +210,23 @@ def test_two_contexts_on_two_host_threads(engine):
         ctxs[0].msa_batch([[""]], jobs[0][0])
     assert ctxs[0].lib.abpoa_hip_ctx_last_error(ctxs[0].h) != b"" and ctxs[1].lib.abpoa_hip_ctx_last_error(ctxs[1].h) == b""
     [c.close() for c in ctxs]
+
+
+@pytest.mark.parametrize("env", [{"ABPOA_HIP_ORDER_LDS": "0"}, {"ABPOA_HIP_ORDER_LDS": "0", "ABPOA_HIP_ORDER_CAP": "0"}, {"ABPOA_HIP_ORDER_CAP": "400"}],
+                         ids=["general_walk_lds_tables", "general_walk_global_tables", "mixed_by_graph_size"])
+def test_order_and_rank_walks_in_every_form(engine, monkeypatch, env):
+    """The row-order kernel has three forms -- everything in LDS with one counter per aligned group (the default for graphs that fit), the general walk with
+    its tables in LDS, and the general walk with its tables in memory (graphs beyond the LDS capacity) -- and the MSA rank walk two.  The switches force
+    each; ABPOA_HIP_ORDER_CAP=400 makes the form change inside one job as the graphs grow.  Local amino-acid and nucleotide MSAs against the oracle-backed run."""
+    import helpers as H
+    from abpoa_amd import api, synth, workloads
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    shim = H.cpu_shim_lib()
+    jobs = [(api.Params(aln_mode=1, is_aa=True, score_matrix=workloads.BLOSUM62), [synth.make_read_set(73, i, 9 + i % 8, 120 + 45 * i, alphabet=synth.AA, rates=(0.08, 0.03, 0.03)) for i in range(8)]),
+            (api.Params(aln_mode=1, gap_open1=4, gap_open2=0, gap_ext1=2), [synth.make_read_set(79, i, 8 + i % 5, 150 + 50 * i, 0.08) for i in range(8)])]
+    for p, sets in jobs:
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        assert api.msa_timing()["n_host_sets"] == 0
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"order walk {env}")
