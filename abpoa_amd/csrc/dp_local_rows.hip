@@ -29,6 +29,8 @@ __global__ void __launch_bounds__(64) dp_local_kernel(const DevBatch b) {
     else rows_local<T, GAP, 9>(b, d, io, s_query, b.out + a);
 }
 
+// (Measured on configs[4], row loops per step: one wavefront 137 ms, teams of two 126 ms, of four 81 ms, of eight 128 ms -- 512 threads per workgroup halve the
+//  residency.)
 // Four wavefronts per alignment (rows_local_team): for launches that leave the GPU's SIMDs short of wavefronts -- BASELINE.json configs[4] is 1000 read-sets,
 // one alignment each at a time: one wavefront per SIMD -- the chunks of a row are split over the four SIMDs of a CU.
 constexpr int LOC_NW = 4;
