@@ -46,67 +46,116 @@ abpoa_hip_msa_timing_t g_timing;
 
 namespace abpoa_hip {
 namespace {
+bool env_on(const char *name) { const char *e = getenv(name); return e && atoi(e) != 0; }
+int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+bool strict_mode() { return env_on("ABPOA_HIP_STRICT"); }
+void free_all(abpoa_hip_msa_t *out, int n) { for (int s = 0; s < n; ++s) abpoa_hip_free_msa(&out[s]); }
+
+void add_stats(DeviceRunStats &t, const DeviceRunStats &d) {
+    t.prepare_ms += d.prepare_ms; t.rows_ms += d.rows_ms; t.tail_ms += d.tail_ms; t.fuse_ms += d.fuse_ms;
+    t.device_s += d.device_s; t.cons_s += d.cons_s; t.total_s += d.total_s;
+    t.n_cells += d.n_cells; t.algo_bytes += d.algo_bytes; t.n_alignments += d.n_alignments; t.n_rounds += d.n_rounds;
+    t.rounds_ms += d.rounds_ms; t.rounds_launches += d.rounds_launches; t.rounds_algo_bytes += d.rounds_algo_bytes;
+}
+
+// What the process learned about jobs of one shape (longest read by power of two, reads per set): when most sets of the last such job
+// outgrew the 3x pass and a later pass ran in one piece, the next one starts there (noisy long reads: 50 x 10 kb at 15 % error grow to
+// 3.9x; the doomed first pass is ~3 % of such a job).  Results do not depend on it.  ABPOA_HIP_NO_PASS_HINT=1: always start at 3x.
+std::mutex g_hint_mu;
+std::map<int, int> g_hint;
+int job_shape_key(const abpoa_hip_readset_t *sets, const std::vector<int> &idx) {
+    int mx = 1, nr = 0;
+    for (int i : idx) {
+        nr = std::max(nr, sets[i].n_reads);
+        for (int r = 0; r < sets[i].n_reads; ++r) mx = std::max(mx, sets[i].lens[r]);
+    }
+    int lg = 0;
+    while ((1 << lg) < mx) ++lg;
+    return lg * 1024 + std::min(nr, 1023);
+}
+
 // The device passes over the sets `idx` on ONE device queue (device, slot): pass 1 gives every set 3x its longest read in graph-node
-// slots (5 %-error reads need ~2.5x), pass 2 retries the sets that outgrew that with 6x; whatever is left (listed in `left`) goes to
-// the host driver.  A pass that does not fit the device memory is split in halves.
+// slots (5 %-error reads need ~2.5x), the next ones retry the sets that outgrew that with 4.5x and 6x; whatever is left (listed in
+// `left`) goes to the host driver.  A pass that does not fit the device memory is split in halves.
 struct PassOut { int rc = ABPOA_HIP_OK; bool device_ok = true; DeviceRunStats tot; std::vector<int> left; };
 PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, const std::vector<int> &idx,
                       int n_threads, int device, int slot, unsigned flags) {
-    PassOut R; memset(&R.tot, 0, sizeof(R.tot));
+    PassOut R;
+    memset(&R.tot, 0, sizeof(R.tot));
     std::vector<int> todo = idx, left;
-    const double factors[3] = {3.0, 4.5, 6.0}; constexpr int NPASS = 3;
-    // What the process learned about jobs of this shape (longest read by power of two, reads per set): when most sets of the last such job outgrew
-    // the 3x pass and the 6x pass ran in one piece, the next one starts at 6x (noisy long reads: 50 x 10 kb at 15 % error grow to 3.9x; the doomed
-    // first pass is ~3 % of such a job).  Results do not depend on it.  ABPOA_HIP_NO_PASS_HINT=1: always start at 3x.
-    static std::mutex hint_mu; static std::map<int, int> hint;
-    int key = 0; { int mx = 1, nr = 0; for (int i : idx) { nr = std::max(nr, sets[i].n_reads); for (int r = 0; r < sets[i].n_reads; ++r) mx = std::max(mx, sets[i].lens[r]); }
-                   int lg = 0; while ((1 << lg) < mx) ++lg; key = lg * 1024 + std::min(nr, 1023); }
+    const double factors[3] = {3.0, 4.5, 6.0};
+    constexpr int NPASS = 3;
+    const bool verbose = getenv("ABPOA_HIP_VERBOSE") != nullptr;
+    const int key = job_shape_key(sets, idx);
     int first_pass = 0;
-    { const char *fp_ = getenv("ABPOA_HIP_FIRST_PASS"); if (fp_ && atoi(fp_) >= 1 && atoi(fp_) < NPASS) first_pass = atoi(fp_); }      // (profiling runs of one step: start where a warmed-up process would)
-    if (!(getenv("ABPOA_HIP_NO_PASS_HINT") && atoi(getenv("ABPOA_HIP_NO_PASS_HINT")))) { std::lock_guard<std::mutex> lk(hint_mu); auto it = hint.find(key); if (it != hint.end()) first_pass = it->second; }
-    bool most_outgrew = false; int n_small = 0, n_done = 0;      // (sets that finished / that would also have fitted the 3x estimate)
+    {   // (profiling runs of one step: start where a warmed-up process would)
+        const int fp = env_int("ABPOA_HIP_FIRST_PASS", 0);
+        if (fp >= 1 && fp < NPASS) first_pass = fp;
+    }
+    if (!env_on("ABPOA_HIP_NO_PASS_HINT")) {
+        std::lock_guard<std::mutex> lk(g_hint_mu);
+        auto it = g_hint.find(key);
+        if (it != g_hint.end()) first_pass = it->second;
+    }
+    bool most_outgrew = false;
+    int n_small = 0, n_done = 0;      // (sets that would also have fitted the 3x estimate / sets that finished)
     for (int pass = first_pass; pass < NPASS && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
-        size_t chunk = todo.size(); bool halved = false;      // (halved: the pass did not fit the device memory in the pieces first tried)
+        size_t chunk = todo.size();
+        bool halved = false;          // (the pass did not fit the device memory in the pieces first tried)
         {   // wide-band jobs: passes of what the device holds at once (msa_device.h)
-            std::vector<abpoa_hip_readset_t> all_(todo.size()); for (size_t i = 0; i < todo.size(); ++i) all_[i] = sets[todo[i]];
+            std::vector<abpoa_hip_readset_t> all_(todo.size());
+            for (size_t i = 0; i < todo.size(); ++i) all_[i] = sets[todo[i]];
             const int res_ = msa_device_resident_sets(sc, (int)all_.size(), all_.data());
             if (res_ > 0 && chunk > (size_t)res_) chunk = (size_t)res_;
-            const char *ps_ = getenv("ABPOA_HIP_PASS_SETS");      // (tests: several passes on a small job)
-            if (ps_ && atoi(ps_) > 0 && chunk > (size_t)atoi(ps_)) chunk = (size_t)atoi(ps_);
+            const int ps_ = env_int("ABPOA_HIP_PASS_SETS", 0);      // (tests: several passes on a small job)
+            if (ps_ > 0 && chunk > (size_t)ps_) chunk = (size_t)ps_;
         }
         for (size_t at = 0; at < todo.size() && R.device_ok;) {
             const size_t nb = std::min(chunk, todo.size() - at);
-            std::vector<abpoa_hip_readset_t> sub(nb); std::vector<abpoa_hip_msa_t> sub_out(nb);
+            std::vector<abpoa_hip_readset_t> sub(nb);
+            std::vector<abpoa_hip_msa_t> sub_out(nb);
             for (size_t i = 0; i < nb; ++i) sub[i] = sets[todo[at + i]];
-            std::vector<int> fb; DeviceRunStats ds;
+            std::vector<int> fb;
+            DeviceRunStats ds;
             const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], flags, device, slot);
-            if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; halved = true; continue; }           // split and retry this chunk
+            if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; halved = true; continue; }      // split and retry this chunk
             if (rc != ABPOA_HIP_OK) {
                 if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; }
-                // not a job for the device path (does not fit even alone / shape): what is still open -- the leftovers of the chunks already done in this
-                // pass and everything from here on -- goes back to the caller; finished results stay in out[]
-                R.device_ok = false; for (size_t i = at; i < todo.size(); ++i) left.push_back(todo[i]); todo.swap(left); break;
+                // not a job for the device path (does not fit even alone / shape): what is still open -- the leftovers of the chunks
+                // already done in this pass and everything from here on -- goes back to the caller; finished results stay in out[]
+                R.device_ok = false;
+                for (size_t i = at; i < todo.size(); ++i) left.push_back(todo[i]);
+                todo.swap(left);
+                break;
             }
             for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
             for (int f : fb) left.push_back(todo[at + f]);
-            DeviceRunStats &tot = R.tot;
-            tot.prepare_ms += ds.prepare_ms; tot.rows_ms += ds.rows_ms; tot.tail_ms += ds.tail_ms; tot.fuse_ms += ds.fuse_ms; tot.device_s += ds.device_s; tot.cons_s += ds.cons_s;
-            tot.total_s += ds.total_s; tot.n_cells += ds.n_cells; tot.algo_bytes += ds.algo_bytes; tot.n_alignments += ds.n_alignments; tot.n_rounds += ds.n_rounds;
-            tot.rounds_ms += ds.rounds_ms; tot.rounds_launches += ds.rounds_launches; tot.rounds_algo_bytes += ds.rounds_algo_bytes;
-            n_small += ds.n_fit_3x; n_done += (int)nb - (int)fb.size();
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %gx): %zu sets, %d rounds: prepare %.1f ms, dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; %zu sets outgrew a device capacity\n",
-                                                     device, pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3, ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
-            if (getenv("ABPOA_HIP_VERBOSE") && ds.rounds_launches) fprintf(stderr, "[abpoa-hip]   all-rounds kernel: %.1f ms (the phase times above are its duration split by the sets' clock ticks); mean set busy %.0f %% of it; mean set, 10^6 ticks: prepare %.1f, row loop %.1f, backtrack %.1f, fuse %.1f\n", ds.rounds_ms, 100.0 * ds.rounds_mean_over_max, ds.rounds_mticks[0], ds.rounds_mticks[1], ds.rounds_mticks[2], ds.rounds_mticks[3]);
+            add_stats(R.tot, ds);
+            n_small += ds.n_fit_3x;
+            n_done += (int)nb - (int)fb.size();
+            if (verbose)
+                fprintf(stderr, "[abpoa-hip] device-resident driver (device %d, pass %d, node slots %gx): %zu sets, %d rounds: prepare %.1f ms, "
+                                "dp rows %.1f ms, backtrack %.1f ms, fuse %.1f ms; device wall %.1f ms, results %.1f ms, total %.1f ms; "
+                                "%zu sets outgrew a device capacity\n",
+                        device, pass + 1, factors[pass], nb, ds.n_rounds, ds.prepare_ms, ds.rows_ms, ds.tail_ms, ds.fuse_ms, ds.device_s * 1e3,
+                        ds.cons_s * 1e3, ds.total_s * 1e3, fb.size());
+            if (verbose && ds.rounds_launches)
+                fprintf(stderr, "[abpoa-hip]   all-rounds kernel: %.1f ms (the phase times above are its duration split by the sets' clock ticks); "
+                                "mean set busy %.0f %% of it; mean set, 10^6 ticks: prepare %.1f, row loop %.1f, backtrack %.1f, fuse %.1f\n",
+                        ds.rounds_ms, 100.0 * ds.rounds_mean_over_max, ds.rounds_mticks[0], ds.rounds_mticks[1], ds.rounds_mticks[2], ds.rounds_mticks[3]);
             at += nb;
         }
         // most sets of the previous pass outgrew it and this one held most of them (in the pieces first tried): jobs of this shape start here next time
         const bool outgrew_now = left.size() * 2 >= todo.size();
-        if (R.device_ok && pass > 0 && most_outgrew && !outgrew_now && !halved) { std::lock_guard<std::mutex> lk(hint_mu); hint[key] = pass; }
+        if (R.device_ok && pass > 0 && most_outgrew && !outgrew_now && !halved) { std::lock_guard<std::mutex> lk(g_hint_mu); g_hint[key] = pass; }
         if (R.device_ok) most_outgrew = outgrew_now;
-        // the hint is dropped again when a job that started higher because of it turns out to fit 3x (a cleaner job of the same shape): more graph
-        // and arena memory for nothing otherwise, for as long as the process lives
-        if (R.device_ok && pass == first_pass && first_pass > 0 && n_done > 0 && n_small * 2 > n_done) { std::lock_guard<std::mutex> lk(hint_mu); hint.erase(key); }
+        // the hint is dropped again when a job that started higher because of it turns out to fit 3x (a cleaner job of the same shape): more
+        // graph and arena memory for nothing otherwise, for as long as the process lives
+        if (R.device_ok && pass == first_pass && first_pass > 0 && n_done > 0 && n_small * 2 > n_done) {
+            std::lock_guard<std::mutex> lk(g_hint_mu);
+            g_hint.erase(key);
+        }
         if (R.device_ok) todo.swap(left);
     }
     R.left = todo;
@@ -115,18 +164,54 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
 
 // ABPOA_GPU_DEVICES: "all", or a comma list of device ordinals (a repeated ordinal = two queues on that
 // device); unset = the device the engine was initialised on.
-bool strict_mode() { const char *e = getenv("ABPOA_HIP_STRICT"); return e && atoi(e) != 0; }
 std::vector<int> device_list() {
     std::vector<int> d;
     const char *e = getenv("ABPOA_GPU_DEVICES");
-    int n = 0; (void)hipGetDeviceCount(&n);
+    int n = 0;
+    (void)hipGetDeviceCount(&n);
     if (e && *e) {
         if (!strcmp(e, "all")) { for (int i = 0; i < n; ++i) d.push_back(i); }
-        else for (const char *q = e; *q;) { char *end; long v = strtol(q, &end, 10); if (end == q) break; if (v >= 0 && v < n) d.push_back((int)v); q = *end == ',' ? end + 1 : end; if (*end && *end != ',') break; }
+        else for (const char *q = e; *q;) {
+            char *end;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            if (v >= 0 && v < n) d.push_back((int)v);
+            if (*end && *end != ',') break;
+            q = *end == ',' ? end + 1 : end;
+        }
     }
     if (d.empty()) d.push_back(engine_device());
     if ((int)d.size() > MSA_DEVICE_SLOTS) d.resize(MSA_DEVICE_SLOTS);
     return d;
+}
+
+// Batches for the device queues: sets sorted by estimated DP cost (sum of read lengths x reads), heaviest first, dealt round-robin so that
+// every batch holds the same mix; the queues pull batches from one shared counter (a fast device simply takes more of them).
+std::vector<std::vector<int>> deal_batches(const abpoa_hip_readset_t *sets, int n_sets, int n_q) {
+    std::vector<std::vector<int>> batches;
+    if (n_q == 1) {
+        batches.emplace_back(n_sets);
+        for (int s = 0; s < n_sets; ++s) batches[0][s] = s;
+        return batches;
+    }
+    std::vector<int64_t> cost(n_sets);
+    for (int s = 0; s < n_sets; ++s) {
+        int64_t sum = 0;
+        for (int r = 0; r < sets[s].n_reads; ++r) sum += sets[s].lens[r];
+        cost[s] = sum * std::max(1, sets[s].n_reads);
+    }
+    std::vector<int> order(n_sets);
+    for (int s = 0; s < n_sets; ++s) order[s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    const int per_q = std::max(1, env_int("ABPOA_GPU_BATCHES_PER_DEVICE", 2));
+    // a batch should hold >= 1024 sets when the job allows: the device kernels run one wavefront per read-set, a GPU has 1024 SIMDs, and the
+    // all-rounds kernel of the narrow-band jobs is at its best with ~1000 resident sets; never fewer batches than queues
+    int nb = std::max(n_q, std::min(n_q * per_q, n_sets / 1024));
+    nb = std::max(1, std::min(nb, n_sets));
+    batches.resize(nb);
+    for (int i = 0; i < n_sets; ++i) batches[i % nb].push_back(order[i]);
+    for (auto &b_ : batches) std::sort(b_.begin(), b_.end());        // (caller order inside a batch)
+    return batches;
 }
 }  // namespace
 }  // namespace abpoa_hip
@@ -136,41 +221,31 @@ std::vector<int> device_list() {
 struct abpoa_hip_ctx { int device; int slot; abpoa_hip_msa_timing_t timing; char err[512]; };
 namespace abpoa_hip {
 namespace {
-std::mutex g_ctx_mu; bool g_ctx_slot_used[MSA_DEVICE_SLOTS] = {false};
+std::mutex g_ctx_mu;
+bool g_ctx_slot_used[MSA_DEVICE_SLOTS] = {false};
 constexpr int CTX_SLOT_LO = MSA_DEVICE_SLOTS / 2;      // the upper half of the device queues belongs to contexts, the lower half to the process-wide entry
-// the batch entry proper: `tm` receives the call's timing record; ctx_device / ctx_slot >= 0: one device queue, the context's
-int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads,
-                   abpoa_hip_msa_timing_t &g_timing, int ctx_device, int ctx_slot) {
-    if (engine_device() < 0) { int rc = abpoa_hip_init(ctx_device >= 0 ? ctx_device : 0); if (rc) return rc; }
-    abpoa_hip_scoring_t sc_norm; const abpoa_hip_scoring_t *sc = sc_in;
-    if (sc_in && sc_in->align_mode == ABPOA_HIP_LOCAL_MODE) { sc_norm = *sc_in; sc_norm.wb = -1; sc = &sc_norm; }      // reference abpoa_post_set_para, src/abpoa_align.c:150: local mode has no band
+
+// The batch entry proper.  `tm` receives the call's timing record; ctx_slot >= 0: one device queue, the context's, on ctx_device.
+int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags,
+                   int n_threads, abpoa_hip_msa_timing_t &tm, int ctx_device, int ctx_slot) {
+    if (engine_device() < 0) { const int rc = abpoa_hip_init(ctx_device >= 0 ? ctx_device : 0); if (rc) return rc; }
+    abpoa_hip_scoring_t sc_norm;
+    const abpoa_hip_scoring_t *sc = sc_in;
+    if (sc_in && sc_in->align_mode == ABPOA_HIP_LOCAL_MODE) { sc_norm = *sc_in; sc_norm.wb = -1; sc = &sc_norm; }      // ref abpoa_align.c:150: local mode has no band
     if (n_sets > 0 && sc && sets && out && msa_device_eligible(sc, flags)) {
         // device-resident driver first; sets that outgrow a device capacity (and whole jobs that do not fit) go to the host driver
         if (n_threads <= 0) n_threads = effective_host_cores();
-        for (int s = 0; s < n_sets; ++s) { if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL; for (int r = 0; r < sets[s].n_reads; ++r) if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) { set_err("read-set %d: read %d is empty", s, r); return ABPOA_HIP_EINVAL; } }
+        for (int s = 0; s < n_sets; ++s) {
+            if (sets[s].n_reads < 0) return ABPOA_HIP_EINVAL;
+            for (int r = 0; r < sets[s].n_reads; ++r)
+                if (sets[s].lens[r] <= 0 || !sets[s].seqs[r]) { set_err("read-set %d: read %d is empty", s, r); return ABPOA_HIP_EINVAL; }
+        }
         for (int s = 0; s < n_sets; ++s) memset(&out[s], 0, sizeof(out[s]));
         std::vector<int> devs = device_list();
         if ((int)devs.size() > CTX_SLOT_LO) devs.resize(CTX_SLOT_LO);
         if (ctx_slot >= 0) devs.assign(1, ctx_device);      // a context: its own device, its own queue
         const int n_q = (int)devs.size();
-        // ---- batches: sets sorted by estimated DP cost (sum of read lengths x reads), heaviest first, dealt round-robin so that every batch
-        //      holds the same mix; device queues pull batches from one shared counter (a fast device simply takes more of them)
-        std::vector<std::vector<int>> batches;
-        if (n_q == 1) { batches.emplace_back(n_sets); for (int s = 0; s < n_sets; ++s) batches[0][s] = s; }
-        else {
-            std::vector<int64_t> cost(n_sets);
-            for (int s = 0; s < n_sets; ++s) { int64_t sum = 0; for (int r = 0; r < sets[s].n_reads; ++r) sum += sets[s].lens[r]; cost[s] = sum * std::max(1, sets[s].n_reads); }
-            std::vector<int> order(n_sets); for (int s = 0; s < n_sets; ++s) order[s] = s;
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-            int per_q = 2; { const char *e_ = getenv("ABPOA_GPU_BATCHES_PER_DEVICE"); if (e_ && atoi(e_) > 0) per_q = atoi(e_); }
-            // a batch should hold >= 1024 sets when the job allows: the device kernels run one wavefront per read-set, a GPU has 1024 SIMDs, and the
-            // all-rounds kernel of the narrow-band jobs is at its best with ~1000 resident sets; never fewer batches than queues
-            int nb = std::max(n_q, std::min(n_q * per_q, n_sets / 1024));
-            nb = std::max(1, std::min(nb, n_sets));
-            batches.resize(nb);
-            for (int i = 0; i < n_sets; ++i) batches[i % nb].push_back(order[i]);
-            for (auto &b_ : batches) std::sort(b_.begin(), b_.end());        // (caller order inside a batch)
-        }
+        const std::vector<std::vector<int>> batches = deal_batches(sets, n_sets, n_q);
         std::atomic<int> next{0};
         std::vector<PassOut> results(batches.size());
         std::vector<double> q_busy(n_q, 0.0);
@@ -188,49 +263,62 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         worker(0);
         for (auto &t : th) t.join();
         (void)hipSetDevice(engine_device());
-        DeviceRunStats tot; memset(&tot, 0, sizeof(tot));
-        const bool device_ok = true; int rc_dev = ABPOA_HIP_OK;
+        DeviceRunStats tot;
+        memset(&tot, 0, sizeof(tot));
+        int rc_dev = ABPOA_HIP_OK;
         std::vector<int> todo;
         for (size_t b_ = 0; b_ < batches.size(); ++b_) {
             const PassOut &R = results[b_];
             if (R.rc != ABPOA_HIP_OK && rc_dev == ABPOA_HIP_OK) rc_dev = R.rc;
-            // a batch the device path could not take (it does not fit even alone, or its shape is not the device driver's): only THAT batch's open
-            // sets go to the host driver -- R.left holds them -- the finished results of the other batches stay
+            // a batch the device path could not take (it does not fit even alone, or its shape is not the device driver's): only THAT batch's
+            // open sets go to the host driver -- R.left holds them -- the finished results of the other batches stay
             todo.insert(todo.end(), R.left.begin(), R.left.end());
-            tot.prepare_ms += R.tot.prepare_ms; tot.rows_ms += R.tot.rows_ms; tot.tail_ms += R.tot.tail_ms; tot.fuse_ms += R.tot.fuse_ms; tot.cons_s += R.tot.cons_s;
-            tot.n_cells += R.tot.n_cells; tot.algo_bytes += R.tot.algo_bytes; tot.n_alignments += R.tot.n_alignments; tot.n_rounds += R.tot.n_rounds;
-            tot.rounds_ms += R.tot.rounds_ms; tot.rounds_launches += R.tot.rounds_launches; tot.rounds_algo_bytes += R.tot.rounds_algo_bytes;
-            tot.device_s += R.tot.device_s; tot.total_s += R.tot.total_s;
+            add_stats(tot, R.tot);
         }
-        if (rc_dev != ABPOA_HIP_OK) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); return rc_dev; }
-        if (n_q > 1) { tot.device_s = tot.total_s = *std::max_element(q_busy.begin(), q_busy.end()); }      // queues ran side by side: the busiest one is the wall time
-        if (n_q > 1 && getenv("ABPOA_HIP_VERBOSE")) { fprintf(stderr, "[abpoa-hip] %d device queues, %zu batches; busy seconds per queue:", n_q, batches.size()); for (int q = 0; q < n_q; ++q) fprintf(stderr, " dev%d %.3f", devs[q], q_busy[q]); fprintf(stderr, "\n"); }
-        if (device_ok) {
-            std::sort(todo.begin(), todo.end());
-            StreamStats ss; ss.n_launches = tot.n_rounds; ss.n_alignments = tot.n_alignments; ss.n_cells = tot.n_cells; ss.algo_bytes = tot.algo_bytes;
-            ss.kernel_ms = tot.rows_ms; ss.tail_ms = tot.tail_ms; ss.rounds_ms = tot.rounds_ms; ss.rounds_launches = tot.rounds_launches; ss.rounds_algo_bytes = tot.rounds_algo_bytes; add_global_stats(ss);
-            memset(&g_timing, 0, sizeof(g_timing));
-            g_timing.engine_s = tot.device_s; g_timing.cons_s = tot.cons_s; g_timing.total_s = tot.total_s; g_timing.n_rounds = tot.n_rounds; g_timing.n_threads = n_threads; g_timing.n_groups = n_q;
-            g_timing.host_sort_s = tot.prepare_ms / 1e3; g_timing.host_fuse_s = tot.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
-            g_timing.n_host_sets = (int32_t)todo.size();             // how many sets take the host driver
-            if (todo.empty()) return ABPOA_HIP_OK;
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] %zu of %d read-sets outgrew a device capacity: host driver for those\n", todo.size(), n_sets);
-            if (strict_mode()) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); set_err("ABPOA_HIP_STRICT: %zu of %d read-sets would take the host driver (device capacities: node / edge / aligned slots, arena)", todo.size(), n_sets); return ABPOA_HIP_ESTRICT; }
-            std::vector<abpoa_hip_readset_t> sub(todo.size()); std::vector<abpoa_hip_msa_t> sub_out(todo.size());
-            for (size_t i = 0; i < todo.size(); ++i) sub[i] = sets[todo[i]];
-            abpoa_hip_msa_timing_t t2;
-            const int rc2 = run_msa_batch(sc, (int)todo.size(), sub.data(), sub_out.data(), flags, n_threads, 0, make_hip_aligner, &t2);
-            if (rc2 != ABPOA_HIP_OK) { for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]); return rc2; }
-            for (size_t i = 0; i < todo.size(); ++i) out[todo[i]] = sub_out[i];
-            return ABPOA_HIP_OK;
+        if (rc_dev != ABPOA_HIP_OK) { free_all(out, n_sets); return rc_dev; }
+        if (n_q > 1) tot.device_s = tot.total_s = *std::max_element(q_busy.begin(), q_busy.end());      // queues ran side by side: the busiest one is the wall time
+        if (n_q > 1 && getenv("ABPOA_HIP_VERBOSE")) {
+            fprintf(stderr, "[abpoa-hip] %d device queues, %zu batches; busy seconds per queue:", n_q, batches.size());
+            for (int q = 0; q < n_q; ++q) fprintf(stderr, " dev%d %.3f", devs[q], q_busy[q]);
+            fprintf(stderr, "\n");
         }
-        for (int s = 0; s < n_sets; ++s) abpoa_hip_free_msa(&out[s]);
+        std::sort(todo.begin(), todo.end());
+        StreamStats ss;
+        ss.n_launches = tot.n_rounds; ss.n_alignments = tot.n_alignments; ss.n_cells = tot.n_cells; ss.algo_bytes = tot.algo_bytes;
+        ss.kernel_ms = tot.rows_ms; ss.tail_ms = tot.tail_ms;
+        ss.rounds_ms = tot.rounds_ms; ss.rounds_launches = tot.rounds_launches; ss.rounds_algo_bytes = tot.rounds_algo_bytes;
+        add_global_stats(ss);
+        memset(&tm, 0, sizeof(tm));
+        tm.engine_s = tot.device_s; tm.cons_s = tot.cons_s; tm.total_s = tot.total_s;
+        tm.n_rounds = tot.n_rounds; tm.n_threads = n_threads; tm.n_groups = n_q;
+        tm.host_sort_s = tot.prepare_ms / 1e3; tm.host_fuse_s = tot.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
+        tm.n_host_sets = (int32_t)todo.size();                                          // how many sets take the host driver
+        if (todo.empty()) return ABPOA_HIP_OK;
+        if (getenv("ABPOA_HIP_VERBOSE"))
+            fprintf(stderr, "[abpoa-hip] %zu of %d read-sets outgrew a device capacity: host driver for those\n", todo.size(), n_sets);
+        if (strict_mode()) {
+            free_all(out, n_sets);
+            set_err("ABPOA_HIP_STRICT: %zu of %d read-sets would take the host driver (device capacities: node / edge / aligned slots, arena)",
+                    todo.size(), n_sets);
+            return ABPOA_HIP_ESTRICT;
+        }
+        std::vector<abpoa_hip_readset_t> sub(todo.size());
+        std::vector<abpoa_hip_msa_t> sub_out(todo.size());
+        for (size_t i = 0; i < todo.size(); ++i) sub[i] = sets[todo[i]];
+        abpoa_hip_msa_timing_t t2;
+        const int rc2 = run_msa_batch(sc, (int)todo.size(), sub.data(), sub_out.data(), flags, n_threads, 0, make_hip_aligner, &t2);
+        if (rc2 != ABPOA_HIP_OK) { free_all(out, n_sets); return rc2; }
+        for (size_t i = 0; i < todo.size(); ++i) out[todo[i]] = sub_out[i];
+        return ABPOA_HIP_OK;
     }
-    // the whole job on the host driver: its options are not the device-resident driver's (linear gaps, extension mode, -s, per-base weights, no band in
-    // global mode, local reads beyond the local row loop), or it does not fit the device even alone
-    if (strict_mode() && n_sets > 0) { set_err("ABPOA_HIP_STRICT: this job's options are the host driver's (see msa_device_eligible)"); return ABPOA_HIP_ESTRICT; }
-    const int rc_host = run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &g_timing);
-    g_timing.n_host_sets = n_sets;
+    // the whole job on the host driver: its options are not the device-resident driver's (linear gaps, extension mode, -s, no band in
+    // global mode, local reads beyond the local row loop)
+    if (strict_mode() && n_sets > 0) {
+        set_err("ABPOA_HIP_STRICT: this job's options are the host driver's (see msa_device_eligible)");
+        return ABPOA_HIP_ESTRICT;
+    }
+    const int rc_host = run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &tm);
+    tm.n_host_sets = n_sets;
     return rc_host;
 }
 }  // namespace
