@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(64) dp_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];
-    if (takes_fast(b, d) || takes_local(b, d)) return;            // the fast row loops'
+    if ((d.flags & ALN_SKIP) || takes_fast(b, d) || takes_local(b, d)) return;            // nothing to do, or the fast row loops'
     if (d.bits == 16) align_one<int16_t, GAP>(b, d, b.out + a);
     else align_one<int32_t, GAP>(b, d, b.out + a);
 }
@@ -25,6 +25,8 @@ hipError_t launch_general(const DevBatch &b, hipStream_t stream) {
         default: return launch_one(dp_kernel<2>, b, stream, -1);
     }
 }
+
+hipError_t launch_dp_general(const DevBatch &b, hipStream_t stream) { return b.n <= 0 ? hipSuccess : launch_general(b, stream); }
 
 // The fast path is two kernels -- row loop, then global best + backtrack -- so that the row loop's register allocation
 // (its SGPR budget above all) is not shared with the tail; the hand-over is the AlnOut record in HBM.

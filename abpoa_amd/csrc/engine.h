@@ -41,6 +41,7 @@ struct AlnOut {
 };
 
 #define ALN_FAST_OK 1
+#define ALN_SKIP 2       // nothing to align (device-resident driver: a set that is done, or fell back): every kernel leaves the descriptor alone
 #define WIDE_RING_COLS 448   // score-ring columns of the single-wave wide kernel (7 chunks of 64)
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
 #define ABPOA_HIP_STATUS_NEED_SCORES 2   // direction-plane arenas (dir_plane.h): the backtrack met the one case the plane cannot decide -> redo with score records
@@ -120,5 +121,6 @@ int lds_fixed_bytes_bt();
 // Launches the DP kernel for the whole batch on `stream`.
 hipError_t launch_dp(const DevBatch &b, int n_fast, hipStream_t stream, hipEvent_t after_rows);
 hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t after_rows);
+hipError_t launch_dp_general(const DevBatch &b, hipStream_t stream);      // the general kernel alone (device-resident driver, jobs outside the fast row loops)
 
 }  // namespace abpoa_hip

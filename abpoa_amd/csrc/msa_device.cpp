@@ -60,12 +60,12 @@ Cache g_cache[MSA_DEVICE_SLOTS]; std::mutex g_cache_mu[MSA_DEVICE_SLOTS];      /
 
 struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
-    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, o_wts, in_bytes;
+    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, o_wts, in_bytes, o_rc, o_wrc, in_dev_bytes;      // (o_rc, o_wrc: device only, behind the uploaded part)
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
-    size_t o_cnode, o_ccov, o_cbase;
+    size_t o_cnode, o_ccov, o_cbase, o_isrc;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, o_rid, o_mrank, o_msaoff, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
-    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, rows_bytes;
+    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, o_ooff, o_orow, o_left, o_right, o_act, o_outfwd, o_cigfwd, o_retry, rows_bytes;
 };
 
 // Heaviest-bundling consensus (reference src/abpoa_output.c:361-415, :343-356) straight from the flat device arrays, walking
@@ -115,9 +115,14 @@ void release_msa_device_caches() {
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;
-    if (sc->gap_mode == ABPOA_HIP_LINEAR_GAP || (flags & ABPOA_HIP_AMB_STRAND) || sc->m - 1 > POA_ALN_MAX || sc->m < 2 || sc->zdrop > 0) return false;
-    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE) return !(getenv("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_LOCAL")));
-    return sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0;
+    if (sc->m - 1 > POA_ALN_MAX || sc->m < 2) return false;
+    if ((flags & ABPOA_HIP_AMB_STRAND) && getenv("ABPOA_HIP_NO_DEVICE_STRAND") && atoi(getenv("ABPOA_HIP_NO_DEVICE_STRAND"))) return false;      // (-s on the host driver, as before round 4)
+    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && getenv("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_LOCAL"))) return false;
+    // every gap model and alignment mode: the fast row loops where they apply (banded global, short local), the general kernel otherwise (linear gaps,
+    // extension mode with or without z-drop, global mode without a band, long local reads).  ABPOA_HIP_NO_DEVICE_GENERAL=1 sends those back to the host driver.
+    const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && ((sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0) || sc->align_mode == ABPOA_HIP_LOCAL_MODE);
+    if (!fast && getenv("ABPOA_HIP_NO_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_GENERAL"))) return false;
+    return true;
 }
 
 int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets) {
@@ -135,9 +140,10 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
 
 int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
                    std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot) {
-    abpoa_hip_scoring_t sc_norm = *sc_in; const bool local = sc_in->align_mode == ABPOA_HIP_LOCAL_MODE;
+    abpoa_hip_scoring_t sc_norm = *sc_in; const bool local = sc_in->align_mode == ABPOA_HIP_LOCAL_MODE, extend = sc_in->align_mode == ABPOA_HIP_EXTEND_MODE;
     if (local) sc_norm.wb = -1;                                  // reference abpoa_post_set_para, src/abpoa_align.c:150
     const abpoa_hip_scoring_t *sc = &sc_norm;
+    const bool amb = flags & ABPOA_HIP_AMB_STRAND;      // -s: low-scoring reads are aligned again as their reverse complement (poa_device.hip poa_strand_check_kernel)
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
     if (slot < 0 || slot >= MSA_DEVICE_SLOTS) { set_err("bad device slot %d", slot); return ABPOA_HIP_EINVAL; }
     std::lock_guard<std::mutex> lk(g_cache_mu[slot]);
@@ -160,27 +166,42 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     fallback->clear();
     if (stats) memset(stats, 0, sizeof(*stats));
     const double t_begin = now_s();
-    const int P = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5, CW = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8;
+    // values per DP column in an arena of score records: one padded cell record of the fast loops (4 / 8 values) = the planes of the general kernel (engine.cpp pv)
+    const int CW = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
+    const bool unbanded = sc->wb < 0;
+    // ---- sizes
+    int max_reads = 0, max_qlen = 0; int64_t tot_reads = 0, tot_bases = 0, max_cap0 = 0;
+    for (int s = 0; s < n_sets; ++s) {
+        max_reads = std::max(max_reads, sets[s].n_reads); tot_reads += sets[s].n_reads;
+        int64_t sum = 0; int mx = 0;
+        for (int r = 0; r < sets[s].n_reads; ++r) { max_qlen = std::max(max_qlen, sets[s].lens[r]); mx = std::max(mx, sets[s].lens[r]); sum += sets[s].lens[r]; }
+        tot_bases += sum; max_cap0 = std::max(max_cap0, std::min<int64_t>(2 + sum, 2 + (int64_t)(node_factor * mx) + 1024));
+    }
+    // Which kernels: the fast row loops (rows_fast.h: banded global, affine / convex; rows_local.h: local, int16, up to 575 columns) or -- `general` -- the
+    // general kernel (rows_general.h: linear gaps, extension mode, global without a band, longer local reads), one launch per round like the wide-band jobs.
+    bool general;
+    {   LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, (int)max_cap0, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
+        const int64_t width_ = (int64_t)((max_qlen + pn_) / pn_) * pn_, w_ = sc->wb + (int)(sc->wf * (float)max_qlen);
+        make_lds_plan(sc, max_qlen, mb, (local || unbanded) ? width_ : std::min<int64_t>(width_, 2LL * w_ + 3 * pn_ + 32), n_sets, &pl);
+        const bool fast_global = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && !unbanded && pl.fr_cols > 0 && max_qlen <= pl.q_cap;
+        const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols && max_qlen <= pl.q_cap;
+        general = !(fast_global || fast_local);
+        if (getenv("ABPOA_HIP_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_DEVICE_GENERAL"))) general = true;      // (tests: the general kernel for every job)
+    }
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
-    const bool dir = !local && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
+    const bool dir = !local && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
                      !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
 
-    // ---- sizes
-    int max_reads = 0, max_qlen = 0; int64_t tot_reads = 0, tot_bases = 0;
-    for (int s = 0; s < n_sets; ++s) {
-        max_reads = std::max(max_reads, sets[s].n_reads); tot_reads += sets[s].n_reads;
-        for (int r = 0; r < sets[s].n_reads; ++r) { max_qlen = std::max(max_qlen, sets[s].lens[r]); tot_bases += sets[s].lens[r]; }
-    }
     std::vector<PoaSet> ps(n_sets);
     int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
     const int aln_cap = std::max(1, sc->m - 1), rid_words = want_msa ? std::max(1, (max_reads + 63) / 64) : 0;
-    auto est_cols = [&](int64_t width, int w, int pn) { return local ? width : std::min<int64_t>(width, 2LL * w + 3 * pn + 32); };      // columns per row: the whole query in local mode
+    auto est_cols = [&](int64_t width, int w, int pn) { return (local || unbanded) ? width : std::min<int64_t>(width, 2LL * w + 3 * pn + 32); };      // columns per row: the whole query without a band
     int wide_lo = 1, wide_hi = 0, wide_ring_rows = 16;      // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off), depth of its score ring
     { LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
       make_lds_plan(sc, max_qlen, mb, est_cols((int64_t)((max_qlen + pn_) / pn_) * pn_, w_max, pn_), n_sets, &pl);
-      if (pl.wide_nw >= 1 && !local) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
+      if (pl.wide_nw >= 1 && !local && !general) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
     // cigar slots: four times the words of a backtrack where the all-rounds kernel's helper wavefronts write their parts (backtrack_dir.h SPEC_WK, dir_walk_pair)
     const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo);
     // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
@@ -240,10 +261,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     bool any_w = false; for (int s = 0; s < n_sets && !any_w; ++s) any_w = sets[s].weights != nullptr;
     L.o_wts = take(any_w ? 4 * (size_t)(tot_bases + 64) : 0);      // (per-base weights, -Q: in front of the reads, so that they go up with the first part)
     L.o_reads = take(tot_bases + 64); L.in_bytes = o;      // reads last: they go up in two parts
+    L.o_rc = take(amb ? tot_bases + 64 : 0); L.o_wrc = take(amb && any_w ? 4 * (size_t)(tot_bases + 64) : 0); L.in_dev_bytes = o;      // -s: reverse complements / reversed weights of the reads under retry
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
     // downloaded part first, contiguous: per-set state and the consensus results
-    L.o_cnode = take(4 * cons_tot); L.o_ccov = take(4 * cons_tot); L.o_cbase = take(cons_tot);
+    L.o_cnode = take(4 * cons_tot); L.o_ccov = take(4 * cons_tot); L.o_cbase = take(cons_tot); L.o_isrc = take(amb ? (size_t)tot_reads : 0);
     const size_t dl_bytes = o;
     L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
     L.o_out = take(4 * node_tot * POA_HOT); L.o_outw = take(4 * node_tot * POA_HOT); L.o_nread = take(4 * node_tot);
@@ -256,17 +278,22 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
     L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rpd = take(8 * node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
-    L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot); L.rows_bytes = o;
+    L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot);
+    // general kernel (rows_general.h): successor CSR, band state per row, the "row is part of the alignment" bytes (all ones: no sub-graph alignments here)
+    const bool gen_io = general || amb;      // (-s: the retry runs in the general kernel)
+    L.o_ooff = take(gen_io ? 4 * node_tot : 0); L.o_orow = take(gen_io ? 4 * (pred_tot + 1) : 0); L.o_left = take(gen_io ? 4 * node_tot : 0); L.o_right = take(gen_io ? 4 * node_tot : 0); L.o_act = take(gen_io ? node_tot : 0);
+    L.o_outfwd = take(amb ? sizeof(AlnOut) * n_sets : 0); L.o_cigfwd = take(amb ? 8 * cig_tot : 0); L.o_retry = take(amb ? (size_t)n_sets : 0);
+    L.rows_bytes = o;
 
     {   // the whole job must fit (the caller splits very large jobs): checked on the computed layout, before any cached buffer is given up
         size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t want[4] = {L.in_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap, C.planes.dev_cap};
+        const size_t want[4] = {L.in_dev_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap, C.planes.dev_cap};
         size_t need = 0, given_back = 0;
         for (int i = 0; i < 4; ++i) if (want[i] > have[i]) { need += want[i]; given_back += have[i]; }      // a buffer that must grow is freed first
         if (need > free_b + given_back && dir_wide_auto && any_wide_set && !dir_wide) {      // the record arenas of the wide-band sets do not fit: direction words for them too
             dir_wide = true; size_arenas(true);
             need = 0; given_back = 0;
-            const size_t want2[4] = {L.in_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot};
+            const size_t want2[4] = {L.in_dev_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot};
             for (int i = 0; i < 4; ++i) if (want2[i] > have[i]) { need += want2[i]; given_back += have[i]; }
             if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device %d: %d sets: score-record arenas do not fit, direction words for the wide-band sets too (arenas %.1f GB)\n", device, n_sets, plane_tot / 1e9);
         }
@@ -276,7 +303,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         }
     }
     int rc;
-    if ((rc = C.in.need_dev(L.in_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc = C.graph.need_host(dl_bytes)) ||
+    if ((rc = C.in.need_dev(L.in_dev_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc = C.graph.need_host(dl_bytes)) ||
         (rc = C.rows.need_dev(L.rows_bytes)) || (rc = C.planes.need_dev((size_t)plane_tot))) return rc;
     const int n_ev = 4 * max_reads + 8;
     while ((int)C.ev.size() < n_ev) { hipEvent_t e; HIP_OK(hipEventCreate(&e), ABPOA_HIP_ENODEV); C.ev.push_back(e); }
@@ -324,11 +351,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2; p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
     p.dig_on = cigar_digest_on() ? 1 : 0;      // (tests: the fuse phase folds every graph cigar into PoaState.cigar_dig)
-    p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = local ? 1 : 0; p.banded = sc->wb >= 0 ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
+    // (the reference's own row order where the best cell is the FIRST row that reaches the maximum: local and extension mode, ref :1012-1026; the remaining
+    //  length where something reads it: the adaptive band and the z-drop test)
+    p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = (local || extend) ? 1 : 0; p.banded = (sc->wb >= 0 || sc->zdrop > 0) ? 1 : 0; p.general = general ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
     // LDS tables of the order / rank kernels (two ints per node; the rank pass packs four tables into the same space): up to 6000 nodes = 52 KB, three workgroups per CU
-    p.order_lds = (local || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
+    p.order_lds = (p.order_mode || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
     // (the all-in-LDS order walk: what is left of 40 KB -- four workgroups per CU -- after 13 bytes a node goes to aligned-list entries, 2 bytes each)
-    p.order_ecap = local ? std::max(1024, std::min(65535, (40 * 1024 - 128 - 13 * p.order_lds) / 2)) : 0;
+    p.order_ecap = p.order_mode ? std::max(1024, std::min(65535, (40 * 1024 - 128 - 13 * p.order_lds) / 2)) : 0;
     { const char *e_ = getenv("ABPOA_HIP_ORDER_LDS"); if (e_ && !atoi(e_)) p.order_ecap = 0; }      // (ABPOA_HIP_ORDER_LDS=0: the general walk everywhere)
     { const char *e_ = getenv("ABPOA_HIP_ORDER_CAP"); if (e_ && atoi(e_) >= 0) p.order_lds = std::min(p.order_lds, atoi(e_) & ~3); }      // (tests: graphs above this many nodes take the walks with tables in memory)
     p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;      // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
@@ -345,6 +374,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
     p.row_base = dr + L.o_rbase; p.row_sdist = dr + L.o_rsd; p.row_pd = (uint32_t *)(dr + L.o_rpd); p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
     p.pred_off = (int32_t *)(dr + L.o_poff); p.pred_row = (int32_t *)(dr + L.o_pred); p.cigar = (uint64_t *)(dr + L.o_cigar);
+    p.out_off = gen_io ? (int32_t *)(dr + L.o_ooff) : nullptr; p.out_row = gen_io ? (int32_t *)(dr + L.o_orow) : nullptr;
+    if (amb) {
+        p.reads_rc = di + L.o_rc; p.wts_rc = any_w ? (int32_t *)(di + L.o_wrc) : nullptr; p.is_rc = dg + L.o_isrc; p.retry = dr + L.o_retry;
+        p.out_fwd = (AlnOut *)(dr + L.o_outfwd); p.cigar_fwd = (uint64_t *)(dr + L.o_cigfwd);
+    }
     p.cons_node = (int32_t *)(dg + L.o_cnode); p.cons_cov = (int32_t *)(dg + L.o_ccov); p.cons_base = dg + L.o_cbase;
 
     DevBatch b; memset(&b, 0, sizeof(b));
@@ -353,7 +387,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
         make_lds_plan(sc, max_qlen, max_bits, est_cols(width, w_max, pn), n_sets, &b.lds);
-        if (local) {      // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the host driver's (general kernel)
+        if (general) { b.lds.wide_nw = 0; b.lds.fr_cols = 0; b.lds.loc_cols = 0; }      // (no fast row loop takes anything: dp_common.h takes_fast / rows_local.h takes_local)
+        else if (local) {      // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the general kernel's
             b.lds.wide_nw = 0;
             if (max_bits != 16 || b.lds.loc_cols <= 0 || (max_qlen / 16 + 1) * 16 > b.lds.loc_cols || max_qlen > b.lds.q_cap) { set_err("local alignment outside the device row loop's range"); return ABPOA_HIP_EINVAL; }
         }
@@ -367,7 +402,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         if (w_max < b.lds.wide_w_lo || w_min > b.lds.wide_w_hi) b.lds.wide_nw = 0;                       // no read takes the wide loop
         b.lds.narrow_off = (b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_max <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
     }
-    if (!local && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
+    if (!local && !general && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
     b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
@@ -377,8 +412,20 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
     b.pred_off = p.pred_off; b.pred_row = p.pred_row; b.out_off = p.pred_off; b.out_row = p.pred_row;
     b.left = p.scratch; b.right = p.scratch;
+    if (gen_io) {
+        b.out_off = p.out_off; b.out_row = p.out_row; b.left = (int32_t *)(dr + L.o_left); b.right = (int32_t *)(dr + L.o_right); b.row_active = dr + L.o_act;
+        HIP_OK(hipMemsetAsync(dr + L.o_act, 1, (size_t)node_tot, st), ABPOA_HIP_ELAUNCH);
+    }
     b.dp_beg_sn = (int32_t *)(dr + L.o_bsn); b.dp_end_sn = (int32_t *)(dr + L.o_esn); b.row_cell_off = (int64_t *)(dr + L.o_coff); b.row_max_i = (int32_t *)(dr + L.o_rmi);
     b.planes = C.planes.dev; b.cigar = p.cigar;
+    // -s: the forward run leaves max_pos_left/right behind (fast row loops: a post-pass, rows_fast.h; general kernel: its own arrays) and the retry starts
+    // from them -- the reference sorts, and so resets them, only before the forward alignment (src/abpoa_align.c:329 calls the DP directly)
+    DevBatch b_rc = b;
+    if (amb) {
+        HIP_OK(hipMemsetAsync(dg + L.o_isrc, 0, (size_t)tot_reads, st), ABPOA_HIP_ELAUNCH);
+        b.want_lr = (sc->wb >= 0 && !general) ? 1 : 0;
+        b_rc = b; b_rc.want_lr = 0; b_rc.fresh_band = sc->wb >= 0 ? 0 : 1;
+    }
 
     // ---- all-rounds kernel (poa_rounds.hip) for jobs whose reads all take the narrow row loop: round 1 runs as separate launches (the upload of the
     //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
@@ -447,7 +494,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
                 std::vector<uint64_t> cg(std::max(1, ao.n_cigar)); (void)hipMemcpy(cg.data(), (uint8_t *)p.cigar + 8 * S.cigar_off, 8 * (size_t)ao.n_cigar, hipMemcpyDeviceToHost);
                 fprintf(stderr, "[poa-device]   set %d round %d: dp status %d score %d n_cigar %d rows %d; device state status %d reason %d nodes %d\n", s, k, ao.status, ao.best_score, ao.n_cigar, ao.n_rows_done, hst.status, hst.pad, n);
                 if (ao.status != 0) continue;
-                dbg_graphs[s].add_alignment(sets[s].seqs[k], sets[s].lens[k], cg.data(), ao.n_cigar, k, sets[s].weights ? sets[s].weights[k] : nullptr);
+                uint8_t rcf = 0; if (amb) (void)hipMemcpy(&rcf, p.is_rc + S.read0 + k, 1, hipMemcpyDeviceToHost);
+                const int ql_ = sets[s].lens[k]; std::vector<uint8_t> rq_; std::vector<int32_t> rw_;
+                if (rcf) { rq_.resize(ql_); for (int j = 0; j < ql_; ++j) { const uint8_t c_ = sets[s].seqs[k][ql_ - 1 - j]; rq_[j] = c_ < 4 ? (uint8_t)(3 - c_) : (uint8_t)4; }
+                           if (sets[s].weights && sets[s].weights[k]) { rw_.resize(ql_); for (int j = 0; j < ql_; ++j) rw_[j] = sets[s].weights[k][ql_ - 1 - j]; } }
+                dbg_graphs[s].add_alignment(rcf ? rq_.data() : sets[s].seqs[k], ql_, cg.data(), ao.n_cigar, k, rcf && !rw_.empty() ? rw_.data() : (sets[s].weights ? sets[s].weights[k] : nullptr));
             }
             if (hst.status != POA_ST_OK) continue;
             std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln((size_t)n * aln_cap), nread(n), row(n), order(n);
@@ -508,8 +559,15 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         HIP_OK(launch_poa_prepare(p, st), ABPOA_HIP_ELAUNCH);
         if (stage("prepare", k)) return ABPOA_HIP_ELAUNCH;
         HIP_OK(hipEventRecord(e[0], st), ABPOA_HIP_ELAUNCH);
-        HIP_OK(launch_dp_fast(b, st, e[1]), ABPOA_HIP_ELAUNCH);
+        if (general) { HIP_OK(launch_dp_general(b, st), ABPOA_HIP_ELAUNCH); HIP_OK(hipEventRecord(e[1], st), ABPOA_HIP_ELAUNCH); }
+        else HIP_OK(launch_dp_fast(b, st, e[1]), ABPOA_HIP_ELAUNCH);
         if (stage("dp rows + tail", k)) return ABPOA_HIP_ELAUNCH;
+        if (amb) {
+            HIP_OK(launch_poa_strand_check(p, st), ABPOA_HIP_ELAUNCH);
+            HIP_OK(launch_dp_general(b_rc, st), ABPOA_HIP_ELAUNCH);
+            HIP_OK(launch_poa_strand_pick(p, st), ABPOA_HIP_ELAUNCH);
+            if (stage("strand retry", k)) return ABPOA_HIP_ELAUNCH;
+        }
         if (dbg_sync && getenv("ABPOA_HIP_IMBAL")) {      // load balance of the round: ticks of the mean and of the slowest alignment
             std::vector<AlnOut> ho(n_sets); (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
             double sd = 0, sb = 0; long long md = 0, mb = 0, ms_ = 0; for (const AlnOut &o_ : ho) { sd += o_.clk_dp; sb += o_.clk_bt; md = std::max<long long>(md, o_.clk_dp); mb = std::max<long long>(mb, o_.clk_bt); ms_ = std::max<long long>(ms_, o_.clk_dp + o_.clk_bt); }
@@ -612,7 +670,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         for (int s = lo; s < hi_; ++s) {
             abpoa_hip_msa_t &o_ = out[s];
             memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
-            if (hs[s].status != POA_ST_OK) { need_fb[s] = 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
+            if (amb) { o_.is_rc = (uint8_t *)calloc((size_t)std::max(1, sets[s].n_reads), 1); if (o_.is_rc && hs[s].status == POA_ST_OK) memcpy(o_.is_rc, hg + L.o_isrc + ps[s].read0, (size_t)sets[s].n_reads); }
+            if (hs[s].status != POA_ST_OK) { need_fb[s] = hs[s].pad == 5 ? 2 : 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
             o_.n_cells = hs[s].n_cells;
             if (p.dig_on && sets[s].n_reads > 0) cigar_digest_set(sets[s].seqs[0], sets[s].lens[0], hs[s].cigar_dig);
             if (want_cons && hs[s].n_nodes > 2) {
@@ -661,11 +720,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             fprintf(stderr, "[poa-device]   set %d: consensus check %s (device %d, host %zu bases)\n", s, same ? "ok" : "FAILED", out[s].cons_len, ids.size());
         }
     }
-    for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(s);
+    // (a set whose edge or aligned lists are full gains nothing from a pass with more node slots: -(s + 1) tells the caller to hand it to the host driver at once)
+    for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(need_fb[s] == 2 ? -(s + 1) : s);
     if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s : *fallback) { const int r = hs[s].pad; hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++; }
-        fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, fuse caps (edge slots / aligned slots / nodes) %d, DP status %d, projected node growth (early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], hist[5], hist[7], hist[6] + hist[0]);
+        int n_slots = 0;
+        for (int f : *fallback) { const int s = f < 0 ? -f - 1 : f; const int r = hs[s].pad; if (r == 5) { n_slots++; continue; } hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++; }
+        fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, node slots in the fuse phase %d, edge / aligned slots of a node full (host driver at once) %d, DP status %d, projected node growth (early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], n_slots, hist[5], hist[7], hist[6] + hist[0]);
     }
     if (stats) {
         stats->cons_s = now_s() - t_done; stats->total_s = now_s() - t_begin;

@@ -18,12 +18,15 @@ struct DeviceRunStats {
     double rounds_mticks[4];      // mean per set: 10^6 shader-clock ticks in prepare / row loop / backtrack / fuse
 };
 
-// true when the scoring / output options can run on the device-resident path (affine or convex gaps; global mode with the adaptive band or local
-// mode; consensus and / or MSA output; alphabets of up to 27 codes); env ABPOA_HIP_HOSTGRAPH=1 forces the host driver
+// true when the scoring / output options can run on the device-resident path: every gap model and alignment mode (the fast row loops for banded global and
+// short local alignments, the general kernel for linear gaps, extension mode, global mode without a band and long local reads), consensus and / or MSA
+// output, alphabets of up to 27 codes, per-base weights, the strand retry (-s).  env ABPOA_HIP_HOSTGRAPH=1 forces the host driver;
+// ABPOA_HIP_NO_DEVICE_LOCAL / _GENERAL / _STRAND=1 send that class of jobs there
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 
 // Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
-// them) and must be redone (with a larger node_factor, or by the host driver).  node_factor: node slots per set = factor x
+// them) and must be redone (with a larger node_factor, or by the host driver; an entry -(s + 1) is set s with a full edge / aligned list: more node slots
+// would not help, host driver at once).  node_factor: node slots per set = factor x
 // longest read.  ABPOA_HIP_ENOMEM: the job does not fit the device (split it); EINVAL: not a job for the device driver.
 // device < 0: the device the engine was initialised on.  slot: which of the per-worker pool caches to use (one worker = one device queue of
 // the multi-GPU batch call; workers may share a device); a slot runs one job at a time.

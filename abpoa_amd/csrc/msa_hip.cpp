@@ -98,6 +98,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
         if (it != g_hint.end()) first_pass = it->second;
     }
     bool most_outgrew = false;
+    std::vector<int> hopeless;      // sets a later pass cannot hold either (run_msa_device marks them): the caller's, with what the last pass leaves
     int n_small = 0, n_done = 0;      // (sets that would also have fitted the 3x estimate / sets that finished)
     for (int pass = first_pass; pass < NPASS && R.device_ok && !todo.empty(); ++pass) {
         left.clear();
@@ -130,7 +131,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
                 break;
             }
             for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
-            for (int f : fb) left.push_back(todo[at + f]);
+            for (int f : fb) { if (f >= 0) left.push_back(todo[at + f]); else hopeless.push_back(todo[at + (-f - 1)]); }      // (f < 0: a full edge list -- no further device pass)
             add_stats(R.tot, ds);
             n_small += ds.n_fit_3x;
             n_done += (int)nb - (int)fb.size();
@@ -159,6 +160,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
         if (R.device_ok) todo.swap(left);
     }
     R.left = todo;
+    R.left.insert(R.left.end(), hopeless.begin(), hopeless.end());
     return R;
 }
 

@@ -92,7 +92,7 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         if (doomed && tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 6; }
     }
     if (status != POA_ST_OK || doomed || k >= S.n_reads) {          // nothing to align for this set in this round: both DP kernels skip it
-        if (tid == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
+        if (tid == 0) { AlnDesc d; memset(&d, 0, sizeof(d)); d.n_rows = 3; d.bits = 16; d.flags = ALN_SKIP; p.aln[s] = d; p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0; }
         return;
     }
     const int64_t N0 = S.node0;
@@ -250,6 +250,29 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         }
     }
     if (tid == 0) p.pred_off[N0 + n] = carry;
+    if (p.out_off) {      // (3b) successor rows per row, out_id order: the general kernel hands a row's arg-max to its successors' band state (reference :1078-1091)
+        int carry_o = 0;
+        for (int t0 = 0; t0 < n; t0 += GT) {
+            const int r = t0 + tid;
+            const int u = r < n ? order[r] : 0;
+            const int no = r < n ? (int)p.nd_nout[N0 + u] : 0;
+            const int incl = wave_scan_add(no);
+            __syncthreads();
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int w_ = 0; w_ < GW; ++w_) { const int x_ = wtot[w_]; all += x_; before += w_ < wave ? x_ : 0; }
+            const int off = carry_o + before + incl - no;
+            if (r < n) {
+                p.out_off[N0 + r] = off;
+                if (off + no > S.pred_cap) overflow = true;
+                else for (int t = 0; t < no; ++t) p.out_row[S.pred0 + off + t] = p.nd_row[N0 + out_slot(p, N0 + u, t)];
+            }
+            carry_o += all;
+        }
+        if (tid == 0) p.out_off[N0 + n] = carry_o;
+    }
     overflow = __syncthreads_or(overflow);
     // (4) alignment descriptor of this round
     if (tid == 0) {
@@ -257,11 +280,11 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         const int qlen = p.read_len[S.read0 + k];
         d.n_rows = n; d.qlen = qlen;
         d.bits = score_bits(p, n, qlen, &d.inf_min);
-        d.w = p.wb + (int)(p.wf * (float)qlen);            // reference :445 (float32 product)
-        d.cigar_cap = S.cigar_cap; d.flags = ALN_FAST_OK; d.pad0 = 0;
-        d.query_off = p.read_off[S.read0 + k]; d.row0 = N0; d.poff0 = N0; d.pred0 = S.pred0; d.out0 = 0;
+        d.w = p.wb < 0 ? qlen : p.wb + (int)(p.wf * (float)qlen);            // reference :445 (float32 product)
+        d.cigar_cap = S.cigar_cap; d.flags = (p.general & 1) ? 0 : ALN_FAST_OK; d.pad0 = 0;
+        d.query_off = p.read_off[S.read0 + k]; d.row0 = N0; d.poff0 = N0; d.pred0 = S.pred0; d.out0 = S.pred0;
         d.plane_off = S.plane_off; d.plane_cap = S.plane_cap / (d.bits / 8); d.cigar_off = S.cigar_off;
-        if (overflow || n + qlen + 8 > S.cigar_cap) { st->status = POA_ST_FALLBACK; st->pad = overflow ? 2 : 3; d.flags = 0; d.n_rows = 3; }
+        if (overflow || n + qlen + 8 > S.cigar_cap) { st->status = POA_ST_FALLBACK; st->pad = overflow ? 2 : 3; d.flags = ALN_SKIP; d.n_rows = 3; }
         p.aln[s] = d;
         p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0;
     }
@@ -280,7 +303,8 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     if (res.status != 0) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 1000 + res.status; } return; }
     const int64_t N0 = S.node0;
     const int n_old = uni(st->n_nodes), qlen = p.read_len[S.read0 + k], n_cigar = res.n_cigar;
-    const uint8_t *seq = p.reads + p.read_off[S.read0 + k];
+    const bool rc_read = p.is_rc && uni((int)p.is_rc[S.read0 + k]) != 0;      // (-s: the reverse complement of this read won, reference :331-334)
+    const uint8_t *seq = (rc_read ? p.reads_rc : p.reads) + p.read_off[S.read0 + k];
     const uint64_t *cg = p.cigar + S.cigar_off;
     const int cur = uni(st->order_buf);
     const int32_t *order_old = p.row_node[cur] + N0; int32_t *order_new = p.row_node[cur ^ 1] + N0;
@@ -307,10 +331,10 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     __syncthreads();
     // F2: walk the query in chunks of 64 positions
     int n_nodes = n_old, prev_c = 0 /* source */, prev_new_c = 0, carry_ar = 0 /* row of the source */, carry_sq = -1;
-    bool fail = false;
+    bool fail = false, fail_slots = false;      // (fail_slots: an edge / aligned list is full -- more node slots would not help, PoaState.pad 5)
     // adds edge from -> to (both lane-private; `from_new` / `to_new`: the node was created by this read, its lists are still empty
     // apart from what this very walk put there, which is known without a load)
-    const int32_t *wq = p.wts ? p.wts + p.read_off[S.read0 + k] : nullptr;      // per-base weights of this read (-Q), reference :634-667: an edge takes the weight of the base it leads to
+    const int32_t *wq = p.wts ? (rc_read ? p.wts_rc : p.wts) + p.read_off[S.read0 + k] : nullptr;      // per-base weights of this read (-Q), reference :634-667: an edge takes the weight of the base it leads to
     auto add_edge = [&](bool act, int from, bool from_new, int to, bool to_new, int w) {
         if (!act) return;
         const int64_t F = N0 + from, T = N0 + to;
@@ -320,7 +344,7 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
         if (hit >= 0) outw_slot(p, F, hit) += w;
         else {
             const int ni = to_new ? 0 : (int)p.nd_nin[T];
-            if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; return; }
+            if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; fail_slots = true; return; }
             out_slot(p, F, no) = to; outw_slot(p, F, no) = w; p.nd_nout[F] = (uint8_t)(no + 1);
             in_slot(p, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
             hit = no;
@@ -372,7 +396,7 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
             p.nd_base[Y] = (uint8_t)b; p.nd_nin[Y] = 0; p.nd_nout[Y] = 0; p.nd_naln[Y] = 0; p.nd_nread[Y] = 0;
             if (c >= 0) {                                                       // mismatch: new node joins c's aligned group, reference :393-401
                 const int na = p.nd_naln[N0 + c];
-                if (na + 1 > p.aln_cap) fail = true;
+                if (na + 1 > p.aln_cap) { fail = true; fail_slots = true; }
                 else {
                     for (int t = 0; t < na; ++t) {
                         const int other = p.nd_aln[(N0 + c) * p.aln_cap + t];
@@ -415,9 +439,10 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     // F3: last node -> sink (reference :667)
     bool any_fail = __syncthreads_or(fail);
     if (!any_fail) { add_edge(tid == 0, prev_c, prev_new_c != 0, 1, false, wq ? wq[qlen - 1] : 1); any_fail = __syncthreads_or(fail); }      // reference :667: the last base's weight
-    if (tid == 0) { sh_fail = any_fail ? 1 : 0; sh_nodes = n_nodes; }
+    const bool any_slots = __syncthreads_or(fail_slots);
+    if (tid == 0) { sh_fail = any_fail ? (any_slots ? 5 : 4) : 0; sh_nodes = n_nodes; }
     __syncthreads();
-    if (sh_fail) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = 4; } return; }
+    if (sh_fail) { if (tid == 0) { st->status = POA_ST_FALLBACK; st->pad = sh_fail; } return; }
     n_nodes = sh_nodes;
     // F4: new row order = old order with every run of new nodes spliced in after its anchor
     int carry = 0;

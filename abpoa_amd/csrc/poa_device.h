@@ -66,7 +66,8 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
                                    // 1: the reference's own order, rebuilt before every alignment (poa_order_kernel: local mode breaks score ties by row index)
     int32_t banded;                // 0: no adaptive band (local mode): the remaining length is not computed
     int32_t msa_rows, msa_cons;    // rows of a set's MSA = its reads (+ 1 when msa_cons: the consensus row, abpoa_output.c:151-164)
-    int32_t order_ecap, pad_e;     // aligned-list entries (16 bits each) the order kernel's all-in-LDS walk holds
+    int32_t order_ecap, general;   // order_ecap: aligned-list entries (16 bits each) the order kernel's all-in-LDS walk holds; general: the job's alignments run in the general
+                                   // kernel (rows_general.h: linear gaps, extension mode, no band, long local reads) -- prepare also writes the successor CSR it reads
     int32_t order_lds, dig_on;     // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice); dig_on: PoaState.cigar_dig is kept
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
@@ -83,18 +84,29 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     // DP inputs produced by the prepare kernel (same arrays DevBatch points at)
     AlnDesc *aln; AlnOut *out;
     uint8_t *row_base; int32_t *row_node_id, *row_remain, *pred_off, *pred_row;
+    int32_t *out_off, *out_row;    // general jobs: successor rows per row (DevBatch.out_off / out_row), offsets indexed like pred_off, entries in the set's pred_row-sized slice
     uint32_t *row_pd;              // per row, two dwords: distances to the first eight predecessors (DevBatch.row_pd)
     uint8_t *row_sdist;            // per row: min(255, largest row distance to a successor), 255 for a predecessor of the sink (DevBatch.row_sdist)
     uint64_t *cigar;
     // consensus results (poa_consensus_kernel), indexed cons0 + position
     int32_t *cons_node, *cons_cov; uint8_t *cons_base;
     // MSA output (poa_msa_rank_kernel / poa_msa_fill_kernel): per node its MSA column + 1 (node0 + node id), the row-major result pool
+    // ambiguous strand (-s; reference abpoa_poa, src/abpoa_align.c:315-336): a read that scores below a third of the best possible is aligned again as its
+    // reverse complement on the same rows; the strand with the strictly better score goes into the graph.  NULL pointers: not an -s job.
+    uint8_t *reads_rc; int32_t *wts_rc;      // reverse complements (and reversed weights) of the reads being retried, same offsets as reads / wts, same allocation as `reads`
+    uint8_t *is_rc;                          // [read]: the reverse complement went into the graph (abpoa_seq_t.is_rc)
+    uint8_t *retry;                          // [set]: this round's alignment is being repeated
+    AlnOut *out_fwd; uint64_t *cigar_fwd;    // forward result of a set under retry (cigar_fwd: same slices as cigar)
     int32_t *msa_rank; uint8_t *msa_out; const int64_t *msa_off;      // msa_off[set]: first byte of the set's rows in msa_out (host prefix sum over rows x msa_len)
 };
 
 hipError_t launch_poa_init(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s);
+// -s: after the forward alignment, pick the reads to repeat as reverse complement (descriptor -> general kernel on the rc read, every other set skipped);
+// after the retry, keep the better strand
+hipError_t launch_poa_strand_check(const PoaDev &p, hipStream_t s);
+hipError_t launch_poa_strand_pick(const PoaDev &p, hipStream_t s);
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s);
 // the reference's row order (abpoa_BFS_set_node_index, src/abpoa_graph.c:186-231) rebuilt on the device: order_mode 1, before every prepare
 hipError_t launch_poa_order(const PoaDev &p, hipStream_t s);

@@ -69,6 +69,52 @@ __global__ void __launch_bounds__(GT) poa_fuse_kernel(const PoaDev p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// -s (ambiguous strand), reference abpoa_poa src/abpoa_align.c:315-336.  After the forward alignment of round k: a read whose score is below
+// min(qlen, nodes - 2) * max_mat * .3333 is aligned again as its reverse complement (codes 0..3 complemented, every other code 4) on the SAME rows -- the
+// reference calls the DP without sorting again, so the adaptive band starts from the bounds the forward run left (DevBatch.fresh_band 0: the general kernel
+// on the left / right arrays the forward run wrote).  The check kernel saves the forward result, writes the reverse complement and re-targets the
+// descriptor; every other set's descriptor gets ALN_SKIP.  The pick kernel keeps the strand with the strictly better score.
+__global__ void __launch_bounds__(GT) poa_strand_check_kernel(const PoaDev p) {
+    const int s = blockIdx.x, tid = threadIdx.x, k = p.round;
+    if (s >= p.n_sets) return;
+    const PoaSet S = p.sets[s];
+    if (tid == 0) p.retry[s] = 0;
+    AlnDesc d = p.aln[s];
+    const AlnOut o = p.out[s];
+    const int status = uni(p.state[s].status), flags = uni(d.flags), o_status = uni(o.status), n_cigar = uni(o.n_cigar), qlen = uni(d.qlen), n_rows = uni(d.n_rows), score = uni(o.best_score);
+    if (status != POA_ST_OK || k >= S.n_reads || (flags & ALN_SKIP)) return;
+    const int lim = qlen < n_rows - 2 ? qlen : n_rows - 2;
+    const bool again = o_status == 0 && (double)score < (double)(lim * p.max_mat) * .3333;
+    __syncthreads();      // (every thread has its copy of the descriptor and of the result)
+    if (!again) { if (tid == 0) p.aln[s].flags = flags | ALN_SKIP; return; }
+    const uint64_t *cg = p.cigar + S.cigar_off; uint64_t *cf = p.cigar_fwd + S.cigar_off;
+    for (int i = tid; i < n_cigar; i += GT) cf[i] = cg[i];
+    const int64_t off = p.read_off[S.read0 + k];
+    const uint8_t *q = p.reads + off; uint8_t *rq = p.reads_rc + off;
+    for (int j = tid; j < qlen; j += GT) { const uint8_t c = q[qlen - 1 - j]; rq[j] = c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; }
+    if (p.wts) for (int j = tid; j < qlen; j += GT) p.wts_rc[off + j] = p.wts[off + qlen - 1 - j];
+    if (tid == 0) {
+        p.out_fwd[s] = o;
+        d.flags = 0; d.query_off = off + (int64_t)(p.reads_rc - p.reads); p.aln[s] = d;
+        p.out[s].status = 0; p.out[s].n_cigar = 0; p.out[s].n_cells = 0;
+        p.retry[s] = 1;
+    }
+}
+__global__ void __launch_bounds__(GT) poa_strand_pick_kernel(const PoaDev p) {
+    const int s = blockIdx.x, tid = threadIdx.x, k = p.round;
+    if (s >= p.n_sets || !uni((int)p.retry[s])) return;
+    const PoaSet S = p.sets[s];
+    const AlnOut rc = p.out[s], fw = p.out_fwd[s];
+    const int rc_status = uni(rc.status), rc_score = uni(rc.best_score), fw_score = uni(fw.best_score), fw_cigar = uni(fw.n_cigar);
+    __syncthreads();
+    if (rc_status != 0) return;      // (the fuse phase sends the set to the host driver)
+    if (rc_score > fw_score) { if (tid == 0) { p.is_rc[S.read0 + k] = 1; p.out[s].n_cells = rc.n_cells + fw.n_cells; } return; }
+    const uint64_t *cf = p.cigar_fwd + S.cigar_off; uint64_t *cg = p.cigar + S.cigar_off;
+    for (int i = tid; i < fw_cigar; i += GT) cg[i] = cf[i];
+    if (tid == 0) { AlnOut r = fw; r.n_cells += rc.n_cells; p.out[s] = r; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // after the last round: heaviest-bundling consensus, reference src/abpoa_output.c:361-415 (scores) and :343-356 (path).
 // score[u] = w* + score[t*] where w* is the largest out-edge weight and t* the target with the best score among the
 // edges of weight w* (ties: the LAST such edge; for the source: best weight, then best score, ties: the FIRST).  The
@@ -556,6 +602,16 @@ hipError_t launch_poa_prepare(const PoaDev &p, hipStream_t s) {
 hipError_t launch_poa_fuse(const PoaDev &p, hipStream_t s) {
     if (p.n_sets <= 0) return hipSuccess;
     hipLaunchKernelGGL(poa_fuse_kernel, dim3(p.n_sets), dim3(GT), (size_t)16 * GT, s, p);      // (path-exchange records of the fuse body: 4 ints per thread)
+    return hipGetLastError();
+}
+hipError_t launch_poa_strand_check(const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(poa_strand_check_kernel, dim3(p.n_sets), dim3(GT), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_poa_strand_pick(const PoaDev &p, hipStream_t s) {
+    if (p.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(poa_strand_pick_kernel, dim3(p.n_sets), dim3(GT), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_poa_consensus(const PoaDev &p, hipStream_t s) { return launch_k(poa_consensus_kernel, p, s); }

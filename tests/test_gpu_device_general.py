@@ -1,0 +1,173 @@
+"""GPU (-m gpu): the device-resident read-set driver on the jobs that are outside the fast row loops -- linear gaps (reference simd_abpoa_lg_dp,
+src/simd_abpoa_align.c:701-779), extension mode with and without z-drop (:1018-1026), global alignment without a band (-b -1), local alignment of reads
+longer than the local row loop holds.  They run in the general kernel (rows_general.h), one launch per round, with the graph resident on the device like
+every other job: the prepare phase also writes the successor lists that kernel hands its band state through, and extension mode gets the reference's own
+row order (its best cell is the first row that reaches the maximum).  Every result is compared with the CPU build of the host layer whose aligner is the
+plain-C oracle (tests/cpu_shim.cpp): MSA rows byte for byte, consensus, coverage -- and `n_host_sets == 0`: nothing went through the host driver."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EXTEND = 2
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from abpoa_amd import ffi
+    lib = ffi.lib()
+    assert lib.abpoa_hip_device_count() >= 1
+    ffi.check(lib.abpoa_hip_init(0))
+    return lib
+
+
+def _same(dev, ref, what):
+    for i, (a, b) in enumerate(zip(dev, ref)):
+        assert a.status == 0 and b.status == 0, f"{what}: set {i} status {a.status} / {b.status}"
+        assert a.msa_len == b.msa_len, f"{what}: set {i}: {a.msa_len} MSA columns, oracle-backed run {b.msa_len}"
+        assert a.msa_seq == b.msa_seq, f"{what}: MSA rows of set {i} differ"
+        assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{what}: consensus of set {i} differs"
+
+
+def _nt_sets(seed, n=10, length=lambda i: 150 + 70 * i):
+    from abpoa_amd import synth
+    return [synth.make_read_set(seed, i, 4 + (3 * i) % 13, length(i), 0.03 + 0.025 * (i % 6)) for i in range(n)]
+
+
+VARIANTS = [
+    ("linear_global_banded", dict(gap_open1=0, gap_open2=0, gap_ext1=2), None),
+    ("linear_global_unbanded", dict(gap_open1=0, gap_open2=0, gap_ext1=3, extra_b=-1), None),
+    ("linear_local", dict(aln_mode=1, gap_open1=0, gap_open2=0, gap_ext1=2), None),
+    ("affine_global_unbanded", dict(gap_open1=4, gap_open2=0, gap_ext1=2, extra_b=-1), None),
+    ("convex_global_unbanded", dict(extra_b=-1), None),
+    ("affine_extend", dict(aln_mode=EXTEND, gap_open1=4, gap_open2=0, gap_ext1=2), None),
+    ("convex_extend", dict(aln_mode=EXTEND), None),
+    ("convex_extend_zdrop", dict(aln_mode=EXTEND, zdrop=40), None),
+    ("linear_extend_unbanded", dict(aln_mode=EXTEND, gap_open1=0, gap_open2=0, gap_ext1=2, extra_b=-1), None),
+    ("convex_local_long_reads", dict(aln_mode=1), lambda i: 640 + 45 * i),
+    ("affine_local_long_reads", dict(aln_mode=1, gap_open1=6, gap_open2=0, gap_ext1=2), lambda i: 600 + 60 * i),
+]
+
+
+@pytest.mark.parametrize("name,kw,length", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_general_kernel_jobs_stay_on_the_device(engine, name, kw, length):
+    import helpers as H
+    from abpoa_amd import api
+    shim = H.cpu_shim_lib()
+    sets = _nt_sets(71, 8, length) if length else _nt_sets(71)
+    p = api.Params(**kw)
+    dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 0, f"{name}: not every set ran on the device-resident driver"
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+    _same(dev, ref, name)
+
+
+def test_protein_linear_and_extend_on_the_device(engine):
+    """27-code alphabet (aligned groups of up to 26 nodes), BLOSUM62: linear gaps global, convex extension."""
+    import helpers as H
+    from abpoa_amd import api, synth, workloads
+    shim = H.cpu_shim_lib()
+    sets = [synth.make_read_set(73, i, 6 + i % 9, 90 + 40 * i, alphabet=synth.AA, rates=(0.08 + 0.02 * (i % 4), 0.02, 0.03)) for i in range(8)]
+    for kw in (dict(gap_open1=0, gap_open2=0, gap_ext1=4), dict(aln_mode=EXTEND)):
+        p = api.Params(is_aa=True, score_matrix=workloads.BLOSUM62, **kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        assert api.msa_timing()["n_host_sets"] == 0
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"protein {kw}")
+
+
+def test_general_kernel_equals_the_fast_row_loops_on_their_jobs(engine, monkeypatch):
+    """ABPOA_HIP_DEVICE_GENERAL=1 sends banded global jobs (the fast row loops' own) through the general kernel on the device: same consensus and MSA, and
+    both equal the oracle-backed run.  (Their cigars: tests/test_gpu_device_msa.py::test_device_driver_cigars_equal_the_oracle_backed_run.)"""
+    import helpers as H
+    from abpoa_amd import api
+    shim = H.cpu_shim_lib()
+    sets = _nt_sets(79, 8)
+    for kw in (dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2)):
+        p = api.Params(**kw)
+        monkeypatch.setenv("ABPOA_HIP_DEVICE_GENERAL", "0")
+        fast = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        monkeypatch.setenv("ABPOA_HIP_DEVICE_GENERAL", "1")
+        gen = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        assert api.msa_timing()["n_host_sets"] == 0
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+        _same(gen, ref, f"general kernel {kw}")
+        _same(fast, ref, f"fast loops {kw}")
+
+
+def test_general_jobs_can_be_kept_off_the_device(engine, monkeypatch):
+    """ABPOA_HIP_NO_DEVICE_GENERAL=1: the jobs of the general kernel go through the host driver as before round 4 (and are counted)."""
+    from abpoa_amd import api
+    sets = _nt_sets(83, 4)
+    monkeypatch.setenv("ABPOA_HIP_NO_DEVICE_GENERAL", "1")
+    r = api.msa_batch(sets, api.Params(gap_open1=0, gap_open2=0, gap_ext1=2), n_threads=4)
+    assert all(x.status == 0 for x in r) and api.msa_timing()["n_host_sets"] == len(sets)
+
+
+# ---------------------------------------------------------------------------------------------------------------- -s (ambiguous strand)
+def _flip(read):
+    return read[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+
+
+def _mixed_strand_sets(seed, shapes):
+    """Read-sets in which about a third of the reads (never the first) are given as their reverse complement."""
+    import numpy as np
+    from abpoa_amd import synth
+    rng = np.random.default_rng(seed)
+    sets = []
+    for i, (n, ln, err) in enumerate(shapes):
+        reads = list(synth.make_read_set(seed, i, n, ln, err))
+        for j in range(1, n):
+            if rng.random() < 0.35:
+                reads[j] = _flip(reads[j])
+        sets.append(reads)
+    return sets
+
+
+def test_strand_retry_goldens_on_the_device(engine):
+    """The reference CLI's own -s outputs (goldens out_rc_cons / out_rc_msa / out_rc_long_msa: the last one is long noisy reads whose retry inherits the
+    forward run's band state) through the device-resident driver: forward alignment in the fast row loop, strand check, retry in the general kernel on the
+    reverse complement, the better strand fused (reference src/abpoa_align.c:315-336)."""
+    import os
+    import helpers as H
+    from abpoa_amd import api, seqio
+    D = H.GOLDEN_DIR
+    for name, src, out_msa, want_rc in (("out_rc_cons", "out_rc_cons", False, [2, 5, 8]), ("out_rc_msa", "out_rc_cons", True, [2, 5, 8]), ("out_rc_long_msa", "out_rc_long_msa", True, [2, 5])):
+        names, seqs, _ = seqio.read_fastx(os.path.join(D, src, "input.fa"))
+        r = api.msa_batch([seqs], api.Params(), out_cons=True, out_msa=out_msa, amb_strand=True)[0]
+        assert api.msa_timing()["n_host_sets"] == 0, f"{name}: not on the device-resident driver"
+        assert [i for i, f in enumerate(r.is_rc) if f] == want_rc, name
+        assert api.format_output(r, names, True, out_msa) == open(os.path.join(D, name, "output.txt")).read(), name
+
+
+@pytest.mark.parametrize("name,kw", [("convex_banded", dict()), ("affine_banded", dict(gap_open1=4, gap_open2=0, gap_ext1=2)), ("linear_banded", dict(gap_open1=0, gap_open2=0, gap_ext1=2)),
+                                     ("affine_unbanded", dict(gap_open1=4, gap_open2=0, gap_ext1=2, extra_b=-1)), ("convex_local", dict(aln_mode=1)), ("convex_extend", dict(aln_mode=EXTEND))])
+def test_mixed_strand_sets_on_the_device(engine, name, kw):
+    """-s on ragged read-sets with about a third of the reads reverse-complemented, every driver form the option meets: forward run in the narrow / wide fast
+    row loops (band state handed to the retry), in the local row loop (no band), in the general kernel (linear gaps, no band, extension); with and without
+    per-base weights (the retry reverses them, reference :323-326).  MSA rows, consensus, coverage and the strand flags against the oracle-backed run."""
+    import numpy as np
+    import helpers as H
+    from abpoa_amd import api
+    shim = H.cpu_shim_lib()
+    shapes = [(5 + (3 * i) % 11, 140 + 80 * i, 0.03 + 0.02 * (i % 5)) for i in range(9)] + [(6, 2600, 0.10), (5, 4200, 0.12)]      # (the last two: band half-widths of 40+, the wide row loop)
+    if kw.get("aln_mode") == 1:
+        shapes = shapes[:9]
+    sets = _mixed_strand_sets(89, shapes)
+    rng = np.random.default_rng(3)
+    weights = [[rng.integers(1, 41, len(r)).astype(np.int32) for r in s] for s in sets]
+    p = api.Params(**kw)
+    for w in (None, weights):
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, weights=w, amb_strand=True)
+        assert api.msa_timing()["n_host_sets"] == 0, f"{name}: not every set ran on the device-resident driver"
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, weights=w, amb_strand=True, lib=shim)
+        _same(dev, ref, f"{name} weights={'yes' if w else 'no'}")
+        assert [list(a.is_rc) for a in dev] == [list(b.is_rc) for b in ref], f"{name}: strand flags differ"
+        assert sum(sum(a.is_rc) for a in dev) > 5, "the inputs were meant to have reverse-complemented reads"
+
+
+def test_strand_retry_can_be_kept_off_the_device(engine, monkeypatch):
+    from abpoa_amd import api
+    sets = _mixed_strand_sets(97, [(6, 300, 0.05)] * 3)
+    monkeypatch.setenv("ABPOA_HIP_NO_DEVICE_STRAND", "1")
+    r = api.msa_batch(sets, api.Params(), n_threads=4, amb_strand=True)
+    assert all(x.status == 0 for x in r) and api.msa_timing()["n_host_sets"] == len(sets)

@@ -241,11 +241,16 @@ CIGAR_JOBS = {
     # wide bands (10 kb reads: the all-chunks row loop, column-slice backtrack windows), 5 % and 15 % errors
     "wide_affine_5": (dict(gap_open1=4, gap_open2=0, gap_ext1=2), [(8, 10000 + 17 * i, 0.05) for i in range(4)]),
     "wide_convex_15": (dict(), [(8, 10000 - 23 * i, 0.15) for i in range(4)]),
+    # the general kernel's own jobs on the device-resident driver (tests/test_gpu_device_general.py): linear gaps, extension mode, no band
+    "linear_banded": (dict(gap_open1=0, gap_open2=0, gap_ext1=2), [(9, 400 + 90 * i, 0.06) for i in range(6)]),
+    "extend_convex": (dict(aln_mode=2), [(9, 500 + 70 * i, 0.10) for i in range(6)]),
+    "affine_unbanded": (dict(gap_open1=4, gap_open2=0, gap_ext1=2, extra_b=-1), [(8, 300 + 60 * i, 0.08) for i in range(6)]),
 }
 
 
 @pytest.mark.parametrize("job,env", [("narrow_affine", {}), ("narrow_affine", {"ABPOA_HIP_LOCKSTEP": "1"}), ("narrow_convex_noisy", {}), ("narrow_convex_noisy", {"ABPOA_HIP_LOCKSTEP": "1"}),
-                                     ("narrow_1500", {}), ("narrow_1500", {"ABPOA_HIP_DBG": "1024"}),
+                                     ("narrow_1500", {}), ("narrow_1500", {"ABPOA_HIP_DBG": "1024"}), ("narrow_1500", {"ABPOA_HIP_DEVICE_GENERAL": "1"}),
+                                     ("linear_banded", {}), ("extend_convex", {}), ("affine_unbanded", {}),
                                      ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "0"}), ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "1"}), ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"}),
                                      ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "0"}), ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "1"}), ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"})],
                          ids=lambda v: v if isinstance(v, str) else ("default" if not v else "_".join(f"{k[10:].lower()}{x}" for k, x in v.items())))
@@ -285,5 +290,5 @@ def test_device_driver_cigars_equal_the_oracle_backed_run(engine, job, env):
     e = dict(os.environ, ABPOA_HIP_CIGAR_DIGEST="1", **env)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=900)
     assert r.returncode == 0 and "CIGARS EQUAL" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-    narrow_all_rounds = job.startswith("narrow") and "ABPOA_HIP_LOCKSTEP" not in env
+    narrow_all_rounds = job.startswith("narrow") and "ABPOA_HIP_LOCKSTEP" not in env and "ABPOA_HIP_DEVICE_GENERAL" not in env
     assert ("ROUNDS_LAUNCHES 0" not in r.stdout) == narrow_all_rounds, r.stdout
