@@ -145,7 +145,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int pbase = __builtin_amdgcn_readlane(po, lo - lo64);
             const int pn_t = imin(BTP, __builtin_amdgcn_readlane(po1, n64 - 1) - pbase);
             if (rv) {
-                B.rinfo[li] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (((po1 - po > 64 || po1 - pbase > BTP) ? 255 : po1 - po) << 16) | (bs_ << 24), nid_);      // n_pred 255: not for the lane-parallel steps
+                // n_pred 255: not for the lane-parallel steps
+                B.rinfo[li] = make_int4(pbc | (W << 16), off_rec * CW, ((po - pbase) & 0xffff) | (((po1 - po > 64 || po1 - pbase > BTP) ? 255 : po1 - po) << 16) | (bs_ << 24), nid_);
                 B.rinfo2[li] = sl | (ns << 16);
                 B.srcoff[li] = c_ + (long long)(sl - pbc) * CW;
             }
@@ -181,7 +182,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                     const long long so = (long long)(unsigned)__builtin_amdgcn_readlane(src_lo, rr) | ((long long)__builtin_amdgcn_readlane(src_hi, rr) << 32);
                     const int4 *src = (const int4 *)(planes + so); unsigned char *dstb = (unsigned char *)bt + ob;
                     for (int i0 = 0; i0 < np16; i0 += 64)
-                        if (i0 + lane < np16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane), (__attribute__((address_space(3))) void *)(dstb + i0 * 16), 16, 0, 0);
+                        if (i0 + lane < np16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
+                                (__attribute__((address_space(3))) void *)(dstb + i0 * 16), 16, 0, 0);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,9 +322,12 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
             bool need = false;
             const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
-            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
+            // (every lane reads the same cell: keep the walk's state in SGPRs)
+            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0,
+                    F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
-            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
+            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]),
+                    F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
             if (local && Hij == 0) { local_done = true; break; }            // reference :126: the local walk ends on a zero cell
             const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
@@ -401,7 +406,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                     int qc_v = (int)s_query[mj - 1];
                     const int e_idx = (mc.z & 0xffff) + (lane < np_ ? lane : 0);        // (n_pred 255 = row not eligible: the reads stay inside the LDS image, the result is not used)
                     int4 er = B.edge[e_idx & (BTP - 1)]; int4 er2 = B.edge2[e_idx & (BTP - 1)];
-                    const int w_lo_n = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH), w_hi_n = sgpr(mc.w << 2), w_idx_n = sgpr(n_cigar & 63), bs_n = sgpr((int)((unsigned)mc.z >> 24));      // (as in the whole-row loop)
+                    // (as in the whole-row loop)
+                    const int w_lo_n = sgpr(((mj - 1) << 4) | ABPOA_HIP_CMATCH), w_hi_n = sgpr(mc.w << 2), w_idx_n = sgpr(n_cigar & 63), bs_n = sgpr((int)((unsigned)mc.z >> 24));
                     asm volatile("" :: "s"(w_lo_n), "s"(w_hi_n), "s"(w_idx_n), "s"(bs_n));
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("" : "+v"(fl_v), "+v"(qc_v), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er2.x), "+v"(er2.y), "+v"(er2.z));      // every load issued before the one wait
@@ -437,10 +443,14 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const bool st_jm1 = xi - 1 >= 0 && xi - 1 < Wi;                      // stored(gi, j-1)
             bool need = !win_narrow && ((unsigned)si >= (unsigned)nsi || (st_jm1 && si - 1 < 0));     // a cell of the own row outside the staged slice
             const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
-            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0, F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;      // (every lane reads the same cell: keep the walk's state in SGPRs)
+            // (every lane reads the same cell: keep the walk's state in SGPRs)
+            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0,
+                    F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
-            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]), F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
-            if (local && Hij == 0 && (win_narrow || (unsigned)si < (unsigned)nsi)) { local_done = true; break; }      // reference :126: the local walk ends on a zero cell (a cell outside the staged slice is re-read after the reload below)
+            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]),
+                    F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
+            // reference :126: the local walk ends on a zero cell (a cell outside the staged slice is re-read after the reload below)
+            if (local && Hij == 0 && (win_narrow || (unsigned)si < (unsigned)nsi)) { local_done = true; break; }
             const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
             const bool act = lane < np;
             // round trip 2: the predecessors' cells (lane k = predecessor k) and the substitution score
@@ -515,7 +525,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             int ps, np, id, bs_;
             { const int t = gi.in_tile ? i - bt_lo : 0; ps = B.poff[t]; np = B.poff[t + 1] - ps; id = B.nid[t]; bs_ = B.base[t]; }
             if (!gi.in_tile) { ps = gld_i32(pred_off + i); np = gld_i32(pred_off + i + 1) - ps; id = gld_i32(row_node_id + i); bs_ = gld_u8(row_base + i); }
-            auto pred_bt = [&](int idx) __attribute__((always_inline)) { const int t = idx - bt_pbase; const bool ok = gi.in_tile && t >= 0 && t < BTP; int v = B.pred[ok ? t : 0]; if (!ok) v = gld_i32(pred_row + idx); return v; };
+            auto pred_bt = [&](int idx) __attribute__((always_inline)) { const int t = idx - bt_pbase; const bool ok = gi.in_tile && t >= 0 && t < BTP; int v = B.pred[ok ? t : 0];
+                    if (!ok) v = gld_i32(pred_row + idx); return v; };
             const int qc = qcode(j - 1);
             const int s = s_mat[m * bs_ + qc];
             const int is_match = bs_ == qc;
@@ -604,7 +615,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = CW;      // pad = arena cell stride (0: plane-major)
         o.n_cells = n_cells; o.cells_used = cursor;
         for (int i_ = 0; i_ < 6; ++i_) o.seg[i_] = seg[i_];
-        if (!(b.dbg & 128)) { o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_flag_steps * 1000; }      // (dbg bit 7: keep the row loop's counters) backtrack: ticks spent staging arena windows, number of windows
+        // (dbg bit 7: keep the row loop's counters) backtrack: ticks spent staging arena windows, number of windows
+        if (!(b.dbg & 128)) { o.seg[5] = bt_win_ticks; o.seg[4] = bt_n_windows * 1000; o.seg[3] = bt_slow_steps * 1000; o.seg[0] = bt_wa; o.seg[1] = bt_wb; o.seg[2] = bt_flag_steps * 1000; }
         o.clk_dp = clk1 - clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - clk1; o.n_rows_done = rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }

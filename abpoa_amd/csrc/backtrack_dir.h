@@ -78,7 +78,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
     // ---- two wavefronts on the walk?
     typedef __attribute__((address_space(3))) volatile int lds_vint_t;
     const bool spec_static = role >= 0 && dir_walk_pair(b, d), spec = spec_static && status == 0;
-    auto start_row = [&](int r_) __attribute__((always_inline)) { return (int)(((long long)gn * (SPEC_WK - r_)) / SPEC_WK); };      // helper r starts at row gn (4 - r) / 4; its table covers the 256 rows below
+    // helper r starts at row gn (4 - r) / 4; its table covers the 256 rows below
+    auto start_row = [&](int r_) __attribute__((always_inline)) { return (int)(((long long)gn * (SPEC_WK - r_)) / SPEC_WK); };
     const int R_g = spec && role >= 1 ? start_row(role) : 0, R_lo = R_g - SPEC_PM_ROWS + 1;
     const int total_lds = b.lds.bt_off + b.lds.bt_bytes_tail;
     const int half_lds = spec_static ? ((total_lds - (SPEC_WK - 1) * SPEC_PM_ROWS * 4) / SPEC_WK) & ~15 : total_lds;      // each walk's share of the backtrack region; the tables sit behind them
@@ -165,7 +166,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             }
             int W[NQ], pc[NQ]; unsigned sa[NQ]; bool vq[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { vq[q] = hi - 64 * q - lane >= 1; W[q] = (es[q] - bs[q] + 1) * PN; pc[q] = bs[q] * PN; sa[q] = (unsigned)(co[q] * S); }      // (arena byte offsets fit 32 bits)
+            // (arena byte offsets fit 32 bits)
+            for (int q = 0; q < NQ; ++q) { vq[q] = hi - 64 * q - lane >= 1; W[q] = (es[q] - bs[q] + 1) * PN; pc[q] = bs[q] * PN; sa[q] = (unsigned)(co[q] * S); }
             const unsigned end_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(sa[0] + (unsigned)(W[0] * DB)));
             // whole rows: rows are adjacent in the arena, [start of row r, end of row hi) must fit
             int r_full = 0;
@@ -225,7 +227,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                         const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)srcq, u);
                         const int4 *sp = (const int4 *)(arena + so); unsigned char *dp = win + ob;
                         for (int i0 = 0; i0 < n_; i0 += 64)
-                            if (i0 + lane < n_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + i0 + lane), (__attribute__((address_space(3))) void *)(dp + i0 * 16), 16, 0, 0);
+                            if (i0 + lane < n_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + i0 + lane),
+                                    (__attribute__((address_space(3))) void *)(dp + i0 * 16), 16, 0, 0);
                     }
                 }
             }
@@ -290,7 +293,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                     const bool in2 = row_ >= 0 && (unsigned)tl_ < (unsigned)SPEC_PM_ROWS;
                     const int e_ = in2 ? ((lds_vint_t *)(pm_all + (t_next - 1) * SPEC_PM_ROWS))[tl_] : 0;
                     const unsigned long long hit_ = __ballot(in2 && e_ != 0 && (e_ & 0xffff) == col_);
-                    if (hit_) { const int f_ = __builtin_ctzll(hit_); idx1 = (int)((unsigned)__builtin_amdgcn_readlane(e_, f_) >> 16); met = t_next; run_n = f_; merged = true; if (run_n == 0) return; }
+                    if (hit_) { const int f_ = __builtin_ctzll(hit_); idx1 = (int)((unsigned)__builtin_amdgcn_readlane(e_, f_) >> 16); met = t_next; run_n = f_; merged = true; if (run_n == 0) return;
+                            }
                 }
                 if (role >= 1) { const int t_ = row_ - R_lo; if (lane < run_n && (unsigned)t_ < (unsigned)SPEC_PM_ROWS) pm[t_] = col_ | ((n_cigar + lane) << 16); }
             }
@@ -298,7 +302,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             // every cell a run passed must lie in its row's staged band (whole-row windows do not test it step by step; the rows of a run are all in the
             // current window: a run is flushed before the window changes): a cell outside is a dead end of the walk
             { const int st_ = B.stg[lane < run_n ? runv - w_lo : 0];
-              if (__any(lane < run_n && (unsigned)(run_j - lane - (st_ & 0x7fff)) >= ((unsigned)st_ >> 16))) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 1; dbg_a = ((long long)run_n << 32) | (unsigned)run_j; dbg_b = ((long long)w_lo << 32) | (unsigned)w_hi; } }
+              if (__any(lane < run_n && (unsigned)(run_j - lane - (st_ & 0x7fff)) >= ((unsigned)st_ >> 16))) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 1;
+                      dbg_a = ((long long)run_n << 32) | (unsigned)run_j; dbg_b = ((long long)w_lo << 32) | (unsigned)w_hi; } }
             n_cigar += run_n; n_aln += run_n; bt_steps += run_n; run_n = 0;
             last_word = (uint64_t)ABPOA_HIP_CMATCH;            // (the last word so far is a match: the next insertion starts a word of its own)
         };
@@ -328,7 +333,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                         int2 rc_v = lds_r(recp); int w_v = lds_w(wb + Ai), st_v = 0;
                         if (TRI) st_v = lds_i(stg_a + ((recp - rec_a) >> 1));
                         asm volatile("" : "+v"(w_v), "+v"(rc_v.x), "+v"(rc_v.y), "+v"(st_v));
-                        if (TRI) { const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane(st_v); if ((unsigned)(j - (int)(st & 0x7fffu)) >= (st >> 16)) break; }      // not staged: the full step sorts it out
+                        // not staged: the full step sorts it out
+                        if (TRI) { const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane(st_v); if ((unsigned)(j - (int)(st & 0x7fffu)) >= (st >> 16)) break; }
                         const unsigned k1 = ((unsigned)__builtin_amdgcn_readfirstlane(w_v) & 15u) - 1u;
                         if (k1 > 1u) break;                      // no match at this cell, or one through a later predecessor: the full step below
                         const unsigned long long pp = ((unsigned long long)(unsigned)rc_v.y << 32) | (unsigned long long)(unsigned)rc_v.x;
@@ -353,7 +359,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             const int2 pd2 = uniform2(B.pd[i - w_lo]);
             const int sli = stw & 0x7fff, cut = (stw >> 15) & 1, nsi = (int)((unsigned)stw >> 16), si = j - sli;
             if ((unsigned)si >= (unsigned)nsi || (si == 0 && cut)) {      // the cell (or, possibly, its stored left neighbour) is not staged: re-centre the window on (i, j) once
-                if (reloaded) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 2; dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)stw << 32) | (unsigned)Ai; break; }      // ... it is not there: outside the row's band, no such cell
+                // ... it is not there: outside the row's band, no such cell
+                if (reloaded) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 2; dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)stw << 32) | (unsigned)Ai; break; }
                 restage = true; continue;
             }
             reloaded = false;
@@ -363,7 +370,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
             const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(w_v), wl = si > 0 ? (unsigned)__builtin_amdgcn_readfirstlane(wl_v) : 0u;      // (wl == 0: column j - 1 is not stored)
             const int kM = (int)(w & 15u);
             int kE[2], uE[2], dF[2], lF[2];
-            if (GAP == 1) { kE[0] = (w >> DIRA_KE1_SH) & 15; uE[0] = (w >> DIRA_UE1_SH) & 7; dF[0] = (w >> DIRA_DF1_SH) & 7; lF[0] = (w >> DIRA_LF1_SH) & 3; kE[1] = 0; uE[1] = 0; dF[1] = 0; lF[1] = 0; }
+            if (GAP == 1) { kE[0] = (w >> DIRA_KE1_SH) & 15; uE[0] = (w >> DIRA_UE1_SH) & 7; dF[0] = (w >> DIRA_DF1_SH) & 7; lF[0] = (w >> DIRA_LF1_SH) & 3; kE[1] = 0; uE[1] = 0; dF[1] = 0;
+                    lF[1] = 0; }
             else { kE[0] = (w >> DIRC_KE1_SH) & 15; kE[1] = (w >> DIRC_KE2_SH) & 15; uE[0] = (w >> DIRC_UE1_SH) & 7; uE[1] = (w >> DIRC_UE2_SH) & 31;
                    dF[0] = (w >> DIRC_DF1_SH) & 7; dF[1] = (w >> DIRC_DF2_SH) & 31; lF[0] = (w >> DIRC_LF1_SH) & 3; lF[1] = (w >> DIRC_LF2_SH) & 3; }
             if (pend) { cur_op = uE[pend - 1] == 0 ? (OP_M | OP_F) : (pend == 1 ? OP_E1 : OP_E2); pend = 0; }      // the deletion that led here: was this cell's E opened from its H? (reference :200)
@@ -413,7 +421,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                         if (GAP == 1) { kMl = wl & 15; uEl0 = 0; uEl1 = 0; dFl = (wl >> DIRA_DF1_SH) & 7; }
                         else { kMl = wl & 15; uEl0 = (wl >> DIRC_UE1_SH) & 7; uEl1 = (wl >> DIRC_UE2_SH) & 31; dFl = x == 0 ? (wl >> DIRC_DF1_SH) & 7 : (wl >> DIRC_DF2_SH) & 31; }
                         const int h_is_hv = kMl != 0 || (GAP == 2 && (uEl0 == o1 || uEl1 == o2));
-                        if ((!h_is_hv && dFl > ox) || (b.dbg & 512)) { status = ABPOA_HIP_STATUS_NEED_SCORES; break; }      // the plane cannot decide this one (dir_plane.h); dbg bit 9: at the first insertion decided from the words (tests of the redo path)
+                        // the plane cannot decide this one (dir_plane.h); dbg bit 9: at the first insertion decided from the words (tests of the redo path)
+                        if ((!h_is_hv && dFl > ox) || (b.dbg & 512)) { status = ABPOA_HIP_STATUS_NEED_SCORES; break; }
                         lit = dir_f_origin(h_is_hv, dFl, ox);
                     }
                     if (lit == DIR_LIT_OPEN) { cur_op = OP_M | OP_E; hit = 1; }
@@ -423,7 +432,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 if (hit) { push(ABPOA_HIP_CINS, 1, i, j - 1); --j; ++n_aln; }
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
-            if (!hit && status == 0) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 3 | ((long long)cur_op << 8) | ((long long)indel_first << 16) | ((long long)n_general << 32); dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)w << 32) | (unsigned)pd2.x; }
+            if (!hit && status == 0) { status = ABPOA_HIP_EBACKTRACK; dbg_why = 3 | ((long long)cur_op << 8) | ((long long)indel_first << 16) | ((long long)n_general << 32);
+                    dbg_a = ((long long)i << 32) | (unsigned)j; dbg_b = ((long long)w << 32) | (unsigned)pd2.x; }
         }
         walk_ticks = (long long)__builtin_amdgcn_s_memtime() - t_walk0;
         if (status == 0) {
@@ -468,14 +478,16 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
                 const int op = (int)(wv & 0xf);
                 if (op == ABPOA_HIP_CINS) return wv;
                 const int row_ = (int)(wv >> 34);
-                if (op == ABPOA_HIP_CMATCH) { const int q = (int)((wv >> 4) & 0x3fffffffu); nm += (int)row_base[row_] == (int)g_query[q] ? 1 : 0; }      // (the query straight from HBM: this backtrack needs it nowhere else)
+                // (the query straight from HBM: this backtrack needs it nowhere else)
+                if (op == ABPOA_HIP_CMATCH) { const int q = (int)((wv >> 4) & 0x3fffffffu); nm += (int)row_base[row_] == (int)g_query[q] ? 1 : 0; }
                 return (wv & 0x3ffffffffull) | ((uint64_t)(int64_t)row_node_id[row_] << 34);
             };
             int nm = 0;
             const int half = n_cigar >> 1;
             static_assert(SPEC_WK == 4, "the chain below is written out for four segments");
             const int c0_ = seg_len[0], c1_ = c0_ + seg_len[1], c2_ = c1_ + seg_len[2];      // (segments that do not exist are empty)
-            const long long p1_ = (long long)seg_wk[1] * d.cigar_cap + seg_off[1] - c0_, p2_ = (long long)seg_wk[2] * d.cigar_cap + seg_off[2] - c1_, p3_ = (long long)seg_wk[3] * d.cigar_cap + seg_off[3] - c2_;
+            const long long p1_ = (long long)seg_wk[1] * d.cigar_cap + seg_off[1] - c0_, p2_ = (long long)seg_wk[2] * d.cigar_cap + seg_off[2] - c1_,
+                    p3_ = (long long)seg_wk[3] * d.cigar_cap + seg_off[3] - c2_;
             auto rd = [&](int k_) __attribute__((always_inline)) -> uint64_t {      // (a chain of walks: the words of the helpers follow this wavefront's)
                 const long long at_ = k_ < c0_ ? (long long)k_ : (k_ < c1_ ? p1_ + k_ : (k_ < c2_ ? p2_ + k_ : p3_ + k_));
                 return cg[at_];
@@ -501,7 +513,8 @@ __device__ __forceinline__ void finish_alignment_dir(const DevBatch &b, const Al
         o.n_aln_bases = n_aln; o.n_matched_bases = n_match; o.n_cigar = n_cigar; o.pad = -DB;      // pad < 0: direction-plane arena (bytes per word)
         o.n_cells = ts.n_cells; o.cells_used = ts.cursor;
         if (b.dbg & 256) { o.seg[0] = dbg_why; o.seg[1] = dbg_a; o.seg[2] = dbg_b; o.seg[3] = ((long long)best_i << 32) | (unsigned)best_j; o.seg[4] = n_cigar; o.seg[5] = bt_steps; }
-        else if (!(b.dbg & 128)) { o.seg[5] = win_ticks; o.seg[4] = (long long)n_windows * 1000; o.seg[3] = (long long)n_general * 1000; o.seg[0] = 0; o.seg[1] = walk_ticks; o.seg[2] = (long long)bt_steps * 1000; }
+        else if (!(b.dbg & 128)) { o.seg[5] = win_ticks; o.seg[4] = (long long)n_windows * 1000; o.seg[3] = (long long)n_general * 1000; o.seg[0] = 0; o.seg[1] = walk_ticks;
+                o.seg[2] = (long long)bt_steps * 1000; }
         o.clk_dp = ts.clk1 - ts.clk0; o.clk_bt = (long long)__builtin_amdgcn_s_memtime() - ts.clk1; o.n_rows_done = ts.rows_done; o.n_bt_steps = bt_steps;
         *out_rec = o;
     }

@@ -28,7 +28,8 @@ struct Blob {                   // device buffer with optional pinned host mirro
     void release();
 };
 
-struct StreamStats { int64_t n_launches = 0, n_alignments = 0, n_cells = 0, algo_bytes = 0, n_need_scores = 0; double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0, tail_ms = 0, rounds_ms = 0; int64_t rounds_launches = 0, rounds_algo_bytes = 0; };
+struct StreamStats { int64_t n_launches = 0, n_alignments = 0, n_cells = 0, algo_bytes = 0, n_need_scores = 0; double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0, tail_ms = 0, rounds_ms = 0;
+        int64_t rounds_launches = 0, rounds_algo_bytes = 0; };
 
 class BatchStream {
   public:
@@ -54,7 +55,8 @@ class BatchStream {
     Blob in_, out_, planes_;
     abpoa_hip_scoring_t sc_{}; std::vector<int32_t> mat_;
     unsigned flags_ = 0; int n_ = 0, P_ = 1;
-    std::vector<AlnDesc> desc_; std::vector<AlnOut> recs_; std::vector<int64_t> full_cells_, est_cells_, dir_full_cells_, dir_est_cells_;      // arena capacities (cells): score records full width / estimate, direction-plane arenas likewise
+    // arena capacities (cells): score records full width / estimate, direction-plane arenas likewise
+    std::vector<AlnDesc> desc_; std::vector<AlnOut> recs_; std::vector<int64_t> full_cells_, est_cells_, dir_full_cells_, dir_est_cells_;
     std::vector<std::vector<uint8_t>> trace_arena_;     // BS_TRACE: arena of every finished alignment, copied out before a retry pass re-uses the device arenas
     int64_t rows_tot_ = 0, preds_tot_ = 0, outs_tot_ = 0, q_tot_ = 0, cig_tot_ = 0;
     size_t o_desc_ = 0, o_mat_ = 0, o_query_ = 0, o_base_ = 0, o_sdist_ = 0, o_pd_ = 0, o_nid_ = 0, o_rem_ = 0, o_act_ = 0, o_poff_ = 0, o_pred_ = 0, o_ooff_ = 0, o_out_ = 0, in_bytes_ = 0;

@@ -28,7 +28,8 @@ static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
         told = true; int nb16 = 0, nb32 = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, dp_wide_kernel<GAP, 16, NW>, NW * 64, (size_t)b.lds.total_wide);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, dp_wide_kernel<GAP, 32, NW>, NW * 64, (size_t)b.lds.total_wide);
-        fprintf(stderr, "[abpoa-hip] wide row loop: %d wavefronts per alignment, %d B of LDS per workgroup, ring %d rows x %d columns, workgroups per CU: %d (int16) %d (int32)\n", NW, b.lds.total_wide, b.lds.wfr_rows, b.lds.wfr_cols, nb16, nb32);
+        fprintf(stderr, "[abpoa-hip] wide row loop: %d wavefronts per alignment, %d B of LDS per workgroup, ring %d rows x %d " "columns, workgroups per CU: %d (int16) %d (int32)\n", NW,
+                b.lds.total_wide, b.lds.wfr_rows, b.lds.wfr_cols, nb16, nb32);
     }
     if (mask == 3 && NW == 1) return launch_one(dp_wide_kernel<GAP, 0, NW, DIR>, b, stream, b.lds.total_wide, NW * 64);
     if (mask & 1) e = launch_one(dp_wide_kernel<GAP, 16, NW, DIR>, b, stream, b.lds.total_wide, NW * 64);

@@ -61,7 +61,8 @@ int engine_device() { return g.ready ? g.device : -1; }
 void add_global_stats(const StreamStats &s) {
     std::lock_guard<std::mutex> lk(g.stats_mu);
     g.stats.n_launches += s.n_launches; g.stats.n_alignments += s.n_alignments; g.stats.n_cells += s.n_cells;
-    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms; g.stats.tail_ms += s.tail_ms; g.stats.rounds_ms += s.rounds_ms; g.stats.rounds_launches += s.rounds_launches; g.stats.rounds_algo_bytes += s.rounds_algo_bytes;
+    g.stats.algo_bytes += s.algo_bytes; g.stats.kernel_ms += s.kernel_ms; g.stats.h2d_ms += s.h2d_ms; g.stats.d2h_ms += s.d2h_ms; g.stats.tail_ms += s.tail_ms; g.stats.rounds_ms += s.rounds_ms;
+    g.stats.rounds_launches += s.rounds_launches; g.stats.rounds_algo_bytes += s.rounds_algo_bytes;
 }
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -204,7 +205,8 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
         const int pv = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
         full_cells_[i] = width * pv * d.n_rows;
         int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
-        { const char *pct_ = getenv("ABPOA_HIP_ARENA_PCT"); if (pct_ && atoi(pct_) > 0 && atoi(pct_) < 100) est = std::max<int64_t>(pn, est * atoi(pct_) / 100); }      // (tests: force the overflow -> full-width retry path)
+        // (tests: force the overflow -> full-width retry path)
+        { const char *pct_ = getenv("ABPOA_HIP_ARENA_PCT"); if (pct_ && atoi(pct_) > 0 && atoi(pct_) < 100) est = std::max<int64_t>(pn, est * atoi(pct_) / 100); }
         d.plane_cap = std::min<int64_t>(full_cells_[i], width * pv + est * pv * (d.n_rows - 1));
         est_cells_[i] = d.plane_cap;
         // direction-plane arenas (dir_plane.h; run() decides whether a pass uses them): words of DB bytes per column for every row, score records for the
@@ -217,7 +219,8 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
     o_desc_ = take(sizeof(AlnDesc) * n); o_mat_ = take(sizeof(int32_t) * sc->m * sc->m); o_query_ = take(q_tot_ + 1);
     o_base_ = take(rows_tot_); o_sdist_ = take(rows_tot_); o_pd_ = take(8 * rows_tot_); o_nid_ = take(4 * rows_tot_); o_rem_ = take(4 * rows_tot_); o_act_ = take(rows_tot_);
-    o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1) + 4 * 512);   // slack: tile prefetch over-reads up to TP entries
+    // slack: tile prefetch over-reads up to TP entries
+    o_poff_ = take(4 * (rows_tot_ + n)); o_pred_ = take(4 * (preds_tot_ + 1)); o_ooff_ = take(4 * (rows_tot_ + n)); o_out_ = take(4 * (outs_tot_ + 1) + 4 * 512);
     in_bytes_ = o;
     o = 0;
     o_rec_ = take(sizeof(AlnOut) * n); o_cig_ = take(8 * cig_tot_); o_left_ = take(4 * rows_tot_); o_right_ = take(4 * rows_tot_);
@@ -386,7 +389,8 @@ int BatchStream::run() {
         std::vector<int> again; bool need_scores = false;
         for (size_t t = 0; t < todo.size(); ++t) {
             const int i = todo[t]; const AlnOut &r = got[t]; const AlnDesc &d = desc_[i];
-            if (r.status == ABPOA_HIP_STATUS_NEED_SCORES && dir) { need_scores = true; again.push_back(i); stats_.n_need_scores += 1; __atomic_fetch_add(&g_dir_counts[1], 1, __ATOMIC_RELAXED); continue; }
+            if (r.status == ABPOA_HIP_STATUS_NEED_SCORES && dir) { need_scores = true; again.push_back(i); stats_.n_need_scores += 1; __atomic_fetch_add(&g_dir_counts[1], 1, __ATOMIC_RELAXED);
+                    continue; }
             if (r.status == ABPOA_HIP_STATUS_OVERFLOW) {
                 if (!first_pass) { set_err("problem %d: arena overflow at full width (internal error)", i); return ABPOA_HIP_ELAUNCH; }
                 again.push_back(i); continue;
@@ -445,7 +449,8 @@ int BatchStream::fetch_trace(int i, const uint8_t *row_active, abpoa_hip_trace_t
             const uint8_t *src = arena.data() + coff[rr] * (d.bits / 8);
             for (int64_t x = 0; x < W; ++x) {
                 const uint32_t wv = cw == -2 ? (uint32_t)((const uint16_t *)src)[x] : ((const uint32_t *)src)[x];
-                if (d.bits == 16) { ((int16_t *)T->planes)[T->row_off[rr] + x] = (int16_t)wv; if (cw == -4) ((int16_t *)T->planes)[T->row_off[rr] + W + x] = (int16_t)(wv >> 16); }      // (32-bit words in 16-bit planes: low half in plane 0, high half in plane 1)
+                // (32-bit words in 16-bit planes: low half in plane 0, high half in plane 1)
+                if (d.bits == 16) { ((int16_t *)T->planes)[T->row_off[rr] + x] = (int16_t)wv; if (cw == -4) ((int16_t *)T->planes)[T->row_off[rr] + W + x] = (int16_t)(wv >> 16); }
                 else ((int32_t *)T->planes)[T->row_off[rr] + x] = (int32_t)wv;
             }
             continue;

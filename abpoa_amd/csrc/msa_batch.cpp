@@ -27,7 +27,8 @@ std::mutex g_dig_mu; std::unordered_map<uint64_t, uint64_t> g_dig;
 // same arithmetic as poa_device.h (poa_mix64 / poa_cigar_word_mix / poa_cigar_digest_round), restated: this file also builds without HIP (tests/cpu_shim.cpp)
 uint64_t digest_mix64(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 uint64_t digest_word_mix(uint64_t word, int i) { return digest_mix64(word + 0xD6E8FEB86659FD93ull * (uint64_t)(i + 1)); }
-uint64_t digest_round(uint64_t before, int read_index, int n_cigar, uint64_t sum) { return (before * 0x9E3779B97F4A7C15ull) ^ (sum + digest_mix64(((uint64_t)(uint32_t)read_index << 32) | (uint32_t)n_cigar)); }
+uint64_t digest_round(uint64_t before, int read_index, int n_cigar, uint64_t sum) { return (before * 0x9E3779B97F4A7C15ull) ^ (sum + digest_mix64(((uint64_t)(uint32_t)read_index
+        << 32) | (uint32_t)n_cigar)); }
 uint64_t fnv64(const void *p, size_t n, uint64_t h = 1469598103934665603ull) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
 }
 bool cigar_digest_on() { static const bool on = getenv("ABPOA_HIP_CIGAR_DIGEST") && atoi(getenv("ABPOA_HIP_CIGAR_DIGEST")); return on; }

@@ -19,6 +19,7 @@
 #include "poa_graph.h"
 #include "dir_plane.h"
 #include "msa_batch.h"
+#include "msa_device_debug.h"
 
 namespace abpoa_hip {
 
@@ -40,61 +41,60 @@ void parallel_ranges(int n_threads, int n, F fn) {
 }
 size_t up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// ABPOA_HIP_DEVICE_AUDIT=1 (multi-GPU runs: SURVEY.md section 8e): every pool allocation of a device queue is looked up with hipPointerGetAttributes and must
+//  sit
+// on the device the queue serves -- and the calling thread's current device must be that one -- or the call fails with ABPOA_HIP_ENODEV; ABPOA_HIP_VERBOSE=1
+// prints where each allocation landed.  (The HIP device is per host thread; a queue thread that forgot hipSetDevice would put its pools on device 0.)
+thread_local int t_queue_device = -1;
+int audit_allocation(const void *ptr, size_t bytes, const char *what) {
+    static const bool on = getenv("ABPOA_HIP_DEVICE_AUDIT") && atoi(getenv("ABPOA_HIP_DEVICE_AUDIT"));
+    if (!on || t_queue_device < 0) return 0;
+    int cur = -1; (void)hipGetDevice(&cur);
+    hipPointerAttribute_t at; memset(&at, 0, sizeof(at));
+    const hipError_t e = hipPointerGetAttributes(&at, ptr);
+    if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] audit: %s, %zu bytes: device %d (queue device %d, thread's current device %d)\n", what,
+            bytes, e == hipSuccess ? at.device : -1, t_queue_device, cur);
+    if (e != hipSuccess || cur != t_queue_device || (at.type == hipMemoryTypeDevice && at.device != t_queue_device)) {
+        set_err("device audit: %s of %zu bytes on device %d, queue serves device %d, thread's current device %d", what, bytes,
+                e == hipSuccess ? at.device : -1, t_queue_device, cur);
+        return ABPOA_HIP_ENODEV;
+    }
+    return 0;
+}
+
 struct Arena {                 // grow-only device / pinned-host buffers kept across calls (one job at a time, see g_mu)
     uint8_t *dev = nullptr, *host = nullptr; size_t dev_cap = 0, host_cap = 0;
     int need_dev(size_t n) {
         if (n <= dev_cap) return 0;
         if (dev) (void)hipFree(dev);
         dev = nullptr; dev_cap = 0;
-        HIP_OK(hipMalloc((void **)&dev, n), ABPOA_HIP_ENOMEM); dev_cap = n; return 0;
+        HIP_OK(hipMalloc((void **)&dev, n), ABPOA_HIP_ENOMEM); dev_cap = n; return audit_allocation(dev, n, "device pool");
     }
     int need_host(size_t n) {
         if (n <= host_cap) return 0;
         if (host) (void)hipHostFree(host);
         host = nullptr; host_cap = 0;
-        HIP_OK(hipHostMalloc((void **)&host, n, hipHostMallocDefault), ABPOA_HIP_ENOMEM); host_cap = n; return 0;
+        HIP_OK(hipHostMalloc((void **)&host, n, hipHostMallocDefault), ABPOA_HIP_ENOMEM); host_cap = n;
+        return audit_allocation(host, n, "pinned staging buffer");
     }
 };
-struct Cache { Arena in, graph, rows, planes, out, msa; hipStream_t stream = nullptr, copy_stream = nullptr; hipEvent_t ev_copy = nullptr; std::vector<hipEvent_t> ev; int device = -1; };
+struct Cache { Arena in, graph, rows, planes, out, msa; hipStream_t stream = nullptr, copy_stream = nullptr; hipEvent_t ev_copy = nullptr;
+        std::vector<hipEvent_t> ev; int device = -1; };
 Cache g_cache[MSA_DEVICE_SLOTS]; std::mutex g_cache_mu[MSA_DEVICE_SLOTS];      // one per worker of the multi-device batch call
 
 struct Layout {                // byte offsets inside the three device blobs
     // in blob (uploaded): sets, read tables, reads, score matrix
-    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, o_wts, in_bytes, o_rc, o_wrc, in_dev_bytes;      // (o_rc, o_wrc: device only, behind the uploaded part)
+    // (o_rc, o_wrc: device only, behind the uploaded part)
+    size_t o_sets, o_roff, o_rlen, o_reads, o_mat, o_rargs, o_msaoff_h, o_wts, in_bytes, o_rc, o_wrc, in_dev_bytes;
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
     size_t o_cnode, o_ccov, o_cbase, o_isrc;
-    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, o_rid, o_mrank, o_msaoff, graph_bytes;
+    size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, o_rid, o_mrank,
+            o_msaoff, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
-    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, o_ooff, o_orow, o_left, o_right, o_act, o_outfwd, o_cigfwd, o_retry, rows_bytes;
+    size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, o_ooff,
+            o_orow, o_left, o_right, o_act, o_outfwd, o_cigfwd, o_retry, rows_bytes;
 };
 
-// Heaviest-bundling consensus (reference src/abpoa_output.c:361-415, :343-356) straight from the flat device arrays, walking
-// the rows in reverse topological order instead of the reference's reverse Kahn queue: every quantity is a function of the
-// successors' values only, so the visiting order does not matter as long as successors come first.
-void consensus_flat(int n, const int32_t *order, const uint8_t *base, const uint8_t *nout, const int32_t *out_id, const int32_t *out_w,
-                    const int32_t *n_read, std::vector<int> *ids, std::vector<uint8_t> *bases, std::vector<int> *cov, std::vector<int> &score, std::vector<int> &max_out) {
-    ids->clear(); bases->clear(); cov->clear();
-    if (n <= 2) return;
-    score.assign(n, 0); max_out.assign(n, -1);
-    for (int r = n - 1; r >= 0; --r) {
-        const int cur = order[r];
-        const int32_t *oi = out_id + (size_t)cur * POA_OUT_CAP, *ow = out_w + (size_t)cur * POA_OUT_CAP; const int no = nout[cur];
-        if (cur == 1) { max_out[cur] = -1; score[cur] = 0; }
-        else if (cur == 0) {
-            int path_score = -1, path_max_w = -1, max_id = -1;
-            for (int i = 0; i < no; ++i) if (ow[i] > path_max_w || (ow[i] == path_max_w && score[oi[i]] > path_score)) { max_id = oi[i]; path_score = score[oi[i]]; path_max_w = ow[i]; }
-            max_out[cur] = max_id;
-        } else {
-            int max_w = INT_MIN, max_id = -1;
-            for (int i = 0; i < no; ++i) {
-                if (max_w < ow[i]) { max_w = ow[i]; max_id = oi[i]; }
-                else if (max_w == ow[i] && score[max_id] <= score[oi[i]]) max_id = oi[i];
-            }
-            score[cur] = max_w + score[max_id]; max_out[cur] = max_id;
-        }
-    }
-    for (int cur = max_out[0]; cur != 1 && cur >= 0; cur = max_out[cur]) { ids->push_back(cur); bases->push_back(base[cur]); cov->push_back(n_read[cur]); }
-}
 }  // namespace
 
 void release_msa_device_caches() {
@@ -105,7 +105,8 @@ void release_msa_device_caches() {
         if (C.device < 0) continue;
         (void)hipSetDevice(C.device);
         if (C.stream) (void)hipStreamSynchronize(C.stream);
-        for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out, &C.msa}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
+        for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out, &C.msa}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host);
+                *a = Arena(); }
     }
     if (cur >= 0) (void)hipSetDevice(cur);
 }
@@ -116,11 +117,13 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;
     if (sc->m - 1 > POA_ALN_MAX || sc->m < 2) return false;
-    if ((flags & ABPOA_HIP_AMB_STRAND) && getenv("ABPOA_HIP_NO_DEVICE_STRAND") && atoi(getenv("ABPOA_HIP_NO_DEVICE_STRAND"))) return false;      // (-s on the host driver, as before round 4)
+    // (-s on the host driver, as before round 4)
+    if ((flags & ABPOA_HIP_AMB_STRAND) && getenv("ABPOA_HIP_NO_DEVICE_STRAND") && atoi(getenv("ABPOA_HIP_NO_DEVICE_STRAND"))) return false;
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && getenv("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_LOCAL"))) return false;
     // every gap model and alignment mode: the fast row loops where they apply (banded global, short local), the general kernel otherwise (linear gaps,
     // extension mode with or without z-drop, global mode without a band, long local reads).  ABPOA_HIP_NO_DEVICE_GENERAL=1 sends those back to the host driver.
-    const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && ((sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0) || sc->align_mode == ABPOA_HIP_LOCAL_MODE);
+    const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && ((sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0)
+            || sc->align_mode == ABPOA_HIP_LOCAL_MODE);
     if (!fast && getenv("ABPOA_HIP_NO_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_GENERAL"))) return false;
     return true;
 }
@@ -132,7 +135,8 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
     LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
     make_lds_plan(sc, max_qlen, mb, std::min<int64_t>((int64_t)((max_qlen + pn_) / pn_) * pn_, 2LL * w_max + 3 * pn_ + 32), n_sets, &pl);
     if (pl.wide_nw != 1 || !(w_max >= pl.wide_w_lo && w_max <= pl.wide_w_hi) || pl.total_wide <= 0) return 0;
-    int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
     // (LDS is handed out in pieces of 1280 B, 128 per CU: tools/probes/lds_granule.hip; 166-192 VGPRs: two wavefronts per SIMD at most)
     const int per_cu = std::max(1, std::min(8, 128 / ((pl.total_wide + 1279) / 1280)));
     return per_cu * cus;
@@ -143,7 +147,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     abpoa_hip_scoring_t sc_norm = *sc_in; const bool local = sc_in->align_mode == ABPOA_HIP_LOCAL_MODE, extend = sc_in->align_mode == ABPOA_HIP_EXTEND_MODE;
     if (local) sc_norm.wb = -1;                                  // reference abpoa_post_set_para, src/abpoa_align.c:150
     const abpoa_hip_scoring_t *sc = &sc_norm;
-    const bool amb = flags & ABPOA_HIP_AMB_STRAND;      // -s: low-scoring reads are aligned again as their reverse complement (poa_device.hip poa_strand_check_kernel)
+    // -s: low-scoring reads are aligned again as their reverse complement (poa_device.hip poa_strand_check_kernel)
+    const bool amb = flags & ABPOA_HIP_AMB_STRAND;
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;
     if (slot < 0 || slot >= MSA_DEVICE_SLOTS) { set_err("bad device slot %d", slot); return ABPOA_HIP_EINVAL; }
     std::lock_guard<std::mutex> lk(g_cache_mu[slot]);
@@ -151,11 +156,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     if (device < 0) device = engine_device();
     if (device < 0) { set_err("engine not initialised"); return ABPOA_HIP_ENODEV; }
     HIP_OK(hipSetDevice(device), ABPOA_HIP_ENODEV);          // (the HIP device is per host thread)
+    t_queue_device = device;
     if (C.device != device) {
         if (C.device >= 0) {      // the slot served another device before: its pools and stream live there
             (void)hipSetDevice(C.device);
-            for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out, &C.msa}) { if (a->dev) (void)hipFree(a->dev); if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
-            if (C.stream) (void)hipStreamDestroy(C.stream); if (C.copy_stream) (void)hipStreamDestroy(C.copy_stream); if (C.ev_copy) (void)hipEventDestroy(C.ev_copy);
+            for (Arena *a : {&C.in, &C.graph, &C.rows, &C.planes, &C.out, &C.msa}) { if (a->dev) (void)hipFree(a->dev);
+                    if (a->host) (void)hipHostFree(a->host); *a = Arena(); }
+            if (C.stream) (void)hipStreamDestroy(C.stream); if (C.copy_stream) (void)hipStreamDestroy(C.copy_stream);
+            if (C.ev_copy) (void)hipEventDestroy(C.ev_copy);
             for (hipEvent_t e : C.ev) (void)hipEventDestroy(e);
             C = Cache();
             HIP_OK(hipSetDevice(device), ABPOA_HIP_ENODEV);
@@ -166,7 +174,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     fallback->clear();
     if (stats) memset(stats, 0, sizeof(*stats));
     const double t_begin = now_s();
-    // values per DP column in an arena of score records: one padded cell record of the fast loops (4 / 8 values) = the planes of the general kernel (engine.cpp pv)
+    // values per DP column in an arena of score records: one padded cell record of the fast loops (4 / 8 values) = the planes of the general kernel (engine.cpp
+    //  pv)
     const int CW = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
     const bool unbanded = sc->wb < 0;
     // ---- sizes
@@ -174,7 +183,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     for (int s = 0; s < n_sets; ++s) {
         max_reads = std::max(max_reads, sets[s].n_reads); tot_reads += sets[s].n_reads;
         int64_t sum = 0; int mx = 0;
-        for (int r = 0; r < sets[s].n_reads; ++r) { max_qlen = std::max(max_qlen, sets[s].lens[r]); mx = std::max(mx, sets[s].lens[r]); sum += sets[s].lens[r]; }
+        for (int r = 0; r < sets[s].n_reads; ++r) { max_qlen = std::max(max_qlen, sets[s].lens[r]); mx = std::max(mx, sets[s].lens[r]); sum += sets[s].lens[r];
+                }
         tot_bases += sum; max_cap0 = std::max(max_cap0, std::min<int64_t>(2 + sum, 2 + (int64_t)(node_factor * mx) + 1024));
     }
     // Which kernels: the fast row loops (rows_fast.h: banded global, affine / convex; rows_local.h: local, int16, up to 575 columns) or -- `general` -- the
@@ -183,13 +193,16 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     {   LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, (int)max_cap0, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
         const int64_t width_ = (int64_t)((max_qlen + pn_) / pn_) * pn_, w_ = sc->wb + (int)(sc->wf * (float)max_qlen);
         make_lds_plan(sc, max_qlen, mb, (local || unbanded) ? width_ : std::min<int64_t>(width_, 2LL * w_ + 3 * pn_ + 32), n_sets, &pl);
-        const bool fast_global = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && !unbanded && pl.fr_cols > 0 && max_qlen <= pl.q_cap;
-        const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols && max_qlen <= pl.q_cap;
+        const bool fast_global = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && !unbanded && pl.fr_cols > 0
+                && max_qlen <= pl.q_cap;
+        const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols
+                && max_qlen <= pl.q_cap;
         general = !(fast_global || fast_local);
         if (getenv("ABPOA_HIP_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_DEVICE_GENERAL"))) general = true;      // (tests: the general kernel for every job)
     }
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
-    const bool dir = !local && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
+    const bool dir = !local && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
+            sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
                      !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
 
@@ -197,12 +210,15 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
     const int aln_cap = std::max(1, sc->m - 1), rid_words = want_msa ? std::max(1, (max_reads + 63) / 64) : 0;
-    auto est_cols = [&](int64_t width, int w, int pn) { return (local || unbanded) ? width : std::min<int64_t>(width, 2LL * w + 3 * pn + 32); };      // columns per row: the whole query without a band
-    int wide_lo = 1, wide_hi = 0, wide_ring_rows = 16;      // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off), depth of its score ring
+    // columns per row: the whole query without a band
+    auto est_cols = [&](int64_t width, int w, int pn) { return (local || unbanded) ? width : std::min<int64_t>(width, 2LL * w + 3 * pn + 32); };
+    // band half-widths that take the wide row loop (LdsPlan.wide_w_lo / hi; none when the wide kernels are off), depth of its score ring
+    int wide_lo = 1, wide_hi = 0, wide_ring_rows = 16;
     { LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, 3 * max_qlen + 1024, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
       make_lds_plan(sc, max_qlen, mb, est_cols((int64_t)((max_qlen + pn_) / pn_) * pn_, w_max, pn_), n_sets, &pl);
       if (pl.wide_nw >= 1 && !local && !general) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
-    // cigar slots: four times the words of a backtrack where the all-rounds kernel's helper wavefronts write their parts (backtrack_dir.h SPEC_WK, dir_walk_pair)
+    // cigar slots: four times the words of a backtrack where the all-rounds kernel's helper wavefronts write their parts (backtrack_dir.h SPEC_WK,
+    //  dir_walk_pair)
     const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo);
     // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
     // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the
@@ -222,8 +238,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         S.read0 = read_i; read_i += sets[s].n_reads;
         S.node0 = node_tot; node_tot += cap + 1;
         S.pred0 = pred_tot; pred_tot += S.pred_cap;
-        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += ((rounds_possible && S.cigar_cap < 65536) ? 4 : 1) * (int64_t)S.cigar_cap;      // (four times: parts 1-3 take the words of the helper wavefronts)
-        S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + 4 * cap + 8;      // (fuse: 3 x qlen + nodes; order / rank passes: up to four tables of one int per node)
+        // (four times: parts 1-3 take the words of the helper wavefronts)
+        S.cigar_cap = (int)(cap + mx + 8); S.cigar_off = cig_tot; cig_tot += ((rounds_possible && S.cigar_cap < 65536) ? 4 : 1) * (int64_t)S.cigar_cap;
+        // (fuse: 3 x qlen + nodes; order / rank passes: up to four tables of one int per node)
+        S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + 4 * cap + 8;
         S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
         const int w = sc->wb + (int)(sc->wf * (float)mx);
         max_node_cap = std::max(max_node_cap, (int)cap);
@@ -245,7 +263,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             const bool wide_s = !local && w >= wide_lo && w <= wide_hi;
             const bool dir_s = dir && (dw || !wide_s);      // (dp_common.h takes_dir)
             const int64_t rec_div = (wide_s && wide_ring_rows <= 4) ? 2 : 4;
-            // (bytes per cell record of a row that keeps its scores: CW values -- the wide kernel's compact records: 4 B int16 affine, else 8 B; rows_fast.h CWR)
+            // (bytes per cell record of a row that keeps its scores: CW values -- the wide kernel's compact records: 4 B int16 affine, else 8 B; rows_fast.h
+            //  CWR)
             const int64_t recb = wide_s ? ((bits == 16 && CW == 4) ? 4 : 8) : CW * (bits / 8);
             // (local row loop, rows_local.h: every row the whole query wide, cell records, 64 records of slack behind the last row)
             const int64_t bytes = local ? (int64_t)up((size_t)((width * cap + 64) * CW * (bits / 8) + 64 * 8 * 4))
@@ -257,11 +276,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     size_arenas(dir_wide);
     Layout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = up(o + bytes); return at; };
-    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m); L.o_rargs = take(poa_rounds_args_bytes()); L.o_msaoff_h = take(want_msa ? 8 * (size_t)n_sets : 0);      // (o_rargs, o_msaoff_h: host-side staging only)
+    // (o_rargs, o_msaoff_h: host-side staging only)
+    L.o_sets = take(sizeof(PoaSet) * n_sets); L.o_roff = take(8 * (tot_reads + 1)); L.o_rlen = take(4 * (tot_reads + 1)); L.o_mat = take(4 * sc->m * sc->m);
+    L.o_rargs = take(poa_rounds_args_bytes()); L.o_msaoff_h = take(want_msa ? 8 * (size_t)n_sets : 0);
     bool any_w = false; for (int s = 0; s < n_sets && !any_w; ++s) any_w = sets[s].weights != nullptr;
     L.o_wts = take(any_w ? 4 * (size_t)(tot_bases + 64) : 0);      // (per-base weights, -Q: in front of the reads, so that they go up with the first part)
     L.o_reads = take(tot_bases + 64); L.in_bytes = o;      // reads last: they go up in two parts
-    L.o_rc = take(amb ? tot_bases + 64 : 0); L.o_wrc = take(amb && any_w ? 4 * (size_t)(tot_bases + 64) : 0); L.in_dev_bytes = o;      // -s: reverse complements / reversed weights of the reads under retry
+    // -s: reverse complements / reversed weights of the reads under retry
+    L.o_rc = take(amb ? tot_bases + 64 : 0); L.o_wrc = take(amb && any_w ? 4 * (size_t)(tot_bases + 64) : 0); L.in_dev_bytes = o;
     o = 0;
     L.o_state = take(sizeof(PoaState) * n_sets);
     // downloaded part first, contiguous: per-set state and the consensus results
@@ -269,41 +291,53 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     const size_t dl_bytes = o;
     L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
     L.o_out = take(4 * node_tot * POA_HOT); L.o_outw = take(4 * node_tot * POA_HOT); L.o_nread = take(4 * node_tot);
-    L.o_outx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_outwx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_inx = take(4 * node_tot * (POA_IN_CAP - POA_HOT));
-    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * (size_t)aln_cap); L.o_row = take(4 * node_tot);
-    L.o_rid = take(8 * node_tot * POA_OUT_CAP * (size_t)rid_words); L.o_mrank = take(want_msa ? 4 * node_tot : 0); L.o_msaoff = take(want_msa ? 8 * (size_t)n_sets : 0);
+    L.o_outx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_outwx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT));
+    L.o_inx = take(4 * node_tot * (POA_IN_CAP - POA_HOT));
+    L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * (size_t)aln_cap);
+    L.o_row = take(4 * node_tot);
+    L.o_rid = take(8 * node_tot * POA_OUT_CAP * (size_t)rid_words); L.o_mrank = take(want_msa ? 4 * node_tot : 0);
+    L.o_msaoff = take(want_msa ? 8 * (size_t)n_sets : 0);
     L.graph_bytes = o;
     o = 0;
     L.o_ticket = take(4 * POA_CU_TICKETS);
     L.o_aln_desc = take(sizeof(AlnDesc) * n_sets); L.o_out_rec = take(sizeof(AlnOut) * n_sets);
-    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rpd = take(8 * node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot); L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
+    L.o_rbase = take(node_tot); L.o_rsd = take(node_tot); L.o_rpd = take(8 * node_tot); L.o_rnid = take(4 * node_tot); L.o_rrem = take(4 * node_tot);
+    L.o_poff = take(4 * node_tot); L.o_pred = take(4 * (pred_tot + 1));
     L.o_bsn = take(4 * node_tot); L.o_esn = take(4 * node_tot); L.o_coff = take(8 * node_tot); L.o_rmi = take(4 * node_tot);
     L.o_cigar = take(8 * cig_tot); L.o_scratch = take(4 * scr_tot);
     // general kernel (rows_general.h): successor CSR, band state per row, the "row is part of the alignment" bytes (all ones: no sub-graph alignments here)
     const bool gen_io = general || amb;      // (-s: the retry runs in the general kernel)
-    L.o_ooff = take(gen_io ? 4 * node_tot : 0); L.o_orow = take(gen_io ? 4 * (pred_tot + 1) : 0); L.o_left = take(gen_io ? 4 * node_tot : 0); L.o_right = take(gen_io ? 4 * node_tot : 0); L.o_act = take(gen_io ? node_tot : 0);
+    L.o_ooff = take(gen_io ? 4 * node_tot : 0); L.o_orow = take(gen_io ? 4 * (pred_tot + 1) : 0); L.o_left = take(gen_io ? 4 * node_tot : 0);
+    L.o_right = take(gen_io ? 4 * node_tot : 0); L.o_act = take(gen_io ? node_tot : 0);
     L.o_outfwd = take(amb ? sizeof(AlnOut) * n_sets : 0); L.o_cigfwd = take(amb ? 8 * cig_tot : 0); L.o_retry = take(amb ? (size_t)n_sets : 0);
     L.rows_bytes = o;
 
     {   // the whole job must fit (the caller splits very large jobs): checked on the computed layout, before any cached buffer is given up
         size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t want[4] = {L.in_dev_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap, C.planes.dev_cap};
+        const size_t want[4] = {L.in_dev_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot}, have[4] = {C.in.dev_cap, C.graph.dev_cap, C.rows.dev_cap,
+                C.planes.dev_cap};
         size_t need = 0, given_back = 0;
         for (int i = 0; i < 4; ++i) if (want[i] > have[i]) { need += want[i]; given_back += have[i]; }      // a buffer that must grow is freed first
-        if (need > free_b + given_back && dir_wide_auto && any_wide_set && !dir_wide) {      // the record arenas of the wide-band sets do not fit: direction words for them too
+        // the record arenas of the wide-band sets do not fit: direction words for them too
+        if (need > free_b + given_back && dir_wide_auto && any_wide_set && !dir_wide) {
             dir_wide = true; size_arenas(true);
             need = 0; given_back = 0;
             const size_t want2[4] = {L.in_dev_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot};
             for (int i = 0; i < 4; ++i) if (want2[i] > have[i]) { need += want2[i]; given_back += have[i]; }
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device %d: %d sets: score-record arenas do not fit, direction words for the wide-band sets too (arenas %.1f GB)\n", device, n_sets, plane_tot / 1e9);
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr,
+                    "[abpoa-hip] device %d: %d sets: score-record arenas do not fit, direction words for the wide-band sets " "too (arenas %.1f GB)\n", device,
+                    n_sets, plane_tot / 1e9);
         }
         if (need > free_b + given_back) {
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] device %d: %d sets need %.1f GB in growing buffers (arenas %.1f GB), %.1f GB free + %.1f GB given back: splitting\n", device, n_sets, need / 1e9, plane_tot / 1e9, free_b / 1e9, given_back / 1e9);
+            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr,
+                    "[abpoa-hip] device %d: %d sets need %.1f GB in growing buffers (arenas %.1f GB), %.1f GB free + %.1f " "GB given back: splitting\n",
+                    device, n_sets, need / 1e9, plane_tot / 1e9, free_b / 1e9, given_back / 1e9);
             set_err("device-resident job needs %zu more bytes, %zu free", need, free_b + given_back); return ABPOA_HIP_ENOMEM;
         }
     }
     int rc;
-    if ((rc = C.in.need_dev(L.in_dev_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc = C.graph.need_host(dl_bytes)) ||
+    if ((rc = C.in.need_dev(L.in_dev_bytes)) || (rc = C.in.need_host(L.in_bytes)) || (rc = C.graph.need_dev(L.graph_bytes)) || (rc =
+            C.graph.need_host(dl_bytes)) ||
         (rc = C.rows.need_dev(L.rows_bytes)) || (rc = C.planes.need_dev((size_t)plane_tot))) return rc;
     const int n_ev = 4 * max_reads + 8;
     while ((int)C.ev.size() < n_ev) { hipEvent_t e; HIP_OK(hipEventCreate(&e), ABPOA_HIP_ENODEV); C.ev.push_back(e); }
@@ -319,14 +353,16 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         int64_t at = 0;
         for (int k = 0; k < max_reads; ++k) {
             if (k == 2) split_at = at;
-            for (int s = 0; s < n_sets; ++s) if (k < sets[s].n_reads) { const int64_t ri = ps[s].read0 + k; roff[ri] = at; rlen[ri] = sets[s].lens[k]; at += sets[s].lens[k]; }
+            for (int s = 0; s < n_sets; ++s) if (k < sets[s].n_reads) { const int64_t ri = ps[s].read0 + k; roff[ri] = at; rlen[ri] = sets[s].lens[k];
+                    at += sets[s].lens[k]; }
         }
         if (max_reads <= 2) split_at = at;
         roff[tot_reads] = at;
     }
     auto stage_reads = [&](int k_lo, int k_hi) {
         parallel_ranges(std::min(n_threads, 16), n_sets, [&](int lo, int hi_) {
-            for (int s = lo; s < hi_; ++s) { const int64_t r0 = ps[s].read0; const int ke = std::min(k_hi, sets[s].n_reads); for (int r = k_lo; r < ke; ++r) memcpy(rd + roff[r0 + r], sets[s].seqs[r], sets[s].lens[r]); }
+            for (int s = lo; s < hi_; ++s) { const int64_t r0 = ps[s].read0; const int ke = std::min(k_hi, sets[s].n_reads);
+                    for (int r = k_lo; r < ke; ++r) memcpy(rd + roff[r0 + r], sets[s].seqs[r], sets[s].lens[r]); }
         });
     };
     stage_reads(0, 2);
@@ -341,26 +377,32 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     }
     memcpy(hi + L.o_mat, sc->mat, 4 * sc->m * sc->m);
     hipStream_t st = C.stream;
-    if (!C.copy_stream) { HIP_OK(hipStreamCreateWithFlags(&C.copy_stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV); HIP_OK(hipEventCreateWithFlags(&C.ev_copy, hipEventDisableTiming), ABPOA_HIP_ENODEV); }
+    if (!C.copy_stream) { HIP_OK(hipStreamCreateWithFlags(&C.copy_stream, hipStreamNonBlocking), ABPOA_HIP_ENODEV);
+            HIP_OK(hipEventCreateWithFlags(&C.ev_copy, hipEventDisableTiming), ABPOA_HIP_ENODEV); }
     HIP_OK(hipMemcpyAsync(C.in.dev, hi, L.o_reads + (size_t)split_at, hipMemcpyHostToDevice, st), ABPOA_HIP_ELAUNCH);
     bool rest_up = split_at >= roff[tot_reads];      // nothing left for the second part
 
     // ---- kernel arguments
     uint8_t *di = C.in.dev, *dg = C.graph.dev, *dr = C.rows.dev;
     PoaDev p; memset(&p, 0, sizeof(p));
-    p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2; p.e2 = sc->gap_ext2;
+    p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2;
+    p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
     p.dig_on = cigar_digest_on() ? 1 : 0;      // (tests: the fuse phase folds every graph cigar into PoaState.cigar_dig)
     // (the reference's own row order where the best cell is the FIRST row that reaches the maximum: local and extension mode, ref :1012-1026; the remaining
     //  length where something reads it: the adaptive band and the z-drop test)
-    p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = (local || extend) ? 1 : 0; p.banded = (sc->wb >= 0 || sc->zdrop > 0) ? 1 : 0; p.general = general ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
-    // LDS tables of the order / rank kernels (two ints per node; the rank pass packs four tables into the same space): up to 6000 nodes = 52 KB, three workgroups per CU
+    p.aln_cap = aln_cap; p.rid_words = rid_words; p.order_mode = (local || extend) ? 1 : 0; p.banded = (sc->wb >= 0 || sc->zdrop > 0) ? 1 : 0;
+    p.general = general ? 1 : 0; p.msa_rows = 0; p.msa_cons = (want_msa && want_cons) ? 1 : 0;
+    // LDS tables of the order / rank kernels (two ints per node; the rank pass packs four tables into the same space): up to 6000 nodes = 52 KB, three
+    //  workgroups per CU
     p.order_lds = (p.order_mode || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
     // (the all-in-LDS order walk: what is left of 40 KB -- four workgroups per CU -- after 13 bytes a node goes to aligned-list entries, 2 bytes each)
     p.order_ecap = p.order_mode ? std::max(1024, std::min(65535, (40 * 1024 - 128 - 13 * p.order_lds) / 2)) : 0;
     { const char *e_ = getenv("ABPOA_HIP_ORDER_LDS"); if (e_ && !atoi(e_)) p.order_ecap = 0; }      // (ABPOA_HIP_ORDER_LDS=0: the general walk everywhere)
-    { const char *e_ = getenv("ABPOA_HIP_ORDER_CAP"); if (e_ && atoi(e_) >= 0) p.order_lds = std::min(p.order_lds, atoi(e_) & ~3); }      // (tests: graphs above this many nodes take the walks with tables in memory)
-    p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;      // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
+    // (tests: graphs above this many nodes take the walks with tables in memory)
+    { const char *e_ = getenv("ABPOA_HIP_ORDER_CAP"); if (e_ && atoi(e_) >= 0) p.order_lds = std::min(p.order_lds, atoi(e_) & ~3); }
+    // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
+    p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;
     p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
     p.read_off = (const int64_t *)(di + L.o_roff); p.read_len = (const int32_t *)(di + L.o_rlen); p.reads = di + L.o_reads;
     p.wts = any_w ? (const int32_t *)(di + L.o_wts) : nullptr;
@@ -372,7 +414,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
     p.scratch = (int32_t *)(dr + L.o_scratch);
     p.aln = (AlnDesc *)(dr + L.o_aln_desc); p.out = (AlnOut *)(dr + L.o_out_rec);
-    p.row_base = dr + L.o_rbase; p.row_sdist = dr + L.o_rsd; p.row_pd = (uint32_t *)(dr + L.o_rpd); p.row_node_id = (int32_t *)(dr + L.o_rnid); p.row_remain = (int32_t *)(dr + L.o_rrem);
+    p.row_base = dr + L.o_rbase; p.row_sdist = dr + L.o_rsd; p.row_pd = (uint32_t *)(dr + L.o_rpd); p.row_node_id = (int32_t *)(dr + L.o_rnid);
+    p.row_remain = (int32_t *)(dr + L.o_rrem);
     p.pred_off = (int32_t *)(dr + L.o_poff); p.pred_row = (int32_t *)(dr + L.o_pred); p.cigar = (uint64_t *)(dr + L.o_cigar);
     p.out_off = gen_io ? (int32_t *)(dr + L.o_ooff) : nullptr; p.out_row = gen_io ? (int32_t *)(dr + L.o_orow) : nullptr;
     if (amb) {
@@ -387,10 +430,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
         make_lds_plan(sc, max_qlen, max_bits, est_cols(width, w_max, pn), n_sets, &b.lds);
-        if (general) { b.lds.wide_nw = 0; b.lds.fr_cols = 0; b.lds.loc_cols = 0; }      // (no fast row loop takes anything: dp_common.h takes_fast / rows_local.h takes_local)
-        else if (local) {      // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the general kernel's
+        // (no fast row loop takes anything: dp_common.h takes_fast / rows_local.h takes_local)
+        if (general) { b.lds.wide_nw = 0; b.lds.fr_cols = 0; b.lds.loc_cols = 0; }
+        // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the general kernel's
+        else if (local) {
             b.lds.wide_nw = 0;
-            if (max_bits != 16 || b.lds.loc_cols <= 0 || (max_qlen / 16 + 1) * 16 > b.lds.loc_cols || max_qlen > b.lds.q_cap) { set_err("local alignment outside the device row loop's range"); return ABPOA_HIP_EINVAL; }
+            if (max_bits != 16 || b.lds.loc_cols <= 0 || (max_qlen / 16 + 1) * 16 > b.lds.loc_cols || max_qlen > b.lds.q_cap) {
+                    set_err("local alignment outside the device row loop's range"); return ABPOA_HIP_EINVAL; }
         }
         // score widths the rounds can meet (the width grows with graph and read size): launch only the kernels that can have work
         int min_qlen = max_qlen;
@@ -402,7 +448,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         if (w_max < b.lds.wide_w_lo || w_min > b.lds.wide_w_hi) b.lds.wide_nw = 0;                       // no read takes the wide loop
         b.lds.narrow_off = (b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_max <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
     }
-    if (!local && !general && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }     // caller falls back to the host driver
+    // caller falls back to the host driver
+    if (!local && !general && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
     b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
@@ -416,7 +463,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         b.out_off = p.out_off; b.out_row = p.out_row; b.left = (int32_t *)(dr + L.o_left); b.right = (int32_t *)(dr + L.o_right); b.row_active = dr + L.o_act;
         HIP_OK(hipMemsetAsync(dr + L.o_act, 1, (size_t)node_tot, st), ABPOA_HIP_ELAUNCH);
     }
-    b.dp_beg_sn = (int32_t *)(dr + L.o_bsn); b.dp_end_sn = (int32_t *)(dr + L.o_esn); b.row_cell_off = (int64_t *)(dr + L.o_coff); b.row_max_i = (int32_t *)(dr + L.o_rmi);
+    b.dp_beg_sn = (int32_t *)(dr + L.o_bsn); b.dp_end_sn = (int32_t *)(dr + L.o_esn); b.row_cell_off = (int64_t *)(dr + L.o_coff);
+    b.row_max_i = (int32_t *)(dr + L.o_rmi);
     b.planes = C.planes.dev; b.cigar = p.cigar;
     // -s: the forward run leaves max_pos_left/right behind (fast row loops: a post-pass, rows_fast.h; general kernel: its own arrays) and the retry starts
     // from them -- the reference sorts, and so resets them, only before the forward alignment (src/abpoa_align.c:329 calls the DP directly)
@@ -431,10 +479,13 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
     //      per phase and round throughout (what the wide-band jobs use, and the per-round diagnostics below).
     const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
-    bool use_rounds = !local && rounds_possible && !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP") && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
+    bool use_rounds = !local && rounds_possible && !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP")
+            && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
     DevBatch b_r = b; size_t rounds_lds = 0;
     if (use_rounds) {
-        auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail), std::max<size_t>((size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), (size_t)16 * 256)); };      // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
+        // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
+        auto dyn_of = [&](const DevBatch &x) { return std::max<size_t>(std::max<size_t>((size_t)x.lds.total_rows, (size_t)x.lds.total_tail),
+                std::max<size_t>((size_t)5 * (size_t)(p.pad > 0 ? p.pad : 0), (size_t)16 * 256)); };
         rounds_lds = dyn_of(b_r);
         int st_lds = 0; int nb = poa_rounds_residency(sc->gap_mode, rounds_lds, &st_lds);
         // four workgroups per CU when the job has that many sets: the kernel's static LDS (graph phases) comes out of the backtrack window
@@ -448,101 +499,29 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         // The kernel pays when every read-set of the job is resident at once (one workgroup each; 4 per CU): a larger job runs faster with one
         // launch per phase and round, whose single-wavefront row-loop kernel then has several alignments per SIMD to hide latency behind
         // (measured, 1 kb reads: 1000 sets 13.0 k vs 10.4 k read-sets/s; 2000 sets 12.9 k vs 13.6 k; 4000 sets 13.2 k vs 17.4 k)
-        int n_cu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cu = pr.multiProcessorCount; }
+        int n_cu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cu =
+                pr.multiProcessorCount; }
         if (nb < 1 || n_sets > nb * n_cu) use_rounds = false;
-        if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] all-rounds kernel: %s, %zu B dynamic + %d B static LDS per workgroup, %d workgroups per CU, backtrack window %d B\n", use_rounds ? "on" : "off", rounds_lds, st_lds, nb, b_r.lds.bt_bytes_tail);
+        if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr,
+                "[abpoa-hip] all-rounds kernel: %s, %zu B dynamic + %d B static LDS per workgroup, %d workgroups per CU, " "backtrack window %d B\n",
+                use_rounds ? "on" : "off", rounds_lds, st_lds, nb, b_r.lds.bt_bytes_tail);
     }
 
     // ---- the whole progressive alignment, queued back to back (ABPOA_HIP_DEVSYNC=1: synchronise and report after every kernel)
-    auto stage = [&](const char *what, int k) -> int {
-        if (!dbg_sync) return 0;
-        fprintf(stderr, "[poa-device] round %d: %s queued\n", k, what); fflush(stderr);
-        hipError_t e_ = hipStreamSynchronize(st);
-        fprintf(stderr, "[poa-device] round %d: %s -> %s\n", k, what, hipGetErrorString(e_)); fflush(stderr);
-        return e_ == hipSuccess ? 0 : 1;
-    };
-    // debug (ABPOA_HIP_DEVSYNC=1): after every fuse, check set 0..3 structurally and against the host graph fed with the same cigars
-    std::vector<PoaGraph> dbg_graphs; if (dbg_sync) { dbg_graphs.resize(std::min(n_sets, 4)); for (size_t i_ = 0; i_ < dbg_graphs.size(); ++i_) dbg_graphs[i_].reset(sets[i_].n_reads, want_msa); }
-    // debug (ABPOA_HIP_DEVSYNC=1, order_mode 1): the row order the order kernel left against the host graph's Kahn walk (poa_graph.cpp topological_sort)
-    auto dbg_order_check = [&](int k) {
-        if (!dbg_sync) return;
-        for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
-            if (k >= sets[s].n_reads) continue;
-            PoaState hst; (void)hipMemcpy(&hst, (uint8_t *)p.state + sizeof(PoaState) * s, sizeof(hst), hipMemcpyDeviceToHost);
-            if (hst.status != POA_ST_OK) { fprintf(stderr, "[poa-device]   set %d round %d: row order: set not ok (status %d reason %d)\n", s, k, hst.status, hst.pad); continue; }
-            const int n = hst.n_nodes; std::vector<int32_t> order(n), row(n);
-            (void)hipMemcpy(order.data(), p.row_node[hst.order_buf] + ps[s].node0, 4 * (size_t)n, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(row.data(), p.nd_row + ps[s].node0, 4 * (size_t)n, hipMemcpyDeviceToHost);
-            PoaGraph &G = dbg_graphs[s]; int bad = 0;
-            try { G.topological_sort(false); } catch (...) { fprintf(stderr, "[poa-device]   set %d round %d: host sort failed\n", s, k); continue; }
-            if (G.n_nodes() != n) { fprintf(stderr, "[poa-device]   set %d round %d: row order check FAILED: node count %d vs host %d\n", s, k, n, G.n_nodes()); continue; }
-            for (int r = 0; r < n; ++r) { if (order[r] != G.index_to_node()[r] && bad++ < 6) fprintf(stderr, "[poa-device]   set %d round %d: row %d: device node %d, host node %d\n", s, k, r, order[r], G.index_to_node()[r]);
-                                          if (order[r] >= 0 && order[r] < n && row[order[r]] != r && bad++ < 6) fprintf(stderr, "[poa-device]   set %d round %d: nd_row / order mismatch at row %d\n", s, k, r); }
-            fprintf(stderr, "[poa-device]   set %d round %d: row order check %s (%d rows)\n", s, k, bad ? "FAILED" : "ok", n);
-        }
-    };
-    auto dbg_check = [&](int k) {
-        if (!dbg_sync) return;
-        for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
-            if (k >= sets[s].n_reads) continue;
-            PoaState hst; (void)hipMemcpy(&hst, (uint8_t *)p.state + sizeof(PoaState) * s, sizeof(hst), hipMemcpyDeviceToHost);
-            const PoaSet &S = ps[s]; const int n = hst.n_nodes;
-            // host graph: same cigar
-            if (k == 0) dbg_graphs[s].add_alignment(sets[s].seqs[0], sets[s].lens[0], nullptr, 0, 0, sets[s].weights ? sets[s].weights[0] : nullptr);
-            else {
-                AlnOut ao; (void)hipMemcpy(&ao, (uint8_t *)p.out + sizeof(AlnOut) * s, sizeof(ao), hipMemcpyDeviceToHost);
-                std::vector<uint64_t> cg(std::max(1, ao.n_cigar)); (void)hipMemcpy(cg.data(), (uint8_t *)p.cigar + 8 * S.cigar_off, 8 * (size_t)ao.n_cigar, hipMemcpyDeviceToHost);
-                fprintf(stderr, "[poa-device]   set %d round %d: dp status %d score %d n_cigar %d rows %d; device state status %d reason %d nodes %d\n", s, k, ao.status, ao.best_score, ao.n_cigar, ao.n_rows_done, hst.status, hst.pad, n);
-                if (ao.status != 0) continue;
-                uint8_t rcf = 0; if (amb) (void)hipMemcpy(&rcf, p.is_rc + S.read0 + k, 1, hipMemcpyDeviceToHost);
-                const int ql_ = sets[s].lens[k]; std::vector<uint8_t> rq_; std::vector<int32_t> rw_;
-                if (rcf) { rq_.resize(ql_); for (int j = 0; j < ql_; ++j) { const uint8_t c_ = sets[s].seqs[k][ql_ - 1 - j]; rq_[j] = c_ < 4 ? (uint8_t)(3 - c_) : (uint8_t)4; }
-                           if (sets[s].weights && sets[s].weights[k]) { rw_.resize(ql_); for (int j = 0; j < ql_; ++j) rw_[j] = sets[s].weights[k][ql_ - 1 - j]; } }
-                dbg_graphs[s].add_alignment(rcf ? rq_.data() : sets[s].seqs[k], ql_, cg.data(), ao.n_cigar, k, rcf && !rw_.empty() ? rw_.data() : (sets[s].weights ? sets[s].weights[k] : nullptr));
-            }
-            if (hst.status != POA_ST_OK) continue;
-            std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP), aln((size_t)n * aln_cap), nread(n), row(n), order(n);
-            auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
-            dl(base.data(), p.nd_base, 1, 1); dl(nin.data(), p.nd_nin, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl(naln.data(), p.nd_naln, 1, 1);
-            // edge lists come back as hot + cold halves and are merged into [node][CAP] arrays
-            auto dl_list = [&](int32_t *dst, const int32_t *hot, const int32_t *cold, int cap_) {
-                std::vector<int32_t> h_((size_t)n * POA_HOT), c_((size_t)n * (cap_ - POA_HOT));
-                (void)hipMemcpy(h_.data(), hot + (size_t)S.node0 * POA_HOT, h_.size() * 4, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(c_.data(), cold + (size_t)S.node0 * (cap_ - POA_HOT), c_.size() * 4, hipMemcpyDeviceToHost);
-                for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_] : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
-            };
-            dl_list(in.data(), p.nd_in, p.nd_inx, POA_IN_CAP); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx, POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, aln_cap);
-            dl(nread.data(), p.nd_nread, 4, 1); dl(row.data(), p.nd_row, 4, 1); dl(order.data(), p.row_node[hst.order_buf], 4, 1);
-            int bad = 0;
-            auto complain = [&](const char *what, int a, int b_) { if (bad++ < 8) fprintf(stderr, "[poa-device]   set %d round %d: %s (%d, %d)\n", s, k, what, a, b_); };
-            const PoaGraph &G = dbg_graphs[s];
-            if (G.n_nodes() != n) complain("node count differs from host graph", n, G.n_nodes());
-            for (int r = 0; r < n; ++r) { if (order[r] < 0 || order[r] >= n) { complain("order entry out of range", r, order[r]); continue; } if (row[order[r]] != r) complain("nd_row / order mismatch", r, order[r]); }
-            for (int u = 0; u < n && u < G.n_nodes(); ++u) {
-                const PoaNode &h = G.node(u);
-                if (h.base != base[u]) complain("base differs", u, base[u]);
-                if (h.in_id.size() != nin[u]) complain("in-degree differs", u, nin[u]);
-                else for (int t = 0; t < nin[u]; ++t) { if (h.in_id[t] != in[u * POA_IN_CAP + t]) complain("in edge differs", u, t); if (row[in[u * POA_IN_CAP + t]] >= row[u]) complain("order violated (pred row >= row)", in[u * POA_IN_CAP + t], u); }
-                if (h.out_id.size() != nout[u]) complain("out-degree differs", u, nout[u]);
-                else for (int t = 0; t < nout[u]; ++t) { if (h.out_id[t] != outv[u * POA_OUT_CAP + t]) complain("out edge differs", u, t); if (h.out_w[t] != outw[u * POA_OUT_CAP + t]) complain("out weight differs", u, t); }
-                if (h.aligned.size() != naln[u]) complain("aligned count differs", u, naln[u]);
-                else for (int t = 0; t < naln[u]; ++t) if (h.aligned[t] != aln[(size_t)u * aln_cap + t]) complain("aligned node differs", u, t);
-                if (h.n_read != nread[u]) complain("n_read differs", u, nread[u]);
-            }
-            fprintf(stderr, "[poa-device]   set %d round %d: graph check %s (%d nodes)\n", s, k, bad ? "FAILED" : "ok", n);
-        }
-    };
+    DeviceDebug dbg(&p, &ps, sets, n_sets, sc->m, aln_cap, max_reads, want_msa, amb, st);      // (ABPOA_HIP_DEVSYNC=1; msa_device_debug.h)
+    auto stage = [&](const char *what, int k) { return dbg.stage(what, k); };
     const double t_queue = now_s();
     HIP_OK(hipEventRecord(C.ev[0], st), ABPOA_HIP_ELAUNCH);
     if (stage("upload", 0)) return ABPOA_HIP_ELAUNCH;
     HIP_OK(launch_poa_init(p, st), ABPOA_HIP_ELAUNCH);
     if (stage("init", 0)) return ABPOA_HIP_ELAUNCH;
-    dbg_check(0);
+    dbg.graph_check(0);
     HIP_OK(hipEventRecord(C.ev[1], st), ABPOA_HIP_ELAUNCH);
     for (int k = 1; k < max_reads; ++k) {
         if (k == 2 && !rest_up) {      // round 1 is queued: stage and send the reads of the later rounds behind it
             stage_reads(2, max_reads);
-            HIP_OK(hipMemcpyAsync(C.in.dev + L.o_reads + (size_t)split_at, hi + L.o_reads + (size_t)split_at, (size_t)(roff[tot_reads] - split_at), hipMemcpyHostToDevice, C.copy_stream), ABPOA_HIP_ELAUNCH);
+            HIP_OK(hipMemcpyAsync(C.in.dev + L.o_reads + (size_t)split_at, hi + L.o_reads + (size_t)split_at, (size_t)(roff[tot_reads] - split_at),
+                    hipMemcpyHostToDevice, C.copy_stream), ABPOA_HIP_ELAUNCH);
             HIP_OK(hipEventRecord(C.ev_copy, C.copy_stream), ABPOA_HIP_ELAUNCH);
             HIP_OK(hipStreamWaitEvent(st, C.ev_copy, 0), ABPOA_HIP_ELAUNCH);
             rest_up = true;
@@ -555,7 +534,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         }
         p.round = k;
         hipEvent_t *e = C.ev.data() + 4 * k;
-        if (p.order_mode) { HIP_OK(launch_poa_order(p, st), ABPOA_HIP_ELAUNCH); if (stage("row order", k)) return ABPOA_HIP_ELAUNCH; dbg_order_check(k); }
+        if (p.order_mode) { HIP_OK(launch_poa_order(p, st), ABPOA_HIP_ELAUNCH); if (stage("row order", k)) return ABPOA_HIP_ELAUNCH; dbg.order_check(k); }
         HIP_OK(launch_poa_prepare(p, st), ABPOA_HIP_ELAUNCH);
         if (stage("prepare", k)) return ABPOA_HIP_ELAUNCH;
         HIP_OK(hipEventRecord(e[0], st), ABPOA_HIP_ELAUNCH);
@@ -568,46 +547,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             HIP_OK(launch_poa_strand_pick(p, st), ABPOA_HIP_ELAUNCH);
             if (stage("strand retry", k)) return ABPOA_HIP_ELAUNCH;
         }
-        if (dbg_sync && getenv("ABPOA_HIP_IMBAL")) {      // load balance of the round: ticks of the mean and of the slowest alignment
-            std::vector<AlnOut> ho(n_sets); (void)hipMemcpy(ho.data(), p.out, sizeof(AlnOut) * n_sets, hipMemcpyDeviceToHost);
-            double sd = 0, sb = 0; long long md = 0, mb = 0, ms_ = 0; for (const AlnOut &o_ : ho) { sd += o_.clk_dp; sb += o_.clk_bt; md = std::max<long long>(md, o_.clk_dp); mb = std::max<long long>(mb, o_.clk_bt); ms_ = std::max<long long>(ms_, o_.clk_dp + o_.clk_bt); }
-            float rows_ms_ = 0; (void)hipEventElapsedTime(&rows_ms_, e[0], e[1]);      // wall time of the row-loop launches: max ticks / this = tick rate the slowest wave saw
-            fprintf(stderr, "[poa-device] round %d balance: rows mean %.0f max %lld (%.2f ms on the stream, %.2f Gticks/s) | tail mean %.0f max %lld | rows+tail mean %.0f max %lld\n", k, sd / n_sets, md, rows_ms_, rows_ms_ > 0 ? md / rows_ms_ * 1e-6 : 0.0, sb / n_sets, mb, (sd + sb) / n_sets, ms_);
-            static std::vector<double> tot_set; static double sum_max = 0;      // (debug) what lock-step costs: sum over rounds of the slowest set vs the slowest set's own total
-            if (k == 1) { tot_set.assign(n_sets, 0.0); sum_max = 0; }
-            for (int s_ = 0; s_ < n_sets; ++s_) tot_set[s_] += (double)ho[s_].clk_dp + (double)ho[s_].clk_bt;
-            sum_max += (double)ms_;
-            if (k == max_reads - 1) { double mx_ = 0, mean_ = 0; for (double v_ : tot_set) { mx_ = std::max(mx_, v_); mean_ += v_; } fprintf(stderr, "[poa-device] rows+tail ticks over all rounds: sum of per-round maxima %.0f | slowest set alone %.0f | mean set %.0f\n", sum_max, mx_, mean_ / n_sets); }
-            double sg[6] = {0, 0, 0, 0, 0, 0}, st_ = 0; for (const AlnOut &o_ : ho) { for (int q_ = 0; q_ < 6; ++q_) sg[q_] += o_.seg[q_]; st_ += o_.n_bt_steps; }
-            if (b.dir_mode) { double cu = 0, nc = 0, rd = 0; for (const AlnOut &o_ : ho) { cu += (double)o_.cells_used; nc += (double)o_.n_cells; rd += o_.n_rows_done; }      // (direction-plane arenas: how much of them is score records of rows kept for later readers)
-                              fprintf(stderr, "[poa-device] round %d arenas: %.0f rows, %.0f columns, %.0f units of 32 B per alignment; words alone would take %.0f (int16 affine) -> rows keeping their records: ~%.1f %%\n", k, rd / n_sets, nc / n_sets, cu / n_sets / 16, nc / n_sets / 16, 100.0 * (cu - nc) / (4.0 * nc + 1)); }
-            if (b.dbg & 128) {      // placement report (row-loop seg[5] = HW_ID | XCC_ID << 32 survives the tail under dbg bit 7): how many alignments shared a SIMD, and how the sharers fared
-                std::vector<std::pair<unsigned long long, int>> pl; for (int s_ = 0; s_ < n_sets; ++s_) { const unsigned long long h_ = (unsigned long long)ho[s_].seg[5]; pl.push_back({((h_ >> 32) & 15) << 16 | (h_ & 0xff30) , s_}); }      // xcc | se, sh, cu | simd
-                std::sort(pl.begin(), pl.end()); double t_sh = 0, t_al = 0; int n_sh = 0, n_al = 0;
-                for (size_t i_ = 0; i_ < pl.size(); ++i_) { const bool sh_ = (i_ > 0 && pl[i_ - 1].first == pl[i_].first) || (i_ + 1 < pl.size() && pl[i_ + 1].first == pl[i_].first); (sh_ ? t_sh : t_al) += (double)ho[pl[i_].second].clk_dp; (sh_ ? n_sh : n_al)++; }
-                fprintf(stderr, "[poa-device] round %d placement: %d alignments alone on their SIMD (mean ticks %.0f), %d sharing one (mean ticks %.0f)\n", k, n_al, n_al ? t_al / n_al : 0.0, n_sh, n_sh ? t_sh / n_sh : 0.0);
-            }
-            if ((b.dbg & 128) && getenv("ABPOA_HIP_ROW_CENSUS")) {      // (library built with -DABPOA_HIP_ROW_CENSUS) rows and ticks per body of the narrow row loop, mean per alignment
-                double rw[6] = {0, 0, 0, 0, 0, 0}, tk[6] = {0, 0, 0, 0, 0, 0}; for (const AlnOut &o_ : ho) for (int q_ = 0; q_ < 6; ++q_) { rw[q_] += (double)(o_.seg[q_] >> 40); tk[q_] += (double)(o_.seg[q_] & ((1ll << 40) - 1)); }
-                const char *nm_[5] = {"1 predecessor", "2 predecessors", "3-4 predecessors", "exact bodies", "tile switches"};
-                fprintf(stderr, "[poa-device] round %d narrow-loop census per alignment:", k);
-                for (int q_ = 0; q_ < 5; ++q_) fprintf(stderr, " %s %.0f x %.0f ticks |", nm_[q_], rw[q_] / n_sets, rw[q_] > 0 ? tk[q_] / rw[q_] : 0.0);
-                { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_; const AlnOut &o_ = ho[w_];
-                  fprintf(stderr, "\n[poa-device] round %d slowest row loop (set %d, %lld ticks):", k, w_, (long long)o_.clk_dp);
-                  for (int q_ = 0; q_ < 5; ++q_) fprintf(stderr, " %s %lld x %.0f |", nm_[q_], (long long)(o_.seg[q_] >> 40), (o_.seg[q_] >> 40) ? (double)(o_.seg[q_] & ((1ll << 40) - 1)) / (double)(o_.seg[q_] >> 40) : 0.0);
-                  fprintf(stderr, " exact-body rows: > 4 predecessors %lld, straight-line declined %lld, beyond the ring %lld;", (long long)(o_.seg[5] >> 40), (long long)((o_.seg[5] >> 20) & 0xfffff), (long long)(o_.seg[5] & 0xfffff)); }
-                double why[3] = {0, 0, 0}; for (const AlnOut &o_ : ho) { why[0] += (double)(o_.seg[5] >> 40); why[1] += (double)((o_.seg[5] >> 20) & 0xfffff); why[2] += (double)(o_.seg[5] & 0xfffff); }
-                fprintf(stderr, " exact-body rows: > 4 predecessors %.0f, straight-line body declined %.0f, predecessor beyond the ring %.0f\n", why[0] / n_sets, why[1] / n_sets, why[2] / n_sets);
-            }
-            if ((b.dbg & 128) && getenv("ABPOA_HIP_WIDE_COUNTERS")) { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_; const AlnOut &o_ = ho[w_];
-                fprintf(stderr, "[poa-device] round %d slowest row loop: set %d ticks %lld rows %d | all-chunk body %lld | not eligible %lld | ring-geometry %lld | > 5 chunks %lld | slow vectors straddle %lld | key window / wrap %lld\n", k, w_, (long long)o_.clk_dp, o_.n_rows_done, (long long)o_.seg[0], (long long)o_.seg[1], (long long)o_.seg[2], (long long)o_.seg[3], (long long)o_.seg[4], (long long)o_.seg[5]); }
-            if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr, "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible (preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key window / wrap %.0f\n", k, sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);
-            fprintf(stderr, "[poa-device] round %d tail means: steps %.0f  flag steps %.0f  slow steps %.0f  windows %.1f  window ticks %.0f (setup %.0f)  walk ticks %.0f\n", k, st_ / n_sets, sg[2] / n_sets / 1000, sg[3] / n_sets / 1000, sg[4] / n_sets / 1000, sg[5] / n_sets, sg[0] / n_sets, sg[1] / n_sets);
-        }
+        dbg.balance_report(k, b, e[0], e[1]);
         HIP_OK(hipEventRecord(e[2], st), ABPOA_HIP_ELAUNCH);
         HIP_OK(launch_poa_fuse(p, st), ABPOA_HIP_ELAUNCH);
         if (stage("fuse", k)) return ABPOA_HIP_ELAUNCH;
-        dbg_check(k);
+        dbg.graph_check(k);
         HIP_OK(hipEventRecord(e[3], st), ABPOA_HIP_ELAUNCH);
     }
     // ---- consensus on the device, then one small download: per-set state + consensus (node ids, bases, coverage)
@@ -616,13 +560,15 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     uint8_t *hg = C.graph.host;
     HIP_OK(hipMemcpyAsync(hg, dg, dl_bytes, hipMemcpyDeviceToHost, st), ABPOA_HIP_ELAUNCH);
     HIP_OK(hipStreamSynchronize(st), ABPOA_HIP_ELAUNCH);
-    // ---- MSA rows (reference abpoa_generate_rc_msa, src/abpoa_output.c:123-166): the rank pass left the column count of every set in its state; the results are
+    // ---- MSA rows (reference abpoa_generate_rc_msa, src/abpoa_output.c:123-166): the rank pass left the column count of every set in its state; the results
+    //  are
     //      laid out back to back (rows x columns bytes per set), filled on the device and downloaded in one piece
     std::vector<int64_t> msa_off; int64_t msa_total = 0;
     if (want_msa) {
         const PoaState *hs_ = (const PoaState *)(hg + L.o_state);
         msa_off.resize(n_sets);
-        for (int s = 0; s < n_sets; ++s) { msa_off[s] = msa_total; if (hs_[s].status == POA_ST_OK && hs_[s].n_nodes > 2) msa_total += (int64_t)(sets[s].n_reads + (want_cons ? 1 : 0)) * std::max(0, hs_[s].msa_len); }
+        for (int s = 0; s < n_sets; ++s) { msa_off[s] = msa_total; if (hs_[s].status == POA_ST_OK && hs_[s].n_nodes > 2) msa_total += (int64_t)(sets[s].n_reads
+                + (want_cons ? 1 : 0)) * std::max(0, hs_[s].msa_len); }
         if (msa_total > 0) {
             if ((rc = C.msa.need_dev((size_t)msa_total)) || (rc = C.msa.need_host((size_t)msa_total))) return rc;
             memcpy(hi + L.o_msaoff_h, msa_off.data(), 8 * (size_t)n_sets);
@@ -635,10 +581,12 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         }
     }
     const double t_done = now_s();
-    if (getenv("ABPOA_HIP_ORDER_PROF") && p.order_mode) {      // (library built with -DABPOA_HIP_ORDER_PROF: the order walk's passes and ticks per kind, mean per set)
+    // (library built with -DABPOA_HIP_ORDER_PROF: the order walk's passes and ticks per kind, mean per set)
+    if (getenv("ABPOA_HIP_ORDER_PROF") && p.order_mode) {
         const PoaState *hs_ = (const PoaState *)(C.graph.host + L.o_state); double a_[4] = {0, 0, 0, 0};
         for (int s = 0; s < n_sets; ++s) for (int i = 0; i < 4; ++i) a_[i] += (double)hs_[s].t_phase[i];
-        fprintf(stderr, "[abpoa-hip] order walk per set: %.0f single-node passes x %.0f ticks, %.0f parallel passes x %.0f ticks\n", a_[2] / n_sets, a_[2] > 0 ? a_[0] / a_[2] : 0.0, a_[3] / n_sets, a_[3] > 0 ? a_[1] / a_[3] : 0.0);
+        fprintf(stderr, "[abpoa-hip] order walk per set: %.0f single-node passes x %.0f ticks, %.0f parallel passes x %.0f ticks\n", a_[2] / n_sets,
+                a_[2] > 0 ? a_[0] / a_[2] : 0.0, a_[3] / n_sets, a_[3] > 0 ? a_[1] / a_[3] : 0.0);
     }
     if (stats) {
         float ms = 0;
@@ -654,10 +602,14 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         if (use_rounds) {      // the all-rounds kernel: its duration, split by the shader-clock ticks the sets spent in each phase (PoaState.t_phase)
             (void)hipEventElapsedTime(&ms, C.ev[2], C.ev[3]); stats->rounds_ms = ms; stats->rounds_launches = 1;
             const PoaState *hs_ = (const PoaState *)(C.graph.host + L.o_state);
-            double tp[4] = {0, 0, 0, 0}, tmax = 0; for (int s = 0; s < n_sets; ++s) { double t_ = 0; if (hs_[s].status == POA_ST_OK) stats->rounds_algo_bytes += hs_[s].algo_bytes - hs_[s].algo_bytes_before; for (int i = 0; i < 4; ++i) { tp[i] += (double)hs_[s].t_phase[i]; t_ += (double)hs_[s].t_phase[i]; } tmax = std::max(tmax, t_); }
+            double tp[4] = {0, 0, 0, 0}, tmax = 0; for (int s = 0; s < n_sets; ++s) { double t_ = 0;
+                    if (hs_[s].status == POA_ST_OK) stats->rounds_algo_bytes += hs_[s].algo_bytes - hs_[s].algo_bytes_before;
+            for (int i = 0; i < 4; ++i) { tp[i] += (double)hs_[s].t_phase[i]; t_ += (double)hs_[s].t_phase[i]; } tmax = std::max(tmax, t_); }
             const double tall = tp[0] + tp[1] + tp[2] + tp[3];
-            if (tall > 0) { stats->prepare_ms += ms * tp[0] / tall; stats->rows_ms += ms * tp[1] / tall; stats->tail_ms += ms * tp[2] / tall; stats->fuse_ms += ms * tp[3] / tall;
-                            for (int i = 0; i < 4; ++i) stats->rounds_mticks[i] = tp[i] / n_sets * 1e-6; stats->rounds_rows_share = tp[1] / tall; stats->rounds_mean_over_max = n_sets > 0 && tmax > 0 ? tall / n_sets / tmax : 0; }
+            if (tall > 0) { stats->prepare_ms += ms * tp[0] / tall; stats->rows_ms += ms * tp[1] / tall; stats->tail_ms += ms * tp[2] / tall;
+                    stats->fuse_ms += ms * tp[3] / tall;
+                            for (int i = 0; i < 4; ++i) stats->rounds_mticks[i] = tp[i] / n_sets * 1e-6; stats->rounds_rows_share = tp[1] / tall;
+                            stats->rounds_mean_over_max = n_sets > 0 && tmax > 0 ? tall / n_sets / tmax : 0; }
         }
         stats->n_rounds = max_reads > 0 ? max_reads - 1 : 0; stats->device_s = t_done - t_queue;
     }
@@ -670,15 +622,19 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         for (int s = lo; s < hi_; ++s) {
             abpoa_hip_msa_t &o_ = out[s];
             memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
-            if (amb) { o_.is_rc = (uint8_t *)calloc((size_t)std::max(1, sets[s].n_reads), 1); if (o_.is_rc && hs[s].status == POA_ST_OK) memcpy(o_.is_rc, hg + L.o_isrc + ps[s].read0, (size_t)sets[s].n_reads); }
-            if (hs[s].status != POA_ST_OK) { need_fb[s] = hs[s].pad == 5 ? 2 : 1; if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad, hs[s].n_nodes, ps[s].node_cap); continue; }
+            if (amb) { o_.is_rc = (uint8_t *)calloc((size_t)std::max(1, sets[s].n_reads), 1);
+                    if (o_.is_rc && hs[s].status == POA_ST_OK) memcpy(o_.is_rc, hg + L.o_isrc + ps[s].read0, (size_t)sets[s].n_reads); }
+            if (hs[s].status != POA_ST_OK) { need_fb[s] = hs[s].pad == 5 ? 2 : 1;
+                    if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad,
+                    hs[s].n_nodes, ps[s].node_cap); continue; }
             o_.n_cells = hs[s].n_cells;
             if (p.dig_on && sets[s].n_reads > 0) cigar_digest_set(sets[s].seqs[0], sets[s].lens[0], hs[s].cigar_dig);
             if (want_cons && hs[s].n_nodes > 2) {
                 const int len = hs[s].cons_len; const int64_t c0 = ps[s].cons0;
                 o_.cons_len = len;
                 o_.cons_base = (uint8_t *)malloc(len + 1); o_.cons_cov = (int32_t *)malloc(4 * (len + 1)); o_.cons_node_id = (int32_t *)malloc(4 * (len + 1));
-                memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len); memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
+                memcpy(o_.cons_base, h_cbase + c0, len); memcpy(o_.cons_cov, h_ccov + c0, 4 * (size_t)len);
+                memcpy(o_.cons_node_id, h_cnode + c0, 4 * (size_t)len);
             }
             if (want_msa && hs[s].n_nodes > 2) {      // (an empty graph has no MSA: the host driver leaves the record zeroed too)
                 const int len = std::max(0, hs[s].msa_len);
@@ -688,45 +644,19 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             }
         }
     });
-    if (dbg_sync && want_msa) {      // cross-check the device MSA of the first sets against the host routine on the host graph that was fed the same cigars
-        for (int s = 0; s < (int)dbg_graphs.size(); ++s) {
-            if (hs[s].status != POA_ST_OK || hs[s].n_nodes <= 2) continue;
-            int ml = 0; std::vector<std::vector<uint8_t>> rows; std::vector<int> col;
-            try { dbg_graphs[s].rc_msa(sc->m, &ml, &rows, &col); } catch (...) { fprintf(stderr, "[poa-device]   set %d: host rc_msa failed\n", s); continue; }
-            bool same = ml == out[s].msa_len;
-            for (int r = 0; same && r < sets[s].n_reads; ++r) same = memcmp(rows[r].data(), out[s].msa_base + (size_t)r * ml, (size_t)ml) == 0;
-            fprintf(stderr, "[poa-device]   set %d: msa check %s (device %d columns, host %d)\n", s, same ? "ok" : "FAILED", out[s].msa_len, ml);
-        }
-    }
-    if (dbg_sync && want_cons) {      // cross-check the device consensus of the first sets against the host routine on the downloaded graph
-        for (int s = 0; s < std::min(n_sets, 4); ++s) {
-            if (hs[s].status != POA_ST_OK) continue;
-            const PoaSet &S = ps[s]; const int n = hs[s].n_nodes;
-            std::vector<uint8_t> base(n), nout(n); std::vector<int32_t> outv((size_t)n * POA_OUT_CAP), outw((size_t)n * POA_OUT_CAP), nread(n), order(n);
-            auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per, (size_t)n * elem * per, hipMemcpyDeviceToHost); };
-            // edge lists come back as hot + cold halves and are merged into [node][CAP] arrays
-            auto dl_list = [&](int32_t *dst, const int32_t *hot, const int32_t *cold, int cap_) {
-                std::vector<int32_t> h_((size_t)n * POA_HOT), c_((size_t)n * (cap_ - POA_HOT));
-                (void)hipMemcpy(h_.data(), hot + (size_t)S.node0 * POA_HOT, h_.size() * 4, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(c_.data(), cold + (size_t)S.node0 * (cap_ - POA_HOT), c_.size() * 4, hipMemcpyDeviceToHost);
-                for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_] : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
-            };
-            dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx, POA_OUT_CAP);
-            dl(nread.data(), p.nd_nread, 4, 1); dl(order.data(), p.row_node[hs[s].order_buf], 4, 1);
-            std::vector<int> ids, cov, sc_, mo; std::vector<uint8_t> bases;
-            consensus_flat(n, order.data(), base.data(), nout.data(), outv.data(), outw.data(), nread.data(), &ids, &bases, &cov, sc_, mo);
-            bool same = (int)ids.size() == out[s].cons_len;
-            for (size_t i = 0; same && i < ids.size(); ++i) same = ids[i] == out[s].cons_node_id[i] && bases[i] == out[s].cons_base[i] && cov[i] == out[s].cons_cov[i];
-            fprintf(stderr, "[poa-device]   set %d: consensus check %s (device %d, host %zu bases)\n", s, same ? "ok" : "FAILED", out[s].cons_len, ids.size());
-        }
-    }
-    // (a set whose edge or aligned lists are full gains nothing from a pass with more node slots: -(s + 1) tells the caller to hand it to the host driver at once)
+    dbg.msa_check(hs, out);
+    dbg.consensus_check(hs, out);
+    // (a set whose edge or aligned lists are full gains nothing from a pass with more node slots: -(s + 1) tells the caller to hand it to the host driver at
+    //  once)
     for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(need_fb[s] == 2 ? -(s + 1) : s);
     if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int n_slots = 0;
-        for (int f : *fallback) { const int s = f < 0 ? -f - 1 : f; const int r = hs[s].pad; if (r == 5) { n_slots++; continue; } hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++; }
-        fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, node slots in the fuse phase %d, edge / aligned slots of a node full (host driver at once) %d, DP status %d, projected node growth (early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], n_slots, hist[5], hist[7], hist[6] + hist[0]);
+        for (int f : *fallback) { const int s = f < 0 ? -f - 1 : f; const int r = hs[s].pad; if (r == 5) { n_slots++; continue;
+                } hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++; }
+        fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, node slots in the fuse "
+                "phase %d, edge / aligned slots of a node full (host driver at once) %d, DP status %d, projected node growth "
+                "(early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], n_slots, hist[5], hist[7], hist[6] + hist[0]);
     }
     if (stats) {
         stats->cons_s = now_s() - t_done; stats->total_s = now_s() - t_begin;

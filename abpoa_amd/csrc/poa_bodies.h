@@ -136,7 +136,8 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
                 if (no[j] == 1) far = nx[j];
                 else {
                     int rr[4] = {0, 0, 0, 0};
-                    if (no[j] > 0) rr[0] = p.nd_row[N0 + o4[j].x]; if (no[j] > 1) rr[1] = p.nd_row[N0 + o4[j].y]; if (no[j] > 2) rr[2] = p.nd_row[N0 + o4[j].z]; if (no[j] > 3) rr[3] = p.nd_row[N0 + o4[j].w];
+                    if (no[j] > 0) rr[0] = p.nd_row[N0 + o4[j].x]; if (no[j] > 1) rr[1] = p.nd_row[N0 + o4[j].y]; if (no[j] > 2) rr[2] = p.nd_row[N0 + o4[j].z];
+                    if (no[j] > 3) rr[3] = p.nd_row[N0 + o4[j].w];
                     far = imax_(imax_(rr[0], rr[1]), imax_(rr[2], rr[3]));
                     for (int t = POA_HOT; t < no[j]; ++t) far = imax_(far, p.nd_row[N0 + out_slot(p, N0 + u[j], t)]);
                 }
@@ -244,7 +245,8 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
                 for (int t = 0; t < 4; ++t) {
                     if (t < np[j]) { dst[t] = pr[j][t]; if (r - pr[j][t] <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr[j][t]) << (8 * t)); }
                 }
-                for (int t = POA_HOT; t < np[j]; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u[j], t)]; dst[t] = pr_; if (t < 8 && r - pr_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr_) << (8 * t)); }
+                for (int t = POA_HOT; t < np[j]; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u[j], t)]; dst[t] = pr_;
+                        if (t < 8 && r - pr_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr_) << (8 * t)); }
                 if (r < n) { p.row_pd[2 * (N0 + r)] = (unsigned)pdv; p.row_pd[2 * (N0 + r) + 1] = (unsigned)(pdv >> 32); }
             }
         }
@@ -334,7 +336,8 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
     bool fail = false, fail_slots = false;      // (fail_slots: an edge / aligned list is full -- more node slots would not help, PoaState.pad 5)
     // adds edge from -> to (both lane-private; `from_new` / `to_new`: the node was created by this read, its lists are still empty
     // apart from what this very walk put there, which is known without a load)
-    const int32_t *wq = p.wts ? (rc_read ? p.wts_rc : p.wts) + p.read_off[S.read0 + k] : nullptr;      // per-base weights of this read (-Q), reference :634-667: an edge takes the weight of the base it leads to
+    // per-base weights of this read (-Q), reference :634-667: an edge takes the weight of the base it leads to
+    const int32_t *wq = p.wts ? (rc_read ? p.wts_rc : p.wts) + p.read_off[S.read0 + k] : nullptr;
     auto add_edge = [&](bool act, int from, bool from_new, int to, bool to_new, int w) {
         if (!act) return;
         const int64_t F = N0 + from, T = N0 + to;

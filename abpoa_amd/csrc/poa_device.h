@@ -49,7 +49,8 @@ struct PoaState {                  // mutable per read-set
 // Test hook (ABPOA_HIP_CIGAR_DIGEST=1): one 64-bit digest per read-set over the graph cigars of all its alignments, computed the same way by the fuse phase on
 // the device (all lanes: a sum of per-word mixes) and by the host driver (msa_batch.cpp), so that the cigars of BOTH forms of the device driver -- the all-rounds
 // kernel with its four-wavefront backtrack included -- can be compared with the oracle-backed host run word for word without leaving the device.
-__host__ __device__ inline uint64_t poa_mix64(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+__host__ __device__ inline uint64_t poa_mix64(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+        }
 __host__ __device__ inline uint64_t poa_cigar_word_mix(uint64_t word, int i) { return poa_mix64(word + 0xD6E8FEB86659FD93ull * (uint64_t)(i + 1)); }
 __host__ __device__ inline uint64_t poa_cigar_digest_round(uint64_t before, int read_index, int n_cigar, uint64_t sum_of_word_mixes) {
     return (before * 0x9E3779B97F4A7C15ull) ^ (sum_of_word_mixes + poa_mix64(((uint64_t)(uint32_t)read_index << 32) | (uint32_t)n_cigar));

@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
     if (s >= p.n_sets) return;
     const PoaSet S = p.sets[s];
     PoaState *st = p.state + s;
-    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; st->cons_len = 0; st->msa_len = 0; st->cigar_dig = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0; st->algo_bytes_before = 0; }
+    if (lane == 0) { st->order_buf = 0; st->n_cells = 0; st->algo_bytes = 0; st->pad = 0; st->cons_len = 0; st->msa_len = 0; st->cigar_dig = 0; for (int i = 0; i < 4; ++i) st->t_phase[i] = 0;
+            st->algo_bytes_before = 0; }
     if (S.n_reads <= 0) { if (lane == 0) { st->n_nodes = 2; st->status = POA_ST_OK; } return; }
     const int L = p.read_len[S.read0];
     const uint8_t *seq = p.reads + p.read_off[S.read0];
@@ -49,7 +50,8 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
         const int32_t *wq = p.wts ? p.wts + p.read_off[S.read0] : nullptr;
         in_slot(p, N0 + u, 0) = in0; out_slot(p, N0 + u, 0) = out0; outw_slot(p, N0 + u, 0) = !wq ? 1 : (u == 0 ? wq[0] : (u == 1 ? 0 : wq[i == L - 1 ? L - 1 : i + 1]));
         p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
-        if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * POA_OUT_CAP) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }      // read 0 went through the node's one edge
+        // read 0 went through the node's one edge
+        if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * POA_OUT_CAP) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }
         // row order: source, the chain, sink
         const int row = u == 0 ? 0 : (u == 1 ? n - 1 : u - 1);
         p.nd_row[N0 + u] = row; p.row_node[0][N0 + row] = u;
@@ -225,8 +227,10 @@ extern __shared__ int ord_lds[];               // [ORD_RING] ring, then -- LDS t
 // (one function per operation, the address space chosen at compile time: a reference picked by `L ? lds : global` is a GENERIC pointer, and every access
 //  through it a FLAT instruction -- which counts on both memory counters, so that waiting for a table entry in LDS also waited for the row-order stores of
 //  the pass before to be acknowledged by memory, ~1 us per pass)
-template <bool L> __device__ __forceinline__ int tbl_ld(const PoaDev &p, int32_t *g, int which, int n, int i) { if constexpr (L) return ord_lds[ORD_RING + which * n + i]; else return ld_fresh(g + (int64_t)which * n + i); }
-template <bool L> __device__ __forceinline__ void tbl_st(const PoaDev &p, int32_t *g, int which, int n, int i, int v) { if constexpr (L) ord_lds[ORD_RING + which * n + i] = v; else g[(int64_t)which * n + i] = v; }
+template <bool L> __device__ __forceinline__ int tbl_ld(const PoaDev &p, int32_t *g, int which, int n, int i) { if constexpr (L) return ord_lds[ORD_RING + which * n + i];
+        else return ld_fresh(g + (int64_t)which * n + i); }
+template <bool L> __device__ __forceinline__ void tbl_st(const PoaDev &p, int32_t *g, int which, int n, int i, int v) { if constexpr (L) ord_lds[ORD_RING + which * n + i] = v;
+        else g[(int64_t)which * n + i] = v; }
 template <bool L> __device__ __forceinline__ void tbl_dec_max(const PoaDev &p, int32_t *g, int n, int i, int key) {      // counter (table 0) - 1, zero time (table 1) = max(., key)
     if constexpr (L) { atomicSub(&ord_lds[ORD_RING + i], 1); atomicMax(&ord_lds[ORD_RING + n + i], key); }
     else { atomicSub(g + i, 1); atomicMax(g + (int64_t)n + i, key); }
@@ -298,7 +302,8 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
                 if (d != 0) continue;
                 const int na = uni(naln_of(v));
                 bool ready = true;
-                if (na > 0) { tbl_fence<L>(); for (int t = 0; t < na && ready; ++t) ready = uni(tbl_ld<L>(p, g, 0, n, p.nd_aln[(N0 + v) * p.aln_cap + t])) == 0; }      // (fence: lane 0's store above may be what an aligned node's entry holds)
+                // (fence: lane 0's store above may be what an aligned node's entry holds)
+                if (na > 0) { tbl_fence<L>(); for (int t = 0; t < na && ready; ++t) ready = uni(tbl_ld<L>(p, g, 0, n, p.nd_aln[(N0 + v) * p.aln_cap + t])) == 0; }
                 if (!ready) continue;
                 if (at + 1 + na > n) return false;
                 if (lane == 0) qput(at, v);

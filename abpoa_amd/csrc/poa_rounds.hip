@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
     {
         const unsigned hwid = __builtin_amdgcn_s_getreg(63492);      // HW_REG_HW_ID: simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]
         if ((tid & 63) == 0) sh_simd[tid >> 6] = (int)((hwid >> 4) & 3);
-        if (tid == 0) { const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15; sh_target = atomicAdd(g_rounds[slot].cu_ticket + ((xcc << 8) | ((hwid >> 8) & 0xff)), 1) & 3; }      // HW_REG_XCC_ID [3:0]
+        // HW_REG_XCC_ID [3:0]
+        if (tid == 0) { const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15; sh_target = atomicAdd(g_rounds[slot].cu_ticket + ((xcc << 8) | ((hwid >> 8) & 0xff)), 1) & 3; }
         __syncthreads();
     }
     if (tid == 0) st->algo_bytes_before = st->algo_bytes;
@@ -87,7 +88,8 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
         long long c2 = c1;
         if ((tid >> 6) == worker) {
             const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags;
-            if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {      // (the host launches this kernel only for jobs whose reads all take the narrow loop)
+            // (the host launches this kernel only for jobs whose reads all take the narrow loop)
+            if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {
                 if (b.dir_mode) {
                     if (bits == 16) { c2 = rounds_rows<int16_t, GAP, true>(slot, s); rounds_tail<int16_t, GAP, true>(slot, s, pair ? 0 : -1, sh_walk, k); }
                     else { c2 = rounds_rows<int32_t, GAP, true>(slot, s); rounds_tail<int32_t, GAP, true>(slot, s, pair ? 0 : -1, sh_walk, k); }
@@ -121,7 +123,8 @@ hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_tic
     e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rounds), &a, sizeof(a), sizeof(RoundsArgs) * (size_t)slot, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     if (lds_bytes > 65536) {      // (above 64 KB the kernel's dynamic-LDS limit has to be raised; without it the launch gets 64 KB and the phases read and write past it)
-        e = hipFuncSetAttribute(b.gap_mode == ABPOA_HIP_AFFINE_GAP ? (const void *)poa_rounds_kernel<1> : (const void *)poa_rounds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = hipFuncSetAttribute(b.gap_mode == ABPOA_HIP_AFFINE_GAP ? (const void *)poa_rounds_kernel<1> : (const void *)poa_rounds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
     if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) hipLaunchKernelGGL(poa_rounds_kernel<1>, dim3(p.n_sets), dim3(GT), lds_bytes, s, slot, k_lo);
@@ -131,7 +134,8 @@ hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_tic
 // workgroups of the all-rounds kernel one CU holds with `lds_bytes` of dynamic LDS (registers and LDS), and its static LDS
 int poa_rounds_residency(int gap_mode, size_t lds_bytes, int *static_lds) {
     int nb = 0; hipFuncAttributes fa; memset(&fa, 0, sizeof(fa));
-    if (gap_mode == ABPOA_HIP_AFFINE_GAP) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<1>, GT, lds_bytes); (void)hipFuncGetAttributes(&fa, (const void *)poa_rounds_kernel<1>); }
+    if (gap_mode == ABPOA_HIP_AFFINE_GAP) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<1>, GT, lds_bytes);
+            (void)hipFuncGetAttributes(&fa, (const void *)poa_rounds_kernel<1>); }
     else { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<2>, GT, lds_bytes); (void)hipFuncGetAttributes(&fa, (const void *)poa_rounds_kernel<2>); }
     if (static_lds) *static_lds = (int)fa.sharedSizeBytes;
     return nb;

@@ -230,7 +230,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (ring0) ring_put(0, i, h, x1, x2);
         }
         cur = (end_sn0 + 1) * CWR;
-        if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = DIR ? cur : 0; }      // (DIR: a row's offset is that of its -- here absent -- words, its records sit in front of them)     // source: successors get left = right = 1 (:556-561)
+        // (DIR: a row's offset is that of its -- here absent -- words, its records sit in front of them) // source: successors get left = right = 1 (:556-561)
+        if (lane == 0) { vg_geo = (end_sn0 << 12) | (ring0 ? GEO_RING : 0); vg_mi = 0; vg_off = DIR ? cur : 0; }
         if (NW > 1) WG_SYNC();               // ring row 0 was written by every wavefront
     }
 
@@ -406,7 +407,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else if (I16 && GAP == 1) { int2 rec; rec.x = he; rec.y = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)F1, 0x05040100u); *(int2 *)(Hrec + (long long)rel * CW) = rec; }
         else if (I16) { int4 rec; rec.x = he; rec.y = (int)(((unsigned)E2out & 0xffffu) | ((unsigned)F1 << 16)); rec.z = F2 & 0xffff; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
         else if (GAP == 1) { int4 rec; rec.x = Hout; rec.y = E1out; rec.z = F1; rec.w = mflag; *(int4 *)(Hrec + (long long)rel * CW) = rec; }
-        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(Hrec + (long long)rel * CW); dst[0] = r0; dst[1] = r1; }
+        else { int4 r0, r1; r0.x = Hout; r0.y = E1out; r0.z = E2out; r0.w = F1; r1.x = F2; r1.y = mflag; r1.z = 0; r1.w = 0; int4 *dst = (int4 *)(Hrec + (long long)rel * CW); dst[0] = r0;
+                dst[1] = r1; }
         if (to_ring && !ABL(2)) {
             int *qd = fr + my_slot + 2 + rel;
             if (I16) { qd[0] = in_band ? he : infw; if (GAP == 2) qd[RCS] = in_band ? E2out : inf; }
@@ -445,7 +447,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     int mi = -1;
     const int lane4 = lane * 4;
     // arg-max key constants (normal / end_sn vector): lane residue, vector priority, and -- never decisive, it only saves the decoding -- the lane
-    const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)(NV - 1 - vvl) << 8) | (unsigned)lane), kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (8u << 8) | (unsigned)lane);
+    const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)(NV - 1 - vvl) << 8) | (unsigned)lane),
+            kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (8u << 8) | (unsigned)lane);
     auto turbo_body = [&](auto npc, auto slowc, int row, int ti) __attribute__((always_inline)) -> int {
         constexpr bool SLOWV = decltype(slowc)::value;      // handles vectors beyond every predecessor's band (the tight loop's copies do not: they decline and the row comes back here)
         constexpr int NPC = decltype(npc)::value;
@@ -635,7 +638,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int Hm1 = wave_shr1(Hout, Hout), F1m1 = wave_shr1(F1, F1);
                 unsigned l1 = dir_literal<T>(Hm1, F1m1, F1, oe1, e1), l2 = 0;
                 if (GAP == 2) { const int F2m1 = wave_shr1(F2, F2); l2 = dir_literal<T>(Hm1, F2m1, F2, oe2, e2); }
-                if (vvl >= nfast_) wd |= GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH);      // (lane 0 of the band -- no stored left neighbour -- is never a masked-scan vector here: nfast_ >= 1)
+                // (lane 0 of the band -- no stored left neighbour -- is never a masked-scan vector here: nfast_ >= 1)
+                if (vvl >= nfast_) wd |= GAP == 1 ? l1 << DIRA_LF1_SH : (l1 << DIRC_LF1_SH | l2 << DIRC_LF2_SH);
             }
             char *const dp = (char *)io.planes + (size_t)rec_off;
             if (GAP == 1) *(uint16_t *)dp = (uint16_t)wd; else *(uint32_t *)dp = wd;
@@ -698,7 +702,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             const int p = __builtin_amdgcn_readlane(tvp, ti), g_ = __builtin_amdgcn_readlane(vg_geo, p & 63), mi_ = __builtin_amdgcn_readlane(vg_mi, p & 63);
             mn_mi = imin(mn_mi, mi_); mx_mi = imax(mx_mi, mi_); min_pb = imin(min_pb, g_ & 0xfff); max_pe = imax(max_pe, (g_ >> 12) & 0xfff); ilp_far |= is_far(p, g_) << k;
         };
-        if (np > 1) { more(tv_p1, 1); if (np > 2) { more(tv_p2, 2); if (np > 3) { more(tv_p3, 3); if (np > 4) { more(tv_p4, 4); if (np > 5) { more(tv_p5, 5); if (np > 6) { more(tv_p6, 6); if (np > 7) more(tv_p7, 7); } } } } } }
+        if (np > 1) { more(tv_p1, 1); if (np > 2) { more(tv_p2, 2); if (np > 3) { more(tv_p3, 3); if (np > 4) { more(tv_p4, 4); if (np > 5) { more(tv_p5, 5); if (np > 6) { more(tv_p6, 6);
+                if (np > 7) more(tv_p7, 7); } } } } } }
         set_band(std::true_type{}, mn_mi, mx_mi, min_pb);
         const int nvr = end_sn - beg_sn + 1, Wr = nvr * PN, nch = (Wr + 63) >> 6;
         bool ok = nch <= NCHX && Wr <= RC && max_pe >= beg_sn;
@@ -755,7 +760,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int x = colb + 64 * c - pb * PN, xh = med3i(x - 1, 0, Wp - 1), xe = med3i(x, 0, Wp - 1);
-                if constexpr (CPK) { gld_async_cell(hc[c], Hp + (long long)xh * CWR); gld_async_cell(ec1[c], Hp + (long long)xe * CWR); gld_async_cell(ec2[c], Hp + (long long)xe * CWR + 1); }      // H[x-1]; H[x], differences
+                // H[x-1]; H[x], differences
+                if constexpr (CPK) { gld_async_cell(hc[c], Hp + (long long)xh * CWR); gld_async_cell(ec1[c], Hp + (long long)xe * CWR); gld_async_cell(ec2[c], Hp + (long long)xe * CWR + 1); }
                 else {
                     gld_async_cell(hc[c], Hp + (long long)xh * CWR); gld_async_cell(ec1[c], Hp + (long long)xe * CWR + PL_E1);
                     if (GAP == 2) gld_async_cell(ec2[c], Hp + (long long)xe * CWR + PL_E2); else ec2[c] = inf;
@@ -763,11 +769,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             // (the wait names the loaded registers: a register-only use must not be scheduled above it)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
+            for (int c = 0; c < NCH; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int x = colb + 64 * c - pb * PN;
-                if constexpr (CPK) { const int h0 = ec1[c]; const unsigned d1_ = (unsigned)ec2[c] & 0xffffu, d2_ = (unsigned)ec2[c] >> 16; ec1[c] = d1_ == 0xffffu ? inf : h0 - (int)d1_; ec2[c] = d2_ == 0xffffu ? inf : h0 - (int)d2_; }
+                if constexpr (CPK) { const int h0 = ec1[c]; const unsigned d1_ = (unsigned)ec2[c] & 0xffffu, d2_ = (unsigned)ec2[c] >> 16; ec1[c] = d1_ == 0xffffu ? inf : h0 - (int)d1_;
+                        ec2[c] = d2_ == 0xffffu ? inf : h0 - (int)d2_; }
                 hc[c] = (unsigned)(x - 1) < (unsigned)Wp ? hc[c] : inf; ec1[c] = (unsigned)x < (unsigned)Wp ? ec1[c] : inf; if (GAP == 2) ec2[c] = (unsigned)x < (unsigned)Wp ? ec2[c] : inf;
             }
         };
@@ -832,7 +840,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int cg = c0 + c, vb = beg_sn + cg * NV;          // chunk index in the row
-            const bool in_band = (!TEAM && c < NCH - 2) ? true : cg * 64 + lane < Wr, is_end = (!TEAM && c < NCH - 2) ? false : (cg * NV + vvl == relv_end);      // (the end vector is in the last chunk)
+            // (the end vector is in the last chunk)
+            const bool in_band = (!TEAM && c < NCH - 2) ? true : cg * 64 + lane < Wr, is_end = (!TEAM && c < NCH - 2) ? false : (cg * NV + vvl == relv_end);
             int cand = hsE[c]; if (end_sn == qlen_sn) cand = (is_end && colb + 64 * c > qlen) ? inf : cand;
             unsigned key;
             if (I16) key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
@@ -973,7 +982,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             }
             if (DIR && !row_spill) {}
             else if (DIR && !in_band) {}      // (the row's words start right behind its last record)
-            else if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {      // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites: same wave, program order)
+            // (teams: in-band lanes only -- another wavefront owns the cells behind the row's end) one record store per lane, all 64 lanes (lanes past the band write cells the next row overwrites:
+            //  same wave, program order)
+            else if (TEAM ? (c < cnt && in_band) : (c < NCH - 1 || nch == NCH)) {
                 T *H = Hrow + c * 64 * CWR;
                 if (CSP) {      // compact records (CWR)
                     if (I16 && GAP == 1) *(int *)H = he;
@@ -992,7 +1003,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 else { qd[c * 64] = in_band ? Hout : inf; qd[RCS + c * 64] = in_band ? E1out : inf; if (GAP == 2) qd[2 * RCS + c * 64] = in_band ? E2out : inf; }
             }
         }
-        if (!TEAM) { for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = EPACK ? 0 : inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; } }      // "inf" up to the ring width
+        // "inf" up to the ring width
+        if (!TEAM) { for (int c = NCH; c < (RC >> 6); ++c) { qd[c * 64] = infw; if (NPW > 1) qd[RCS + c * 64] = EPACK ? 0 : inf; if (NPW > 2) qd[2 * RCS + c * 64] = inf; } }
         else {                                                       // (teams: chunk c of the padding is written by wavefront c % NW)
             int *const qrow = (int *)ring_at(__builtin_amdgcn_readlane(vslot, ti) + 4 * lane, 0);
             for (int c = nch; c < (RC >> 6); ++c) if (c % NW == wid) { qrow[c * 64] = infw; if (NPW > 1) qrow[RCS + c * 64] = EPACK ? 0 : inf; if (NPW > 2) qrow[2 * RCS + c * 64] = inf; }
@@ -1094,7 +1106,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     const T *Hp = io.planes + (long long)(uint32_t)(off_ - (DIR ? (pe - pb + 1) * CWR : 0)) * PN;      // (DIR: its score records, in front of its direction words)
                     int hval = inf, ev1 = inf, ev2 = inf;
                     if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CWR));
-                    if constexpr (CPK) { if (inE) { const int h0 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR)); const unsigned dd = (unsigned)gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + 1));
+                    if constexpr (CPK) { if (inE) { const int h0 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR));
+                            const unsigned dd = (unsigned)gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + 1));
                                                     ev1 = (dd & 0xffffu) == 0xffffu ? inf : h0 - (int)(dd & 0xffffu); ev2 = (dd >> 16) == 0xffffu ? inf : h0 - (int)(dd >> 16); } }
                     else
                     if (inE) { ev1 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + PL_E1)); if (GAP == 2) ev2 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + PL_E2)); }
@@ -1117,7 +1130,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const long long cen_ts = (long long)__builtin_amdgcn_s_memtime();
 #endif
         if (t0 > 0) {       // geometry of the finished tile goes to HBM in one coalesced burst (older predecessors, backtrack, trace)
-            const int rb = t0 - 64 + lane; if (wid == 0) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN; io.row_max_i[rb] = vg_mi; }
+            const int rb = t0 - 64 + lane; if (wid == 0) { io.g_bsn[rb] = vg_geo & 0xfff; io.g_esn[rb] = (vg_geo >> 12) & 0xfff; io.g_coff[rb] = (long long)(uint32_t)vg_off * PN;
+                    io.row_max_i[rb] = vg_mi; }
             if (rb >= 1) n_vec_lane += ((vg_geo >> 12) & 0xfff) - (vg_geo & 0xfff) + 1;
         }
         switch_tile(t0);
@@ -1234,7 +1248,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (!WPLAN && ((meta >> 20) & 1)) {                       // five to eight predecessors
                 if (turbo_body(std::integral_constant<int, 8>{}, std::true_type{}, row, ti) == 1) { commit_row(ti, true); CENSUS(2) ++row; continue; }
             }
-            if (!WPLAN && (((meta >> 17) & 1) ? ok_ == 0 : (DIR && ((meta >> 22) & 1)))) {                       // one or two predecessors and the tight loop declined: most often the row's band reaches one
+            // one or two predecessors and the tight loop declined: most often the row's band reaches one
+            if (!WPLAN && (((meta >> 17) & 1) ? ok_ == 0 : (DIR && ((meta >> 22) & 1)))) {
                                                                       // vector beyond its predecessors' (every PN-th row of a chain) -- the copies that take those vectors
                 const int ok3 = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, std::true_type{}, row, ti) : turbo_body(std::integral_constant<int, 2>{}, std::true_type{}, row, ti);
                 if (ok3 == 1) { commit_row(ti, true); CENSUS(np == 1 ? 0 : 1) ++row; continue; }
@@ -1249,7 +1264,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int nch_ = ilp_band(row, ti);
                 if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
                 if (nch_ >= 2) {
-                    const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : (nch_ <= 5 ? ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 7>{}, nch_, row, ti));
+                    const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : (nch_ <= 5 ? ilp_chunks(std::integral_constant<int, 5>{}, nch_, row,
+                            ti) : ilp_chunks(std::integral_constant<int, 7>{}, nch_, row, ti));
                     if (ok2 == 1) { WCOUNT(0); commit_row(ti, true); FSTAMP(5) ++row; continue; }
                     WCOUNT(5);
                 }
@@ -1330,7 +1346,8 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     uint8_t *s_query = lds_raw + b.lds.q_off;
     { GLOBAL_AS const uint8_t *g_query = vgpr_ptr(b.query + d.query_off);
       if constexpr (NW > 1 || WIDEB) {      // two codes to a byte (rows_fast: qat)
-          for (int i = (NW > 1 ? (int)threadIdx.x : lane); 2 * i < d.qlen; i += NW * 64) { const int lo_ = g_query[2 * i], hi_ = 2 * i + 1 < d.qlen ? (int)g_query[2 * i + 1] : 0; s_query[i] = (uint8_t)((lo_ & 15) | (hi_ << 4)); }
+          for (int i = (NW > 1 ? (int)threadIdx.x : lane); 2 * i < d.qlen; i += NW * 64) { const int lo_ = g_query[2 * i], hi_ = 2 * i + 1 < d.qlen ? (int)g_query[2 * i + 1] : 0;
+                  s_query[i] = (uint8_t)((lo_ & 15) | (hi_ << 4)); }
       } else for (int i = (NW > 1 ? (int)threadIdx.x : lane); i < d.qlen; i += NW * 64) s_query[i] = g_query[i]; }
     WG_SYNC();
     long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
@@ -1341,7 +1358,8 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
 #if !defined(ABPOA_HIP_WIDE_COUNTERS) && !defined(ABPOA_HIP_ROW_CENSUS)
     fseg[5] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);      // HW_ID | XCC_ID << 32: where the wave ran (ABPOA_HIP_IMBAL placement report)
 #endif
-    if (NW > 1 ? threadIdx.x == 0 : lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0; o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
+    if (NW > 1 ? threadIdx.x == 0 : lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0;
+            o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
 }
 
 

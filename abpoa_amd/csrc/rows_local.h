@@ -134,7 +134,8 @@ __device__ __forceinline__ void rows_local(const DevBatch &b, const AlnDesc &d, 
                         if (GAP == 2) gld_async_cell(ec2[c], Hp + (long long)xe * CW + PL_E2); else ec2[c] = inf;
                     }
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
+                    for (int c = 0; c < NCH; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
                     if (lane == 0) hc[0] = 0;                        // H_p[-1] = 0
                 }
             };
@@ -149,8 +150,10 @@ __device__ __forceinline__ void rows_local(const DevBatch &b, const AlnDesc &d, 
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) { kb[c] = hd[c] > Mv[c] ? kidx : kb[c]; Mv[c] = imax(Mv[c], hd[c]); E1v[c] = imax(E1v[c], ed1[c]); if (GAP == 2) E2v[c] = imax(E2v[c], ed2[c]); }
                 };
-                if (np > 1) { another(__builtin_amdgcn_readlane(tv_p[1], ti), 2); if (np > 2) { another(__builtin_amdgcn_readlane(tv_p[2], ti), 3); if (np > 3) { another(__builtin_amdgcn_readlane(tv_p[3], ti), 4);
-                    if (np > 4) { another(__builtin_amdgcn_readlane(tv_p[4], ti), 5); if (np > 5) { another(__builtin_amdgcn_readlane(tv_p[5], ti), 6); if (np > 6) { another(__builtin_amdgcn_readlane(tv_p[6], ti), 7);
+                if (np > 1) { another(__builtin_amdgcn_readlane(tv_p[1], ti), 2); if (np > 2) { another(__builtin_amdgcn_readlane(tv_p[2], ti), 3);
+                        if (np > 3) { another(__builtin_amdgcn_readlane(tv_p[3], ti), 4);
+                    if (np > 4) { another(__builtin_amdgcn_readlane(tv_p[4], ti), 5); if (np > 5) { another(__builtin_amdgcn_readlane(tv_p[5], ti), 6);
+                            if (np > 6) { another(__builtin_amdgcn_readlane(tv_p[6], ti), 7);
                     if (np > 7) { another(__builtin_amdgcn_readlane(tv_p[7], ti), 8);
                         const int ps = __builtin_amdgcn_readlane(tv_ps, ti);
                         for (int k = 8; k < np; ++k) another(__builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)), imin(k + 1, 65)); } } } } } } }
@@ -380,7 +383,8 @@ __device__ __forceinline__ void rows_local_team(const DevBatch &b, const AlnDesc
                         if (GAP == 2) gld_async_cell(ec2[c], Hp + (long long)xe * CW + PL_E2); else ec2[c] = inf;
                     }
 #pragma unroll
-                    for (int c = 0; c < NCW; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
+                    for (int c = 0; c < NCW; ++c) { if (GAP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]), "+v"(ec2[c]) :: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc[c]), "+v"(ec1[c]) :: "memory"); }
                     if (lane == 0 && c0 == 0) hc[0] = 0;             // H_p[-1] = 0
                 }
             };

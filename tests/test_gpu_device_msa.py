@@ -159,6 +159,25 @@ def test_device_graph_equals_host_graph_after_every_read(engine):
     assert "graph check ok" in p.stderr and "consensus check ok" in p.stderr and "FAILED" not in p.stderr, p.stderr[-3000:]
 
 
+def test_device_audit_mode_reports_where_every_pool_landed():
+    """ABPOA_HIP_DEVICE_AUDIT=1 (child process: the switch is read once): every pool and staging allocation of every device queue is looked up with
+    hipPointerGetAttributes and must sit on the device its queue serves, with the queue thread's current device set to it -- a call fails with ENODEV
+    otherwise.  Two queues on device 0 here (the pool has one GPU per box); on a multi-GPU node the same switch checks the distinct-ordinal path."""
+    code = ("import os,sys; sys.path.insert(0, %r)\n"
+            "from abpoa_amd import api, ffi, synth\n"
+            "lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))\n"
+            "sets = [synth.make_read_set(13, i, 5 + i %% 4, 150 + 30 * (i %% 5), 0.06) for i in range(600)]\n"
+            "r = api.msa_batch(sets, api.Params(gap_open1=4, gap_open2=0, gap_ext1=2), n_threads=8)\n"
+            "print('OK', all(x.status == 0 for x in r), api.msa_timing()['n_groups'], api.msa_timing()['n_host_sets'])\n" % ROOT)
+    env = dict(os.environ, ABPOA_HIP_DEVICE_AUDIT="1", ABPOA_HIP_VERBOSE="1", ABPOA_GPU_DEVICES="0,0", ABPOA_GPU_BATCHES_PER_DEVICE="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "OK True 2 0" in p.stdout, (p.stdout, p.stderr[-2000:])
+    lines = [ln for ln in p.stderr.splitlines() if "audit:" in ln]
+    assert len(lines) >= 8, p.stderr[-2000:]      # (two queues x at least four pools)
+    assert all("device 0 (queue device 0, thread's current device 0)" in ln for ln in lines), lines
+
+
 def test_multi_queue_batch_call_matches_single_queue(engine):
     """abpoa_hip_msa_batch with ABPOA_GPU_DEVICES: cost-sorted batches dealt to per-device queues on worker threads, results in caller
     order.  One GPU here, so the list names device 0 twice (two queues, two pool caches, two streams): same records as the single queue.
