@@ -155,9 +155,10 @@ class EncodedSets:
     """Read-sets encoded once into residue codes and laid out for abpoa_hip_msa_batch (kept alive on self)."""
 
     def __init__(self, read_sets, m=5, weights=None):
-        """weights: None, or per set a list of per-read integer sequences (the reference's qv weights with -Q: seqio.qv_weights)."""
+        """weights: None, or per set a list of per-read integer sequences (the reference's qv weights with -Q: seqio.qv_weights).
+        A read given as a numpy uint8 array is taken as residue codes already (seqio.encode done elsewhere, e.g. in a generator process)."""
         self.n = len(read_sets)
-        self.codes = [[np.ascontiguousarray(seqio.encode(r, m)) for r in rs] for rs in read_sets]
+        self.codes = [[np.ascontiguousarray(r if isinstance(r, np.ndarray) and r.dtype == np.uint8 else seqio.encode(r, m)) for r in rs] for rs in read_sets]
         self.sets = (ReadSet * self.n)()
         self._keep = []
         for i, rs in enumerate(self.codes):
