@@ -171,3 +171,62 @@ def test_strand_retry_can_be_kept_off_the_device(engine, monkeypatch):
     monkeypatch.setenv("ABPOA_HIP_NO_DEVICE_STRAND", "1")
     r = api.msa_batch(sets, api.Params(), n_threads=4, amb_strand=True)
     assert all(x.status == 0 for x in r) and api.msa_timing()["n_host_sets"] == len(sets)
+
+
+def test_random_option_mixes_and_degenerate_inputs(engine):
+    """A seeded sweep over the option space (gap model x alignment mode x band on / off x -s x weights x output kind) on small ragged sets that include the
+    degenerate shapes -- one read, two reads, reads of 1-5 bases, identical reads, reads of N only, a read far longer than the rest -- device-resident driver
+    against the oracle-backed run.  Whatever the device cannot hold may go to the host driver (counted, not asserted here); results must be equal either way."""
+    import numpy as np
+    import helpers as H
+    from abpoa_amd import api, synth, workloads
+    shim = H.cpu_shim_lib()
+    rng = np.random.default_rng(2024)
+
+    def rnd_read(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    base_sets = [
+        [rnd_read(40)],                                              # one read
+        [rnd_read(30), rnd_read(33)],                                # two unrelated reads
+        ["A", "C", "A", "AC"],                                       # reads of one and two bases
+        ["ACGTA", "ACGA", "ACGTTA", "CGTA", "ACGTA"],
+        ["NNNNNNNN", "NNNNNNN", "NNNNNNNNN"],
+        [rnd_read(60)] * 5,                                          # identical reads
+        list(synth.make_read_set(101, 0, 7, 90, 0.08)) + [rnd_read(400)],      # one read far longer than the rest (and unrelated)
+        list(synth.make_read_set(101, 1, 9, 260, 0.12)),
+        list(synth.make_read_set(101, 2, 5, 700, 0.05)),
+    ]
+    n_dev = n_host = 0
+    aa_sets = [list(synth.make_read_set(103, i, 3 + 2 * i, 30 + 45 * i, alphabet=synth.AA, rates=(0.08, 0.03, 0.03))) for i in range(5)] + [["MKV", "MKLV", "M"]]
+    for it in range(40):
+        gap = [dict(gap_open1=0, gap_open2=0, gap_ext1=int(rng.integers(1, 5))), dict(gap_open1=int(rng.integers(2, 9)), gap_open2=0, gap_ext1=int(rng.integers(1, 4))), dict()][it % 3]
+        mode = int(rng.integers(0, 3))
+        kw = dict(gap, aln_mode=mode)
+        if mode != 1 and rng.random() < 0.4:
+            kw["extra_b"] = -1
+        if mode == EXTEND and rng.random() < 0.5:
+            kw["zdrop"] = int(rng.integers(10, 80))
+        amb = bool(rng.random() < 0.4)
+        out_msa = bool(rng.random() < 0.7)
+        aa = it % 4 == 3
+        if aa:
+            amb = False
+            kw.update(is_aa=True, score_matrix=workloads.BLOSUM62)
+        sets = [list(s) for s in (aa_sets if aa else base_sets)]
+        if amb:
+            sets = [[(_flip(r) if (j and rng.random() < 0.3) else r) for j, r in enumerate(s)] for s in sets]
+        weights = [[rng.integers(1, 30, len(r)).astype(np.int32) for r in s] for s in sets] if rng.random() < 0.4 else None
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=out_msa, n_threads=4, weights=weights, amb_strand=amb)
+        nh = api.msa_timing()["n_host_sets"]
+        n_host += nh; n_dev += len(sets) - nh
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=out_msa, n_threads=4, weights=weights, amb_strand=amb, lib=shim)
+        what = f"iteration {it}: {kw} amb={amb} msa={out_msa} weights={weights is not None}"
+        for i, (a, b) in enumerate(zip(dev, ref)):
+            assert a.status == 0 and b.status == 0, f"{what}: set {i} status {a.status} / {b.status}"
+            assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{what}: consensus of set {i} differs"
+            if out_msa:
+                assert a.msa_seq == b.msa_seq, f"{what}: MSA rows of set {i} differ"
+            if amb:
+                assert list(a.is_rc) == list(b.is_rc), f"{what}: strand flags of set {i} differ"
+    assert n_dev > 8 * n_host, (n_dev, n_host)      # (the sweep is meant to exercise the device-resident driver)
