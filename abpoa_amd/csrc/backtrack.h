@@ -391,6 +391,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 cr_row = i;
             }
         }
+        // (the whole-row loop above carries no cr2: a walk that leaves it for a slow step -- a predecessor that is not staged even in the window centred on the
+        //  cell -- passes through here first, and with a stale cr2 the cell index below fell on column 0 of the row, which in local mode reads as the zero
+        //  cell that ends the walk: found with reads of ragged ends, whose local alignments reach predecessors hundreds of rows away)
+        cr_row = -1;
         while (CW > 0 && i > 0 && j > 0 && status == 0 && !local_done) {
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }

@@ -304,8 +304,11 @@ __device__ __forceinline__ bool takes_fast(const DevBatch &b, const AlnDesc &d) 
 }
 
 // ... and among those, the ones whose rows are wide enough for NW wavefronts per alignment (dp_wide_rows.hip); the rest keep one wavefront
+// (AlnDesc.pad0: columns the rows are expected to be wider than 2 w -- the device-resident driver sets it for read-sets whose reads differ much in length;
+//  half of it counts as band half-width for the choice of the row loop, nothing else reads it)
 __device__ __forceinline__ bool takes_wide(const DevBatch &b, const AlnDesc &d) {
-    return b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi;
+    const int weff = d.w + (d.pad0 >> 1);
+    return b.lds.wide_nw >= 1 && weff >= b.lds.wide_w_lo && weff <= b.lds.wide_w_hi;
 }
 
 // ... and which of the fast alignments write direction words instead of score records (dir_plane.h): dir_mode 1 = the narrow-band ones of the launch,

@@ -14,7 +14,7 @@ struct AlnDesc {
     int32_t w;           // band half-width, reference :445
     int32_t cigar_cap;   // entries
     int32_t flags;       // ALN_FAST_OK: every row active and max_pos_left/right start as (n_rows, 0) -> the register-resident row loop may be used
-    int32_t pad0;
+    int32_t pad0;        // expected extra band columns (device-resident driver, PoaSet.band_extra; 0 elsewhere): dp_common.h takes_wide
     int64_t query_off;   // into query pool (bytes)
     int64_t row0;        // index of DP row 0 in every per-row pool
     int64_t poff0;       // index of pred_off[0] / out_off[0] in the (n_rows+1)-sized offset pools

@@ -89,7 +89,7 @@ struct Layout {                // byte offsets inside the three device blobs
     // graph blob (device only, the tail of it downloaded at the end): per-node pools
     size_t o_cnode, o_ccov, o_cbase, o_isrc;
     size_t o_state, o_base, o_nin, o_nout, o_naln, o_in, o_out, o_outw, o_inx, o_outx, o_outwx, o_aln, o_nread, o_row, o_order0, o_order1, o_rid, o_mrank,
-            o_msaoff, graph_bytes;
+            o_msaoff, o_tout, o_toutw, o_tin, graph_bytes;
     // rows blob: DP inputs / outputs per row, descriptors, cigars, scratch
     size_t o_ticket, o_aln_desc, o_out_rec, o_rbase, o_rsd, o_rpd, o_rnid, o_rrem, o_poff, o_pred, o_bsn, o_esn, o_coff, o_rmi, o_cigar, o_scratch, o_ooff,
             o_orow, o_left, o_right, o_act, o_outfwd, o_cigfwd, o_retry, rows_bytes;
@@ -207,7 +207,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
 
     std::vector<PoaSet> ps(n_sets);
-    int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0; int max_node_cap = 0;
+    int64_t node_tot = 0, pred_tot = 0, cig_tot = 0, scr_tot = 0, plane_tot = 0, read_i = 0, cons_tot = 0, term_tot = 0; int max_node_cap = 0;
     const int w_max = sc->wb + (int)(sc->wf * (float)max_qlen);
     const int aln_cap = std::max(1, sc->m - 1), rid_words = want_msa ? std::max(1, (max_reads + 63) / 64) : 0;
     // columns per row: the whole query without a band
@@ -219,7 +219,24 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
       if (pl.wide_nw >= 1 && !local && !general) { wide_lo = pl.wide_w_lo; wide_hi = pl.wide_w_hi; wide_ring_rows = pl.wfr_rows; } }
     // cigar slots: four times the words of a backtrack where the all-rounds kernel's helper wavefronts write their parts (backtrack_dir.h SPEC_WK,
     //  dir_walk_pair)
-    const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo);
+    // Reads of very different lengths (ends cut at different places; a short read against a long graph): the band is anchored at `qlen - remaining length`
+    // (reference abpoa_align.h:34-35), which then sits as far from the alignment's path as the lengths differ, and every row is that much wider than 2 w.
+    // Such a set gets `extra` columns in its arena and ring estimates, and its alignments take the wide row loop as if half of them were band half-width
+    // (AlnDesc.pad0, dp_common.h takes_wide). Lengths within an eighth of the longest read (at least 64 bases; indel noise: a 25 %-error 400-base set spreads 8
+    //  %) count as equal: the estimates' own slack
+    // (3 vectors + 32 columns) covers those.
+    std::vector<int> extra(n_sets, 0); int max_extra = 0, weff_lo = INT_MAX, weff_hi = 0;
+    if (!local && !general && sc->wb >= 0) for (int s = 0; s < n_sets; ++s) {
+        int mx = 0, mn = INT_MAX; for (int r = 0; r < sets[s].n_reads; ++r) { mx = std::max(mx, sets[s].lens[r]); mn = std::min(mn, sets[s].lens[r]); }
+        if (sets[s].n_reads < 2) continue;
+        const int spread = mx - mn, tol = std::max(64, mx / 8);
+        extra[s] = spread > tol ? std::min((spread + 15) & ~15, 2048) : 0;
+        max_extra = std::max(max_extra, extra[s]);
+        weff_lo = std::min(weff_lo, sc->wb + (int)(sc->wf * (float)mn) + extra[s] / 2);
+        weff_hi = std::max(weff_hi, sc->wb + (int)(sc->wf * (float)mx) + extra[s] / 2);
+    }
+    if (weff_hi == 0) { weff_lo = 0; }
+    const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo) && max_extra == 0;
     // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
     // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the
     // read-sets are in flight instead of two passes with half the SIMDs idle.  ABPOA_HIP_DIR_WIDE=1 / 0: always / never.
@@ -236,6 +253,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         const int64_t cap = std::min<int64_t>(2 + sum, 2 + (int64_t)(node_factor * mx) + 1024);      // graph nodes this set may grow to on the device
         S.n_reads = sets[s].n_reads; S.node_cap = (int)cap; S.pred_cap = (int)(4 * cap);
         S.read0 = read_i; read_i += sets[s].n_reads;
+        S.term0 = term_tot; term_tot += sets[s].n_reads + 2;      // (source out-edges / sink in-edges beyond the per-node slots: at most one of each per read)
         S.node0 = node_tot; node_tot += cap + 1;
         S.pred0 = pred_tot; pred_tot += S.pred_cap;
         // (four times: parts 1-3 take the words of the helper wavefronts)
@@ -243,7 +261,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         // (fuse: 3 x qlen + nodes; order / rank passes: up to four tables of one int per node)
         S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + 4 * cap + 8;
         S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
-        const int w = sc->wb + (int)(sc->wf * (float)mx);
+        const int w = sc->wb + (int)(sc->wf * (float)mx) + extra[s] / 2;      // (for the choice of the row loop: dp_common.h takes_wide)
+        S.band_extra = extra[s];
         max_node_cap = std::max(max_node_cap, (int)cap);
         any_wide_set |= (w >= wide_lo && w <= wide_hi);
     }
@@ -256,11 +275,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
             const int64_t width = (int64_t)((mx + pn) / pn) * pn;
             const int w = sc->wb + (int)(sc->wf * (float)mx);
-            const int64_t est = est_cols(width, w, pn);
+            const int64_t est = std::min<int64_t>(width, est_cols(width, w, pn) + extra[s]);
             // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
             //  global best will read from HBM; half of the rows where the wide loop's ring is only four rows deep; a set that needs more is flagged and
             //  redone like any other capacity miss)
-            const bool wide_s = !local && w >= wide_lo && w <= wide_hi;
+            const bool wide_s = !local && w + extra[s] / 2 >= wide_lo && w + extra[s] / 2 <= wide_hi;
             const bool dir_s = dir && (dw || !wide_s);      // (dp_common.h takes_dir)
             const int64_t rec_div = (wide_s && wide_ring_rows <= 4) ? 2 : 4;
             // (bytes per cell record of a row that keeps its scores: CW values -- the wide kernel's compact records: 4 B int16 affine, else 8 B; rows_fast.h
@@ -297,6 +316,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     L.o_row = take(4 * node_tot);
     L.o_rid = take(8 * node_tot * POA_OUT_CAP * (size_t)rid_words); L.o_mrank = take(want_msa ? 4 * node_tot : 0);
     L.o_msaoff = take(want_msa ? 8 * (size_t)n_sets : 0);
+    L.o_tout = take(4 * term_tot); L.o_toutw = take(4 * term_tot); L.o_tin = take(4 * term_tot);
     L.graph_bytes = o;
     o = 0;
     L.o_ticket = take(4 * POA_CU_TICKETS);
@@ -410,6 +430,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.nd_in = (int32_t *)(dg + L.o_in); p.nd_out = (int32_t *)(dg + L.o_out); p.nd_outw = (int32_t *)(dg + L.o_outw); p.nd_aln = (int32_t *)(dg + L.o_aln);
     p.nd_inx = (int32_t *)(dg + L.o_inx); p.nd_outx = (int32_t *)(dg + L.o_outx); p.nd_outwx = (int32_t *)(dg + L.o_outwx);
     p.nd_nread = (int32_t *)(dg + L.o_nread); p.nd_row = (int32_t *)(dg + L.o_row);
+    p.t_out = (int32_t *)(dg + L.o_tout); p.t_outw = (int32_t *)(dg + L.o_toutw); p.t_in = (int32_t *)(dg + L.o_tin);
     p.nd_rid = (uint64_t *)(dg + L.o_rid); p.msa_rank = (int32_t *)(dg + L.o_mrank); p.msa_off = (const int64_t *)(dg + L.o_msaoff); p.msa_out = nullptr;
     p.row_node[0] = (int32_t *)(dg + L.o_order0); p.row_node[1] = (int32_t *)(dg + L.o_order1);
     p.scratch = (int32_t *)(dr + L.o_scratch);
@@ -429,7 +450,10 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     {
         int32_t inf_dummy; const int max_bits = abpoa_hip_score_bits(sc, max_node_cap, max_qlen, &inf_dummy); const int pn = max_bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
-        make_lds_plan(sc, max_qlen, max_bits, est_cols(width, w_max, pn), n_sets, &b.lds);
+        // (the rings hold the widest rows expected -- up to 1024 columns: beyond that the plan has no fast row loop at all, and a few ragged sets must not send
+        //  the whole job to the host driver; theirs overflow on their own)
+        make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(std::max<int64_t>(est_cols(width, w_max, pn), std::min<int64_t>(1024, width)), est_cols(width,
+                w_max, pn) + max_extra), n_sets, &b.lds);
         // (no fast row loop takes anything: dp_common.h takes_fast / rows_local.h takes_local)
         if (general) { b.lds.wide_nw = 0; b.lds.fr_cols = 0; b.lds.loc_cols = 0; }
         // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the general kernel's
@@ -444,9 +468,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         const int min_bits = abpoa_hip_score_bits(sc, 3, min_qlen, &inf_dummy);
         b.bits_mask = (min_bits == 16 ? 1 : 0) | (max_bits == 32 ? 2 : 0);
         // which row-loop kernels can have work at all: band half-widths of the reads that get aligned (w = b + f * length)
-        const int w_min = sc->wb + (int)(sc->wf * (float)min_qlen);
-        if (w_max < b.lds.wide_w_lo || w_min > b.lds.wide_w_hi) b.lds.wide_nw = 0;                       // no read takes the wide loop
-        b.lds.narrow_off = (b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_max <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
+        // (band half-widths as dp_common.h takes_wide counts them: with half of a ragged set's extra columns)
+        const int w_min = std::min(sc->wb + (int)(sc->wf * (float)min_qlen), max_extra ? weff_lo : INT_MAX), w_top = std::max(w_max, weff_hi);
+        const bool mixed = max_extra > 0;      // (sets with and without extra columns: both loops may have work whatever the extremes say)
+        if (!mixed && (w_top < b.lds.wide_w_lo || w_min > b.lds.wide_w_hi)) b.lds.wide_nw = 0;                       // no read takes the wide loop
+        b.lds.narrow_off = (!mixed && b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_top <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
     }
     // caller falls back to the host driver
     if (!local && !general && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }
@@ -652,8 +678,16 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int n_slots = 0;
-        for (int f : *fallback) { const int s = f < 0 ? -f - 1 : f; const int r = hs[s].pad; if (r == 5) { n_slots++; continue;
-                } hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++; }
+        int dp_arena = 0, dp_scores = 0, dp_other = 0;      // DP status: arena too small for the rows' bands / direction words could not decide / anything else
+        for (int f : *fallback) {
+            const int s = f < 0 ? -f - 1 : f; const int r = hs[s].pad;
+            if (r == 5) { n_slots++; continue; }
+            if (r >= 1000) { if (r - 1000 == ABPOA_HIP_STATUS_OVERFLOW) dp_arena++; else if (r - 1000 == ABPOA_HIP_STATUS_NEED_SCORES) dp_scores++;
+                    else dp_other++; }
+            hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++;
+        }
+        if (hist[5]) fprintf(stderr, "[abpoa-hip]   DP status: arena too small for the bands %d, direction words undecided %d, other %d\n", dp_arena,
+                dp_scores, dp_other);
         fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, node slots in the fuse "
                 "phase %d, edge / aligned slots of a node full (host driver at once) %d, DP status %d, projected node growth "
                 "(early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], n_slots, hist[5], hist[7], hist[6] + hist[0]);

@@ -135,10 +135,12 @@ void DeviceDebug::graph_check(int k) {
             const PoaNode &h = G.node(u);
             if (h.base != base[u]) complain("base differs", u, base[u]);
             if (h.in_id.size() != nin[u]) complain("in-degree differs", u, nin[u]);
-            else for (int t = 0; t < nin[u]; ++t) { if (h.in_id[t] != in[u * POA_IN_CAP + t]) complain("in edge differs", u, t); if (row[in[u * POA_IN_CAP
+            else for (int t = 0; t < std::min<int>(nin[u], POA_IN_CAP); ++t) { if (h.in_id[t] != in[u * POA_IN_CAP + t]) complain("in edge differs", u, t);
+                    if (row[in[u * POA_IN_CAP
                     + t]] >= row[u]) complain("order violated (pred row >= row)", in[u * POA_IN_CAP + t], u); }
             if (h.out_id.size() != nout[u]) complain("out-degree differs", u, nout[u]);
-            else for (int t = 0; t < nout[u]; ++t) { if (h.out_id[t] != outv[u * POA_OUT_CAP + t]) complain("out edge differs", u, t);
+            else for (int t = 0; t < std::min<int>(nout[u], POA_OUT_CAP); ++t) { if (h.out_id[t] != outv[u * POA_OUT_CAP + t]) complain("out edge differs", u,
+                    t);
                     if (h.out_w[t] != outw[u * POA_OUT_CAP + t]) complain("out weight differs", u, t); }
             if (h.aligned.size() != naln[u]) complain("aligned count differs", u, naln[u]);
             else for (int t = 0; t < naln[u]; ++t) if (h.aligned[t] != aln[(size_t)u * aln_cap + t]) complain("aligned node differs", u, t);
@@ -260,7 +262,10 @@ void DeviceDebug::consensus_check(const PoaState *hs, const abpoa_hip_msa_t *out
             for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_]
                     : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
         };
-        dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(),
+        dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1);
+        if (nout[0] > POA_OUT_CAP) { fprintf(stderr, "[poa-device]   set %d: consensus check skipped (the source has %d out-edges: the check's arrays hold "
+                "%d per node)\n", s, (int)nout[0], POA_OUT_CAP); continue; }
+        dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(),
                 p.nd_outw, p.nd_outwx, POA_OUT_CAP);
         dl(nread.data(), p.nd_nread, 4, 1); dl(order.data(), p.row_node[hs[s].order_buf], 4, 1);
         std::vector<int> ids, cov, sc_, mo; std::vector<uint8_t> bases;

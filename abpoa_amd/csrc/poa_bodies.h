@@ -18,10 +18,18 @@ __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 // loads of data that OTHER lanes of this wave stored earlier in the same kernel: agent scope = not served from this CU's L1
 __device__ __forceinline__ int ld_fresh(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// slot t of a node's edge lists (X = node0 + node id): the first POA_HOT slots are in the hot arrays
-__device__ __forceinline__ int32_t &in_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_in[X * POA_HOT + t] : p.nd_inx[X * (POA_IN_CAP - POA_HOT) + t - POA_HOT]; }
-__device__ __forceinline__ int32_t &out_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_out[X * POA_HOT + t] : p.nd_outx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT]; }
-__device__ __forceinline__ int32_t &outw_slot(const PoaDev &p, int64_t X, int t) { return t < POA_HOT ? p.nd_outw[X * POA_HOT + t] : p.nd_outwx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT]; }
+// slot t of a node's edge lists (X = node0 + node id): the first POA_HOT slots are in the hot arrays, the next ones in the cold arrays; slots from the
+// capacity on exist for the source's out-edges and the sink's in-edges only (PoaSet.term0: the set's slice of the terminal pools)
+constexpr int POA_TERM_MAX = 250;      // edges of the source / into the sink at most (the counts are bytes)
+__device__ __forceinline__ int32_t &in_slot(const PoaDev &p, const PoaSet &S, int64_t X, int t) {
+    return t < POA_HOT ? p.nd_in[X * POA_HOT + t] : (t < POA_IN_CAP ? p.nd_inx[X * (POA_IN_CAP - POA_HOT) + t - POA_HOT] : p.t_in[S.term0 + t - POA_IN_CAP]);
+}
+__device__ __forceinline__ int32_t &out_slot(const PoaDev &p, const PoaSet &S, int64_t X, int t) {
+    return t < POA_HOT ? p.nd_out[X * POA_HOT + t] : (t < POA_OUT_CAP ? p.nd_outx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT] : p.t_out[S.term0 + t - POA_OUT_CAP]);
+}
+__device__ __forceinline__ int32_t &outw_slot(const PoaDev &p, const PoaSet &S, int64_t X, int t) {
+    return t < POA_HOT ? p.nd_outw[X * POA_HOT + t] : (t < POA_OUT_CAP ? p.nd_outwx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT] : p.t_outw[S.term0 + t - POA_OUT_CAP]);
+}
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value that is the same in every lane -> scalar register
 __device__ __forceinline__ int shfl(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
@@ -123,7 +131,7 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
                 if (no[j] > 1 && w4[j].y > bw) { bw = w4[j].y; bb = o4[j].y; }
                 if (no[j] > 2 && w4[j].z > bw) { bw = w4[j].z; bb = o4[j].z; }
                 if (no[j] > 3 && w4[j].w > bw) { bw = w4[j].w; bb = o4[j].w; }
-                for (int t = POA_HOT; t < no[j]; ++t) { const int w = outw_slot(p, N0 + u[j], t); if (w > bw) { bw = w; bb = out_slot(p, N0 + u[j], t); } }
+                for (int t = POA_HOT; t < no[j]; ++t) { const int w = outw_slot(p, S, N0 + u[j], t); if (w > bw) { bw = w; bb = out_slot(p, S, N0 + u[j], t); } }
                 best[j] = bb;
             }
 #pragma unroll
@@ -139,7 +147,7 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
                     if (no[j] > 0) rr[0] = p.nd_row[N0 + o4[j].x]; if (no[j] > 1) rr[1] = p.nd_row[N0 + o4[j].y]; if (no[j] > 2) rr[2] = p.nd_row[N0 + o4[j].z];
                     if (no[j] > 3) rr[3] = p.nd_row[N0 + o4[j].w];
                     far = imax_(imax_(rr[0], rr[1]), imax_(rr[2], rr[3]));
-                    for (int t = POA_HOT; t < no[j]; ++t) far = imax_(far, p.nd_row[N0 + out_slot(p, N0 + u[j], t)]);
+                    for (int t = POA_HOT; t < no[j]; ++t) far = imax_(far, p.nd_row[N0 + out_slot(p, S, N0 + u[j], t)]);
                 }
                 sd[j] = far >= n - 1 ? 255 : imin_(imax_(far - r, 0), 255);      // (the sink is the last row)
             }
@@ -245,7 +253,7 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
                 for (int t = 0; t < 4; ++t) {
                     if (t < np[j]) { dst[t] = pr[j][t]; if (r - pr[j][t] <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr[j][t]) << (8 * t)); }
                 }
-                for (int t = POA_HOT; t < np[j]; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, N0 + u[j], t)]; dst[t] = pr_;
+                for (int t = POA_HOT; t < np[j]; ++t) { const int pr_ = p.nd_row[N0 + in_slot(p, S, N0 + u[j], t)]; dst[t] = pr_;
                         if (t < 8 && r - pr_ <= 254) pdv = (pdv & ~(0xffull << (8 * t))) | ((unsigned long long)(r - pr_) << (8 * t)); }
                 if (r < n) { p.row_pd[2 * (N0 + r)] = (unsigned)pdv; p.row_pd[2 * (N0 + r) + 1] = (unsigned)(pdv >> 32); }
             }
@@ -269,7 +277,7 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
             if (r < n) {
                 p.out_off[N0 + r] = off;
                 if (off + no > S.pred_cap) overflow = true;
-                else for (int t = 0; t < no; ++t) p.out_row[S.pred0 + off + t] = p.nd_row[N0 + out_slot(p, N0 + u, t)];
+                else for (int t = 0; t < no; ++t) p.out_row[S.pred0 + off + t] = p.nd_row[N0 + out_slot(p, S, N0 + u, t)];
             }
             carry_o += all;
         }
@@ -283,7 +291,7 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
         d.n_rows = n; d.qlen = qlen;
         d.bits = score_bits(p, n, qlen, &d.inf_min);
         d.w = p.wb < 0 ? qlen : p.wb + (int)(p.wf * (float)qlen);            // reference :445 (float32 product)
-        d.cigar_cap = S.cigar_cap; d.flags = (p.general & 1) ? 0 : ALN_FAST_OK; d.pad0 = 0;
+        d.cigar_cap = S.cigar_cap; d.flags = (p.general & 1) ? 0 : ALN_FAST_OK; d.pad0 = S.band_extra;
         d.query_off = p.read_off[S.read0 + k]; d.row0 = N0; d.poff0 = N0; d.pred0 = S.pred0; d.out0 = S.pred0;
         d.plane_off = S.plane_off; d.plane_cap = S.plane_cap / (d.bits / 8); d.cigar_off = S.cigar_off;
         if (overflow || n + qlen + 8 > S.cigar_cap) { st->status = POA_ST_FALLBACK; st->pad = overflow ? 2 : 3; d.flags = ALN_SKIP; d.n_rows = 3; }
@@ -343,18 +351,22 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
         const int64_t F = N0 + from, T = N0 + to;
         int no = from_new ? 0 : (int)p.nd_nout[F];
         int hit = -1;
-        if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (out_slot(p, F, t) == to) { hit = t; break; }
-        if (hit >= 0) outw_slot(p, F, hit) += w;
+        if (!from_new && !to_new) for (int t = 0; t < no; ++t) if (out_slot(p, S, F, t) == to) { hit = t; break; }
+        if (hit >= 0) outw_slot(p, S, F, hit) += w;
         else {
             const int ni = to_new ? 0 : (int)p.nd_nin[T];
-            if (no >= POA_OUT_CAP || ni >= POA_IN_CAP) { fail = true; fail_slots = true; return; }
-            out_slot(p, F, no) = to; outw_slot(p, F, no) = w; p.nd_nout[F] = (uint8_t)(no + 1);
-            in_slot(p, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
+            // (the source may have any number of out-edges, the sink of in-edges: reads that start / end on different nodes; PoaSet.term0)
+            if (no >= (from == 0 ? imin_(POA_TERM_MAX, POA_OUT_CAP + S.n_reads + 2) : POA_OUT_CAP) || ni >= (to == 1 ? imin_(POA_TERM_MAX, POA_IN_CAP + S.n_reads + 2) : POA_IN_CAP)) { fail = true;
+                    fail_slots = true; return; }
+            out_slot(p, S, F, no) = to; outw_slot(p, S, F, no) = w; p.nd_nout[F] = (uint8_t)(no + 1);
+            in_slot(p, S, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
             hit = no;
-            for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + w_] = 0;      // (a new edge: no read went through it yet)
+            // (a new edge: no read went through it yet.  The source's edges beyond the capacity keep no read ids: nothing reads the source's -- the MSA rows
+            //  come from the out-edges of nodes 2.., reference abpoa_output.c:142-150)
+            if (hit < POA_OUT_CAP) for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + w_] = 0;
         }
         // read k went through this edge (reference :453-472; a node is the tail of at most one edge per read, so no other lane touches these words)
-        if (p.rid_words) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + (k >> 6)] |= 1ull << (k & 63);
+        if (p.rid_words && hit < POA_OUT_CAP) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + (k >> 6)] |= 1ull << (k & 63);
         p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
     };
     // all wavefronts walk the query together, GT positions per pass: per-position work (node lookup, new node, edge) is private to

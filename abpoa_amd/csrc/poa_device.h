@@ -26,7 +26,8 @@ constexpr int POA_ALN_MAX = 26;    // aligned (mismatch-alternative) nodes per n
 
 struct PoaSet {                    // immutable per read-set
     int32_t n_reads, node_cap;     // node_cap: slots in every per-node / per-row pool
-    int32_t pred_cap, pad;         // entries of this set's pred_row slice
+    int32_t pred_cap, band_extra;  // entries of this set's pred_row slice; band_extra: columns a row's band may be wider than 2 w (reads of very different lengths:
+                                   // the band's anchor `qlen - remaining length` then sits that far from the path) -- AlnDesc.pad0 of the set's alignments
     int64_t read0;                 // first read in the read tables
     int64_t node0;                 // first slot in the node / row pools
     int64_t pred0;                 // first slot in pred_row
@@ -34,6 +35,7 @@ struct PoaSet {                    // immutable per read-set
     int64_t cigar_off; int32_t cigar_cap, pad2;
     int64_t scratch0;              // first slot of this set's int32 scratch (3 * max_qlen + node_cap + 1 entries)
     int64_t cons0; int32_t cons_cap, pad3;     // this set's slice of the consensus result pools
+    int64_t term0;                 // first slot of this set's terminal edge pools (PoaDev.t_out / t_outw / t_in): n_reads + 2 entries each
 };
 
 struct PoaState {                  // mutable per read-set
@@ -77,6 +79,9 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     uint8_t *nd_base, *nd_nin, *nd_nout, *nd_naln;
     int32_t *nd_in, *nd_out, *nd_outw;              // hot slots  [node][POA_HOT]: in ids, out ids, out weights
     int32_t *nd_inx, *nd_outx, *nd_outwx;           // cold slots [node][CAP - POA_HOT]
+    // The source's out-edges beyond POA_OUT_CAP and the sink's in-edges beyond POA_IN_CAP (reads that do not all start / end on the same node: every read adds
+    // at most one of each, so n_reads + 2 entries per set hold them all); slot t >= CAP of node 0 / node 1 is entry t - CAP of the set's slice (poa_bodies.h out_slot / in_slot)
+    int32_t *t_out, *t_outw, *t_in;
     int32_t *nd_aln;                                // [node][aln_cap]
     uint64_t *nd_rid;                               // [node][POA_OUT_CAP][rid_words]: reads that went through the out-edge (reference abpoa_node_t.read_ids)
     int32_t *nd_nread, *nd_row;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
         p.nd_nin[N0 + u] = (uint8_t)nin; p.nd_nout[N0 + u] = (uint8_t)nout;
         // (edge weight = weight of the base the edge leads to; the edge into the sink takes the last base's: reference abpoa_add_graph_sequence :486-499)
         const int32_t *wq = p.wts ? p.wts + p.read_off[S.read0] : nullptr;
-        in_slot(p, N0 + u, 0) = in0; out_slot(p, N0 + u, 0) = out0; outw_slot(p, N0 + u, 0) = !wq ? 1 : (u == 0 ? wq[0] : (u == 1 ? 0 : wq[i == L - 1 ? L - 1 : i + 1]));
+        in_slot(p, S, N0 + u, 0) = in0; out_slot(p, S, N0 + u, 0) = out0; outw_slot(p, S, N0 + u, 0) = !wq ? 1 : (u == 0 ? wq[0] : (u == 1 ? 0 : wq[i == L - 1 ? L - 1 : i + 1]));
         p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
         // read 0 went through the node's one edge
         if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * POA_OUT_CAP) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }
@@ -143,15 +143,15 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
         const int no = valid ? (int)p.nd_nout[N0 + u] : 0;
         // heaviest weight and the rows of the candidate targets (edges with that weight), as a dependency mask inside the block
         int wmax = INT_MIN;
-        for (int t = 0; t < no; ++t) wmax = imax_(wmax, outw_slot(p, N0 + u, t));
+        for (int t = 0; t < no; ++t) wmax = imax_(wmax, outw_slot(p, S, N0 + u, t));
         // candidates = targets of the heaviest edges, in edge order: their rows (and, for targets in later blocks, their final scores)
         // are fetched once, so that a row's turn in the loop below costs LDS reads only; a row with more than NCAND candidates re-reads
         constexpr int NCAND = 4;
         unsigned long long dep = 0; int ctr[NCAND], csc[NCAND], ncand = 0;
 #pragma unroll
         for (int c_ = 0; c_ < NCAND; ++c_) { ctr[c_] = -1; csc[c_] = 0; }
-        for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
-            const int tr = p.nd_row[N0 + out_slot(p, N0 + u, t)];
+        for (int t = 0; t < no; ++t) if (outw_slot(p, S, N0 + u, t) == wmax) {
+            const int tr = p.nd_row[N0 + out_slot(p, S, N0 + u, t)];
             if (tr < t0 + 64) dep |= 1ull << (tr - t0);
 #pragma unroll
             for (int c_ = 0; c_ < NCAND; ++c_) if (c_ == ncand) { ctr[c_] = tr; csc[c_] = tr >= t0 + 64 ? ld_fresh(score + tr) : 0; }
@@ -173,8 +173,8 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
                         const int sc_ = tr < t0 + 64 ? sh_score[tr - t0] : csc[c_];
                         if (best_row < 0 || (is_src ? sc_ > best_sc : sc_ >= best_sc)) { best_sc = sc_; best_row = tr; }
                     }
-                } else for (int t = 0; t < no; ++t) if (outw_slot(p, N0 + u, t) == wmax) {
-                    const int tr = p.nd_row[N0 + out_slot(p, N0 + u, t)];
+                } else for (int t = 0; t < no; ++t) if (outw_slot(p, S, N0 + u, t) == wmax) {
+                    const int tr = p.nd_row[N0 + out_slot(p, S, N0 + u, t)];
                     const int sc_ = tr < t0 + 64 ? sh_score[tr - t0] : ld_fresh(score + tr);
                     if (best_row < 0 || (is_src ? sc_ > best_sc : sc_ >= best_sc)) { best_sc = sc_; best_row = tr; }
                 }
@@ -215,12 +215,13 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const PoaDev p) {
 // nodes.  Local mode needs exactly this order: the best cell of a local alignment is the first row that reaches the maximum (reference :1012-1016).
 //
 // One wavefront per read-set.  The queue IS the order array; up to 64 queue entries are processed per pass, a lane each, and the pass reproduces what the
-// sequential walk would have done with them.  Every in-degree decrement has a time stamp  key = 16 * (queue position of the node popped) + (index of
+// sequential walk would have done with them.  Every in-degree decrement has a time stamp  key = ORD_KEY * (queue position of the node popped) + (index of
 // the out-edge)  -- the order in which the reference performs them.  zt[v] = the largest key that touched v, so once v's count is zero zt[v] is the moment it
 // became zero.  The reference enqueues a group at the moment its LAST member reaches zero, that member first and then its aligned list in list order
 // (a member that reaches zero earlier fails the check at :212-215 and is not looked at again): so the edge (lane, k) whose key equals zt[v], with every
 // aligned node of v at zero and none of them later than v, pushes the group, and the groups of a pass are pushed in key order (prefix sum over the lanes,
 // edges in order inside a lane).  A chain graph degenerates to one node per pass: a pass costs one round trip to the node's edge record plus LDS work.
+constexpr int ORD_KEY = 256;                  // time stamps: ORD_KEY * queue position + edge index (the source may have up to POA_TERM_MAX out-edges)
 constexpr int ORD_RING = 1024;                 // the most recent queue entries, in LDS (the frontier of a POA graph is a few nodes wide)
 extern __shared__ int ord_lds[];               // [ORD_RING] ring, then -- LDS tables -- [cap] in-degree counters, [cap] zero times (rank pass: + [cap] rank, [cap] stack)
 // table `which`, entry i; n: the stride between tables (LDS: the launch's table capacity; global: the node count)
@@ -296,9 +297,9 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
             else { no = uni((int)p.nd_nout[N0 + u]); o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
             int at = tail;
             for (int k = 0; k < no; ++k) {
-                const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))));
+                const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, S, N0 + u, k)))));
                 const int d = uni(tbl_ld<L>(p, g, 0, n, v)) - 1;
-                if (lane == 0) { tbl_st<L>(p, g, 0, n, v, d); tbl_st<L>(p, g, 1, n, v, head * 16 + k); }
+                if (lane == 0) { tbl_st<L>(p, g, 0, n, v, d); tbl_st<L>(p, g, 1, n, v, head * ORD_KEY + k); }
                 if (d != 0) continue;
                 const int na = uni(naln_of(v));
                 bool ready = true;
@@ -320,8 +321,8 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
         if (!QL && tail - head > ORD_RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a frontier wider than the ring: from the order array, once its stores are acknowledged)
         if (act) u = qget(pos, head, tail);
         if (act) { no = p.nd_nout[N0 + u]; o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
-        auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))); };
-        for (int k = 0; k < no; ++k) tbl_dec_max<L>(p, g, n, target(k), pos * 16 + k);
+        auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, S, N0 + u, k)))); };
+        for (int k = 0; k < no; ++k) tbl_dec_max<L>(p, g, n, target(k), pos * ORD_KEY + k);
         tbl_fence<L>();
         // Which edges push a group.  The first four edges of a lane and the first four aligned nodes of their targets are looked at together, so that the
         // memory loads of this half of the pass -- the aligned lists -- are all in flight at once (as a loop with an early exit they were one dependent
@@ -332,7 +333,7 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
 #pragma unroll
         for (int k = 0; k < KQ; ++k) {
             vq[k] = k < no ? target(k) : 0;
-            cq[k] = k < no && tbl_ld<L>(p, g, 0, n, vq[k]) == 0 && tbl_ld<L>(p, g, 1, n, vq[k]) == pos * 16 + k;
+            cq[k] = k < no && tbl_ld<L>(p, g, 0, n, vq[k]) == 0 && tbl_ld<L>(p, g, 1, n, vq[k]) == pos * ORD_KEY + k;
             naq[k] = cq[k] ? naln_of(vq[k]) : 0;
         }
 #pragma unroll
@@ -341,14 +342,14 @@ __device__ __forceinline__ bool poa_order_body(const PoaDev &p, const PoaSet &S,
             for (int t = 0; t < TQ; ++t) aq[k][t] = (cq[k] && t < naq[k]) ? p.nd_aln[(N0 + vq[k]) * p.aln_cap + t] : 0;
 #pragma unroll
         for (int k = 0; k < KQ; ++k) if (cq[k]) {
-            const int key = pos * 16 + k; bool ready = true;
+            const int key = pos * ORD_KEY + k; bool ready = true;
 #pragma unroll
             for (int t = 0; t < TQ; ++t) if (t < naq[k]) ready = ready && tbl_ld<L>(p, g, 0, n, aq[k][t]) == 0 && tbl_ld<L>(p, g, 1, n, aq[k][t]) < key;
             for (int t = TQ; t < naq[k] && ready; ++t) { const int a = p.nd_aln[(N0 + vq[k]) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
             if (ready) { trig |= 1u << k; total += 1 + naq[k]; }
         }
         for (int k = KQ; k < no; ++k) {
-            const int v = target(k), key = pos * 16 + k;
+            const int v = target(k), key = pos * ORD_KEY + k;
             if (tbl_ld<L>(p, g, 0, n, v) != 0 || tbl_ld<L>(p, g, 1, n, v) != key) continue;
             const int na = naln_of(v); bool ready = true;
             for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
@@ -435,7 +436,7 @@ __device__ __forceinline__ int poa_order_body_lds(const PoaDev &p, const PoaSet 
             else { no = uni((int)p.nd_nout[N0 + u]); o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
             int at = tail;
             for (int k = 0; k < no; ++k) {
-                const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))));
+                const int v = uni(k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, S, N0 + u, k)))));
                 const int r = uni((int)s_rep[v]);
                 const int d = uni(cnt[r]) - 1;
                 if (lane == 0) cnt[r] = d != 0 ? d : 0x7fffffff;          // (a group that was pushed keeps a value no decrement reaches)
@@ -458,7 +459,7 @@ __device__ __forceinline__ int poa_order_body_lds(const PoaDev &p, const PoaSet 
             const int nx = s_next[u];
             if (nx != 0xffff) { no = 1; o4.x = nx; } else { no = p.nd_nout[N0 + u]; o4 = *(const int4 *)(p.nd_out + (N0 + u) * POA_HOT); }
         }
-        auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, N0 + u, k)))); };
+        auto target = [&](int k) { return k == 0 ? o4.x : (k == 1 ? o4.y : (k == 2 ? o4.z : (k == 3 ? o4.w : out_slot(p, S, N0 + u, k)))); };
         for (int k = 0; k < no; ++k) atomicSub(&cnt[s_rep[target(k)]], 1);
         fence();
         unsigned zero = 0;                                               // edges whose group's sum is zero now
@@ -525,25 +526,29 @@ __device__ __forceinline__ int poa_msa_rank_body(const PoaDev &p, const PoaSet &
             ++msa_rank;
         }
         if (cur == 1) { done = true; break; }
-        const int key = pops * 16 + lane; ++pops;
-        int v = -1;
-        if (lane < no) { v = out_slot(p, N0 + cur, lane); tbl_dec_max<L>(p, g, n, v, key); }
-        __syncthreads();
-        int total = 0, na = 0;
-        if (lane < no && tbl_ld<L>(p, g, 0, n, v) == 0) {
-            na = p.nd_naln[N0 + v]; bool ready = true;
-            for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
-            if (ready) total = 1 + na;
+        // (64 out-edges at a time, a lane each -- only the source can have more: PoaSet.term0 -- chunk after chunk as the sequential walk would take them)
+        for (int e0 = 0; e0 < no; e0 += 64) {
+            const int e = e0 + lane, key = pops * ORD_KEY + e;
+            int v = -1;
+            if (e < no) { v = out_slot(p, S, N0 + cur, e); tbl_dec_max<L>(p, g, n, v, key); }
+            __syncthreads();
+            int total = 0, na = 0;
+            if (e < no && tbl_ld<L>(p, g, 0, n, v) == 0) {
+                na = p.nd_naln[N0 + v]; bool ready = true;
+                for (int t = 0; t < na && ready; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; ready = tbl_ld<L>(p, g, 0, n, a) == 0 && tbl_ld<L>(p, g, 1, n, a) < key; }
+                if (ready) total = 1 + na;
+            }
+            const int incl = wave_scan_add(total), all = __builtin_amdgcn_readlane(incl, 63);
+            if (sp + all > n) return -1;
+            if (total) {
+                int at = sp + incl - total;
+                tbl_st<L>(p, g, 3, n, at, v); tbl_st<L>(p, g, 2, n, v, -1); ++at;
+                for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; tbl_st<L>(p, g, 3, n, at, a); tbl_st<L>(p, g, 2, n, a, -1); ++at; }
+            }
+            sp += all;
+            __syncthreads();
         }
-        const int incl = wave_scan_add(total), all = __builtin_amdgcn_readlane(incl, 63);
-        if (sp + all > n) return -1;
-        if (total) {
-            int at = sp + incl - total;
-            tbl_st<L>(p, g, 3, n, at, v); tbl_st<L>(p, g, 2, n, v, -1); ++at;
-            for (int t = 0; t < na; ++t) { const int a = p.nd_aln[(N0 + v) * p.aln_cap + t]; tbl_st<L>(p, g, 3, n, at, a); tbl_st<L>(p, g, 2, n, a, -1); ++at; }
-        }
-        sp += all;
-        __syncthreads();
+        ++pops;
     }
     if (!done) return -1;
     __syncthreads();

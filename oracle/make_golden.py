@@ -56,6 +56,20 @@ def cases(tmp):
     out.append(("s20k_ag_i32", s20k, AG, "3", 0, None))
     out.append(("aa_blosum_loc", aa, ["-m", "1", "-c", "-t", os.path.join(REF, "BLOSUM62.mtx"), "-r", "1"], "3,7", 0, None))
     out.append(("aa_blosum_gb", aa, ["-c", "-t", os.path.join(REF, "BLOSUM62.mtx")], "7", 0, None))
+    # local alignment of reads with ragged ends (every read but the first a random substring of its noisy full-length version): read 9's best path enters the
+    # graph through a node 24 rows above its successor -- the backtrack leaves its staged window for a slow step there (the case that showed a stale
+    # window record in the tail kernel's local walk: tests/test_gpu_device_general.py::test_reads_with_ragged_ends...)
+    import numpy as np
+    rg = os.path.join(tmp, "ragged.fa")
+    rng = np.random.default_rng(109)
+    full = synth.make_read_set(109, 0, 45, 260, 0.04)
+    cut = [full[0]]
+    for r in full[1:]:
+        a = int(rng.integers(0, int(0.15 * len(r)) + 1)); b = len(r) - int(rng.integers(0, int(0.15 * len(r)) + 1))
+        cut.append(r[a:b])
+    synth.write_fasta(rg, cut[:10])
+    out.append(("ragged_cg_loc", rg, ["-m", "1"], "5,9", 0, None))
+    out.append(("ragged_ag_loc", rg, AG + ["-m", "1"], "9", 0, None))
     # whole-pipeline text goldens (consensus / MSA) used by the host-layer tests
     out.append(("out_seq_cons", seq, AG, "none", 0, None))
     out.append(("out_test_msa", tst, ["-r", "1"], "none", 0, None))

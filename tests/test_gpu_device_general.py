@@ -230,3 +230,60 @@ def test_random_option_mixes_and_degenerate_inputs(engine):
             if amb:
                 assert list(a.is_rc) == list(b.is_rc), f"{what}: strand flags of set {i} differ"
     assert n_dev > 8 * n_host, (n_dev, n_host)      # (the sweep is meant to exercise the device-resident driver)
+
+
+# ---------------------------------------------------------------------------------------------------------------- reads with ragged ends
+def _ragged_sets(seed, shapes, frac):
+    """every read but the first is a random substring of its noisy full-length version: up to `frac` of the length cut from each end"""
+    import numpy as np
+    from abpoa_amd import synth
+    rng = np.random.default_rng(seed)
+    sets = []
+    for i, (n, ln, err) in enumerate(shapes):
+        reads = list(synth.make_read_set(seed, i, n, ln, err))
+        out = [reads[0]]
+        for r in reads[1:]:
+            a = int(rng.integers(0, int(frac * len(r)) + 1)); b = len(r) - int(rng.integers(0, int(frac * len(r)) + 1))
+            out.append(r[a:b])
+        sets.append(out)
+    return sets
+
+
+@pytest.mark.parametrize("lockstep", [0, 1], ids=["all_rounds_kernel", "lockstep_rounds"])
+def test_reads_with_ragged_ends_stay_on_the_device(engine, monkeypatch, lockstep):
+    """Reads that do not start and end on the same node (window-cut or partly sequenced reads): the source collects an out-edge, the sink an in-edge per
+    distinct end -- far more than the 16 / 15 slots of a node (PoaSet.term0: the terminal pools) -- and the band, anchored at `qlen - remaining length`, sits
+    as far from the path as the lengths differ (PoaSet.band_extra: wider arena rows, the wide row loop).  60 reads per set so that the source passes 16 edges;
+    consensus, MSA and -- with 70 reads -- the rank walk over more than 64 out-edges of one node, against the oracle-backed run."""
+    import helpers as H
+    from abpoa_amd import api
+    monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", str(lockstep))
+    shim = H.cpu_shim_lib()
+    sets = _ragged_sets(107, [(60, 300, 0.04), (40, 500, 0.06), (70, 240, 0.03), (25, 900, 0.05), (12, 1500, 0.08)], 0.12)
+    sets.append([sets[2][0]] + [sets[2][0][k:] for k in range(1, 80)])      # 80 reads, every one starting one base later: 80 out-edges of the source
+    for kw in (dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict()):
+        p = api.Params(**kw)
+        for out_msa in (False, True):
+            dev = api.msa_batch(sets, p, out_cons=True, out_msa=out_msa, n_threads=4)
+            assert api.msa_timing()["n_host_sets"] == 0, f"{kw}: not every set ran on the device-resident driver"
+            ref = api.msa_batch(sets, p, out_cons=True, out_msa=out_msa, n_threads=4, lib=shim)
+            for i, (a, b) in enumerate(zip(dev, ref)):
+                assert a.status == 0 and b.status == 0
+                assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{kw}: consensus of set {i} differs"
+                if out_msa:
+                    assert a.msa_seq == b.msa_seq, f"{kw}: MSA rows of set {i} differ"
+
+
+def test_ragged_local_and_general_jobs(engine):
+    """The terminal pools under the other drivers of the device path: local mode (order walk over a source with dozens of out-edges: the time stamps of its
+    edges must not collide with later queue positions), linear gaps and extension mode (general kernel: successor lists of row 0)."""
+    import helpers as H
+    from abpoa_amd import api
+    shim = H.cpu_shim_lib()
+    sets = _ragged_sets(109, [(45, 260, 0.04), (30, 420, 0.06), (50, 180, 0.03)], 0.15)
+    for kw in (dict(aln_mode=1), dict(aln_mode=1, gap_open1=5, gap_open2=0, gap_ext1=2), dict(gap_open1=0, gap_open2=0, gap_ext1=2), dict(aln_mode=EXTEND)):
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        assert api.msa_timing()["n_host_sets"] == 0, f"{kw}: not every set ran on the device-resident driver"
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"ragged {kw}")
