@@ -408,6 +408,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     p.n_sets = n_sets; p.m = sc->m; p.max_mat = sc->max_mat; p.min_mis = sc->min_mis; p.o1 = sc->gap_open1; p.e1 = sc->gap_ext1; p.o2 = sc->gap_open2;
     p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
+    p.last_pass = node_factor >= 6.0 ? 1 : 0;      // (msa_hip.cpp device_passes: 3x, 4.5x, 6x)
     p.dig_on = cigar_digest_on() ? 1 : 0;      // (tests: the fuse phase folds every graph cigar into PoaState.cigar_dig)
     // (the reference's own row order where the best cell is the FIRST row that reaches the maximum: local and extension mode, ref :1012-1026; the remaining
     //  length where something reads it: the adaptive band and the z-drop test)
@@ -452,8 +453,11 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         const int64_t width = (int64_t)((max_qlen + pn) / pn) * pn;
         // (the rings hold the widest rows expected -- up to 1024 columns: beyond that the plan has no fast row loop at all, and a few ragged sets must not send
         //  the whole job to the host driver; theirs overflow on their own)
-        make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>(std::max<int64_t>(est_cols(width, w_max, pn), std::min<int64_t>(1024, width)), est_cols(width,
-                w_max, pn) + max_extra), n_sets, &b.lds);
+        const int64_t est_plain = est_cols(width, w_max, pn), est_ragged = std::min<int64_t>(std::max<int64_t>(est_plain, std::min<int64_t>(1024, width)),
+                est_plain + max_extra);
+        make_lds_plan(sc, max_qlen, max_bits, est_ragged, n_sets, &b.lds);
+        // (a ring that wide does not fit -- int32 scores, convex gaps: the plain estimate then, and the ragged sets' rows that outgrow it are theirs alone)
+        if (max_extra > 0 && b.lds.fr_cols == 0) make_lds_plan(sc, max_qlen, max_bits, est_plain, n_sets, &b.lds);
         // (no fast row loop takes anything: dp_common.h takes_fast / rows_local.h takes_local)
         if (general) { b.lds.wide_nw = 0; b.lds.fr_cols = 0; b.lds.loc_cols = 0; }
         // the local row loop (rows_local.h takes_local): int16 scores, at most loc_cols columns, query codes in LDS; anything else is the general kernel's

@@ -71,6 +71,8 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     int32_t msa_rows, msa_cons;    // rows of a set's MSA = its reads (+ 1 when msa_cons: the consensus row, abpoa_output.c:151-164)
     int32_t order_ecap, general;   // order_ecap: aligned-list entries (16 bits each) the order kernel's all-in-LDS walk holds; general: the job's alignments run in the general
                                    // kernel (rows_general.h: linear gaps, extension mode, no band, long local reads) -- prepare also writes the successor CSR it reads
+    int32_t last_pass, pad_lp;     // last_pass: the largest node capacity there is -- no early exit on projected growth (the projection errs on ragged read-sets,
+                                   // whose reads add their nodes in bursts; a set that really outgrows this pass goes to the host driver either way)
     int32_t order_lds, dig_on;     // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice); dig_on: PoaState.cigar_dig is kept
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1

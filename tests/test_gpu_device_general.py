@@ -259,7 +259,8 @@ def test_reads_with_ragged_ends_stay_on_the_device(engine, monkeypatch, lockstep
     from abpoa_amd import api
     monkeypatch.setenv("ABPOA_HIP_LOCKSTEP", str(lockstep))
     shim = H.cpu_shim_lib()
-    sets = _ragged_sets(107, [(60, 300, 0.04), (40, 500, 0.06), (70, 240, 0.03), (25, 900, 0.05), (12, 1500, 0.08)], 0.12)
+    # (the last two: rows a few hundred columns wider than 2 w -- beyond the wide row loop's 448 columns they take the narrow kernel's chunk-by-chunk bodies)
+    sets = _ragged_sets(107, [(60, 300, 0.04), (40, 500, 0.06), (70, 240, 0.03), (25, 900, 0.05), (12, 1500, 0.08), (24, 3000, 0.05), (10, 5000, 0.08)], 0.12)
     sets.append([sets[2][0]] + [sets[2][0][k:] for k in range(1, 80)])      # 80 reads, every one starting one base later: 80 out-edges of the source
     for kw in (dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict()):
         p = api.Params(**kw)
