@@ -288,3 +288,41 @@ def test_ragged_local_and_general_jobs(engine):
         assert api.msa_timing()["n_host_sets"] == 0, f"{kw}: not every set ran on the device-resident driver"
         ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
         _same(dev, ref, f"ragged {kw}")
+
+
+def test_random_option_mixes_on_ragged_reads(engine):
+    """The seeded option sweep again, on reads with ragged ends (5-25 % cut per end, 8-70 reads, 60-1200 bases): every gap model, alignment mode, band on / off,
+    -s, weights; consensus, MSA and strand flags against the oracle-backed run."""
+    import numpy as np
+    import helpers as H
+    from abpoa_amd import api
+    shim = H.cpu_shim_lib()
+    rng = np.random.default_rng(4242)
+    n_dev = n_host = 0
+    for it in range(24):
+        shapes = [(int(rng.integers(8, 70)), int(rng.integers(60, 1200)), float(rng.uniform(0.02, 0.12))) for _ in range(5)]
+        sets = _ragged_sets(1000 + it, shapes, float(rng.uniform(0.05, 0.25)))
+        gap = [dict(gap_open1=0, gap_open2=0, gap_ext1=int(rng.integers(1, 5))), dict(gap_open1=int(rng.integers(2, 9)), gap_open2=0, gap_ext1=int(rng.integers(1, 4))), dict()][it % 3]
+        mode = int(rng.integers(0, 3))
+        kw = dict(gap, aln_mode=mode)
+        if mode != 1 and rng.random() < 0.3:
+            kw["extra_b"] = -1
+        if mode == EXTEND and rng.random() < 0.5:
+            kw["zdrop"] = int(rng.integers(10, 80))
+        amb = bool(rng.random() < 0.3)
+        if amb:
+            sets = [[(_flip(r) if (j and rng.random() < 0.3) else r) for j, r in enumerate(s)] for s in sets]
+        weights = [[rng.integers(1, 30, len(r)).astype(np.int32) for r in s] for s in sets] if rng.random() < 0.3 else None
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, weights=weights, amb_strand=amb)
+        nh = api.msa_timing()["n_host_sets"]
+        n_host += nh; n_dev += len(sets) - nh
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, weights=weights, amb_strand=amb, lib=shim)
+        what = f"iteration {it}: {kw} amb={amb} weights={weights is not None} shapes={shapes}"
+        for i, (a, b) in enumerate(zip(dev, ref)):
+            assert a.status == 0 and b.status == 0, f"{what}: set {i} status {a.status} / {b.status}"
+            assert a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov, f"{what}: consensus of set {i} differs"
+            assert a.msa_seq == b.msa_seq, f"{what}: MSA rows of set {i} differ"
+            if amb:
+                assert list(a.is_rc) == list(b.is_rc), f"{what}: strand flags of set {i} differ"
+    assert n_dev > 4 * n_host, (n_dev, n_host)
