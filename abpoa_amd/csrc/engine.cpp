@@ -322,7 +322,12 @@ int BatchStream::run() {
         for (size_t t = 0; t < todo.size(); ++t) {
             AlnDesc &d = desc_[todo[t]];
             // direction-plane arenas for the narrow-band alignments of a dir pass; the wide-band ones keep score records (dp_common.h takes_dir / takes_wide)
-            const bool dir_a = dir && (dir_wide || !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi));
+            // (an alignment the general kernel will run -- seeded band of the -s retry, a row with more predecessors than a word names, no fast row loop in the
+            //  plan -- stores its planes: the records' estimate, not the words'; host mirror of dp_common.h takes_fast)
+            const int dbg_ = getenv("ABPOA_HIP_DBG") ? atoi(getenv("ABPOA_HIP_DBG")) : 0;
+            const bool fast_a = (d.flags & ALN_FAST_OK) && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && b.lds.fr_cols > 0 &&
+                                d.qlen <= b.lds.q_cap && !(dbg_ & 64);
+            const bool dir_a = dir && fast_a && (dir_wide || !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi));
             d.plane_cap = dir_a ? (first_pass ? dir_est_cells_[todo[t]] : dir_full_cells_[todo[t]]) : (first_pass ? est_cells_[todo[t]] : full_cells_[todo[t]]);
             d.plane_off = plane_bytes; plane_bytes += (int64_t)align_up((size_t)d.plane_cap * (d.bits / 8) + 64 * 8 * 4);   // + 64 records of slack (fast loop stores whole 64-lane chunks)
             pass[t] = d;
