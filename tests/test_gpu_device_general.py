@@ -326,3 +326,20 @@ def test_random_option_mixes_on_ragged_reads(engine):
             if amb:
                 assert list(a.is_rc) == list(b.is_rc), f"{what}: strand flags of set {i} differ"
     assert n_dev > 4 * n_host, (n_dev, n_host)
+
+
+def test_more_start_nodes_than_the_terminal_pools_hold(engine):
+    """300 reads that all start on different nodes: the source would need 300 out-edges, the pools stop at 250 (the counts are bytes) -- the set is handed to the host
+    driver at once (no retry passes: more node slots would not help) and the result is the reference's all the same; its neighbour in the job stays on the device."""
+    import helpers as H
+    from abpoa_amd import api, synth
+    shim = H.cpu_shim_lib()
+    base = synth.make_read_set(113, 0, 1, 420, 0.0)[0]
+    many = [base] + [base[k:] for k in range(1, 300)]
+    sets = [many, list(synth.make_read_set(113, 1, 12, 300, 0.05))]
+    p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
+    dev = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 1
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
+    for a, b in zip(dev, ref):
+        assert a.status == 0 and a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov
