@@ -343,3 +343,17 @@ def test_more_start_nodes_than_the_terminal_pools_hold(engine):
     ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
     for a, b in zip(dev, ref):
         assert a.status == 0 and a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov
+
+
+def test_hundreds_of_reads_per_set(engine):
+    """400 and 130 reads per set (seven and three words of read ids per edge, read counts beyond a byte), MSA + consensus, uncut and ragged."""
+    import helpers as H
+    from abpoa_amd import api, synth
+    shim = H.cpu_shim_lib()
+    sets = [list(synth.make_read_set(127, 0, 400, 180, 0.04)), list(synth.make_read_set(127, 1, 130, 420, 0.07))] + _ragged_sets(131, [(200, 260, 0.05)], 0.1)
+    for kw in (dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict(aln_mode=1)):
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        assert api.msa_timing()["n_host_sets"] == 0, kw
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"many reads {kw}")
