@@ -1,7 +1,7 @@
 // Host side of the device-resident read-set driver (poa_device.h): pool allocation, one upload of the reads, the per-round
 // kernel sequence (prepare -> DP rows -> backtrack -> fuse) queued back to back with NO host work or synchronisation in
-// between, one download of the finished graphs, heaviest-bundling consensus on host threads.  Sets that exceed a device
-// capacity (edge slots, nodes, arena) are reported back and redone by the host driver (msa_batch.cpp).
+// between, consensus / MSA kernels, one download of the results.  Sets that exceed a device capacity (nodes, edge slots of an
+// inner node, arena) are reported back: redone in a pass with more node slots or by the host driver (msa_batch.cpp).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -111,8 +111,8 @@ void release_msa_device_caches() {
     if (cur >= 0) (void)hipSetDevice(cur);
 }
 
-// What the device-resident driver takes: affine / convex gaps, any alphabet of up to 27 codes, consensus and / or MSA output; global alignment with the
-// adaptive band, or local alignment (no band, abpoa_align.c:150) of reads the local row loop holds (checked per job in run_msa_device: EINVAL -> host driver).
+// What the device-resident driver takes: every gap model and alignment mode (run_msa_device picks the fast row loops or the general kernel per job), any
+// alphabet of up to 27 codes, consensus and / or MSA output, per-base weights, the strand retry.
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;
