@@ -357,3 +357,16 @@ def test_hundreds_of_reads_per_set(engine):
         assert api.msa_timing()["n_host_sets"] == 0, kw
         ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
         _same(dev, ref, f"many reads {kw}")
+
+
+def test_reads_beyond_the_fast_loops_query_limit(engine):
+    """Reads of 34 000 bases (the fast row loops keep query codes in LDS up to 32 000): the job runs device-resident in the general kernel."""
+    import helpers as H
+    from abpoa_amd import api, synth
+    shim = H.cpu_shim_lib()
+    sets = [list(synth.make_read_set(137, 0, 4, 34000, 0.03))]
+    p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
+    dev = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 0
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
+    assert dev[0].status == 0 and dev[0].cons_seq == ref[0].cons_seq and dev[0].cons_cov == ref[0].cons_cov
