@@ -72,9 +72,12 @@ class _BatchOut:
 
     def __del__(self):
         try:
-            free_msa, out = self.lib.abpoa_hip_free_msa, self.out
-            for i in range(self.n):
-                free_msa(C.byref(out[i]))
+            if hasattr(self.lib, "abpoa_hip_free_msa_array"):
+                self.lib.abpoa_hip_free_msa_array(self.out, self.n)
+            else:
+                free_msa, out = self.lib.abpoa_hip_free_msa, self.out
+                for i in range(self.n):
+                    free_msa(C.byref(out[i]))
         except Exception:      # interpreter shutdown: the library may already be gone
             pass
 
@@ -147,6 +150,9 @@ def _bind_msa(lib):
         lib.abpoa_hip_msa_batch.argtypes = [C.POINTER(ffi.Scoring), C.c_int, C.POINTER(ReadSet), C.POINTER(Msa), C.c_uint, C.c_int]
         lib.abpoa_hip_msa_batch.restype = C.c_int
         lib.abpoa_hip_free_msa.argtypes = [C.POINTER(Msa)]
+        if hasattr(lib, "abpoa_hip_free_msa_array"):
+            lib.abpoa_hip_free_msa_array.argtypes = [C.POINTER(Msa), C.c_int]
+            lib.abpoa_hip_free_msa_array.restype = None
         lib.abpoa_hip_get_msa_timing.argtypes = [C.POINTER(MsaTiming)]
         lib._msa_bound = True
 

@@ -315,6 +315,7 @@ unsigned long long abpoa_hip__cigar_digest(const uint8_t *seq0, int len0, int re
     if (reset) g_dig.clear();
     return v;
 }
+void abpoa_hip_free_msa_array(abpoa_hip_msa_t *r, int n) { for (int i = 0; r && i < n; ++i) abpoa_hip_free_msa(&r[i]); }
 void abpoa_hip_free_msa(abpoa_hip_msa_t *r) {
     if (!r) return;
     free(r->cons_base); free(r->cons_cov); free(r->cons_node_id); free(r->msa_base); free(r->is_rc);

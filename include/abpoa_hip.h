@@ -207,6 +207,7 @@ typedef struct abpoa_hip_msa_t {
 int  abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets,
                          abpoa_hip_msa_t *out, unsigned flags, int n_threads);
 void abpoa_hip_free_msa(abpoa_hip_msa_t *r);
+void abpoa_hip_free_msa_array(abpoa_hip_msa_t *r, int n);   /* abpoa_hip_free_msa on r[0..n): one call for a whole batch (bindings whose calls are dear) */
 
 /* Phase timers of the last abpoa_hip_msa_batch call (seconds): host graph work, engine calls. */
 typedef struct abpoa_hip_msa_timing_t {
