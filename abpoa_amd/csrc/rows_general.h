@@ -130,6 +130,8 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     }
     // ---- max_pos_left/right look-ahead window: LDS holds rows [lr_blk, lr_blk + RL)
     int lr_blk = 0;
+    // (far_seen: some row beyond the window had its band state written to the HBM copy -- from then on a row entering the window is loaded, not assumed untouched)
+    bool far_seen = false;
     if (banded && status == 0) {
         if (b.fresh_band) {       // reference abpoa_topological_sort resets them before every alignment (abpoa_graph.c:303-308)
             for (int i = lane; i < gn; i += 64) { g_left[i] = gn; g_right[i] = 0; }
@@ -138,12 +140,16 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             for (int i = lane; i < RL; i += 64) { const int r = i; if (r < gn) S.l_lr[i] = make_int2(g_left[r], g_right[r]); }
         __syncthreads();
         if (lane == 0) S.l_lr[0] = make_int2(0, 0);                            // reference :556
+        bool far0 = false;
         for (int t = out_off[0] + lane; t < out_off[1]; t += 64) {            // reference :557-561
             const int o = out_row[t];
             if (o >= 0 && row_active[o]) {
-                if (o < RL) S.l_lr[o] = make_int2(1, 1); else { g_left[o] = 1; g_right[o] = 1; }
+                if (o < RL) S.l_lr[o] = make_int2(1, 1); else { g_left[o] = 1; g_right[o] = 1; far0 = true; }
             }
         }
+        // (a successor of the source beyond the window -- a read that starts in the middle of the graph: without this the row, when it entered the window, was
+        //  taken for untouched and lost its (1, 1); found by tools/fuzz_device_vs_oracle.py on ragged reads in extension mode)
+        if (__any(far0)) { far_seen = true; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
     __syncthreads();
 
@@ -165,7 +171,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
     // ------------------------------------------------------------------ rows 1 .. gn-2, reference :1105
     // next-tile prefetch registers (static graph metadata of rows [nt_t0, nt_t0 + TS))
     int4 nt_rec0 = make_int4(0, 0, 0, 0), nt_rec1 = make_int4(0, 0, 0, 0); int nt_pred[TP / 64], nt_out[TP / 64];
-    int nt_t0 = 1, nt_pb0 = 0, nt_ob0 = 0; bool far_seen = false;
+    int nt_t0 = 1, nt_pb0 = 0, nt_ob0 = 0;
     // per-lane copy of the CURRENT tile's metadata (lane i <-> row tile_beg + i): the row loop fetches a field with one
     // v_readlane instead of an LDS round trip.  tv_meta = base | active<<8 | fast<<9 | np<<16 | n_out<<24
     int tv_meta = 0, tv_rterm = 0, tv_ps = 0, tv_os = 0, tv_pid[4] = {0, 0, 0, 0}, tv_o[2] = {-1, -1};

@@ -88,6 +88,17 @@ def cases(tmp):
     rl = synth.make_read_set(21, 0, 8, 2500, 0.15)
     synth.write_fasta(rcl, [r[::-1].translate(comp) if i in (2, 5) else r for i, r in enumerate(rl)])
     out.append(("out_rc_long_msa", rcl, ["-s", "-r", "2"], "none", 0, None))
+    # extension mode on ragged reads: read 6 of this set finds no alignment to speak of (best score 2: one base on a successor of the source 800 rows down the
+    # order) -- the general kernel's band state of far successors of the source (tools/fuzz_device_vs_oracle.py, seed 100049, set 3)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import numpy as np
+    import fuzz_device_vs_oracle as fz
+    frng = np.random.default_rng(100049)
+    faa = frng.random() < 0.2
+    rext = os.path.join(tmp, "ragged_ext.fa")
+    synth.write_fasta(rext, fz.make_sets(frng, 100049, faa)[3])
+    out.append(("out_ragged_ext_cons", rext, ["-m", "2"], "none", 0, None))
+    out.append(("out_ragged_ext_msa", rext, ["-m", "2", "-r", "1"], "none", 0, None))
     qfq = os.path.join(tmp, "qv.fq")
     rng = synth.SplitMix64(99)
     with open(qfq, "w") as f:

@@ -370,3 +370,20 @@ def test_reads_beyond_the_fast_loops_query_limit(engine):
     assert api.msa_timing()["n_host_sets"] == 0
     ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
     assert dev[0].status == 0 and dev[0].cons_seq == ref[0].cons_seq and dev[0].cons_cov == ref[0].cons_cov
+
+
+@pytest.mark.parametrize("host", [0, 1], ids=["device_driver", "host_driver"])
+def test_extension_mode_goldens_on_ragged_reads(engine, monkeypatch, host):
+    """The reference CLI's own output (-m 2, consensus and MSA) for a ragged read-set in which one read hardly aligns at all: its best cell is one base on a
+    successor of the source 800 rows down the row order.  The general kernel used to lose the band state of such far successors of the source (it assumed
+    a row that enters its look-ahead window untouched unless a LATER row had pushed to it) -- in both drivers; found by tools/fuzz_device_vs_oracle.py."""
+    import os
+    import helpers as H
+    from abpoa_amd import api, seqio
+    monkeypatch.setenv("ABPOA_HIP_HOSTGRAPH", str(host))
+    D = H.GOLDEN_DIR
+    names, seqs, _ = seqio.read_fastx(os.path.join(D, "out_ragged_ext_cons", "input.fa"))
+    for name, out_cons, out_msa in (("out_ragged_ext_cons", True, False), ("out_ragged_ext_msa", False, True)):
+        r = api.msa_batch([seqs], api.Params(aln_mode=2), out_cons=out_cons, out_msa=out_msa)[0]
+        assert api.msa_timing()["n_host_sets"] == host
+        assert api.format_output(r, names, out_cons, out_msa) == open(os.path.join(D, name, "output.txt")).read(), name

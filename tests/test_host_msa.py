@@ -82,6 +82,12 @@ def test_ambiguous_strand_retry_long_noisy_reads():
     assert txt == _golden("out_rc_long_msa") and [i for i, f in enumerate(r.is_rc) if f] == [2, 5]
 
 
+def test_extension_mode_on_ragged_reads():      # reference -m 2 on reads cut at random places (goldens from the reference CLI; the GPU twin is in test_gpu_device_general.py)
+    fa = os.path.join(D, "out_ragged_ext_cons", "input.fa")
+    assert _run_fx(fa, api.Params(aln_mode=2), True, False)[0] == _golden("out_ragged_ext_cons")
+    assert _run_fx(fa, api.Params(aln_mode=2), False, True)[0] == _golden("out_ragged_ext_msa")
+
+
 def test_quality_weights():                     # reference -Q, src/abpoa_align.c:462-467, abpoa_graph.c:486-499 / :634-667
     fq = os.path.join(D, "out_qv_cons", "input.fq")
     txt, _ = _run_fx(fq, api.Params(**AG), True, False, qv=True)
