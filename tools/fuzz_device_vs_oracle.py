@@ -17,9 +17,10 @@ def make_sets(rng, seed, aa):
     sets = []
     for i in range(int(rng.integers(2, 7))):
         kind = rng.random()
-        n = int(rng.integers(2, 60)); ln = int(rng.integers(30, 1400)) if rng.random() < 0.85 else int(rng.integers(1400, 4000))
+        u = rng.random()
+        n = int(rng.integers(2, 60)); ln = int(rng.integers(30, 1400)) if u < 0.8 else (int(rng.integers(1400, 4000)) if u < 0.94 else int(rng.integers(5000, 12000)))
         if ln > 1400:
-            n = min(n, 14)
+            n = min(n, 14 if ln < 5000 else 6)
         err = float(rng.uniform(0.01, 0.15))
         if aa:
             reads = list(synth.make_read_set(seed, i, n, min(ln, 560), alphabet=synth.AA, rates=(err, err / 3, err / 3)))
@@ -44,7 +45,7 @@ def main():
     a = ap.parse_args()
     lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))
     shim = H.cpu_shim_lib()
-    n_dev = n_host = 0
+    n_dev = n_host = n_err = 0
     for it in range(a.iters):
         seed = a.seed * 100000 + it
         rng = np.random.default_rng(seed)
@@ -75,8 +76,11 @@ def main():
         ref = api.msa_batch(sets, p, out_cons=out_cons, out_msa=out_msa, n_threads=8, weights=weights, amb_strand=amb, lib=shim)
         for i, (x, y) in enumerate(zip(dev, ref)):
             bad = None
-            if x.status != 0 or y.status != 0:
-                bad = f"status {x.status} / {y.status}"
+            if x.status != 0 or y.status != 0:      # (both -5: the reference itself dies in its backtrack on such input -- z-drop breaks that leave the best cell's row behind)
+                bad = f"status {x.status} / {y.status}" if x.status != y.status else None
+                n_err += x.status == y.status
+                if bad is None:
+                    continue
             elif out_cons and (x.cons_seq != y.cons_seq or x.cons_cov != y.cons_cov):
                 bad = "consensus"
             elif out_msa and x.msa_seq != y.msa_seq:
@@ -88,7 +92,7 @@ def main():
                 sys.exit(1)
         if it % 20 == 19:
             print(f"{it + 1} iterations ok ({n_dev} sets on the device, {n_host} through the host driver)", flush=True)
-    print(f"fuzz ok: {a.iters} iterations, {n_dev} sets on the device, {n_host} through the host driver")
+    print(f"fuzz ok: {a.iters} iterations, {n_dev} sets on the device, {n_host} through the host driver, {n_err} sets on which both sides report the same error status")
 
 
 if __name__ == "__main__":
