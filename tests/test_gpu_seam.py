@@ -49,3 +49,28 @@ def test_seeded_windows_on_long_reads(tmp_path):
     synth.write_fasta(fa, synth.make_read_set(17, 0, 8, 3000, 0.05))
     a, b = _both(["-S", "-O", "4,0", "-E", "2", fa])
     assert a == b and len(a) > 3000
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(GPU)), reason="prebuilt reference binaries not shipped")
+def test_seam_on_reads_with_ragged_ends(tmp_path):
+    """The stock reference's own graph code over the GPU DP on reads cut at random places (local walks that reach predecessors hundreds of rows away, sources
+    with dozens of successors, bands anchored off the path), every alignment mode and gap model, the strand retry and sub-graph windows: byte-identical to the
+    pure reference binary."""
+    import numpy as np
+    rng = np.random.default_rng(211)
+    comp = str.maketrans("ACGT", "TGCA")
+    files = []
+    for i, (n, ln, err) in enumerate([(30, 260, 0.04), (45, 420, 0.06), (20, 900, 0.05), (12, 2400, 0.08)]):
+        reads = list(synth.make_read_set(23, i, n, ln, err))
+        cut = [reads[0]]
+        for r in reads[1:]:
+            a = int(rng.integers(0, int(0.15 * len(r)) + 1)); b = len(r) - int(rng.integers(0, int(0.15 * len(r)) + 1))
+            cut.append(r[a:b])
+        fa = str(tmp_path / f"r{i}.fa"); synth.write_fasta(fa, cut); files.append(fa)
+        fr = str(tmp_path / f"rc{i}.fa"); synth.write_fasta(fr, [(r[::-1].translate(comp) if (j and j % 3 == 0) else r) for j, r in enumerate(cut)]); files.append(fr)
+    for fa in files:
+        rc_input = os.path.basename(fa).startswith("rc")
+        for opts in ([["-s", "-r", "2"], ["-s", "-O", "4,0", "-E", "2"]] if rc_input else
+                     [[], ["-r", "2"], ["-m", "1", "-r", "1"], ["-m", "1", "-O", "4,0", "-E", "2"], ["-m", "2", "-r", "2"], ["-O", "0,0", "-E", "2"], ["-b", "-1"], ["-S", "-r", "1"]]):
+            a, b = _both(opts + [fa])
+            assert a == b and len(a) > 0, (opts, fa)
