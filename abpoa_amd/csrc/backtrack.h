@@ -133,12 +133,15 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             const int cum = wave_scan_add_i32(lane < n64 ? Wrev : 0x100000);
             const int r_full = __builtin_popcountll(__ballot(cum <= max_rec));
             const bool narrow = r_full >= imin(16, n64);
-            const int R = narrow ? r_full : imin(n64, imax(4, max_rec / WC));
+            // (8-byte records: a slice starts and ends on an even column -- it is up to two columns wider than WC, and the rows of a window must leave room for
+            //  that: sized by WC alone, 48 rows of 34 records overran a 12 KB window by 96 records and the topmost row read back zeros -- EBACKTRACK on ragged reads
+            //  in the wide loop; the retry passes hid it)
+            constexpr int EVEN = (CW * (int)sizeof(T) == 8) ? 1 : 0;
+            const int R = narrow ? r_full : imin(n64, imax(4, max_rec / (WC + 2 * EVEN)));
             const int lo = hi - R + 1, nrow = R, li = lane - (lo - lo64);           // li: index of this lane's row inside the window
             const bool rv = rv64 && li >= 0;
             // (8-byte records: a slice starts and ends on an even column, so that it is a whole number of 16-byte pieces at a 16-byte address -- the band
             //  starts on a multiple of PN columns and is a multiple of PN wide)
-            constexpr int EVEN = (CW * (int)sizeof(T) == 8) ? 1 : 0;
             const int sl = narrow ? pbc : imax(pbc, (jtop - WC + 1) & ~EVEN), sh = narrow ? pbc + W : imin(pbc + W, (jtop + 1 + EVEN) & ~EVEN), ns = rv ? imax(0, sh - sl) : 0;
             const int incl = wave_scan_add_i32(ns);
             const int off_rec = incl - ns;

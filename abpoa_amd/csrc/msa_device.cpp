@@ -225,15 +225,19 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     // (AlnDesc.pad0, dp_common.h takes_wide). Lengths within an eighth of the longest read (at least 64 bases; indel noise: a 25 %-error 400-base set spreads 8
     //  %) count as equal: the estimates' own slack
     // (3 vectors + 32 columns) covers those.
-    std::vector<int> extra(n_sets, 0); int max_extra = 0, weff_lo = INT_MAX, weff_hi = 0;
+    // (route: the part of `extra` that counts for the choice of the row loop)
+    std::vector<int> extra(n_sets, 0), route(n_sets, 0); int max_extra = 0, weff_lo = INT_MAX, weff_hi = 0;
+    // (experiments: sets with less extra keep the narrow loop)
+    const int route_min = getenv("ABPOA_HIP_EXTRA_ROUTE_MIN") ? atoi(getenv("ABPOA_HIP_EXTRA_ROUTE_MIN")) : 0;
     if (!local && !general && sc->wb >= 0) for (int s = 0; s < n_sets; ++s) {
         int mx = 0, mn = INT_MAX; for (int r = 0; r < sets[s].n_reads; ++r) { mx = std::max(mx, sets[s].lens[r]); mn = std::min(mn, sets[s].lens[r]); }
         if (sets[s].n_reads < 2) continue;
         const int spread = mx - mn, tol = std::max(64, mx / 8);
         extra[s] = spread > tol ? std::min((spread + 15) & ~15, 2048) : 0;
         max_extra = std::max(max_extra, extra[s]);
-        weff_lo = std::min(weff_lo, sc->wb + (int)(sc->wf * (float)mn) + extra[s] / 2);
-        weff_hi = std::max(weff_hi, sc->wb + (int)(sc->wf * (float)mx) + extra[s] / 2);
+        route[s] = extra[s] >= route_min ? extra[s] : 0;
+        weff_lo = std::min(weff_lo, sc->wb + (int)(sc->wf * (float)mn) + route[s] / 2);
+        weff_hi = std::max(weff_hi, sc->wb + (int)(sc->wf * (float)mx) + route[s] / 2);
     }
     if (weff_hi == 0) { weff_lo = 0; }
     const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo) && max_extra == 0;
@@ -250,7 +254,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         PoaSet &S = ps[s]; memset(&S, 0, sizeof(S));
         int64_t sum = 0; int mx = 0;
         for (int r = 0; r < sets[s].n_reads; ++r) { sum += sets[s].lens[r]; mx = std::max(mx, sets[s].lens[r]); }
-        const int64_t cap = std::min<int64_t>(2 + sum, 2 + (int64_t)(node_factor * mx) + 1024);      // graph nodes this set may grow to on the device
+        // graph nodes this set may grow to on the device (a set with ragged ends gets one read length more: its reads reach beyond each other's ends, and a
+        // straggler that needs a second pass costs the whole job that pass's latency -- 3 of 1024 such sets were 149 ms on top of 216)
+        const int64_t cap = std::min<int64_t>(2 + sum, 2 + (int64_t)((node_factor + (extra[s] > 0 ? 1.0 : 0.0)) * mx) + 1024);
         S.n_reads = sets[s].n_reads; S.node_cap = (int)cap; S.pred_cap = (int)(4 * cap);
         S.read0 = read_i; read_i += sets[s].n_reads;
         S.term0 = term_tot; term_tot += sets[s].n_reads + 2;      // (source out-edges / sink in-edges beyond the per-node slots: at most one of each per read)
@@ -261,8 +267,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         // (fuse: 3 x qlen + nodes; order / rank passes: up to four tables of one int per node)
         S.scratch0 = scr_tot; scr_tot += 3LL * max_qlen + 4 * cap + 8;
         S.cons_cap = (int)std::min<int64_t>(cap, 2LL * mx + 64); S.cons0 = cons_tot; cons_tot += S.cons_cap;
-        const int w = sc->wb + (int)(sc->wf * (float)mx) + extra[s] / 2;      // (for the choice of the row loop: dp_common.h takes_wide)
-        S.band_extra = extra[s];
+        const int w = sc->wb + (int)(sc->wf * (float)mx) + route[s] / 2;      // (for the choice of the row loop: dp_common.h takes_wide)
+        S.band_extra = route[s];
         max_node_cap = std::max(max_node_cap, (int)cap);
         any_wide_set |= (w >= wide_lo && w <= wide_hi);
     }
@@ -279,7 +285,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
             //  global best will read from HBM; half of the rows where the wide loop's ring is only four rows deep; a set that needs more is flagged and
             //  redone like any other capacity miss)
-            const bool wide_s = !local && w + extra[s] / 2 >= wide_lo && w + extra[s] / 2 <= wide_hi;
+            const bool wide_s = !local && w + route[s] / 2 >= wide_lo && w + route[s] / 2 <= wide_hi;
             const bool dir_s = dir && (dw || !wide_s);      // (dp_common.h takes_dir)
             const int64_t rec_div = (wide_s && wide_ring_rows <= 4) ? 2 : 4;
             // (bytes per cell record of a row that keeps its scores: CW values -- the wide kernel's compact records: 4 B int16 affine, else 8 B; rows_fast.h
@@ -689,6 +695,8 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             if (r >= 1000) { if (r - 1000 == ABPOA_HIP_STATUS_OVERFLOW) dp_arena++; else if (r - 1000 == ABPOA_HIP_STATUS_NEED_SCORES) dp_scores++;
                     else dp_other++; }
             hist[r >= 1000 ? 5 : (r >= 0 && r < 5 ? r : (r == 6 ? 7 : 6))]++;
+            if (!(r >= 1000 || (r >= 0 && r < 7))) fprintf(stderr,
+                    "[abpoa-hip]   set %d: reason code %d (7: row order walk, 8: MSA rank walk, 1000 + a negative DP status: " "%d)\n", s, r, r - 1000);
         }
         if (hist[5]) fprintf(stderr, "[abpoa-hip]   DP status: arena too small for the bands %d, direction words undecided %d, other %d\n", dp_arena,
                 dp_scores, dp_other);

@@ -81,7 +81,9 @@ __device__ __forceinline__ void poa_prepare_body(const PoaDev &p, const int s, c
     // read 49; 5 %: 338, 331, 230) -- fitted to the mean gain of reads 3-6 and 7-10, summed over the remaining reads, +10 %.  (The linear test of round 2
     // projected 50 k nodes for graphs that end at 38.7 k and so sent every 15 % job to 6x node slots, twice the arena memory it needs.)
     bool doomed = false;
-    if (status == POA_ST_OK && S.n_reads > 20 && !p.last_pass) {
+    // (not for read-sets with ragged ends, band_extra > 0: their first reads add nodes in bursts -- ends that reach beyond the graph -- and the projection sent a
+    //  quarter of them through two more passes although they fit the first)
+    if (status == POA_ST_OK && S.n_reads > 20 && !p.last_pass && S.band_extra == 0) {
         if (k == 2 && tid == 0) st->grow_n2 = n;
         if (k == 6 && tid == 0) st->grow_n6 = n;
         if (k == 5) {

@@ -88,6 +88,18 @@ def cases(tmp):
     rl = synth.make_read_set(21, 0, 8, 2500, 0.15)
     synth.write_fasta(rcl, [r[::-1].translate(comp) if i in (2, 5) else r for i, r in enumerate(rl)])
     out.append(("out_rc_long_msa", rcl, ["-s", "-r", "2"], "none", 0, None))
+    # global alignment of a short read against a longer graph (set 98 of bench.py's ragged entry): in the wide row loop with a 12 KB backtrack window the
+    # int16-affine records' slices (two columns wider than planned: even-column rounding) overran the window -- EBACKTRACK, hidden by the retry passes
+    rng98 = np.random.default_rng(20240)
+    for i98 in range(99):
+        full98 = synth.make_read_set(1, i98, **synth.CONFIGS[2])
+        cut98 = [full98[0]]
+        for r in full98[1:]:
+            a = int(rng98.integers(0, len(r) // 10 + 1)); b = len(r) - int(rng98.integers(0, len(r) // 10 + 1))
+            cut98.append(r[a:b])
+    r98 = os.path.join(tmp, "ragged98.fa")
+    synth.write_fasta(r98, cut98[:6])
+    out.append(("ragged_ag_gb", r98, AG, "1,4", 0, None))
     # extension mode on ragged reads: read 6 of this set finds no alignment to speak of (best score 2: one base on a successor of the source 800 rows down the
     # order) -- the general kernel's band state of far successors of the source (tools/fuzz_device_vs_oracle.py, seed 100049, set 3)
     sys.path.insert(0, os.path.join(ROOT, "tools"))

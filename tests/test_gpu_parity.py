@@ -90,6 +90,27 @@ def test_local_row_loops_plane_level(engine, monkeypatch, team):
         assert a.status == 0 and a.msa_seq == b.msa_seq and a.cons_seq == b.cons_seq and a.n_cells == b.n_cells, f"team={team}: set {i}"
 
 
+@pytest.mark.parametrize("bt_bytes", ["8192", "12288", "28672"])
+@pytest.mark.parametrize("nodir", ["0", "1"], ids=["words", "records"])
+def test_wide_loop_on_narrow_w_alignments_with_small_windows(engine, monkeypatch, bt_bytes, nodir):
+    """Goldens ragged_ag_gb (a short read against a longer graph: rows ~150-250 columns wide although w = 19) through the WIDE row loop (ABPOA_HIP_WIDE_LO=10:
+    what the device-resident driver does for read-sets with ragged ends) and the tail's column-slice windows of 8 / 12 / 28 KB.  int16-affine records are 8 bytes
+    and their slices two columns wider than planned (even-column rounding): the window used to be sized without that and its topmost rows read back zeros."""
+    monkeypatch.setenv("ABPOA_HIP_WIDE_LO", "10")
+    monkeypatch.setenv("ABPOA_HIP_BT_BYTES", bt_bytes)
+    monkeypatch.setenv("ABPOA_HIP_NODIR", nodir)
+    n = 0
+    for label, path in CASES:
+        if not label.startswith("ragged_ag_gb"):
+            continue
+        g = H.read_abpg(path)
+        case = H.FlatCase(g)
+        h = H.run_hip([case], want_trace=False)[0]
+        assert h.status == 0 and h.n_cigar == len(g["cigar"]) and (h.cigar == g["cigar"]).all() and h.best_score == int(g["best_score"][0]), f"{label} window {bt_bytes}"
+        n += 1
+    assert n == 2
+
+
 def test_need_scores_redo_path(engine, monkeypatch):
     """The direction-plane walk gives up (ABPOA_HIP_STATUS_NEED_SCORES) where the words cannot decide where an F value came from -- never seen on real
     data -- and the alignment is redone with score records.  ABPOA_HIP_DBG=512 makes the walk give up at the first insertion it would decide from
