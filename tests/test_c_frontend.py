@@ -28,7 +28,7 @@ def _cpu_binary():
     exe, src = os.path.join(bdir, "abpoa_batch_cpu"), os.path.join(ROOT, "abpoa_amd", "host", "abpoa_batch.c")
     shim = os.path.join(bdir, "libcpu_shim.so")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(shim)):
-        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-L" + bdir, "-lcpu_shim", "-lz",
+        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-L" + bdir, "-lcpu_shim", "-lz", "-lpthread",
                                "-Wl,-rpath," + bdir])
     return exe
 
@@ -97,6 +97,83 @@ def test_c_front_end_list_is_one_batch_and_equals_the_reference_cli(tmp_path):
         assert _run(exe, opts + ["-l", job]) == ref.stdout, opts
 
 
+def _degenerate_job(tmp_path):
+    """files the reference treats specially: records without bases in the middle and at the end of a file, a file without records.
+    Returns the list, the files, and a twin list whose files lack the empty records (None where a file has none to lose)."""
+    files, twins, where = [], [], []
+    for i in range(5):
+        reads = list(synth.make_read_set(31, i, 5 + i, 90 + 30 * i, 0.08))
+        full = list(reads)
+        if i == 1:
+            full.insert(2, "")
+        if i == 2:
+            full.append(""); full.insert(1, ""); full.insert(1, "")
+        if i == 3:
+            full, reads = [], []
+        fn, tw = str(tmp_path / f"d{i}.fa"), str(tmp_path / f"t{i}.fa")
+        with open(fn, "w") as f:
+            f.write("".join(f">q{j}\n{r}\n" if r else f">q{j}\n" for j, r in enumerate(full)))
+        with open(tw, "w") as f:
+            f.write("".join(f">q{j}\n{r}\n" for j, r in enumerate(full) if r))
+        files.append(fn); twins.append(tw); where.append([j for j, r in enumerate(full) if not r])
+    lst, lst_t = str(tmp_path / "deg.txt"), str(tmp_path / "twin.txt")
+    open(lst, "w").write("\n".join(files) + "\n"); open(lst_t, "w").write("\n".join(twins) + "\n")
+    return lst, lst_t, files, twins, where
+
+
+def _check_degenerate(exe, tmp_path):
+    """A record without bases after the first one: the reference aligns the empty query, then abpoa_add_subgraph_alignment reads weight[seq_l - 1] = weight[-1]
+    (src/abpoa_graph.c:662) for a source -> sink edge: undefined behaviour, its output depends on what the heap holds.  The engine's rule is the defined part of
+    that: the record is an MSA row of gaps and adds nothing to the graph, i.e. the file's output is that of the file without the record, plus the row.
+    Deterministic in the reference and compared with it: a file without records prints nothing; a FIRST record without bases ends the run."""
+    lst, lst_t, files, twins, where = _degenerate_job(tmp_path)
+    for opts in ([], ["-r", "1"], ["-r", "2"], ["-O", "4,0", "-E", "2", "-r", "2"]):
+        got = _run(exe, opts + ["-l", lst])
+        assert _run(exe, opts + ["-l", lst, "--piece", "2", "--readers", "3"]) == got, ("pieces of two files", opts)
+        want = ""
+        for fn, tw, gaps in zip(files, twins, where):
+            ref = subprocess.run([REF] + opts + [tw], capture_output=True, text=True, timeout=600)
+            assert ref.returncode == 0, ref.stderr[-500:]
+            lines = ref.stdout.splitlines()
+            if gaps and "-r" in opts and lines:      # MSA rows: put the rows of gaps where the empty records were
+                width = len(lines[1]); recs = [lines[k:k + 2] for k in range(0, len(lines), 2)]
+                cons = [r for r in recs if r[0] == ">Consensus_sequence"]; rows = [r for r in recs if r[0] != ">Consensus_sequence"]
+                for g in gaps:
+                    rows.insert(g, [f">q{g}", "-" * width])
+                lines = [x for r in rows + cons for x in r]
+            want += "".join(x + "\n" for x in lines)
+        assert got == want, opts
+    # a first record without bases: the reference dies in abpoa_add_graph_sequence (single file, or the first of a list).  Later in a list the reference
+    # aligns the bases the PREVIOUS file had at that record position (its abpoa_seq_t is not cleared between files: abpoa_cpy_str, src/abpoa_seq.c:123-130) --
+    # a state leak, not reproduced: the engine ends the run there too, after the output of the files before it
+    bad = str(tmp_path / "first_empty.fa"); open(bad, "w").write(">a\n>b\nACGTACGTAGCTAGCTAGCATCGATCGATGCA\n>c\nACGTACGTAGCTAGCTAGCATCGTCGATGCA\n")
+    ref = subprocess.run([REF, bad], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe, bad], capture_output=True, text=True, timeout=600)
+    assert ref.returncode != 0 and p.returncode == 1 and p.stdout == ref.stdout == "" and "seq_l: 0" in p.stderr and "seq_l: 0" in ref.stderr
+    lst2 = str(tmp_path / "deg2.txt"); open(lst2, "w").write(files[0] + "\n" + files[3] + "\n" + bad + "\n" + files[4] + "\n")
+    p = subprocess.run([exe, "-l", lst2], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and p.stdout == _run(exe, [files[0]]) and "seq_l: 0" in p.stderr
+
+
+def test_c_front_end_degenerate_inputs_equal_the_reference(tmp_path):
+    if not os.path.exists(REF):
+        pytest.skip("compiled reference not present")
+    _check_degenerate(_cpu_binary(), tmp_path)
+
+
+def test_c_front_end_streams_the_list_in_pieces(tmp_path):
+    """`-l` is streamed: pieces of --piece files, the next piece read by --readers threads while the current one is in the batch call; the output is the
+    same text in list order whatever the piece size (sticky record names cross piece borders like they cross files)."""
+    exe = _cpu_binary()
+    job = _list_job(tmp_path, 9)
+    whole = _run(exe, ["-r", "2", "-l", job, "--piece", "100"])
+    for piece, readers in ((1, 1), (2, 4), (4, 2), (9, 8)):
+        assert _run(exe, ["-r", "2", "-l", job, "--piece", str(piece), "--readers", str(readers)]) == whole, (piece, readers)
+    if os.path.exists(REF):
+        ref = subprocess.run([REF, "-r", "2", "-l", job], capture_output=True, text=True, timeout=600)
+        assert ref.returncode == 0 and ref.stdout == whole
+
+
 def test_c_front_end_refuses_what_the_engine_does_not_build():
     exe = _cpu_binary()
     seq = os.path.join(D, "data", "seq.fa")
@@ -118,6 +195,8 @@ def test_shipped_binary_on_the_gpu(tmp_path):
             ref = subprocess.run([REF] + opts + ["-l", job], capture_output=True, text=True, timeout=600)
             assert ref.returncode == 0
             assert _run(exe, opts + ["-l", job]) == ref.stdout, opts
+            assert _run(exe, opts + ["-l", job, "--piece", "7"]) == ref.stdout, ("streamed in pieces of 7 files", opts)
+        _check_degenerate(exe, tmp_path)
 
 
 @pytest.mark.gpu
