@@ -142,8 +142,10 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
     return per_cu * cus;
 }
 
-int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot) {
+// force_general: every alignment through the general kernel; *want_general: the final LDS plan has no fast row loop for this job although the first estimate had
+// one (ragged sets: one node factor more, wider rows -- the score width can flip to 32 bits): the caller runs the job again with force_general
+static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
+                               std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot, bool force_general, bool *want_general) {
     abpoa_hip_scoring_t sc_norm = *sc_in; const bool local = sc_in->align_mode == ABPOA_HIP_LOCAL_MODE, extend = sc_in->align_mode == ABPOA_HIP_EXTEND_MODE;
     if (local) sc_norm.wb = -1;                                  // reference abpoa_post_set_para, src/abpoa_align.c:150
     const abpoa_hip_scoring_t *sc = &sc_norm;
@@ -199,6 +201,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
                 && max_qlen <= pl.q_cap;
         general = !(fast_global || fast_local);
         if (getenv("ABPOA_HIP_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_DEVICE_GENERAL"))) general = true;      // (tests: the general kernel for every job)
+        if (force_general) general = true;
     }
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
     const bool dir = !local && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
@@ -485,7 +488,7 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         b.lds.narrow_off = (!mixed && b.lds.wide_nw >= 1 && w_min >= b.lds.wide_w_lo && w_top <= b.lds.wide_w_hi) ? 1 : 0;      // every read does
     }
     // caller falls back to the host driver
-    if (!local && !general && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }
+    if (!local && !general && (b.lds.fr_cols == 0 || max_qlen > b.lds.q_cap)) { *want_general = true; set_err("band too wide for the fast row loop"); return ABPOA_HIP_EINVAL; }
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
     b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
@@ -658,8 +661,9 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         for (int s = lo; s < hi_; ++s) {
             abpoa_hip_msa_t &o_ = out[s];
             memset(&o_, 0, sizeof(o_)); o_.n_reads = sets[s].n_reads;
-            if (amb) { o_.is_rc = (uint8_t *)calloc((size_t)std::max(1, sets[s].n_reads), 1);
-                    if (o_.is_rc && hs[s].status == POA_ST_OK) memcpy(o_.is_rc, hg + L.o_isrc + ps[s].read0, (size_t)sets[s].n_reads); }
+            // (only for a set that finished here: the record of a set that goes to another pass or to the host driver is overwritten there)
+            if (amb && hs[s].status == POA_ST_OK) { o_.is_rc = (uint8_t *)calloc((size_t)std::max(1, sets[s].n_reads), 1);
+                    if (o_.is_rc) memcpy(o_.is_rc, hg + L.o_isrc + ps[s].read0, (size_t)sets[s].n_reads); }
             if (hs[s].status != POA_ST_OK) { need_fb[s] = hs[s].pad == 5 ? 2 : 1;
                     if (dbg_sync) fprintf(stderr, "[poa-device] set %d falls back to the host driver: reason %d, %d nodes of %d\n", s, hs[s].pad,
                     hs[s].n_nodes, ps[s].node_cap); continue; }
@@ -713,6 +717,17 @@ int run_msa_device(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         }
     }
     return ABPOA_HIP_OK;
+}
+
+
+int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot) {
+    bool want_general = false;
+    const int rc = run_msa_device_body(sc, n_sets, sets, out, n_threads, fallback, stats, node_factor, flags, device, slot, false, &want_general);
+    if (rc != ABPOA_HIP_EINVAL || !want_general) return rc;
+    // the job stays on the device: the general kernel takes what the fast row loops' final plan could not (it used to leave for the host driver)
+    want_general = false;
+    return run_msa_device_body(sc, n_sets, sets, out, n_threads, fallback, stats, node_factor, flags, device, slot, true, &want_general);
 }
 
 }  // namespace abpoa_hip

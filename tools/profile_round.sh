@@ -1,7 +1,8 @@
 # One GPU-box call that produces every profile record of a round (copied to profiles/ afterwards):
 #   kernel tables (rocprofv3 --kernel-trace --stats) of the four bench workloads, PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and PMC instruction
 #   counts for each.  usage: bash tools/profile_round.sh <round tag, e.g. r4>
-R=$GRAFT_REPO_ROOT; TAG=${1:-r4}
+R=$GRAFT_REPO_ROOT; TAG=${1:-r5}
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for spec in "cfg2 1000 5 2" "cfg5 1000 3 1" "cfg4 2048 2 1" "cfg3 2048 1 1"; do
   set -- $spec; WL=$1; N=$2; ST=$3; WU=$4

@@ -17,7 +17,8 @@
 
 constexpr int UNROLL = 32;      // independent instructions per loop trip (8 registers x 4 passes: no instruction depends on the one before it)
 
-// KIND: 0 v_add_u32, 1 v_max_i32, 2 v_pk_max_i16, 3 v_max_i32 DPP row_shr:1, 4 s_add_u32, 5 v_add_u32 + s_add_u32 interleaved 1:1, 6 v_add3_u32 (VOP3, three sources)
+// KIND: 0 v_add_u32, 1 v_max_i32, 2 v_pk_max_i16, 3 v_max_i32 DPP row_shr:1, 4 s_add_u32, 5 v_add_u32 + s_add_u32 interleaved 1:1, 6 v_add3_u32 (VOP3, three sources),
+//       7-14 further single ops, 15 the row loops' instruction mix, 16 v_readlane_b32
 template <int KIND>
 __global__ void __launch_bounds__(256) issue_probe(long long *cycles, int *sink, int trips) {
     int v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7, k = 3;
@@ -43,6 +44,27 @@ __global__ void __launch_bounds__(256) issue_probe(long long *cycles, int *sink,
                                         : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) :: "scc");
             if (KIND == 5) asm volatile("v_add_u32 %0, %0, %8\n s_add_u32 %9, %9, 3\n v_add_u32 %1, %1, %8\n s_add_u32 %10, %10, 3\n v_add_u32 %2, %2, %8\n s_add_u32 %11, %11, 3\n v_add_u32 %3, %3, %8\n s_add_u32 %12, %12, 3"
                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(k), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) :: "scc");
+#define OP8(OPSTR) asm volatile(OPSTR " %0, %0, %8\n " OPSTR " %1, %1, %8\n " OPSTR " %2, %2, %8\n " OPSTR " %3, %3, %8\n " OPSTR " %4, %4, %8\n " OPSTR " %5, %5, %8\n " OPSTR " %6, %6, %8\n " OPSTR " %7, %7, %8" \
+                                        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(k))
+            if (KIND == 7) OP8("v_sub_u32");
+            if (KIND == 8) OP8("v_min_i32");
+            if (KIND == 9) OP8("v_and_b32");
+            if (KIND == 10) OP8("v_lshlrev_b32");
+            if (KIND == 11) OP8("v_pk_add_i16");
+            if (KIND == 12) asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n"
+                                         "v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(k) : "vcc");
+            if (KIND == 13) asm volatile("v_cmp_gt_i32 vcc, %0, %8\n v_cmp_gt_i32 vcc, %1, %8\n v_cmp_gt_i32 vcc, %2, %8\n v_cmp_gt_i32 vcc, %3, %8\n v_cmp_gt_i32 vcc, %4, %8\n v_cmp_gt_i32 vcc, %5, %8\n v_cmp_gt_i32 vcc, %6, %8\n"
+                                         "v_cmp_gt_i32 vcc, %7, %8" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(k) : "vcc");
+            if (KIND == 14) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                                         "v_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                                         "v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf"
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(k));
+            // the row loops' mix: add, max, compare + select, shift-or, DPP max, subtract, min (one of each + one more max)
+            if (KIND == 15) asm volatile("v_add_u32 %0, %0, %8\n v_max_i32 %1, %1, %8\n v_cmp_gt_i32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n v_lshl_or_b32 %4, %4, 3, %8\n"
+                                         "v_max_i32_dpp %5, %8, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_sub_u32 %6, %6, %8\n v_min_i32 %7, %7, %8"
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(k) : "vcc");
+            if (KIND == 16) asm volatile("v_readlane_b32 %8, %0, 3\n v_readlane_b32 %9, %1, 3\n v_readlane_b32 %10, %2, 3\n v_readlane_b32 %11, %3, 3\n v_readlane_b32 %8, %4, 3\n v_readlane_b32 %9, %5, 3\n v_readlane_b32 %10, %6, 3\n"
+                                         "v_readlane_b32 %11, %7, 3" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3));
             if (KIND == 6) asm volatile("v_add3_u32 %0, %0, %8, %8\n v_add3_u32 %1, %1, %8, %8\n v_add3_u32 %2, %2, %8, %8\n v_add3_u32 %3, %3, %8, %8\n v_add3_u32 %4, %4, %8, %8\n v_add3_u32 %5, %5, %8, %8\n v_add3_u32 %6, %6, %8, %8\n v_add3_u32 %7, %7, %8, %8"
                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(k));
         }
@@ -113,6 +135,16 @@ int main(int argc, char **argv) {
     printf("%s,\n  ", run_issue<2>("v_pk_max_i16", n_cu, d_cyc, d_sink, 2).c_str());
     printf("%s,\n  ", run_issue<3>("v_max_i32_dpp_row_shr", n_cu, d_cyc, d_sink, 1).c_str());
     printf("%s,\n  ", run_issue<6>("v_add3_u32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<7>("v_sub_u32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<8>("v_min_i32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<9>("v_and_b32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<10>("v_lshlrev_b32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<11>("v_pk_add_i16", n_cu, d_cyc, d_sink, 2).c_str());
+    printf("%s,\n  ", run_issue<12>("v_cndmask_b32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<13>("v_cmp_gt_i32", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<14>("v_mov_b32_dpp_row_shr", n_cu, d_cyc, d_sink, 1).c_str());
+    printf("%s,\n  ", run_issue<16>("v_readlane_b32", n_cu, d_cyc, d_sink, 0).c_str());
+    printf("%s,\n  ", run_issue<15>("row_loop_mix(add,max,cmp,cndmask,lshl_or,max_dpp,sub,min)", n_cu, d_cyc, d_sink, 1).c_str());
     printf("%s,\n  ", run_issue<4>("s_add_u32", n_cu, d_cyc, d_sink, 0).c_str());
     printf("%s\n },\n", run_issue<5>("v_add_u32+s_add_u32", n_cu, d_cyc, d_sink, 1).c_str());
     // ---- HBM
