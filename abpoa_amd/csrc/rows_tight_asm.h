@@ -1,0 +1,225 @@
+#pragma once
+// The narrow row loop's tight loop as hand-placed gfx950 assembly (round 5): int16 scores, affine gaps, direction words.
+//
+// What it is: the rows that rows_fast.h's tile word marks "straight-line body" (bit 17: one or two predecessors, both inside the geometry ring and the score
+// ring, not a row that keeps its score records) -- turbo_body<1 | 2, SLOWV = false> + commit_row, instruction for instruction the same arithmetic
+// (reference src/simd_abpoa_align.c:781-885 for the cells, :1043-1067 for the arg-max and the band hand-over, :710-720 for the band), written by hand because
+// the compiler's version of this loop is 162 instructions for a one-predecessor row of which ~45 are not the algorithm: copies of every loop-carried value
+// on the way to the structuriser's single loop latch, exit flags, a four-instruction loop condition, s_nop wait states between the DPP steps.  One
+// wavefront per SIMD issues one instruction per 5 cycles (tools/ubench/roofs.hip: v_max_i32 / s_add_u32 / DPP alike), so a row costs its instruction
+// count x 5 cycles.  Here: ~114 instructions for a one-predecessor row, ~147 for two; the DPP wait states carry the ring / arena address arithmetic.
+//
+// Contract with rows_fast.h (the only includer):
+//   * runs rows row, row + 1, ... while each is a bit-17 row that passes the straight-line body's own conditions (band of at most 64 columns inside the
+//     predecessors' bands, predecessors in the score ring, no value near the wrap limit); stops BEFORE any side effect of the first row that does not,
+//     with code 0 = not a bit-17 row, 1 = declined but the copy that takes vectors beyond the predecessors' bands would accept it (turbo_body's 0),
+//     2 = declined for good / a value near the wrap limit (turbo_body's -1), 3 = reached r_hi;
+//   * the caller guarantees cur + 4 * (r_hi - row) <= cap_turbo (a row takes at most NV = 4 arena units), so the loop carries no arena-room test;
+//   * refreshes the cached query codes (qoff0 / qoff1, qc_beg_sn) itself when the band start moves;
+//   * VGPRs v100-v127 and the listed scalar temporaries are its scratch; exec is all ones (one-wavefront phase).
+// Hazards observed (CDNA3 ISA 4.5): two wait states between a VALU write and a DPP read of the same VGPR (partner chain + one filler per step);
+// lane selects of v_readlane / v_writelane come from SALU-written registers (row, M0) only; no VALU-written SGPR feeds a memory instruction.
+#define TA_SDWA0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+#define TA_SDWA_S1W0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+#define TA_SDWA_S1W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+#define TA_SDWA_S0W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+#define TA_DPP(CTRL) " " CTRL " bank_mask:0xf\n\t"
+// scratch VGPRs
+#define vQA "v104"
+#define vCOL "v105"
+#define vX "v106"
+#define vQ "v107"
+#define vR0 "v108"
+#define vR1 "v109"
+#define vR01 "v[108:109]"
+#define vKC "v110"
+#define vH "v111"
+#define vHSE "v112"
+#define vAK "v113"
+#define vS1 "v114"
+#define vG "v115"
+#define vF "v115"
+#define vQD "v116"
+#define vRO "v117"
+#define vHO "v118"
+#define vT2A "v119"
+#define vEN "v120"
+#define vE "v121"
+#define vHE "v121"
+#define vU "v122"
+#define vD "v123"
+#define vKF "v124"
+#define vWD "v124"
+#define vX1 "v125"
+#define vB0 "v126"
+#define vB1 "v127"
+#define vB01 "v[126:127]"
+#define vMV "v100"
+#define vE1 "v101"
+#define vMV2 "v102"
+#define vE12 "v103"
+#define vT "v106"
+
+// band of the row from (mn + 1 in sA, mx + 1 in sB): beg_sn -> sA (before the max with min_pb), end_sn -> sESN      reference :710-720
+#define TA_BAND                                                                                              \
+    "s_min_i32 %[sA], %[gn], %[sA]\n\t"   "s_min_i32 %[sA], %[sA], %[sRT]\n\t"  "s_sub_i32 %[sA], %[sA], %[w]\n\t"      \
+    "s_max_i32 %[sA], %[sA], 0\n\t"       "s_lshr_b32 %[sA], %[sA], 4\n\t"                                              \
+    "s_max_i32 %[sB], %[sB], %[sRT]\n\t"  "s_add_i32 %[sB], %[sB], %[w]\n\t"    "s_min_i32 %[sB], %[sB], %[qlen]\n\t"   \
+    "s_lshr_b32 %[sESN], %[sB], 4\n\t"
+// conditions of the straight-line body (max_pe in sPE0, ring word in sG0), then the query-code cache; LBL = path suffix
+#define TA_CHECKS(LBL)                                                                                       \
+    "s_sub_i32 %[sNV1], %[sESN], %[sBSN]\n\t"                                                                \
+    "s_cmp_gt_u32 %[sNV1], 3\n\t"          "s_cbranch_scc1 L_dec_%=\n\t"                                     \
+    "s_cmp_gt_i32 %[sESN], %[sPE0]\n\t"    "s_cbranch_scc1 L_dec_%=\n\t"                                     \
+    "s_bitcmp0_b32 %[sG0], 24\n\t"         "s_cbranch_scc1 L_dec_%=\n\t"                                     \
+    "s_cmp_lg_u32 %[sBSN], %[qcb]\n\t"     "s_cbranch_scc1 L_ref" LBL "_%=\n\t"                              \
+    "L_refd" LBL "_%=:\n\t"
+// out of line: this lane's query codes for band start sBSN (chunks 0 and 1), rows_fast.h refresh_qc
+#define TA_REFRESH(LBL)                                                                                      \
+    "L_ref" LBL "_%=:\n\t"                                                                                   \
+    "s_mov_b32 %[qcb], %[sBSN]\n\t"        "s_lshl_b32 %[sA], %[sBSN], 4\n\t"     "s_add_i32 %[sA], %[sA], -1\n\t"      \
+    "v_add_u32 " vX ", %[sA], %[lane]\n\t" "v_cmp_gt_u32 vcc, %[qlen], " vX "\n\t" "v_add_u32 " vQ ", %[qb], " vX "\n\t" \
+    "ds_read_u8 " vQ ", " vQ "\n\t"                                                                          \
+    "v_add_u32 " vX ", 64, " vX "\n\t"     "v_cmp_gt_u32_e64 %[msk], %[qlen], " vX "\n\t" "v_add_u32 " vG ", %[qb], " vX "\n\t" \
+    "ds_read_u8 " vG ", " vG "\n\t"        "v_mov_b32 " vX ", %[m]\n\t"                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+    "v_cndmask_b32 %[qoff0], " vX ", " vQ ", vcc\n\t"   "v_cndmask_b32_e64 %[qoff1], " vX ", " vG ", %[msk]\n\t"  \
+    "v_lshl_add_u32 " vQA ", %[qoff0], 2, %[mxb]\n\t"                                                        \
+    "s_branch L_refd" LBL "_%=\n\t"
+// column, substitution score and the first predecessor's ring words (two LDS reads in flight)
+#define TA_READS                                                                                             \
+    "s_lshl_b32 %[sC0], %[sBSN], 4\n\t"    "v_add_u32 " vCOL ", %[sC0], %[lane]\n\t"                         \
+    "s_ashr_i32 %[sA], %[sTB], 16\n\t"     "v_add_u32 " vX ", %[sA], " vQA "\n\t"    "ds_read_b32 " vQ ", " vX "\n\t"   \
+    "s_lshl_b32 %[sA], %[sPB0], 4\n\t"     "v_xad_u32 " vX ", %[sA], -1, " vCOL "\n\t"  "v_med3_i32 " vX ", " vX ", -2, %[rc]\n\t" \
+    "v_lshl_add_u32 " vX ", " vX ", 2, %[sSL0]\n\t"   "ds_read2_b32 " vR01 ", " vX " offset1:1\n\t"
+// band mask, arg-max key constant, "column inside the query" mask
+#define TA_MASKS                                                                                             \
+    "v_cmp_ge_u32_e64 %[inb], %[sNV1], %[vvl]\n\t"                                                               \
+    "v_cmp_eq_u32 vcc, %[sNV1], %[vvl]\n\t"      "v_cndmask_b32 " vKC ", %[kN], %[kE], vcc\n\t"              \
+    "v_cmp_ge_i32_e64 %[amok], %[qlen], " vCOL "\n\t"  "s_and_b64 %[amok], %[amok], %[inb]\n\t"
+// from h (vH) and max(h, E) (vHSE): the arg-max key, the F scan's input, both 64-lane scans interleaved; the six wait-state slots carry the ring / arena
+// addresses of the row's stores and the geometry word
+#define TA_SCAN                                                                                              \
+    "v_add_u32 " vG ", " vH ", %[le1]\n\t"                                                                  \
+    "v_lshl_add_u32 " vAK ", " vHSE ", 16, " vKC "\n\t"   "v_cndmask_b32_e64 " vAK ", 0, " vAK ", %[amok]\n\t" \
+    "v_subrev_u32 " vS1 ", %[e1], " vH "\n\t"                                                               \
+    "v_mov_b32_dpp " vS1 ", " vG " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                \
+    "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_shr:1 row_mask:0xf")                                  \
+    "v_readlane_b32 %[sP0], %[vslot], %[row]\n\t"                                                            \
+    "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_shr:1 row_mask:0xf")                                  \
+    "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_shr:2 row_mask:0xf")                                  \
+    "s_lshl_b32 %[sM0], %[cur], 5\n\t"                                                                       \
+    "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_shr:2 row_mask:0xf")                                  \
+    "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_shr:4 row_mask:0xf")                                  \
+    "v_lshl_add_u32 " vQD ", %[lane], 2, %[sP0]\n\t"                                                         \
+    "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_shr:4 row_mask:0xf")                                  \
+    "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_shr:8 row_mask:0xf")                                  \
+    "v_lshl_add_u32 " vRO ", %[lane], 1, %[sM0]\n\t"                                                         \
+    "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_shr:8 row_mask:0xf")                                  \
+    "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_bcast:15 row_mask:0xa")                               \
+    "s_lshl_b32 %[sB], %[sESN], 12\n\t"                                                                      \
+    "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_bcast:15 row_mask:0xa")                               \
+    "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_bcast:31 row_mask:0xc")                               \
+    "s_or_b32 %[sB], %[sB], %[sBSN]\n\t"                                                                     \
+    "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_bcast:31 row_mask:0xc")
+// F, H, E; EIN = the VGPR operand text that yields E entering the cell minus e1 (path-specific instruction passed whole)
+#define TA_HEF(EN_INSTR)                                                                                     \
+    "v_sub_u32 " vF ", " vS1 ", %[cf1]\n\t"     "v_max_i32 " vF ", " vF ", %[inj1]\n\t"                      \
+    "v_max_i32 " vHO ", " vHSE ", " vF "\n\t"   "v_subrev_u32 " vT2A ", %[oe1], " vHO "\n\t"                 \
+    EN_INSTR                                                                                                 \
+    "v_max_i32 " vEN ", " vEN ", " vT2A "\n\t"                                                               \
+    "v_cmp_lt_i32 vcc, " vHSE ", " vF "\n\t"    "v_cndmask_b32 " vE ", " vEN ", %[infv], vcc\n\t"            \
+    "v_sub_u32 " vU ", " vEN ", " vT2A "\n\t"   "v_sub_u32 " vD ", " vHO ", " vF "\n\t"     "v_min_u32 " vD ", 7, " vD "\n\t" \
+    "v_perm_b32 " vHE ", " vE ", " vHO ", %[perm]\n\t"
+// direction word (kf in vKF), stores, arg-max decode, commit, loop
+#define TA_TAIL                                                                                              \
+    "v_lshl_or_b32 " vU ", " vD ", 3, " vU "\n\t"   "v_lshl_or_b32 " vWD ", " vU ", 8, " vKF "\n\t"           \
+    "global_store_short " vRO ", " vWD ", %[planes]\n\t"                                                     \
+    "v_cndmask_b32_e64 " vHE ", %[infwv], " vHE ", %[inb]\n\t"                                                   \
+    "ds_write2st64_b32 " vQD ", " vHE ", %[infwv] offset1:1\n\t"                                             \
+    "v_readlane_b32 %[sA], " vAK ", 63\n\t"                                                                  \
+    "s_bitset1_b32 %[sB], 24\n\t"                                                                            \
+    "v_writelane_b32 %[geo], %[sB], m0\n\t"     "v_writelane_b32 %[off], %[cur], m0\n\t"                     \
+    "s_lshr_b32 %[sM0], %[sA], 16\n\t"          "s_and_b32 %[sA], %[sA], 63\n\t"      "s_add_i32 %[sA], %[sA], %[sC0]\n\t" \
+    "s_cmp_gt_i32 %[sM0], %[infk]\n\t"          "s_cselect_b32 %[sA], %[sA], -1\n\t"                         \
+    "v_writelane_b32 %[mi], %[sA], m0\n\t"                                                                   \
+    "s_add_i32 %[cur], %[cur], %[sNV1]\n\t"     "s_add_i32 %[cur], %[cur], 1\n\t"                            \
+    "s_add_i32 %[row], %[row], 1\n\t"           "s_cmp_lt_i32 %[row], %[rhi]\n\t"     "s_cbranch_scc1 L_row_%=\n\t"
+
+#define TIGHT_ASM_I16_AFFINE_DIR                                                                             \
+    "v_lshl_add_u32 " vQA ", %[qoff0], 2, %[mxb]\n\t"                                                        \
+    "s_mov_b32 %[code], 3\n\t"                                                                               \
+    "L_row_%=:\n\t"                                                                                          \
+    "v_readlane_b32 %[sM], %[tvmeta], %[row]\n\t"   "v_readlane_b32 %[sTB], %[tvtb], %[row]\n\t"   "v_readlane_b32 %[sRT], %[tvrt], %[row]\n\t" \
+    "s_and_b32 m0, %[row], 63\n\t"                                                                           \
+    "s_bitcmp0_b32 %[sM], 17\n\t"               "s_cbranch_scc1 L_x0_%=\n\t"                                 \
+    "s_and_b32 %[sA], %[sTB], 0xff\n\t"         "s_sub_i32 %[sP0], %[row], %[sA]\n\t"                        \
+    "v_readlane_b32 %[sM0], %[mi], %[sP0]\n\t"  "v_readlane_b32 %[sG0], %[geo], %[sP0]\n\t"   "v_readlane_b32 %[sSL0], %[vslot], %[sP0]\n\t" \
+    "s_bitcmp1_b32 %[sM], 9\n\t"                "s_cbranch_scc1 L_two_%=\n\t"                                \
+    /* ---------------- one predecessor */                                                                   \
+    "s_add_i32 %[sA], %[sM0], 1\n\t"            "s_mov_b32 %[sB], %[sA]\n\t"                                 \
+    TA_BAND                                                                                                  \
+    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                     \
+    "s_max_u32 %[sBSN], %[sA], %[sPB0]\n\t"                                                                  \
+    TA_CHECKS("1")                                                                                           \
+    TA_READS                                                                                                 \
+    TA_MASKS                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+    "v_add_u32_sdwa " vH ", sext(" vR0 "), " vQ TA_SDWA0                                                     \
+    "v_min_i32_sdwa " vT ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                              \
+    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"   "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
+    "v_max_i32_sdwa " vHSE ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                            \
+    TA_SCAN                                                                                                  \
+    TA_HEF("v_sub_u32_sdwa " vEN ", sext(" vR1 "), %[e1]" TA_SDWA_S0W1)                                      \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32_e64 " vKF ", 16, 17, vcc\n\t"                     \
+    TA_TAIL                                                                                                  \
+    "s_branch L_end_%=\n\t"                                                                                  \
+    /* ---------------- two predecessors */                                                                  \
+    "L_two_%=:\n\t"                                                                                          \
+    "s_bfe_u32 %[sA], %[sTB], 0x80008\n\t"      "s_sub_i32 %[sP1], %[row], %[sA]\n\t"                        \
+    "v_readlane_b32 %[sM1], %[mi], %[sP1]\n\t"  "v_readlane_b32 %[sG1], %[geo], %[sP1]\n\t"   "v_readlane_b32 %[sSL1], %[vslot], %[sP1]\n\t" \
+    "s_min_i32 %[sA], %[sM0], %[sM1]\n\t"       "s_max_i32 %[sB], %[sM0], %[sM1]\n\t"                        \
+    "s_add_i32 %[sA], %[sA], 1\n\t"             "s_add_i32 %[sB], %[sB], 1\n\t"                              \
+    TA_BAND                                                                                                  \
+    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                     \
+    "s_and_b32 %[sPB1], %[sG1], 0xfff\n\t"      "s_bfe_u32 %[sPE1], %[sG1], 0xc000c\n\t"                     \
+    "s_min_u32 %[sB], %[sPB0], %[sPB1]\n\t"     "s_max_u32 %[sBSN], %[sA], %[sB]\n\t"                        \
+    "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"   "s_and_b32 %[sG0], %[sG0], %[sG1]\n\t"                       \
+    TA_CHECKS("2")                                                                                           \
+    TA_READS                                                                                                 \
+    "s_lshl_b32 %[sA], %[sPB1], 4\n\t"          "v_subrev_u32 " vX1 ", %[sA], " vCOL "\n\t"                  \
+    "v_add_u32 " vX ", -1, " vX1 "\n\t"         "v_med3_i32 " vX ", " vX ", -2, %[rc]\n\t"                   \
+    "v_lshl_add_u32 " vX ", " vX ", 2, %[sSL1]\n\t"   "ds_read2_b32 " vB01 ", " vX " offset1:1\n\t"           \
+    "s_sub_i32 %[sM1], %[sPE1], %[sPB1]\n\t"    "s_lshl_b32 %[sM1], %[sM1], 4\n\t"                           \
+    "s_add_i32 %[sM1], %[sM1], 16\n\t"          "s_add_i32 %[sP1], %[sM1], 16\n\t"                           \
+    TA_MASKS                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+    "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"     "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                     \
+    "v_max_i32_sdwa " vT ", " vMV ", sext(" vB0 ")" TA_SDWA_S1W0                                             \
+    "v_cmp_gt_u32 vcc, %[sP1], " vX1 "\n\t"     "v_cndmask_b32 " vMV2 ", " vMV ", " vT ", vcc\n\t"           \
+    "v_max_i32_sdwa " vT ", " vE1 ", sext(" vB1 ")" TA_SDWA_S1W1                                             \
+    "v_cmp_gt_u32 vcc, %[sM1], " vX1 "\n\t"     "v_cndmask_b32 " vE12 ", " vE1 ", " vT ", vcc\n\t"           \
+    "v_add_u32 " vH ", " vMV2 ", " vQ "\n\t"                                                                 \
+    "v_min_i32 " vT ", " vH ", " vE12 "\n\t"                                                                 \
+    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"   "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
+    "v_max_i32 " vHSE ", " vH ", " vE12 "\n\t"                                                               \
+    TA_SCAN                                                                                                  \
+    TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE12 "\n\t")                                                      \
+    "v_cmp_ne_u32 vcc, " vMV2 ", " vMV "\n\t"   "v_cndmask_b32_e64 " vKF ", 1, 2, vcc\n\t"                       \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32 " vKF ", 0, " vKF ", vcc\n\t"                 \
+    "v_cmp_ne_u32 vcc, " vE12 ", " vE1 "\n\t"   "v_cndmask_b32_e64 " vX ", 16, 32, vcc\n\t"                      \
+    "v_or_b32 " vKF ", " vKF ", " vX "\n\t"                                                                  \
+    TA_TAIL                                                                                                  \
+    "s_branch L_end_%=\n\t"                                                                                  \
+    /* ---------------- out of line */                                                                       \
+    TA_REFRESH("1")                                                                                          \
+    TA_REFRESH("2")                                                                                          \
+    "L_dec_%=:\n\t"                                                                                          \
+    "s_mov_b32 %[code], 2\n\t"                                                                               \
+    "s_cmp_gt_u32 %[sNV1], 3\n\t"               "s_cbranch_scc1 L_end_%=\n\t"                                \
+    "s_cmp_gt_i32 %[sBSN], %[sPE0]\n\t"         "s_cbranch_scc1 L_end_%=\n\t"                                \
+    "s_bitcmp0_b32 %[sG0], 24\n\t"              "s_cbranch_scc1 L_end_%=\n\t"                                \
+    "s_mov_b32 %[code], 1\n\t"                  "s_branch L_end_%=\n\t"                                      \
+    "L_x0_%=:\n\t"  "s_mov_b32 %[code], 0\n\t"  "s_branch L_end_%=\n\t"                                      \
+    "L_x2_%=:\n\t"  "s_mov_b32 %[code], 2\n\t"                                                               \
+    "L_end_%=:\n\t"

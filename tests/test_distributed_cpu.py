@@ -120,6 +120,13 @@ def test_bench_self_launch_over_gloo():
     assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["max_rank_plus_1"] == 2.0
     assert rec["sets_all_ranks"] == rec["total_sets"] == 40 and rec["sum_of_first_indices"] == shard_range(40, 2, 1)[0]
     assert rec["records_gathered"] == 40          # the result gather: every record on rank 0, in order (asserted inside the run)
+    assert rec["secondary_rehearsed"] is None     # (a strong-scaling job has no per-GPU secondary entry)
+    # the default multi-rank form (weak scaling, headline workload): BASELINE.json configs[3] runs as a secondary entry on EVERY rank -- its collectives rehearsed
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"], capture_output=True, text=True, env=env, timeout=300)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    rec2 = json.loads([ln for ln in p2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec2["secondary_rehearsed"] == {"name": "cfg4_x2048_per_gpu", "max_time": 1.5, "sets_all_ranks": 4096, "parity_checked_all_ranks": 4096}
+    assert rec2["sets_all_ranks"] == 2000 and rec2["ranks_seen"] == 2
     if torch.cuda.device_count() < 2:
         q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sets", "8"], capture_output=True, text=True, env=env, timeout=300)
         assert q.returncode == 2 and "nothing was launched" in q.stderr and "Traceback" not in q.stderr
