@@ -1228,18 +1228,20 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #if !defined(ABPOA_HIP_ABLATE) && !defined(ABPOA_HIP_PROFILE) && !defined(ABPOA_HIP_ROW_CENSUS) && !defined(ABPOA_HIP_NO_ASM_TIGHT)
             if constexpr (!WPLAN && I16 && GAP == 1 && DIR) {
                 if (asm_tight_on && cur + NV * (r_hi - row) <= cap_turbo) {
-                    int code, sM, sTB, sRT, sP0, sM0, sG0, sSL0, sA, sB, sESN, sBSN, sPB0, sPE0, sNV1, sC0, sP1, sM1, sG1, sSL1, sPB1, sPE1; long long inb, amok, msk;
+                    int code, sM, sTB, sRT, sP0, sM0, sG0, sSL0, sA, sB, sESN, sBSN, sPB0, sPE0, sNV1, sC0, sP1, sM1, sG1, sSL1, sPB1, sPE1, sP2, sSL2, sPB2, sPE2, sP3, sSL3, sPB3, sPE3;
+                    long long inb, amok, msk;
                     int infw_v = infw, inf_v = inf; asm("" : "+v"(infw_v), "+v"(inf_v));
                     const int mxb = (int)(unsigned)(size_t)(lds_int_t *)s_mx, qb = (int)(unsigned)(size_t)(lds_int_t *)(const void *)s_query;
                     asm volatile(TIGHT_ASM_I16_AFFINE_DIR
                         : [row] "+s"(row), [cur] "+s"(cur), [qcb] "+s"(qc_beg_sn), [code] "=&s"(code), [geo] "+v"(vg_geo), [mi] "+v"(vg_mi), [off] "+v"(vg_off), [qoff0] "+v"(qoff0),
                           [qoff1] "+v"(qoff1), [sM] "=&s"(sM), [sTB] "=&s"(sTB), [sRT] "=&s"(sRT), [sP0] "=&s"(sP0), [sM0] "=&s"(sM0), [sG0] "=&s"(sG0), [sSL0] "=&s"(sSL0), [sA] "=&s"(sA),
                           [sB] "=&s"(sB), [sESN] "=&s"(sESN), [sBSN] "=&s"(sBSN), [sPB0] "=&s"(sPB0), [sPE0] "=&s"(sPE0), [sNV1] "=&s"(sNV1), [sC0] "=&s"(sC0), [sP1] "=&s"(sP1),
-                          [sM1] "=&s"(sM1), [sG1] "=&s"(sG1), [sSL1] "=&s"(sSL1), [sPB1] "=&s"(sPB1), [sPE1] "=&s"(sPE1), [inb] "=&s"(inb), [amok] "=&s"(amok), [msk] "=&s"(msk)
-                        : [lane] "v"(lane), [tvmeta] "v"(tv_meta), [tvtb] "v"(tv_tb), [tvrt] "v"(tv_rterm), [vslot] "v"(vslot), [le1] "v"(le1), [cf1] "v"(cf1), [inj1] "v"(inj1), [kN] "v"(kN),
+                          [sM1] "=&s"(sM1), [sG1] "=&s"(sG1), [sSL1] "=&s"(sSL1), [sPB1] "=&s"(sPB1), [sPE1] "=&s"(sPE1), [sP2] "=&s"(sP2), [sSL2] "=&s"(sSL2), [sPB2] "=&s"(sPB2),
+                          [sPE2] "=&s"(sPE2), [sP3] "=&s"(sP3), [sSL3] "=&s"(sSL3), [sPB3] "=&s"(sPB3), [sPE3] "=&s"(sPE3), [inb] "=&s"(inb), [amok] "=&s"(amok), [msk] "=&s"(msk)
+                        : [lane] "v"(lane), [tvmeta] "v"(tv_meta), [tvtb] "v"(tv_tb), [tvrt] "v"(tv_rterm), [tvp2] "v"(tv_p2), [tvp3] "v"(tv_p3), [vslot] "v"(vslot), [le1] "v"(le1), [cf1] "v"(cf1), [inj1] "v"(inj1), [kN] "v"(kN),
                           [kE] "v"(kE), [vvl] "v"(vvl), [infwv] "v"(infw_v), [infv] "v"(inf_v), [gn] "s"(gn), [w] "s"(w), [qlen] "s"(qlen), [rc] "s"(RC), [mxb] "s"(mxb), [fastlo] "s"(fast_lo),
                           [e1] "s"(e1), [oe1] "s"(oe1), [infk] "s"(inf + 32768), [planes] "s"(io.planes), [rhi] "s"(r_hi), [qb] "s"(qb), [m] "s"(m), [perm] "s"(0x05040100)
-                        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
+                        : "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
                           "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc", "m0", "memory");
                     ok_ = code == 1 ? 0 : (code == 2 ? -1 : 1);
                     cxx_tight = false;

@@ -16,7 +16,7 @@
 //     2 = declined for good / a value near the wrap limit (turbo_body's -1), 3 = reached r_hi;
 //   * the caller guarantees cur + 4 * (r_hi - row) <= cap_turbo (a row takes at most NV = 4 arena units), so the loop carries no arena-room test;
 //   * refreshes the cached query codes (qoff0 / qoff1, qc_beg_sn) itself when the band start moves;
-//   * VGPRs v100-v127 and the listed scalar temporaries are its scratch; exec is all ones (one-wavefront phase).
+//   * VGPRs v92-v127 and the listed scalar temporaries are its scratch; exec is all ones (one-wavefront phase).
 // Hazards observed (CDNA3 ISA 4.5): two wait states between a VALU write and a DPP read of the same VGPR (partner chain + one filler per step);
 // lane selects of v_readlane / v_writelane come from SALU-written registers (row, M0) only; no VALU-written SGPR feeds a memory instruction.
 #define TA_SDWA0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
@@ -59,6 +59,16 @@
 #define vMV2 "v102"
 #define vE12 "v103"
 #define vT "v106"
+#define vKM "v92"
+#define vKE "v93"
+#define vX2 "v94"
+#define vX3 "v95"
+#define vC0 "v96"
+#define vC1 "v97"
+#define vC01 "v[96:97]"
+#define vD0 "v98"
+#define vD1 "v99"
+#define vD01 "v[98:99]"
 
 // band of the row from (mn + 1 in sA, mx + 1 in sB): beg_sn -> sA (before the max with min_pb), end_sn -> sESN      reference :710-720
 #define TA_BAND                                                                                              \
@@ -146,15 +156,74 @@
     "s_add_i32 %[cur], %[cur], %[sNV1]\n\t"     "s_add_i32 %[cur], %[cur], 1\n\t"                            \
     "s_add_i32 %[row], %[row], 1\n\t"           "s_cmp_lt_i32 %[row], %[rhi]\n\t"     "s_cbranch_scc1 L_row_%=\n\t"
 
+// ---- three / four predecessors (tile bit 18, not a row that keeps its records): the band from all of them first, then every ring read in flight
+//      together, then the merges in list order with the running "first predecessor that holds the maximum" of M and E (turbo_body<4>: kfirst, kE1)
+#define TA_IF4_YES(x) x
+#define TA_IF4_NO(x) ""
+// one more predecessor's geometry folded into (sA, sB) = (min, max) arg-max, ring word sG0; its band start / end -> PB / PE.  LANE = SGPR holding its row
+#define TA_FOLD(LANE, SL, PB, PE)                                                                            \
+    "v_readlane_b32 %[sM1], %[mi], " LANE "\n\t"  "v_readlane_b32 %[sG1], %[geo], " LANE "\n\t"  "v_readlane_b32 " SL ", %[vslot], " LANE "\n\t" \
+    "s_min_i32 %[sA], %[sA], %[sM1]\n\t"          "s_max_i32 %[sB], %[sB], %[sM1]\n\t"           "s_and_b32 %[sG0], %[sG0], %[sG1]\n\t" \
+    "s_and_b32 " PB ", %[sG1], 0xfff\n\t"         "s_bfe_u32 " PE ", %[sG1], 0xc000c\n\t"
+// ring read of a further predecessor: X = its column offset (kept for the range masks), PAIR = destination; then PE becomes its band width in columns
+#define TA_READK(X, PAIR, SL, PB, PE)                                                                        \
+    "s_lshl_b32 %[sA], " PB ", 4\n\t"             "v_subrev_u32 " X ", %[sA], " vCOL "\n\t"                  \
+    "v_add_u32 " vT ", -1, " X "\n\t"             "v_med3_i32 " vT ", " vT ", -2, %[rc]\n\t"                 \
+    "v_lshl_add_u32 " vT ", " vT ", 2, " SL "\n\t"  "ds_read2_b32 " PAIR ", " vT " offset1:1\n\t"            \
+    "s_sub_i32 " PE ", " PE ", " PB "\n\t"        "s_lshl_b32 " PE ", " PE ", 4\n\t"             "s_add_i32 " PE ", " PE ", 16\n\t"
+// merge of predecessor KIDX (1 + list index): words W0 / W1, column offset X, band width PE      turbo_body merge_pred, reference :812-851
+#define TA_MERGE(KIDX, W0, W1, X, PE)                                                                        \
+    "v_max_i32_sdwa " vT ", " vMV ", sext(" W0 ")" TA_SDWA_S1W0                                              \
+    "v_cmp_lt_i32 vcc, " vMV ", " vT "\n\t"                                                                  \
+    "s_add_i32 %[sA], " PE ", 16\n\t"             "v_cmp_gt_u32_e64 %[msk], %[sA], " X "\n\t"    "s_and_b64 vcc, vcc, %[msk]\n\t" \
+    "v_cndmask_b32_e64 " vKM ", " vKM ", " KIDX ", vcc\n\t"   "v_cndmask_b32_e64 " vMV ", " vMV ", " vT ", %[msk]\n\t" \
+    "v_max_i32_sdwa " vT ", " vE1 ", sext(" W1 ")" TA_SDWA_S1W1                                              \
+    "v_cmp_lt_i32 vcc, " vE1 ", " vT "\n\t"                                                                  \
+    "v_cmp_gt_u32_e64 %[msk], " PE ", " X "\n\t"  "s_and_b64 vcc, vcc, %[msk]\n\t"                           \
+    "v_cndmask_b32_e64 " vKE ", " vKE ", " KIDX ", vcc\n\t"   "v_cndmask_b32_e64 " vE1 ", " vE1 ", " vT ", %[msk]\n\t"
+#define TA_MULTI(IF4, LBL)                                                                                   \
+    "s_mov_b32 %[sA], %[sM0]\n\t"                "s_mov_b32 %[sB], %[sM0]\n\t"                              \
+    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"        "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                   \
+    TA_FOLD("%[sP1]", "%[sSL1]", "%[sPB1]", "%[sPE1]")                                                       \
+    TA_FOLD("%[sP2]", "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                       \
+    IF4(TA_FOLD("%[sP3]", "%[sSL3]", "%[sPB3]", "%[sPE3]"))                                                  \
+    "s_add_i32 %[sA], %[sA], 1\n\t"               "s_add_i32 %[sB], %[sB], 1\n\t"                            \
+    TA_BAND                                                                                                  \
+    "s_min_u32 %[sB], %[sPB0], %[sPB1]\n\t"       "s_min_u32 %[sB], %[sB], %[sPB2]\n\t"   IF4("s_min_u32 %[sB], %[sB], %[sPB3]\n\t") \
+    "s_max_u32 %[sBSN], %[sA], %[sB]\n\t"                                                                    \
+    "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"     "s_max_u32 %[sPE0], %[sPE0], %[sPE2]\n\t" IF4("s_max_u32 %[sPE0], %[sPE0], %[sPE3]\n\t") \
+    TA_CHECKS(LBL)                                                                                           \
+    TA_READS                                                                                                 \
+    TA_READK(vX1, vB01, "%[sSL1]", "%[sPB1]", "%[sPE1]")                                                     \
+    TA_READK(vX2, vC01, "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                     \
+    IF4(TA_READK(vX3, vD01, "%[sSL3]", "%[sPB3]", "%[sPE3]"))                                                \
+    TA_MASKS                                                                                                 \
+    "v_mov_b32 " vKM ", 1\n\t"                    "v_mov_b32 " vKE ", 1\n\t"                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+    "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"       "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                   \
+    TA_MERGE("2", vB0, vB1, vX1, "%[sPE1]")                                                                  \
+    TA_MERGE("3", vC0, vC1, vX2, "%[sPE2]")                                                                  \
+    IF4(TA_MERGE("4", vD0, vD1, vX3, "%[sPE3]"))                                                             \
+    "v_add_u32 " vH ", " vMV ", " vQ "\n\t"                                                                  \
+    "v_min_i32 " vT ", " vH ", " vE1 "\n\t"                                                                  \
+    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"     "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
+    "v_max_i32 " vHSE ", " vH ", " vE1 "\n\t"                                                                \
+    TA_SCAN                                                                                                  \
+    TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE1 "\n\t")                                                       \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"       "v_cndmask_b32 " vKF ", 0, " vKM ", vcc\n\t"               \
+    "v_lshl_or_b32 " vKF ", " vKE ", 4, " vKF "\n\t"                                                         \
+    TA_TAIL                                                                                                  \
+    "s_branch L_end_%=\n\t"
+
 #define TIGHT_ASM_I16_AFFINE_DIR                                                                             \
     "v_lshl_add_u32 " vQA ", %[qoff0], 2, %[mxb]\n\t"                                                        \
     "s_mov_b32 %[code], 3\n\t"                                                                               \
     "L_row_%=:\n\t"                                                                                          \
     "v_readlane_b32 %[sM], %[tvmeta], %[row]\n\t"   "v_readlane_b32 %[sTB], %[tvtb], %[row]\n\t"   "v_readlane_b32 %[sRT], %[tvrt], %[row]\n\t" \
     "s_and_b32 m0, %[row], 63\n\t"                                                                           \
-    "s_bitcmp0_b32 %[sM], 17\n\t"               "s_cbranch_scc1 L_x0_%=\n\t"                                 \
     "s_and_b32 %[sA], %[sTB], 0xff\n\t"         "s_sub_i32 %[sP0], %[row], %[sA]\n\t"                        \
     "v_readlane_b32 %[sM0], %[mi], %[sP0]\n\t"  "v_readlane_b32 %[sG0], %[geo], %[sP0]\n\t"   "v_readlane_b32 %[sSL0], %[vslot], %[sP0]\n\t" \
+    "s_bitcmp1_b32 %[sM], 17\n\t"               "s_cbranch_scc0 L_n17_%=\n\t"                                \
     "s_bitcmp1_b32 %[sM], 9\n\t"                "s_cbranch_scc1 L_two_%=\n\t"                                \
     /* ---------------- one predecessor */                                                                   \
     "s_add_i32 %[sA], %[sM0], 1\n\t"            "s_mov_b32 %[sB], %[sA]\n\t"                                 \
@@ -171,7 +240,7 @@
     "v_max_i32_sdwa " vHSE ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                            \
     TA_SCAN                                                                                                  \
     TA_HEF("v_sub_u32_sdwa " vEN ", sext(" vR1 "), %[e1]" TA_SDWA_S0W1)                                      \
-    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32_e64 " vKF ", 16, 17, vcc\n\t"                     \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32_e64 " vKF ", 16, 17, vcc\n\t"                 \
     TA_TAIL                                                                                                  \
     "s_branch L_end_%=\n\t"                                                                                  \
     /* ---------------- two predecessors */                                                                  \
@@ -205,15 +274,27 @@
     "v_max_i32 " vHSE ", " vH ", " vE12 "\n\t"                                                               \
     TA_SCAN                                                                                                  \
     TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE12 "\n\t")                                                      \
-    "v_cmp_ne_u32 vcc, " vMV2 ", " vMV "\n\t"   "v_cndmask_b32_e64 " vKF ", 1, 2, vcc\n\t"                       \
+    "v_cmp_ne_u32 vcc, " vMV2 ", " vMV "\n\t"   "v_cndmask_b32_e64 " vKF ", 1, 2, vcc\n\t"                   \
     "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32 " vKF ", 0, " vKF ", vcc\n\t"                 \
-    "v_cmp_ne_u32 vcc, " vE12 ", " vE1 "\n\t"   "v_cndmask_b32_e64 " vX ", 16, 32, vcc\n\t"                      \
+    "v_cmp_ne_u32 vcc, " vE12 ", " vE1 "\n\t"   "v_cndmask_b32_e64 " vX ", 16, 32, vcc\n\t"                  \
     "v_or_b32 " vKF ", " vKF ", " vX "\n\t"                                                                  \
     TA_TAIL                                                                                                  \
     "s_branch L_end_%=\n\t"                                                                                  \
+    /* ---------------- three / four predecessors */                                                         \
+    "L_n17_%=:\n\t"                                                                                          \
+    "s_bitcmp1_b32 %[sM], 18\n\t"               "s_cbranch_scc0 L_x0_%=\n\t"                                 \
+    "s_bitcmp1_b32 %[sM], 21\n\t"               "s_cbranch_scc1 L_x0_%=\n\t"                                 \
+    "v_readlane_b32 %[sP2], %[tvp2], %[row]\n\t"  "v_readlane_b32 %[sP3], %[tvp3], %[row]\n\t"               \
+    "s_bfe_u32 %[sA], %[sTB], 0x80008\n\t"      "s_sub_i32 %[sP1], %[row], %[sA]\n\t"                        \
+    "s_bitcmp1_b32 %[sM], 10\n\t"               "s_cbranch_scc1 L_four_%=\n\t"                               \
+    TA_MULTI(TA_IF4_NO, "3")                                                                                 \
+    "L_four_%=:\n\t"                                                                                         \
+    TA_MULTI(TA_IF4_YES, "4")                                                                                \
     /* ---------------- out of line */                                                                       \
     TA_REFRESH("1")                                                                                          \
     TA_REFRESH("2")                                                                                          \
+    TA_REFRESH("3")                                                                                          \
+    TA_REFRESH("4")                                                                                          \
     "L_dec_%=:\n\t"                                                                                          \
     "s_mov_b32 %[code], 2\n\t"                                                                               \
     "s_cmp_gt_u32 %[sNV1], 3\n\t"               "s_cbranch_scc1 L_end_%=\n\t"                                \
