@@ -70,20 +70,25 @@
 #define vD1 "v99"
 #define vD01 "v[98:99]"
 
-// band of the row from (mn + 1 in sA, mx + 1 in sB): beg_sn -> sA (before the max with min_pb), end_sn -> sESN      reference :710-720
-#define TA_BAND                                                                                              \
+// band of the row, reference :710-720, in two halves so that the ring reads -- which need the band START only -- go out before the band END and the row's
+// conditions are computed (LDS latency under ~17 scalar instructions instead of ~5):  TA_BAND_BEG: mn + 1 in sA -> beg_sn before the max with min_pb;
+// TA_BAND_END: mx + 1 in sB -> end_sn in sESN
+#define TA_BAND_BEG                                                                                          \
     "s_min_i32 %[sA], %[gn], %[sA]\n\t"   "s_min_i32 %[sA], %[sA], %[sRT]\n\t"  "s_sub_i32 %[sA], %[sA], %[w]\n\t"      \
-    "s_max_i32 %[sA], %[sA], 0\n\t"       "s_lshr_b32 %[sA], %[sA], 4\n\t"                                              \
+    "s_max_i32 %[sA], %[sA], 0\n\t"       "s_lshr_b32 %[sA], %[sA], 4\n\t"
+#define TA_BAND_END                                                                                          \
     "s_max_i32 %[sB], %[sB], %[sRT]\n\t"  "s_add_i32 %[sB], %[sB], %[w]\n\t"    "s_min_i32 %[sB], %[sB], %[qlen]\n\t"   \
     "s_lshr_b32 %[sESN], %[sB], 4\n\t"
-// conditions of the straight-line body (max_pe in sPE0, ring word in sG0), then the query-code cache; LBL = path suffix
-#define TA_CHECKS(LBL)                                                                                       \
+// the query-code cache (before the reads: the substitution score's address comes from it); LBL = path suffix
+#define TA_QCACHE(LBL)                                                                                       \
+    "s_cmp_lg_u32 %[sBSN], %[qcb]\n\t"     "s_cbranch_scc1 L_ref" LBL "_%=\n\t"                              \
+    "L_refd" LBL "_%=:\n\t"
+// conditions of the straight-line body (max_pe in sPE0, ring word in sG0); the reads of the row are in flight: L_dec waits for them
+#define TA_CHECKS                                                                                            \
     "s_sub_i32 %[sNV1], %[sESN], %[sBSN]\n\t"                                                                \
     "s_cmp_gt_u32 %[sNV1], 3\n\t"          "s_cbranch_scc1 L_dec_%=\n\t"                                     \
     "s_cmp_gt_i32 %[sESN], %[sPE0]\n\t"    "s_cbranch_scc1 L_dec_%=\n\t"                                     \
-    "s_bitcmp0_b32 %[sG0], 24\n\t"         "s_cbranch_scc1 L_dec_%=\n\t"                                     \
-    "s_cmp_lg_u32 %[sBSN], %[qcb]\n\t"     "s_cbranch_scc1 L_ref" LBL "_%=\n\t"                              \
-    "L_refd" LBL "_%=:\n\t"
+    "s_bitcmp0_b32 %[sG0], 24\n\t"         "s_cbranch_scc1 L_dec_%=\n\t"
 // out of line: this lane's query codes for band start sBSN (chunks 0 and 1), rows_fast.h refresh_qc
 #define TA_REFRESH(LBL)                                                                                      \
     "L_ref" LBL "_%=:\n\t"                                                                                   \
@@ -188,15 +193,17 @@
     TA_FOLD("%[sP2]", "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                       \
     IF4(TA_FOLD("%[sP3]", "%[sSL3]", "%[sPB3]", "%[sPE3]"))                                                  \
     "s_add_i32 %[sA], %[sA], 1\n\t"               "s_add_i32 %[sB], %[sB], 1\n\t"                            \
-    TA_BAND                                                                                                  \
-    "s_min_u32 %[sB], %[sPB0], %[sPB1]\n\t"       "s_min_u32 %[sB], %[sB], %[sPB2]\n\t"   IF4("s_min_u32 %[sB], %[sB], %[sPB3]\n\t") \
-    "s_max_u32 %[sBSN], %[sA], %[sB]\n\t"                                                                    \
-    "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"     "s_max_u32 %[sPE0], %[sPE0], %[sPE2]\n\t" IF4("s_max_u32 %[sPE0], %[sPE0], %[sPE3]\n\t") \
-    TA_CHECKS(LBL)                                                                                           \
+    TA_BAND_BEG                                                                                              \
+    "s_min_u32 %[sESN], %[sPB0], %[sPB1]\n\t"     "s_min_u32 %[sESN], %[sESN], %[sPB2]\n\t"   IF4("s_min_u32 %[sESN], %[sESN], %[sPB3]\n\t") \
+    "s_max_u32 %[sBSN], %[sA], %[sESN]\n\t"                                                                  \
+    TA_QCACHE(LBL)                                                                                           \
     TA_READS                                                                                                 \
+    "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"     "s_max_u32 %[sPE0], %[sPE0], %[sPE2]\n\t" IF4("s_max_u32 %[sPE0], %[sPE0], %[sPE3]\n\t") \
     TA_READK(vX1, vB01, "%[sSL1]", "%[sPB1]", "%[sPE1]")                                                     \
     TA_READK(vX2, vC01, "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                     \
     IF4(TA_READK(vX3, vD01, "%[sSL3]", "%[sPB3]", "%[sPE3]"))                                                \
+    TA_BAND_END                                                                                              \
+    TA_CHECKS                                                                                                \
     TA_MASKS                                                                                                 \
     "v_mov_b32 " vKM ", 1\n\t"                    "v_mov_b32 " vKE ", 1\n\t"                                 \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
@@ -226,12 +233,14 @@
     "s_bitcmp1_b32 %[sM], 17\n\t"               "s_cbranch_scc0 L_n17_%=\n\t"                                \
     "s_bitcmp1_b32 %[sM], 9\n\t"                "s_cbranch_scc1 L_two_%=\n\t"                                \
     /* ---------------- one predecessor */                                                                   \
-    "s_add_i32 %[sA], %[sM0], 1\n\t"            "s_mov_b32 %[sB], %[sA]\n\t"                                 \
-    TA_BAND                                                                                                  \
-    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                     \
-    "s_max_u32 %[sBSN], %[sA], %[sPB0]\n\t"                                                                  \
-    TA_CHECKS("1")                                                                                           \
+    "s_add_i32 %[sB], %[sM0], 1\n\t"            "s_mov_b32 %[sA], %[sB]\n\t"                                 \
+    TA_BAND_BEG                                                                                              \
+    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_max_u32 %[sBSN], %[sA], %[sPB0]\n\t"                      \
+    TA_QCACHE("1")                                                                                           \
     TA_READS                                                                                                 \
+    TA_BAND_END                                                                                              \
+    "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                                                                 \
+    TA_CHECKS                                                                                                \
     TA_MASKS                                                                                                 \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
     "v_add_u32_sdwa " vH ", sext(" vR0 "), " vQ TA_SDWA0                                                     \
@@ -249,18 +258,20 @@
     "v_readlane_b32 %[sM1], %[mi], %[sP1]\n\t"  "v_readlane_b32 %[sG1], %[geo], %[sP1]\n\t"   "v_readlane_b32 %[sSL1], %[vslot], %[sP1]\n\t" \
     "s_min_i32 %[sA], %[sM0], %[sM1]\n\t"       "s_max_i32 %[sB], %[sM0], %[sM1]\n\t"                        \
     "s_add_i32 %[sA], %[sA], 1\n\t"             "s_add_i32 %[sB], %[sB], 1\n\t"                              \
-    TA_BAND                                                                                                  \
-    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                     \
-    "s_and_b32 %[sPB1], %[sG1], 0xfff\n\t"      "s_bfe_u32 %[sPE1], %[sG1], 0xc000c\n\t"                     \
-    "s_min_u32 %[sB], %[sPB0], %[sPB1]\n\t"     "s_max_u32 %[sBSN], %[sA], %[sB]\n\t"                        \
-    "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"   "s_and_b32 %[sG0], %[sG0], %[sG1]\n\t"                       \
-    TA_CHECKS("2")                                                                                           \
+    TA_BAND_BEG                                                                                              \
+    "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_and_b32 %[sPB1], %[sG1], 0xfff\n\t"                       \
+    "s_min_u32 %[sESN], %[sPB0], %[sPB1]\n\t"   "s_max_u32 %[sBSN], %[sA], %[sESN]\n\t"                      \
+    TA_QCACHE("2")                                                                                           \
     TA_READS                                                                                                 \
     "s_lshl_b32 %[sA], %[sPB1], 4\n\t"          "v_subrev_u32 " vX1 ", %[sA], " vCOL "\n\t"                  \
     "v_add_u32 " vX ", -1, " vX1 "\n\t"         "v_med3_i32 " vX ", " vX ", -2, %[rc]\n\t"                   \
     "v_lshl_add_u32 " vX ", " vX ", 2, %[sSL1]\n\t"   "ds_read2_b32 " vB01 ", " vX " offset1:1\n\t"           \
+    TA_BAND_END                                                                                              \
+    "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"    "s_bfe_u32 %[sPE1], %[sG1], 0xc000c\n\t"                     \
     "s_sub_i32 %[sM1], %[sPE1], %[sPB1]\n\t"    "s_lshl_b32 %[sM1], %[sM1], 4\n\t"                           \
     "s_add_i32 %[sM1], %[sM1], 16\n\t"          "s_add_i32 %[sP1], %[sM1], 16\n\t"                           \
+    "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"   "s_and_b32 %[sG0], %[sG0], %[sG1]\n\t"                       \
+    TA_CHECKS                                                                                                \
     TA_MASKS                                                                                                 \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
     "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"     "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                     \
@@ -296,6 +307,7 @@
     TA_REFRESH("3")                                                                                          \
     TA_REFRESH("4")                                                                                          \
     "L_dec_%=:\n\t"                                                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                  /* (the row's ring reads land in scratch registers the compiler may use after the block) */ \
     "s_mov_b32 %[code], 2\n\t"                                                                               \
     "s_cmp_gt_u32 %[sNV1], 3\n\t"               "s_cbranch_scc1 L_end_%=\n\t"                                \
     "s_cmp_gt_i32 %[sBSN], %[sPE0]\n\t"         "s_cbranch_scc1 L_end_%=\n\t"                                \
