@@ -248,6 +248,20 @@ def msa_timing(lib=None):
     return d
 
 
+HOST_REASONS = ["other", "node slots at the first read", "predecessor-list slots", "cigar slots", "node slots while fusing", "edge / aligned slots of a node",
+                "projected graph growth", "row-order walk", "MSA rank walk", "DP arena too small for the bands", "other DP status", "job options / pass did not fit"]
+
+
+def host_reasons(lib=None):
+    """{reason: sets} for the read-sets the last msa_batch call handed to the host driver (abpoa_hip_get_host_reasons)."""
+    lib = lib or ffi.lib()
+    a = (C.c_int32 * 12)()
+    lib.abpoa_hip_get_host_reasons.argtypes = [C.POINTER(C.c_int32)]
+    lib.abpoa_hip_get_host_reasons.restype = None
+    lib.abpoa_hip_get_host_reasons(a)
+    return {HOST_REASONS[i]: int(a[i]) for i in range(12) if a[i]}
+
+
 def format_output(result, names=None, out_cons=True, out_msa=False):
     """Text exactly as the reference prints it: abpoa_output_rc_msa (src/abpoa_output.c:70-101) when MSA is
     requested, else abpoa_output_fx_consensus (:495-512), single consensus."""

@@ -145,7 +145,8 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
 // force_general: every alignment through the general kernel; *want_general: the final LDS plan has no fast row loop for this job although the first estimate had
 // one (ragged sets: one node factor more, wider rows -- the score width can flip to 32 bits): the caller runs the job again with force_general
 static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                               std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot, bool force_general, bool *want_general) {
+                               std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot, bool force_general, bool *want_general,
+                               std::vector<int> *fallback_reason) {
     abpoa_hip_scoring_t sc_norm = *sc_in; const bool local = sc_in->align_mode == ABPOA_HIP_LOCAL_MODE, extend = sc_in->align_mode == ABPOA_HIP_EXTEND_MODE;
     if (local) sc_norm.wb = -1;                                  // reference abpoa_post_set_para, src/abpoa_align.c:150
     const abpoa_hip_scoring_t *sc = &sc_norm;
@@ -689,6 +690,11 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     // (a set whose edge or aligned lists are full gains nothing from a pass with more node slots: -(s + 1) tells the caller to hand it to the host driver at
     //  once)
     for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(need_fb[s] == 2 ? -(s + 1) : s);
+    if (fallback_reason) {
+        fallback_reason->clear();
+        for (int s = 0; s < n_sets; ++s) if (need_fb[s]) { const int r = hs[s].pad;
+                fallback_reason->push_back(r >= 1000 ? (r - 1000 == ABPOA_HIP_STATUS_OVERFLOW ? 9 : 10) : (r >= 1 && r <= 8 ? r : 0)); }
+    }
     if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int n_slots = 0;
@@ -721,13 +727,13 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
 
 
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot) {
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device, int slot, std::vector<int> *fallback_reason) {
     bool want_general = false;
-    const int rc = run_msa_device_body(sc, n_sets, sets, out, n_threads, fallback, stats, node_factor, flags, device, slot, false, &want_general);
+    const int rc = run_msa_device_body(sc, n_sets, sets, out, n_threads, fallback, stats, node_factor, flags, device, slot, false, &want_general, fallback_reason);
     if (rc != ABPOA_HIP_EINVAL || !want_general) return rc;
     // the job stays on the device: the general kernel takes what the fast row loops' final plan could not (it used to leave for the host driver)
     want_general = false;
-    return run_msa_device_body(sc, n_sets, sets, out, n_threads, fallback, stats, node_factor, flags, device, slot, true, &want_general);
+    return run_msa_device_body(sc, n_sets, sets, out, n_threads, fallback, stats, node_factor, flags, device, slot, true, &want_general, fallback_reason);
 }
 
 }  // namespace abpoa_hip

@@ -38,6 +38,11 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
 // frees every cached pool of every device queue (abpoa_hip_trim)
 void release_msa_device_caches();
 int run_msa_device(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, int n_threads,
-                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device = -1, int slot = 0);
+                   std::vector<int> *fallback, DeviceRunStats *stats, double node_factor, unsigned flags, int device = -1, int slot = 0,
+                   std::vector<int> *fallback_reason = nullptr);
+// fallback_reason (optional, parallel to fallback): why the set left the pass -- 1 node slots at the first read, 2 predecessor list slots, 3 cigar slots,
+// 4 node slots in the fuse phase, 5 edge / aligned slots of a node, 6 projected node growth, 7 row-order walk, 8 MSA rank walk, 9 DP arena too small for the
+// bands, 10 other DP status, 0 other (abpoa_hip_get_host_reasons)
+constexpr int MSA_HOST_REASONS = 12;
 
 }  // namespace abpoa_hip

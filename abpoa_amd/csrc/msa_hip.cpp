@@ -77,7 +77,11 @@ int job_shape_key(const abpoa_hip_readset_t *sets, const std::vector<int> &idx) 
 // The device passes over the sets `idx` on ONE device queue (device, slot): pass 1 gives every set 3x its longest read in graph-node
 // slots (5 %-error reads need ~2.5x), the next ones retry the sets that outgrew that with 4.5x and 6x; whatever is left (listed in
 // `left`) goes to the host driver.  A pass that does not fit the device memory is split in halves.
-struct PassOut { int rc = ABPOA_HIP_OK; bool device_ok = true; DeviceRunStats tot; std::vector<int> left; };
+struct PassOut { int rc = ABPOA_HIP_OK; bool device_ok = true; DeviceRunStats tot; std::vector<int> left; std::map<int, int> why; };      // why: set -> reason it left its last pass
+// reasons of the read-sets that the last batch call handed to the host driver (abpoa_hip_get_host_reasons; index = msa_device.h reason code, 11 = the job's
+// options / a pass that did not fit)
+std::mutex g_reason_mu;
+int32_t g_host_reasons[MSA_HOST_REASONS];
 PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, const std::vector<int> &idx,
                       int n_threads, int device, int slot, unsigned flags) {
     PassOut R;
@@ -117,9 +121,9 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             std::vector<abpoa_hip_readset_t> sub(nb);
             std::vector<abpoa_hip_msa_t> sub_out(nb);
             for (size_t i = 0; i < nb; ++i) sub[i] = sets[todo[at + i]];
-            std::vector<int> fb;
+            std::vector<int> fb, fb_why;
             DeviceRunStats ds;
-            const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], flags, device, slot);
+            const int rc = run_msa_device(sc, (int)nb, sub.data(), sub_out.data(), n_threads, &fb, &ds, factors[pass], flags, device, slot, &fb_why);
             if (rc == ABPOA_HIP_ENOMEM && nb > 1) { chunk = (nb + 1) / 2; halved = true; continue; }      // split and retry this chunk
             if (rc != ABPOA_HIP_OK) {
                 if (rc != ABPOA_HIP_ENOMEM && rc != ABPOA_HIP_EINVAL) { R.rc = rc; return R; }
@@ -132,6 +136,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
             }
             for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
             for (int f : fb) { if (f >= 0) left.push_back(todo[at + f]); else hopeless.push_back(todo[at + (-f - 1)]); }      // (f < 0: a full edge list -- no further device pass)
+            for (size_t i = 0; i < fb.size() && i < fb_why.size(); ++i) R.why[todo[at + (fb[i] < 0 ? -fb[i] - 1 : fb[i])]] = fb_why[i];
             add_stats(R.tot, ds);
             n_small += ds.n_fit_3x;
             n_done += (int)nb - (int)fb.size();
@@ -277,6 +282,11 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
             todo.insert(todo.end(), R.left.begin(), R.left.end());
             add_stats(tot, R.tot);
         }
+        {   // why those sets left the device (the last pass each of them was in; 11: its batch as a whole was not the device's)
+            std::lock_guard<std::mutex> lk(g_reason_mu);
+            memset(g_host_reasons, 0, sizeof(g_host_reasons));
+            for (const PassOut &R : results) for (int i_ : R.left) { auto it = R.why.find(i_); g_host_reasons[it == R.why.end() ? 11 : std::min(std::max(it->second, 0), 10)]++; }
+        }
         if (rc_dev != ABPOA_HIP_OK) { free_all(out, n_sets); return rc_dev; }
         if (n_q > 1) tot.device_s = tot.total_s = *std::max_element(q_busy.begin(), q_busy.end());      // queues ran side by side: the busiest one is the wall time
         if (n_q > 1 && getenv("ABPOA_HIP_VERBOSE")) {
@@ -321,12 +331,17 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
     }
     const int rc_host = run_msa_batch(sc, n_sets, sets, out, flags, n_threads, 0, make_hip_aligner, &tm);
     tm.n_host_sets = n_sets;
+    { std::lock_guard<std::mutex> lk(g_reason_mu); memset(g_host_reasons, 0, sizeof(g_host_reasons)); g_host_reasons[11] = n_sets; }
     return rc_host;
 }
 }  // namespace
 }  // namespace abpoa_hip
 
 extern "C" {
+void abpoa_hip_get_host_reasons(int32_t *out12) {
+    std::lock_guard<std::mutex> lk(abpoa_hip::g_reason_mu);
+    for (int i = 0; i < abpoa_hip::MSA_HOST_REASONS; ++i) out12[i] = abpoa_hip::g_host_reasons[i];
+}
 int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
     return abpoa_hip::msa_batch_impl(sc, n_sets, sets, out, flags, n_threads, abpoa_hip::g_timing, -1, -1);
 }

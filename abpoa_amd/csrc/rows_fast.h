@@ -1239,7 +1239,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                           [sM1] "=&s"(sM1), [sG1] "=&s"(sG1), [sSL1] "=&s"(sSL1), [sPB1] "=&s"(sPB1), [sPE1] "=&s"(sPE1), [sP2] "=&s"(sP2), [sSL2] "=&s"(sSL2), [sPB2] "=&s"(sPB2),
                           [sPE2] "=&s"(sPE2), [sP3] "=&s"(sP3), [sSL3] "=&s"(sSL3), [sPB3] "=&s"(sPB3), [sPE3] "=&s"(sPE3), [inb] "=&s"(inb), [amok] "=&s"(amok), [msk] "=&s"(msk)
                         : [lane] "v"(lane), [tvmeta] "v"(tv_meta), [tvtb] "v"(tv_tb), [tvrt] "v"(tv_rterm), [tvp2] "v"(tv_p2), [tvp3] "v"(tv_p3), [vslot] "v"(vslot), [le1] "v"(le1), [cf1] "v"(cf1), [inj1] "v"(inj1), [kN] "v"(kN),
-                          [kE] "v"(kE), [vvl] "v"(vvl), [infwv] "v"(infw_v), [infv] "v"(inf_v), [gn] "s"(gn), [w] "s"(w), [qlen] "s"(qlen), [rc] "s"(RC), [mxb] "s"(mxb), [fastlo] "s"(fast_lo),
+                          [kE] "v"(kE), [vvl] "v"(vvl), [vl] "v"(l), [infwv] "v"(infw_v), [infv] "v"(inf_v), [gn] "s"(gn), [w] "s"(w), [qlen] "s"(qlen), [rc] "s"(RC), [mxb] "s"(mxb), [fastlo] "s"(fast_lo),
                           [e1] "s"(e1), [oe1] "s"(oe1), [infk] "s"(inf + 32768), [planes] "s"(io.planes), [rhi] "s"(r_hi), [qb] "s"(qb), [m] "s"(m), [perm] "s"(0x05040100)
                         : "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
                           "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc", "m0", "memory");

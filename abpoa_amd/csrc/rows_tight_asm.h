@@ -59,6 +59,9 @@
 #define vMV2 "v102"
 #define vE12 "v103"
 #define vT "v106"
+#define vP "v125"
+#define vFS "v126"
+#define vSH "v127"
 #define vKM "v92"
 #define vKE "v93"
 #define vX2 "v94"
@@ -83,12 +86,21 @@
 #define TA_QCACHE(LBL)                                                                                       \
     "s_cmp_lg_u32 %[sBSN], %[qcb]\n\t"     "s_cbranch_scc1 L_ref" LBL "_%=\n\t"                              \
     "L_refd" LBL "_%=:\n\t"
-// conditions of the straight-line body (max_pe in sPE0, ring word in sG0); the reads of the row are in flight: L_dec waits for them
-#define TA_CHECKS                                                                                            \
+// conditions of the straight-line body (max_pe in sPE0, ring word in sG0); the reads of the row are in flight: L_dec waits for them.  A row whose band ends
+// beyond every predecessor's (one new vector every PN rows as the band moves right) continues at SLOWLBL: the copy of the path with the literal masked scan
+#define TA_CHECKS(SLOWLBL)                                                                                   \
     "s_sub_i32 %[sNV1], %[sESN], %[sBSN]\n\t"                                                                \
     "s_cmp_gt_u32 %[sNV1], 3\n\t"          "s_cbranch_scc1 L_dec_%=\n\t"                                     \
-    "s_cmp_gt_i32 %[sESN], %[sPE0]\n\t"    "s_cbranch_scc1 L_dec_%=\n\t"                                     \
+    "s_cmp_gt_i32 %[sESN], %[sPE0]\n\t"    "s_cbranch_scc1 " SLOWLBL "_%=\n\t"
+#define TA_RINGCHK                                                                                           \
     "s_bitcmp0_b32 %[sG0], 24\n\t"         "s_cbranch_scc1 L_dec_%=\n\t"
+// entry of a path's slow copy: exactly ONE vector beyond the predecessors' bands (the row's last), at least one inside (else: the C++ bodies)
+#define TA_SLOW_ENTRY(SLOWLBL)                                                                               \
+    SLOWLBL "_%=:\n\t"                                                                                       \
+    "s_add_i32 %[sA], %[sPE0], 1\n\t"      "s_cmp_lg_u32 %[sESN], %[sA]\n\t"      "s_cbranch_scc1 L_dec_%=\n\t" \
+    "s_cmp_gt_u32 %[sBSN], %[sPE0]\n\t"    "s_cbranch_scc1 L_dec_%=\n\t"
+#define TA_S_YES(x) x
+#define TA_S_NO(x) ""
 // out of line: this lane's query codes for band start sBSN (chunks 0 and 1), rows_fast.h refresh_qc
 #define TA_REFRESH(LBL)                                                                                      \
     "L_ref" LBL "_%=:\n\t"                                                                                   \
@@ -137,18 +149,55 @@
     "v_max_u32_dpp " vAK ", " vAK ", " vAK TA_DPP("row_bcast:31 row_mask:0xc")                               \
     "s_or_b32 %[sB], %[sB], %[sBSN]\n\t"                                                                     \
     "v_max_i32_dpp " vS1 ", " vS1 ", " vS1 TA_DPP("row_bcast:31 row_mask:0xc")
-// F, H, E; EIN = the VGPR operand text that yields E entering the cell minus e1 (path-specific instruction passed whole)
-#define TA_HEF(EN_INSTR)                                                                                     \
+// SLOW rows, after the scans: F of the row's last vector (vg = max_pre_end_sn + 1: set_num 2) by the reference's literal masked scan, :859-875 / :665-699 --
+// rows_fast.h slow_f_vectors + set_f for exactly that vector, in the score width (int16: wrapping subtractions, compared as sign-extended low halves):
+//   first = carry out of the closed-form vectors; prev = H shifted by one inside the vector (lane 0: first); f = prev - oe; four log steps
+//   f = max(f, shift_S(f - S e)) with the shifted-in lanes and the lanes l > cov set to "inf" (cov = 2, 4, 8, 16).          result: vFS (sign-extended)
+#define TA_SLOW_STEP(SH, COV, CTRL)                                                                          \
+    "s_lshl_b32 %[sM0], %[e1], " SH "\n\t"      "v_subrev_u32 " vT ", %[sM0], " vFS "\n\t"     "v_mov_b32 " vSH ", %[infv]\n\t" \
+    "v_cmp_lt_u32_e64 %[msk], " COV ", %[vl]\n\t"                                                            \
+    "v_mov_b32_dpp " vSH ", " vT " " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                  \
+    "v_cndmask_b32_e64 " vSH ", " vSH ", %[infv], %[msk]\n\t"                                                \
+    "v_max_i32_sdwa " vFS ", sext(" vFS "), sext(" vSH ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+#define TA_SLOW_A                                                                                            \
+    "v_max_i32 " vT ", " vS1 ", " vG "\n\t"                                                                  \
+    "s_lshl_b32 %[sA], %[sNV1], 4\n\t"          "s_add_i32 %[sA], %[sA], -1\n\t"       "s_mul_i32 %[sM0], %[sA], %[e1]\n\t" \
+    "v_readlane_b32 %[sP0], " vT ", %[sA]\n\t"                                                               \
+    "s_sub_i32 %[sP0], %[sP0], %[sM0]\n\t"      "s_sext_i32_i16 %[sP0], %[sP0]\n\t"                          \
+    "v_mov_b32 " vP ", %[sP0]\n\t"                                                                           \
+    "v_mov_b32_dpp " vP ", " vH " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                  \
+    "v_subrev_u32 " vFS ", %[oe1], " vP "\n\t"                                                               \
+    TA_SLOW_STEP("0", "2", "row_shr:1")                                                                      \
+    TA_SLOW_STEP("1", "4", "row_shr:2")                                                                      \
+    TA_SLOW_STEP("2", "8", "row_shr:4")                                                                      \
+    TA_SLOW_STEP("3", "16", "row_shr:8")
+// ... taken by the lanes of that vector
+#define TA_SLOW_F                                                                                            \
+    "v_cmp_eq_u32 vcc, %[sNV1], %[vvl]\n\t"     "v_cndmask_b32 " vF ", " vF ", " vFS ", vcc\n\t"
+// ... whose direction words carry the literal "where F came from" (dir_plane.h; rows_fast.h dir_literal, reference :260-300): 1 opened from H of the left
+// neighbour, 2 extended from its F, 3 neither -- in vSH, 0 for the other lanes
+#define TA_SLOW_LIT                                                                                          \
+    "v_mov_b32_dpp " vP ", " vHO " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                \
+    "v_mov_b32_dpp " vSH ", " vF " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                \
+    "v_subrev_u32 " vP ", %[oe1], " vP "\n\t"   "v_bfe_i32 " vP ", " vP ", 0, 16\n\t"   "v_cmp_eq_i32_e64 %[msk], " vP ", " vF "\n\t" \
+    "v_subrev_u32 " vSH ", %[e1], " vSH "\n\t"  "v_bfe_i32 " vSH ", " vSH ", 0, 16\n\t" "v_cmp_eq_i32 vcc, " vSH ", " vF "\n\t" \
+    "v_cndmask_b32_e64 " vSH ", 3, 2, vcc\n\t"  "v_cndmask_b32_e64 " vSH ", " vSH ", 1, %[msk]\n\t"          \
+    "v_cmp_le_u32 vcc, %[sNV1], %[vvl]\n\t"     "v_cndmask_b32 " vSH ", 0, " vSH ", vcc\n\t"
+// F, H, E; EN_INSTR = the path's instruction that yields (E entering the cell) - e1 in vEN; S: slow-row text
+#define TA_HEF(EN_INSTR, S)                                                                                  \
     "v_sub_u32 " vF ", " vS1 ", %[cf1]\n\t"     "v_max_i32 " vF ", " vF ", %[inj1]\n\t"                      \
+    S(TA_SLOW_F)                                                                                             \
     "v_max_i32 " vHO ", " vHSE ", " vF "\n\t"   "v_subrev_u32 " vT2A ", %[oe1], " vHO "\n\t"                 \
     EN_INSTR                                                                                                 \
     "v_max_i32 " vEN ", " vEN ", " vT2A "\n\t"                                                               \
     "v_cmp_lt_i32 vcc, " vHSE ", " vF "\n\t"    "v_cndmask_b32 " vE ", " vEN ", %[infv], vcc\n\t"            \
     "v_sub_u32 " vU ", " vEN ", " vT2A "\n\t"   "v_sub_u32 " vD ", " vHO ", " vF "\n\t"     "v_min_u32 " vD ", 7, " vD "\n\t" \
-    "v_perm_b32 " vHE ", " vE ", " vHO ", %[perm]\n\t"
+    "v_perm_b32 " vHE ", " vE ", " vHO ", %[perm]\n\t"                                                       \
+    S(TA_SLOW_LIT)
 // direction word (kf in vKF), stores, arg-max decode, commit, loop
-#define TA_TAIL                                                                                              \
+#define TA_TAIL(S)                                                                                           \
     "v_lshl_or_b32 " vU ", " vD ", 3, " vU "\n\t"   "v_lshl_or_b32 " vWD ", " vU ", 8, " vKF "\n\t"           \
+    S("v_lshl_or_b32 " vWD ", " vSH ", 14, " vWD "\n\t")                                                     \
     "global_store_short " vRO ", " vWD ", %[planes]\n\t"                                                     \
     "v_cndmask_b32_e64 " vHE ", %[infwv], " vHE ", %[inb]\n\t"                                                   \
     "ds_write2st64_b32 " vQD ", " vHE ", %[infwv] offset1:1\n\t"                                             \
@@ -186,8 +235,29 @@
     "v_cmp_lt_i32 vcc, " vE1 ", " vT "\n\t"                                                                  \
     "v_cmp_gt_u32_e64 %[msk], " PE ", " X "\n\t"  "s_and_b64 vcc, vcc, %[msk]\n\t"                           \
     "v_cndmask_b32_e64 " vKE ", " vKE ", " KIDX ", vcc\n\t"   "v_cndmask_b32_e64 " vE1 ", " vE1 ", " vT ", %[msk]\n\t"
+// the part of the multi-predecessor path behind its conditions; S: slow-row text
+#define TA_MULTI_POST(IF4, S)                                                                                \
+    TA_RINGCHK                                                                                               \
+    TA_MASKS                                                                                                 \
+    "v_mov_b32 " vKM ", 1\n\t"                    "v_mov_b32 " vKE ", 1\n\t"                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+    "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"       "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                   \
+    TA_MERGE("2", vB0, vB1, vX1, "%[sPE1]")                                                                  \
+    TA_MERGE("3", vC0, vC1, vX2, "%[sPE2]")                                                                  \
+    IF4(TA_MERGE("4", vD0, vD1, vX3, "%[sPE3]"))                                                             \
+    "v_add_u32 " vH ", " vMV ", " vQ "\n\t"                                                                  \
+    "v_min_i32 " vT ", " vH ", " vE1 "\n\t"                                                                  \
+    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"     "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
+    "v_max_i32 " vHSE ", " vH ", " vE1 "\n\t"                                                                \
+    TA_SCAN                                                                                                  \
+    S(TA_SLOW_A)                                                                                             \
+    TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE1 "\n\t", S)                                                    \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"       "v_cndmask_b32 " vKF ", 0, " vKM ", vcc\n\t"               \
+    "v_lshl_or_b32 " vKF ", " vKE ", 4, " vKF "\n\t"                                                         \
+    TA_TAIL(S)                                                                                               \
+    "s_branch L_end_%=\n\t"
 #define TA_MULTI(IF4, LBL)                                                                                   \
-    "s_mov_b32 %[sA], %[sM0]\n\t"                "s_mov_b32 %[sB], %[sM0]\n\t"                              \
+    "s_mov_b32 %[sA], %[sM0]\n\t"                 "s_mov_b32 %[sB], %[sM0]\n\t"                              \
     "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"        "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                   \
     TA_FOLD("%[sP1]", "%[sSL1]", "%[sPB1]", "%[sPE1]")                                                       \
     TA_FOLD("%[sP2]", "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                       \
@@ -203,23 +273,48 @@
     TA_READK(vX2, vC01, "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                     \
     IF4(TA_READK(vX3, vD01, "%[sSL3]", "%[sPB3]", "%[sPE3]"))                                                \
     TA_BAND_END                                                                                              \
-    TA_CHECKS                                                                                                \
+    TA_CHECKS("L_s" LBL)                                                                                     \
+    TA_MULTI_POST(IF4, TA_S_NO)                                                                              \
+    TA_SLOW_ENTRY("L_s" LBL)                                                                                 \
+    TA_MULTI_POST(IF4, TA_S_YES)
+
+// one predecessor, behind its conditions
+#define TA_ONE_POST(S)                                                                                       \
+    TA_RINGCHK                                                                                               \
     TA_MASKS                                                                                                 \
-    "v_mov_b32 " vKM ", 1\n\t"                    "v_mov_b32 " vKE ", 1\n\t"                                 \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
-    "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"       "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                   \
-    TA_MERGE("2", vB0, vB1, vX1, "%[sPE1]")                                                                  \
-    TA_MERGE("3", vC0, vC1, vX2, "%[sPE2]")                                                                  \
-    IF4(TA_MERGE("4", vD0, vD1, vX3, "%[sPE3]"))                                                             \
-    "v_add_u32 " vH ", " vMV ", " vQ "\n\t"                                                                  \
-    "v_min_i32 " vT ", " vH ", " vE1 "\n\t"                                                                  \
-    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"     "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
-    "v_max_i32 " vHSE ", " vH ", " vE1 "\n\t"                                                                \
+    "v_add_u32_sdwa " vH ", sext(" vR0 "), " vQ TA_SDWA0                                                     \
+    "v_min_i32_sdwa " vT ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                              \
+    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"   "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
+    "v_max_i32_sdwa " vHSE ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                            \
     TA_SCAN                                                                                                  \
-    TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE1 "\n\t")                                                       \
-    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"       "v_cndmask_b32 " vKF ", 0, " vKM ", vcc\n\t"               \
-    "v_lshl_or_b32 " vKF ", " vKE ", 4, " vKF "\n\t"                                                         \
-    TA_TAIL                                                                                                  \
+    S(TA_SLOW_A)                                                                                             \
+    TA_HEF("v_sub_u32_sdwa " vEN ", sext(" vR1 "), %[e1]" TA_SDWA_S0W1, S)                                   \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32_e64 " vKF ", 16, 17, vcc\n\t"                 \
+    TA_TAIL(S)                                                                                               \
+    "s_branch L_end_%=\n\t"
+// two predecessors, behind their conditions
+#define TA_TWO_POST(S)                                                                                       \
+    TA_RINGCHK                                                                                               \
+    TA_MASKS                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+    "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"     "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                     \
+    "v_max_i32_sdwa " vT ", " vMV ", sext(" vB0 ")" TA_SDWA_S1W0                                             \
+    "v_cmp_gt_u32 vcc, %[sP1], " vX1 "\n\t"     "v_cndmask_b32 " vMV2 ", " vMV ", " vT ", vcc\n\t"           \
+    "v_max_i32_sdwa " vT ", " vE1 ", sext(" vB1 ")" TA_SDWA_S1W1                                             \
+    "v_cmp_gt_u32 vcc, %[sM1], " vX1 "\n\t"     "v_cndmask_b32 " vE12 ", " vE1 ", " vT ", vcc\n\t"           \
+    "v_add_u32 " vH ", " vMV2 ", " vQ "\n\t"                                                                 \
+    "v_min_i32 " vT ", " vH ", " vE12 "\n\t"                                                                 \
+    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"   "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
+    "v_max_i32 " vHSE ", " vH ", " vE12 "\n\t"                                                               \
+    TA_SCAN                                                                                                  \
+    S(TA_SLOW_A)                                                                                             \
+    TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE12 "\n\t", S)                                                   \
+    "v_cmp_ne_u32 vcc, " vMV2 ", " vMV "\n\t"   "v_cndmask_b32_e64 " vKF ", 1, 2, vcc\n\t"                   \
+    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32 " vKF ", 0, " vKF ", vcc\n\t"                 \
+    "v_cmp_ne_u32 vcc, " vE12 ", " vE1 "\n\t"   "v_cndmask_b32_e64 " vX ", 16, 32, vcc\n\t"                  \
+    "v_or_b32 " vKF ", " vKF ", " vX "\n\t"                                                                  \
+    TA_TAIL(S)                                                                                               \
     "s_branch L_end_%=\n\t"
 
 #define TIGHT_ASM_I16_AFFINE_DIR                                                                             \
@@ -240,18 +335,10 @@
     TA_READS                                                                                                 \
     TA_BAND_END                                                                                              \
     "s_bfe_u32 %[sPE0], %[sG0], 0xc000c\n\t"                                                                 \
-    TA_CHECKS                                                                                                \
-    TA_MASKS                                                                                                 \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
-    "v_add_u32_sdwa " vH ", sext(" vR0 "), " vQ TA_SDWA0                                                     \
-    "v_min_i32_sdwa " vT ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                              \
-    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"   "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
-    "v_max_i32_sdwa " vHSE ", " vH ", sext(" vR1 ")" TA_SDWA_S1W1                                            \
-    TA_SCAN                                                                                                  \
-    TA_HEF("v_sub_u32_sdwa " vEN ", sext(" vR1 "), %[e1]" TA_SDWA_S0W1)                                      \
-    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32_e64 " vKF ", 16, 17, vcc\n\t"                 \
-    TA_TAIL                                                                                                  \
-    "s_branch L_end_%=\n\t"                                                                                  \
+    TA_CHECKS("L_s1")                                                                                        \
+    TA_ONE_POST(TA_S_NO)                                                                                     \
+    TA_SLOW_ENTRY("L_s1")                                                                                    \
+    TA_ONE_POST(TA_S_YES)                                                                                    \
     /* ---------------- two predecessors */                                                                  \
     "L_two_%=:\n\t"                                                                                          \
     "s_bfe_u32 %[sA], %[sTB], 0x80008\n\t"      "s_sub_i32 %[sP1], %[row], %[sA]\n\t"                        \
@@ -271,26 +358,10 @@
     "s_sub_i32 %[sM1], %[sPE1], %[sPB1]\n\t"    "s_lshl_b32 %[sM1], %[sM1], 4\n\t"                           \
     "s_add_i32 %[sM1], %[sM1], 16\n\t"          "s_add_i32 %[sP1], %[sM1], 16\n\t"                           \
     "s_max_u32 %[sPE0], %[sPE0], %[sPE1]\n\t"   "s_and_b32 %[sG0], %[sG0], %[sG1]\n\t"                       \
-    TA_CHECKS                                                                                                \
-    TA_MASKS                                                                                                 \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
-    "v_bfe_i32 " vMV ", " vR0 ", 0, 16\n\t"     "v_ashrrev_i32 " vE1 ", 16, " vR1 "\n\t"                     \
-    "v_max_i32_sdwa " vT ", " vMV ", sext(" vB0 ")" TA_SDWA_S1W0                                             \
-    "v_cmp_gt_u32 vcc, %[sP1], " vX1 "\n\t"     "v_cndmask_b32 " vMV2 ", " vMV ", " vT ", vcc\n\t"           \
-    "v_max_i32_sdwa " vT ", " vE1 ", sext(" vB1 ")" TA_SDWA_S1W1                                             \
-    "v_cmp_gt_u32 vcc, %[sM1], " vX1 "\n\t"     "v_cndmask_b32 " vE12 ", " vE1 ", " vT ", vcc\n\t"           \
-    "v_add_u32 " vH ", " vMV2 ", " vQ "\n\t"                                                                 \
-    "v_min_i32 " vT ", " vH ", " vE12 "\n\t"                                                                 \
-    "v_cmp_gt_i32 vcc, %[fastlo], " vT "\n\t"   "s_and_b64 %[msk], %[inb], vcc\n\t"   "s_cbranch_scc1 L_x2_%=\n\t"  \
-    "v_max_i32 " vHSE ", " vH ", " vE12 "\n\t"                                                               \
-    TA_SCAN                                                                                                  \
-    TA_HEF("v_subrev_u32 " vEN ", %[e1], " vE12 "\n\t")                                                      \
-    "v_cmp_ne_u32 vcc, " vMV2 ", " vMV "\n\t"   "v_cndmask_b32_e64 " vKF ", 1, 2, vcc\n\t"                   \
-    "v_cmp_eq_u32 vcc, " vH ", " vHO "\n\t"     "v_cndmask_b32 " vKF ", 0, " vKF ", vcc\n\t"                 \
-    "v_cmp_ne_u32 vcc, " vE12 ", " vE1 "\n\t"   "v_cndmask_b32_e64 " vX ", 16, 32, vcc\n\t"                  \
-    "v_or_b32 " vKF ", " vKF ", " vX "\n\t"                                                                  \
-    TA_TAIL                                                                                                  \
-    "s_branch L_end_%=\n\t"                                                                                  \
+    TA_CHECKS("L_s2")                                                                                        \
+    TA_TWO_POST(TA_S_NO)                                                                                     \
+    TA_SLOW_ENTRY("L_s2")                                                                                    \
+    TA_TWO_POST(TA_S_YES)                                                                                    \
     /* ---------------- three / four predecessors */                                                         \
     "L_n17_%=:\n\t"                                                                                          \
     "s_bitcmp1_b32 %[sM], 18\n\t"               "s_cbranch_scc0 L_x0_%=\n\t"                                 \

@@ -218,6 +218,11 @@ typedef struct abpoa_hip_msa_timing_t {
                                      With ABPOA_HIP_STRICT=1 in the environment such a call fails with ABPOA_HIP_ESTRICT instead of slowing down silently. */
 } abpoa_hip_msa_timing_t;
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out);
+/* Why the n_host_sets read-sets of the last abpoa_hip_msa_batch call left the device-resident driver: out12[r] = sets with reason r -- 1 node slots at the
+ * first read, 2 predecessor-list slots, 3 cigar slots, 4 node slots while a read was fused, 5 edge / aligned slots of one node, 6 projected graph growth,
+ * 7 row-order walk, 8 MSA rank walk, 9 DP arena too small for the bands, 10 other DP status, 0 other, 11 the job's options (or a pass that did not fit the
+ * device memory even alone).  Process-wide like the timing record. */
+void abpoa_hip_get_host_reasons(int32_t *out12);
 
 /* ---- contexts (additive; SURVEY.md 8b: "the replacement should be re-entrant per abpoa_t") --------------------------------------------------
  * abpoa_hip_msa_batch keeps its timing record and last error per PROCESS and drives the device queues named by ABPOA_GPU_DEVICES: one caller at a

@@ -387,3 +387,28 @@ def test_extension_mode_goldens_on_ragged_reads(engine, monkeypatch, host):
         r = api.msa_batch([seqs], api.Params(aln_mode=2), out_cons=out_cons, out_msa=out_msa)[0]
         assert api.msa_timing()["n_host_sets"] == host
         assert api.format_output(r, names, out_cons, out_msa) == open(os.path.join(D, name, "output.txt")).read(), name
+
+
+def test_seeded_fuzz_sweep_of_the_device_driver(engine):
+    """200 iterations of tools/fuzz_device_vs_oracle.py (read-set shapes x gap model x alignment mode x band x -s x weights x output kind; reads up to 700
+    bases so that the oracle-backed leg stays short) inside the suite: every output of the device-resident driver equals the oracle-backed run's, and the
+    sweep reports how many sets left the device and why (abpoa_hip_get_host_reasons) -- a set may leave only for a capacity of the device layout."""
+    import importlib.util
+    import os
+    import time
+    import helpers as H
+    spec = importlib.util.spec_from_file_location("fuzz_device_vs_oracle", os.path.join(H.ROOT, "tools", "fuzz_device_vs_oracle.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    shim = H.cpu_shim_lib()
+    t0 = time.time(); n_dev = n_host = 0; hist = {}
+    for it in range(200):
+        d, h, _, why = fz.iteration(5 * 100000 + it, shim, small=True)
+        n_dev += d; n_host += h
+        for k, v in why.items():
+            hist[k] = hist.get(k, 0) + v
+        if time.time() - t0 > 150:      # (a slow box: what ran is the test)
+            break
+    print(f"fuzz sweep: {it + 1} iterations in {time.time() - t0:.0f} s, {n_dev} sets on the device, {n_host} through the host driver: {hist}")
+    assert set(hist) <= {"edge / aligned slots of a node", "node slots while fusing", "node slots at the first read", "projected graph growth", "cigar slots",
+                         "predecessor-list slots", "DP arena too small for the bands"}, hist
+    assert n_host <= 0.1 * (n_dev + n_host), (n_dev, n_host, hist)
