@@ -36,7 +36,9 @@ static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
     if (e == hipSuccess && (mask & 2)) e = launch_one(dp_wide_kernel<GAP, 32, NW, DIR>, b, stream, b.lds.total_wide, NW * 64);
     return e;
 }
+hipError_t launch_xl_rows(const DevBatch &b, hipStream_t stream);      // dp_xl_rows.hip
 hipError_t launch_wide_rows(const DevBatch &b, hipStream_t stream) {
+    if (b.lds.wide_nw == 1 && b.lds.wfr_cols == WIDE_RING_COLS_XL) return launch_xl_rows(b, stream);      // rows wider than 448 columns: the long-read form
     // (wide-band alignments keep their score records in dir_mode 1 and write direction words in dir_mode 2: dp_common.h takes_dir)
     if (b.lds.wide_nw == 1 && b.dir_mode == 2) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, 1, true>(b, stream) : launch_wide_gap<2, 1, true>(b, stream);
     if (b.lds.wide_nw == 1) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_wide_gap<1, 1>(b, stream) : launch_wide_gap<2, 1>(b, stream);

@@ -147,7 +147,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           // of the team and outweigh the ~28 instructions per chunk that the split saves (profiles/r2_team_vs_single.txt).
           L.wide_nw = 1;
           if (mw_ && (atoi(mw_) == 1 || atoi(mw_) == 2 || atoi(mw_) == 4)) L.wide_nw = atoi(mw_);
-          L.wfr_cols = WIDE_RING_COLS; L.wfr_rows = 16;
+          // (rows wider than the 448-column ring -- reads of 20 kb and more: w = 10 + 0.01 L -- take the kernel's long-read form: 704 columns, 8 - 11 chunks a row)
+          L.wfr_cols = (est_cols > WIDE_RING_COLS && !(getenv("ABPOA_HIP_NOXL") && atoi(getenv("ABPOA_HIP_NOXL")))) ? WIDE_RING_COLS_XL : WIDE_RING_COLS; L.wfr_rows = 16;
           if (sc->m > 16) L.wide_nw = 0;      // (4-bit query codes)
           L.w_mx_off = (int)align_up((size_t)(max_qlen + 2) / 2, 16); L.w_phase_off = L.w_mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
           // ring words per column of the wide kernels: as the narrow loop's, but two instead of three for convex int32 (rows_fast.h EPACK: E as 16-bit
@@ -325,7 +326,8 @@ int BatchStream::run() {
             // (an alignment the general kernel will run -- seeded band of the -s retry, a row with more predecessors than a word names, no fast row loop in the
             //  plan -- stores its planes: the records' estimate, not the words'; host mirror of dp_common.h takes_fast)
             const int dbg_ = getenv("ABPOA_HIP_DBG") ? atoi(getenv("ABPOA_HIP_DBG")) : 0;
-            const bool fast_a = (d.flags & ALN_FAST_OK) && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && b.lds.fr_cols > 0 &&
+            const bool fast_a = (d.flags & ALN_FAST_OK) && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) &&
+                                b.lds.fr_cols > 0 &&
                                 d.qlen <= b.lds.q_cap && !(dbg_ & 64);
             const bool dir_a = dir && fast_a && (dir_wide || !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi));
             d.plane_cap = dir_a ? (first_pass ? dir_est_cells_[todo[t]] : dir_full_cells_[todo[t]]) : (first_pass ? est_cells_[todo[t]] : full_cells_[todo[t]]);
@@ -369,7 +371,7 @@ int BatchStream::run() {
         }
         HIP_TRY(hipEventRecord(ev_[1], stream_), ABPOA_HIP_ELAUNCH);
         int n_fast = 0;       // mirrors takes_fast() in dp_kernel.hip
-        if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && b.lds.fr_cols > 0 && !(b.dbg & 64))
+        if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) && b.lds.fr_cols > 0 && !(b.dbg & 64))
             for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.qlen <= b.lds.q_cap) ? 1 : 0;
         if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && b.lds.loc_cols > 0 && !(b.dbg & 64))      // mirrors takes_local() in rows_local.h
             for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.bits == 16 && (d.qlen / 16 + 1) * 16 <= b.lds.loc_cols && d.qlen <= b.lds.q_cap) ? 1 : 0;

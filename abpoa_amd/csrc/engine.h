@@ -43,6 +43,7 @@ struct AlnOut {
 #define ALN_FAST_OK 1
 #define ALN_SKIP 2       // nothing to align (device-resident driver: a set that is done, or fell back): every kernel leaves the descriptor alone
 #define WIDE_RING_COLS 448   // score-ring columns of the single-wave wide kernel (7 chunks of 64)
+#define WIDE_RING_COLS_XL 704   // ... of its long-read form (11 chunks: band half-widths up to 343 = reads up to the fast loops' 32 000 bases)
 #define ABPOA_HIP_STATUS_OVERFLOW 1   // arena too small: host retries with a full-width arena
 #define ABPOA_HIP_STATUS_NEED_SCORES 2   // direction-plane arenas (dir_plane.h): the backtrack met the one case the plane cannot decide -> redo with score records
 

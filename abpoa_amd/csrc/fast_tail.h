@@ -25,7 +25,7 @@ __device__ __forceinline__ void align_fast_tail(const DevBatch &b, const AlnDesc
     TailState ts;
     ts.status = out_rec->status; ts.n_cells = out_rec->n_cells; ts.cursor = out_rec->cells_used; ts.rows_done = out_rec->n_rows_done;
     ts.best_score = d.inf_min; ts.best_i = 0; ts.best_j = 0;
-    if (b.align_mode == ABPOA_HIP_LOCAL_MODE) { ts.best_score = out_rec->best_score; ts.best_i = out_rec->best_row; ts.best_j = out_rec->best_col; }      // (the local row loop keeps the best cell)
+    if (b.align_mode == ABPOA_HIP_LOCAL_MODE || b.align_mode == ABPOA_HIP_EXTEND_MODE) { ts.best_score = out_rec->best_score; ts.best_i = out_rec->best_row; ts.best_j = out_rec->best_col; }      // (the local row loop and the extension-mode rows keep the best cell)
     for (int i_ = 0; i_ < 6; ++i_) ts.seg[i_] = out_rec->seg[i_];
     ts.clk1 = (long long)__builtin_amdgcn_s_memtime(); ts.clk0 = ts.clk1 - out_rec->clk_dp;
     WG_SYNC();

@@ -122,7 +122,7 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && getenv("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_LOCAL"))) return false;
     // every gap model and alignment mode: the fast row loops where they apply (banded global, short local), the general kernel otherwise (linear gaps,
     // extension mode with or without z-drop, global mode without a band, long local reads).  ABPOA_HIP_NO_DEVICE_GENERAL=1 sends those back to the host driver.
-    const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && ((sc->align_mode == ABPOA_HIP_GLOBAL_MODE && sc->wb >= 0)
+    const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && (((sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) && sc->wb >= 0)
             || sc->align_mode == ABPOA_HIP_LOCAL_MODE);
     if (!fast && getenv("ABPOA_HIP_NO_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_GENERAL"))) return false;
     return true;
@@ -196,7 +196,8 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     {   LdsPlan pl; int32_t inf_d; const int mb = abpoa_hip_score_bits(sc, (int)max_cap0, max_qlen, &inf_d); const int pn_ = mb == 16 ? 16 : 8;
         const int64_t width_ = (int64_t)((max_qlen + pn_) / pn_) * pn_, w_ = sc->wb + (int)(sc->wf * (float)max_qlen);
         make_lds_plan(sc, max_qlen, mb, (local || unbanded) ? width_ : std::min<int64_t>(width_, 2LL * w_ + 3 * pn_ + 32), n_sets, &pl);
-        const bool fast_global = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && !unbanded && pl.fr_cols > 0
+        // (extension mode, round 5: the same banded rows plus the running best cell / z-drop of reference :1018-1026 -- rows_fast.h commit_row)
+        const bool fast_global = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || extend) && !unbanded && pl.fr_cols > 0
                 && max_qlen <= pl.q_cap;
         const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols
                 && max_qlen <= pl.q_cap;
@@ -205,7 +206,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         if (force_general) general = true;
     }
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
-    const bool dir = !local && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
+    const bool dir = !local && !extend && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
             sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
                      !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;

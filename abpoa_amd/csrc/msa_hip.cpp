@@ -87,8 +87,10 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
     PassOut R;
     memset(&R.tot, 0, sizeof(R.tot));
     std::vector<int> todo = idx, left;
-    const double factors[3] = {3.0, 4.5, 6.0};
-    constexpr int NPASS = 3;
+    // (the last pass bounds nothing: a set's graph cannot have more nodes than its reads have bases, and run_msa_device takes the smaller of the two -- so
+    //  node slots are never what sends a set to the host driver; round-4 fuzzing: 22 of 813 sets, all for that reason -- protein sets at 15 % error)
+    const double factors[4] = {3.0, 4.5, 6.0, 4096.0};
+    constexpr int NPASS = 4;
     const bool verbose = getenv("ABPOA_HIP_VERBOSE") != nullptr;
     const int key = job_shape_key(sets, idx);
     int first_pass = 0;

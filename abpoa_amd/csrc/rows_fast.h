@@ -117,9 +117,9 @@ __device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pr
 #else
 #define ABL(BIT) false
 #endif
-template <typename T, int GAP, int NW = 1, bool WIDEB = false, bool DIR = false>
+template <typename T, int GAP, int NW = 1, bool WIDEB = false, bool DIR = false, bool XL = false>
 __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, const FastIO<T> &io, const uint8_t *s_query,
-                                          long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done, long long *fseg) {
+                                          long long &cursor_out, long long &n_cells_out, int &status, int &rows_done_out, int &last_done, long long *fseg, int *best_out = nullptr) {
 #ifdef ABPOA_HIP_PROFILE
     long long fseg_last = 0;
 #endif
@@ -156,7 +156,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     const int inf = d.inf_min;
     const int e1 = b.e1, o1 = b.o1, oe1 = b.o1 + b.e1, e2 = b.e2, o2 = b.o2, oe2 = b.o2 + b.e2;
     // (the single-wave wide kernel's ring width is a compile-time constant: address offsets and clamps fold into the instructions)
-    const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WIDEB ? WIDE_RING_COLS : (WPLAN ? b.lds.wfr_cols : b.lds.fr_cols), RCS = RC + 4;
+    const int RR = WPLAN ? b.lds.wfr_rows : b.lds.fr_rows, RC = WIDEB ? (XL ? WIDE_RING_COLS_XL : WIDE_RING_COLS) : (WPLAN ? b.lds.wfr_cols : b.lds.fr_cols), RCS = RC + 4;
     // (the wide kernels have their own carve-up of the LDS: the query packed two codes to a byte -- LdsPlan.w_*)
     const int ph_off = WPLAN ? b.lds.w_phase_off : b.lds.phase_off;
     int *fr = (int *)(lds_raw + ph_off + b.lds.fr_off);
@@ -199,7 +199,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         else { q[0] = H; q[RCS] = E1; if (GAP == 2) q[2 * RCS] = E2; }
     };
 
-    const bool asm_tight_on = sgpr(!(b.dbg & 2048) && RC == 128 ? 1 : 0) != 0;      // (rows_tight_asm.h; read once: the argument record lives in constant memory)
+    // extension mode (reference :1018-1026, set_extend_max_score): the rows are the global rows; after every row the running best cell (strictly greater: the
+    // first row that reaches the maximum, in the reference's own row order) and, with z-drop, the test that ends the row loop
+    const bool extend = sgpr(b.align_mode == ABPOA_HIP_EXTEND_MODE ? 1 : 0) != 0;
+    int ex_best = inf, ex_i = 0, ex_j = 0, ex_rem = 0; bool zstop = false;
+    const bool asm_tight_on = sgpr(!(b.dbg & 2048) && RC == 128 && b.align_mode != ABPOA_HIP_EXTEND_MODE ? 1 : 0) != 0;      // (rows_tight_asm.h; read once: the argument record lives in constant memory)
     int cur = 0, n_vec_lane = 0;                    // arena cursor in units of PN cells (one reference SIMD vector); cell count: per-lane sums of the flushed rows' vectors
     const int cap_pn = (int)(d.plane_cap / PN > 0x7fffffffLL ? 0x7fffffffLL : d.plane_cap / PN);
     const int cap_turbo = cap_pn - (DIR ? dir_units(NV) + NV * CWR : NV * CW);       // arena room test of the straight-line rows (at most NV vectors)
@@ -661,7 +665,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         // ---- arg-max (keys reduced above)
         if (I16) {
             const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)akey, 63);
-            mi = ((int)(kb >> 16) - 32768 > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
+            rowmax = (int)(kb >> 16) - 32768;
+            mi = (rowmax > inf) ? beg_sn * PN + (int)(kb & 63) : -1;      // the winning lane IS the column offset
         } else {
             const int vmax = __builtin_amdgcn_readlane(aval, 63);
             rowmax = vmax;
@@ -687,10 +692,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     //      contiguous share of the row's chunks (c0 .. c0 + cnt - 1); ONE exchange through LDS per row carries each wavefront's carry-chain result
     //      (seed out of its last chunk, computed as if nothing came in: the chain is max-plus, the incoming seed is folded in afterwards), its
     //      arg-max key and its wrap flag; a second barrier at the end of the row publishes the ring slot.
-    constexpr int NCHX = 7;
+    constexpr int NCHX = XL ? 11 : 7;      // (XL: the long-read form of the wide kernel, 704-column ring, one wavefront per SIMD's worth of registers)
     constexpr bool TEAM = NW > 1;
     int two_chunk_streak = 0;                                       // (narrow kernel) the last row took the two-chunk body with a band of 65-128 columns: the next one tries it first
-    int qcx_beg_sn = -1, qcx_c0 = -1, qoffx[NCHX] = {0, 0, 0, 0, 0, 0, 0};            // cached query codes of this lane's column in every chunk of this wavefront, for band start qcx_beg_sn
+    int qcx_beg_sn = -1, qcx_c0 = -1, qoffx[NCHX] = {};            // cached query codes of this lane's column in every chunk of this wavefront, for band start qcx_beg_sn
     int ilp_far = 0;                                                // bit k: predecessor k of the row is not in the score ring (older than its depth, or a row too wide for it): HBM gather
     auto ilp_band = [&](int row, int ti) __attribute__((always_inline)) -> int {
         int mn_mi, mx_mi, min_pb;
@@ -1127,7 +1132,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #ifdef ABPOA_HIP_PROFILE
     fseg_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    for (int t0 = 0; t0 < gn - 1 && status == 0; t0 += 64) {
+    for (int t0 = 0; t0 < gn - 1 && status == 0 && !zstop; t0 += 64) {
 #ifdef ABPOA_HIP_ROW_CENSUS
         const long long cen_ts = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -1143,6 +1148,11 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const int r_hi = imin(t0 + 64, gn - 1);
         auto commit_row = [&](int ti, bool ring) __attribute__((always_inline)) {   // v_writelane x3 (no clang builtin); M0 = lane select (two different SGPRs would break the constant-bus limit)
             const int geo_new = sgpr(beg_sn | (end_sn << 12) | (ring ? GEO_RING : 0)), off_new = sgpr(off_pn); mi = sgpr(mi);
+            if (__builtin_expect(extend, 0)) {
+                const int mx = sgpr(rowmax > inf ? rowmax : inf), rem_row = qlen - rterm + remain_end + 1;      // (a row without a finite cell: max = inf, max_i = -1)
+                if (mx > ex_best) { ex_best = mx; ex_i = t0 + ti; ex_j = mi; ex_rem = rem_row; }      // (t0 + ti = the row)
+                else if (b.zdrop > 0) { int dd = (ex_rem - rem_row) - (mi - ex_j); if (dd < 0) dd = -dd; if (ex_best - mx > b.zdrop + e1 * dd) zstop = true; }
+            }
             if constexpr (WPLAN || !I16) {            // (vg_vm: the all-chunks body centres its int32 arg-max keys on the first predecessor's row maximum)
                 const int vm_new = sgpr(rowmax);
                 asm volatile("s_mov_b32 m0, %8\n\ts_nop 3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
@@ -1152,7 +1162,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                          : "+v"(vg_geo), "+v"(vg_mi), "+v"(vg_off) : "s"(geo_new), "s"(mi), "s"(off_new), "s"(ti) : "m0");
         };
         int row = imax(t0, 1);
-        while (row < r_hi) {
+        while (row < r_hi && !zstop) {
             if constexpr (NW > 1) {
                 // ---- NW wavefronts per alignment: the wide body, else wavefront 0 alone with the single-wave bodies below
                 const int ti = row & 63;
@@ -1260,10 +1270,10 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 if (__builtin_expect(ok_ != 1, 0)) break;
                 commit_row(ti_, true);
                 CENSUS(np == 1 ? 0 : 1)
-                if (++row >= r_hi) break;
+                if (++row >= r_hi || zstop) break;
             }
             last_done = row - 1;
-            if (row >= r_hi) break;
+            if (row >= r_hi || zstop) break;
             const int ti = row & 63;
             last_done = row;
             CENSUS_T0()
@@ -1293,8 +1303,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int nch_ = ilp_band(row, ti);
                 if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
                 if (nch_ >= 2) {
-                    const int ok2 = nch_ <= 3 ? ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti) : (nch_ <= 5 ? ilp_chunks(std::integral_constant<int, 5>{}, nch_, row,
-                            ti) : ilp_chunks(std::integral_constant<int, 7>{}, nch_, row, ti));
+                    int ok2;
+                    if (nch_ <= 3) ok2 = ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti);
+                    else if (nch_ <= 5) ok2 = ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti);
+                    else if (nch_ <= 7) ok2 = ilp_chunks(std::integral_constant<int, 7>{}, nch_, row, ti);
+                    else if constexpr (XL) ok2 = nch_ <= 9 ? ilp_chunks(std::integral_constant<int, 9>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 11>{}, nch_, row, ti);
+                    else ok2 = 0;
                     if (ok2 == 1) { WCOUNT(0); commit_row(ti, true); FSTAMP(5) ++row; continue; }
                     WCOUNT(5);
                 }
@@ -1348,22 +1362,26 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     WG_SYNC();
     // ---- max_pos_left/right as the reference leaves them (only when the caller reads them back)
     if (status == 0 && b.want_lr && wid == 0) {
+        const int push_lim = zstop ? last_done : gn;
         for (int r = lane; r < gn; r += 64) {
             int lf = gn, rt = 0;
             if (r == 0) { lf = 0; rt = 0; }
             else for (int k = io.pred_off[r]; k < io.pred_off[r + 1]; ++k) {
-                const int p = io.pred_row[k]; const int oi = (p == 0 ? 0 : io.row_max_i[p]) + 1;
+                const int p = io.pred_row[k];
+                if (p >= push_lim) continue;      // (extension mode, z-drop: the row that ended the loop and the rows behind it pushed nothing, reference :1021-1024)
+                const int oi = (p == 0 ? 0 : io.row_max_i[p]) + 1;
                 lf = imin(lf, oi); rt = imax(rt, oi);
             }
             io.g_left[r] = lf; io.g_right[r] = rt;
         }
     }
+    if (best_out) { best_out[0] = ex_best; best_out[1] = ex_i; best_out[2] = ex_j; }
     cursor_out = (long long)cur * PN; n_cells_out = (long long)__builtin_amdgcn_readlane(wave_scan_add_i32(n_vec_lane), 63) * PN; rows_done_out = last_done;
 }
 
 // The fast path is two kernels -- row loop, then global best + backtrack -- so that the row loop's register allocation
 // (its SGPR budget above all) is not shared with the tail; the hand-over is the AlnOut record in HBM.
-template <typename T, int GAP, int NW = 1, bool WIDEB = false, bool DIR = false>
+template <typename T, int GAP, int NW = 1, bool WIDEB = false, bool DIR = false, bool XL = false>
 __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc &d, AlnOut *out_rec) {
     const int lane = threadIdx.x & 63;
     FastIO<T> io;
@@ -1382,13 +1400,15 @@ __device__ __forceinline__ void align_fast_rows(const DevBatch &b, const AlnDesc
     long long cursor = 0, n_cells = 0; int status = 0, rows_done = 0, last_done = 0;
     const long long clk0 = (long long)__builtin_amdgcn_s_memtime();
     long long fseg[6] = {0, 0, 0, 0, 0, 0};
-    rows_fast<T, GAP, NW, WIDEB, DIR>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg);
+    int best3[3] = {d.inf_min, 0, 0};
+    rows_fast<T, GAP, NW, WIDEB, DIR, XL>(b, d, io, s_query, cursor, n_cells, status, rows_done, last_done, fseg, best3);
     const long long clk1 = (long long)__builtin_amdgcn_s_memtime();
 #if !defined(ABPOA_HIP_WIDE_COUNTERS) && !defined(ABPOA_HIP_ROW_CENSUS)
     fseg[5] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);      // HW_ID | XCC_ID << 32: where the wave ran (ABPOA_HIP_IMBAL placement report)
 #endif
     if (NW > 1 ? threadIdx.x == 0 : lane == 0) { GLOBAL_AS AlnOut *o = vgpr_ptr(out_rec); o->status = status; o->n_cells = n_cells; o->cells_used = cursor; o->clk_dp = clk1 - clk0;
-            o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_]; }
+            o->n_rows_done = rows_done; for (int i_ = 0; i_ < 6; ++i_) o->seg[i_] = fseg[i_];
+            if (b.align_mode == ABPOA_HIP_EXTEND_MODE) { o->best_score = best3[0]; o->best_row = best3[1]; o->best_col = best3[2]; } }
 }
 
 

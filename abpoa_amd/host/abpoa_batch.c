@@ -6,7 +6,7 @@
  * (abpoa_output_fx_consensus, src/abpoa_output.c:495-512; abpoa_output_rc_msa, :70-101).  The one difference is the
  * reason it exists: with -l the reference runs the files of the list one after the other through one abpoa_t
  * (src/abpoa.c:131-141); here every file of the list is one read-set and a PIECE of the list (--piece, default 2048 files) goes to the GPU in
- * one call.  Like the reference's loop the list is STREAMED: reader threads (--readers, default 4) parse and encode the files of piece k + 1
+ * one call.  Like the reference's loop the list is STREAMED: reader threads (--readers, default 8) parse and encode the files of piece k + 1
  * while abpoa_hip_msa_batch runs piece k, so memory is two pieces whatever the length of the list (BASELINE.json configs[3]: 100 k files of
  * 50 x 10 kb reads = 50 GB of bases), and the output comes in list order.
  *
@@ -15,7 +15,7 @@
  *     -O INT[,INT] gap open [4,24]   -E INT[,INT] gap extension [2,1]   -b INT [10] / -f FLOAT [0.01] adaptive band (b < 0: off)
  *     -c amino acids   -l the input is a list of files   -o FILE output [stdout]   -r INT 0 consensus, 1 MSA, 2 both
  *     -s ambiguous strand   -Q base qualities as edge weights   -T INT host threads [all]   -v version
- *     --piece INT files per GPU call with -l [2048]   --readers INT reader threads [4]      (no reference counterpart)
+ *     --piece INT files per GPU call with -l [2048]   --readers INT reader threads [8]      (no reference counterpart)
  * Degenerate inputs as the reference treats them: a file without records prints nothing; a record without bases after the first one is an MSA row
  * of gaps and adds nothing to the graph; a first record without bases ends the run as abpoa_add_graph_sequence does (src/abpoa_graph.c:487).
  * Options of the reference that the engine does not cover (-S -k -w -n -p -i -g -d -q -z -e, -r 3/4/5) are refused, not ignored.
@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <zlib.h>
 #include "abpoa_hip.h"
 
@@ -81,6 +82,7 @@ static void rs_add(readset_t *r, const char *name, const str_t *seq, const str_t
 static void read_file(const char *fn, readset_t *r, const uint8_t *tbl, int use_qv) {
     gzFile fp = gzopen(fn, "r");
     if (!fp) DIE("cannot open %s", fn);
+    gzbuffer(fp, 1 << 20);
     enum { LINE_CAP = 1 << 16 };
     char *line = (char *)malloc(LINE_CAP);      /* (own buffer: files are read by several threads) */
     if (!line) DIE("out of memory");
@@ -101,7 +103,15 @@ static void read_file(const char *fn, readset_t *r, const uint8_t *tbl, int use_
             seq.n = 0; seq.s[0] = 0; qual.n = 0; qual.s[0] = 0; have = 1; in_qual = 0;
         } else if (have && !cont && !in_qual && line[0] == '+') in_qual = 1;
         else if (have && in_qual) { str_push(&qual, line, k); if (qual.n >= seq.n) in_qual = 0; }
-        else if (have) { for (size_t j = 0; j < k; ++j) if (line[j] != ' ' && line[j] != '\t') str_push(&seq, line + j, 1); }
+        else if (have) {      /* sequence text: whole runs between blanks (a 10 kb read is one line: one copy) */
+            size_t j = 0;
+            while (j < k) {
+                while (j < k && (line[j] == ' ' || line[j] == '\t')) ++j;
+                size_t e = j; while (e < k && line[e] != ' ' && line[e] != '\t') ++e;
+                if (e > j) str_push(&seq, line + j, e - j);
+                j = e;
+            }
+        }
         cont = !whole;
     }
     gzclose(fp); free(seq.s); free(qual.s); free(name.s); free(line);
@@ -152,6 +162,15 @@ static void rs_free(readset_t *r) {
     free(r->name); free(r->code); free(r->len); free(r->weight); memset(r, 0, sizeof *r);
 }
 
+/* one output line of `n` residue codes (a 10 kb consensus per file, thousands of files per piece: one fwrite each, not a putchar per base) */
+static void put_codes(const uint8_t *row, int n, const char *letter) {
+    static char *buf = NULL; static int cap = 0;
+    if (n + 1 > cap) { cap = 2 * (n + 1) + 1024; buf = (char *)realloc(buf, (size_t)cap); if (!buf) DIE("out of memory"); }
+    for (int j = 0; j < n; ++j) buf[j] = letter[row[j]];
+    buf[n] = '\n';
+    fwrite(buf, 1, (size_t)n + 1, stdout);
+}
+
 /* ---- a piece of the list: files [lo, hi) parsed and encoded by `readers` threads (one file at a time each, off a shared counter) */
 typedef struct { char **files; int n; readset_t *rs; const uint8_t *tbl; int use_qv, readers; pthread_mutex_t mu; int next; pthread_t th; int started; } piece_t;
 static void *piece_worker(void *arg) {
@@ -192,9 +211,13 @@ static void piece_free(piece_t *p) {
     free(p->rs); free(p->files); pthread_mutex_destroy(&p->mu); free(p);
 }
 
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
 int main(int argc, char **argv) {
+    const int timing = getenv("ABPOA_BATCH_TIMING") != NULL;      /* per piece on stderr: wait for the readers, the batch call, output */
+    const double t_start = now_s();
     int mode = 0, match = 2, mismatch = 4, o1 = 4, o2 = 24, e1 = 2, e2 = 1, wb = 10, m = 5, in_list = 0, out_cons = 1, out_msa = 0, amb = 0, use_qv = 0, threads = 0, c;
-    int piece_sets = 2048, readers = 4;
+    int piece_sets = 2048, readers = 8;
     float wf = 0.01f; const char *mat_fn = NULL; char *s;
     while ((c = getopt_long(argc, argv, "m:M:X:t:O:E:b:f:z:e:QSk:w:n:i:clpso:r:g:d:q:T:hvV:", long_opt, NULL)) >= 0) {
         switch (c) {
@@ -247,9 +270,14 @@ int main(int argc, char **argv) {
     int sticky_n = 0; char **sticky = NULL;
 
     piece_t *next = piece_start(lf, argv[optind], &single_done, in_list ? piece_sets : 1, tbl, use_qv, readers);
+    if (next && in_list) {      /* the GPU comes up while the first piece is being read (a single input keeps the lazy start: an empty file needs no GPU) */
+        const int rc0 = abpoa_hip_init(0); if (rc0 != ABPOA_HIP_OK) DIE("no usable GPU (%d): %s", rc0, abpoa_hip_last_error()); gpu_up = 1;
+    }
     while (next) {
         piece_t *cur = next;
+        const double t0 = now_s();
         piece_wait(cur);
+        const double t1 = now_s();
         next = piece_start(lf, argv[optind], &single_done, piece_sets, tbl, use_qv, readers);      /* ... is read while the GPU works on `cur` */
 
         /* ---- the sets of the call: files with records; within a set the records that have bases (kept[]: index in the file) */
@@ -274,6 +302,7 @@ int main(int argc, char **argv) {
             const int rc = abpoa_hip_msa_batch(&sc, n_call, sets, out, flags, threads);
             if (rc != ABPOA_HIP_OK) DIE("abpoa_hip_msa_batch failed (%d): %s", rc, abpoa_hip_last_error());
         }
+        const double t2 = now_s();
 
         /* ---- output, file by file as the reference prints it (src/abpoa_align.c:346-371: MSA when asked for -- with the consensus row if both --, else consensus) */
         const int n_print = fatal_at >= 0 ? fatal_at : cur->n;
@@ -293,22 +322,20 @@ int main(int argc, char **argv) {
                 for (int q = 0; q < r->n; ++q) {
                     const int has = k < n_kept[i] && kept[i][k] == q;
                     if (r->name[q][0]) printf(">%s%s\n", r->name[q], (has && o->is_rc && o->is_rc[k]) ? "_reverse_complement" : ""); else printf(">Seq_%d\n", q + 1);
-                    if (has) { const uint8_t *row = o->msa_base + (size_t)k * o->msa_len; for (int j = 0; j < o->msa_len; ++j) putchar(letter[row[j]]); ++k; }
-                    else for (int j = 0; j < o->msa_len; ++j) putchar(gap_letter);      /* a record without bases: a row of gaps */
-                    putchar('\n');
+                    if (has) { put_codes(o->msa_base + (size_t)k * o->msa_len, o->msa_len, letter); ++k; }
+                    else { for (int j = 0; j < o->msa_len; ++j) putchar(gap_letter); putchar('\n'); }      /* a record without bases: a row of gaps */
                 }
                 if (out_cons) {
                     printf(">Consensus_sequence\n");
-                    const uint8_t *row = o->msa_base + (size_t)n_kept[i] * o->msa_len;
-                    for (int j = 0; j < o->msa_len; ++j) putchar(letter[row[j]]);
-                    putchar('\n');
+                    put_codes(o->msa_base + (size_t)n_kept[i] * o->msa_len, o->msa_len, letter);
                 }
             } else if (out_cons && o->cons_len > 0) {                    /* (abpoa_output_fx_consensus prints nothing without a consensus) */
                 printf(">Consensus_sequence\n");
-                for (int j = 0; j < o->cons_len; ++j) putchar(letter[o->cons_base[j]]);
-                putchar('\n');
+                put_codes(o->cons_base, o->cons_len, letter);
             }
         }
+        if (timing) fprintf(stderr, "[abpoa_batch] piece of %d files at %.2f s: waited %.2f s for the readers, batch call %.2f s, output %.2f s\n", cur->n, t0 - t_start, t1 - t0, t2 - t1,
+                            now_s() - t2);
         abpoa_hip_free_msa_array(out, n_call);
         for (int i = 0; i < cur->n; ++i) { free(kept[i]); free((void *)seqv[i]); free((void *)wgtv[i]); free(lenv[i]); }
         free(kept); free(n_kept); free((void *)seqv); free((void *)wgtv); free(lenv); free(set_of); free(sets); free(out);

@@ -390,7 +390,7 @@ def test_extension_mode_goldens_on_ragged_reads(engine, monkeypatch, host):
 
 
 def test_seeded_fuzz_sweep_of_the_device_driver(engine):
-    """200 iterations of tools/fuzz_device_vs_oracle.py (read-set shapes x gap model x alignment mode x band x -s x weights x output kind; reads up to 700
+    """200 iterations of tools/fuzz_device_vs_oracle.py (read-set shapes x gap model x alignment mode x band x -s x weights x output kind; reads up to 600
     bases so that the oracle-backed leg stays short) inside the suite: every output of the device-resident driver equals the oracle-backed run's, and the
     sweep reports how many sets left the device and why (abpoa_hip_get_host_reasons) -- a set may leave only for a capacity of the device layout."""
     import importlib.util

@@ -20,7 +20,7 @@ def make_sets(rng, seed, aa, small=False):
         u = rng.random()
         n = int(rng.integers(2, 60)); ln = int(rng.integers(30, 1400)) if u < 0.8 else (int(rng.integers(1400, 4000)) if u < 0.94 else int(rng.integers(5000, 12000)))
         if small:      # (the sweep inside the GPU test suite: the oracle-backed leg must stay at a fraction of a second per iteration)
-            n = min(n, 24); ln = min(ln, 700)
+            n = min(n, 20); ln = min(ln, 600)
         if ln > 1400:
             n = min(n, 14 if ln < 5000 else 6)
         err = float(rng.uniform(0.01, 0.15))
@@ -93,7 +93,7 @@ def iteration(seed, shim, small=False):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=100); ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--small", action="store_true", help="the shapes of the in-suite sweep (reads up to 700 bases, 24 per set)")
+    ap.add_argument("--small", action="store_true", help="the shapes of the in-suite sweep (reads up to 600 bases, 20 per set)")
     a = ap.parse_args()
     lib = ffi.lib(); ffi.check(lib.abpoa_hip_init(0))
     shim = H.cpu_shim_lib()

@@ -47,8 +47,9 @@ def main():
     opts = workloads.ref_options("cfg4")
     cmd = [exe] + opts + ["-l", lst, "--piece", str(a.piece), "--readers", str(a.readers)] + (["-T", str(a.threads)] if a.threads else [])
     t0 = time.time()
-    p = subprocess.run(cmd, capture_output=True, text=True)
+    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, ABPOA_BATCH_TIMING="1"))
     wall = time.time() - t0
+    sys.stderr.write(p.stderr[-4000:])
     if p.returncode != 0:
         raise SystemExit(f"abpoa_batch failed ({p.returncode}): {p.stderr[-2000:]}")
     rss_gb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6
