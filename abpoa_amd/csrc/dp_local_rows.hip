@@ -2,6 +2,7 @@
 // alignment, every chunk of a row in registers; the chunk count is fixed per alignment (rows span the whole query), so the kernel picks one of
 // three straight-line variants (3 / 5 / 9 chunks of 64 columns) once, outside the row loop.
 #include <stdlib.h>
+#include "engine_options.h"
 #include "rows_local.h"
 
 namespace abpoa_hip {
@@ -68,7 +69,7 @@ hipError_t launch_local_rows(const DevBatch &b, hipStream_t stream) {
     // teams while the launch has fewer alignments than the GPU has room for workgroups of four wavefronts at two per SIMD (8 wavefronts per CU x 256 CUs /
     // 4 = 2048 alignments would fill it; beyond ~1500 the single-wavefront kernel's SIMDs are busy anyway); ABPOA_HIP_LOCAL_TEAM=0 / 1 forces a form
     bool team = b.n <= 1536;
-    { const char *e_ = getenv("ABPOA_HIP_LOCAL_TEAM"); if (e_) team = atoi(e_) != 0; }
+    { const char *e_ = opt_env("ABPOA_HIP_LOCAL_TEAM"); if (e_) team = atoi(e_) != 0; }
     if (team) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_team(dp_local_team_kernel<1>, b, stream) : launch_team(dp_local_team_kernel<2>, b, stream);
     return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_one(dp_local_kernel<1>, b, stream, b.lds.total_local) : launch_one(dp_local_kernel<2>, b, stream, b.lds.total_local);
 }

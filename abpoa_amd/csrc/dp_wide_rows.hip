@@ -3,6 +3,7 @@
 // chunks of every row (small batches: fewer alignments than SIMDs).  Rows the all-chunk body cannot take are done with the single-chunk bodies.
 #include <stdio.h>
 #include <stdlib.h>
+#include "engine_options.h"
 #include "rows_fast.h"
 
 namespace abpoa_hip {
@@ -24,7 +25,7 @@ static hipError_t launch_wide_gap(const DevBatch &b, hipStream_t stream) {
     const int mask = b.bits_mask ? b.bits_mask : 3;
     hipError_t e = hipSuccess;
     static bool told = false;
-    if (!told && getenv("ABPOA_HIP_VERBOSE")) {      // residency of the wide kernels on one CU
+    if (!told && opt_env("ABPOA_HIP_VERBOSE")) {      // residency of the wide kernels on one CU
         told = true; int nb16 = 0, nb32 = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, dp_wide_kernel<GAP, 16, NW>, NW * 64, (size_t)b.lds.total_wide);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, dp_wide_kernel<GAP, 32, NW>, NW * 64, (size_t)b.lds.total_wide);

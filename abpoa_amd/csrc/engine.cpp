@@ -14,6 +14,7 @@
 #include <mutex>
 #include <vector>
 #include <algorithm>
+#include "engine_options.h"
 #include "batch_stream.h"
 #include "dir_plane.h"
 
@@ -111,7 +112,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
     if (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget) L.fr_cols = 0;
     if (L.q_cap == 0 || est_cols > 1024) L.fr_cols = 0;
-    { const char *nf_ = getenv("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
+    { const char *nf_ = opt_env("ABPOA_HIP_NOFAST"); if (nf_ && atoi(nf_)) L.fr_cols = 0; }
     const int fr_bytes = L.fr_cols ? L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 : 0;
     L.total = L.phase_off + std::max(std::max(L.ring_off + ring_bytes, L.bt_off + L.bt_bytes), L.fr_off + fr_bytes);
     // the fast path's tail kernel: its own window size -- 28 KB, less when a long query already takes much of the 38 (62) KB that let four (two) of
@@ -124,12 +125,12 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // more alignments than a GPU holds tail workgroups at the 24 KB window (4 per CU): a 12 KB window doubles the residency, and the tail kernel of such
     // a launch runs in as many turns as it has workgroups per resident set (8000 x 1 kb alignments: tail 153 -> 127 ms per step)
     if (n_aln > 4 * 256 && L.fr_cols && L.fr_cols <= 128) L.bt_bytes_tail = std::min(L.bt_bytes_tail, 12 * 1024);
-    { const char *tb_ = getenv("ABPOA_HIP_BT_BYTES"); if (tb_ && atoi(tb_) >= 4096 && atoi(tb_) <= 65536) L.bt_bytes_tail = atoi(tb_) & ~15; }
+    { const char *tb_ = opt_env("ABPOA_HIP_BT_BYTES"); if (tb_ && atoi(tb_) >= 4096 && atoi(tb_) <= 65536) L.bt_bytes_tail = atoi(tb_) & ~15; }
     L.total_rows = L.phase_off + L.fr_off + fr_bytes; L.total_tail = L.phase_off + L.bt_off + L.bt_bytes_tail;
-    L.bt_wc = 0; { const char *wc_ = getenv("ABPOA_HIP_BT_WC"); if (wc_ && atoi(wc_) >= 8 && atoi(wc_) <= 64) L.bt_wc = atoi(wc_) & ~7; }
+    L.bt_wc = 0; { const char *wc_ = opt_env("ABPOA_HIP_BT_WC"); if (wc_ && atoi(wc_) >= 8 && atoi(wc_) <= 64) L.bt_wc = atoi(wc_) & ~7; }
     // local row loop (rows_local.h): unbanded local alignments of at most 9 x 64 columns, int16; ring depth by what 60 KB hold
     L.loc_rows = L.loc_cols = L.total_local = 0;
-    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && P != 1 && L.q_cap && !(getenv("ABPOA_HIP_NOFAST") && atoi(getenv("ABPOA_HIP_NOFAST")))) {
+    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && P != 1 && L.q_cap && !(opt_env("ABPOA_HIP_NOFAST") && atoi(opt_env("ABPOA_HIP_NOFAST")))) {
         const int lw = P == 3 ? 1 : 2;                 // ring words per column (int16: H | E1 packed, E2)
         L.loc_cols = 9 * 64; L.loc_rows = 16;
         while ((int64_t)L.loc_rows * lw * (L.loc_cols + 4) * 4 > 60 * 1024 - L.phase_off && L.loc_rows > 4) L.loc_rows /= 2;
@@ -140,7 +141,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     // predecessors up to 15 rows back are common in a graph of noisy reads).  ABPOA_HIP_NOWIDE=1 turns it off, ABPOA_HIP_RING_ROWS sets
     // the depth, ABPOA_HIP_TEAM=1|2|4 sets the wavefronts per alignment.
     L.wide_nw = 0; L.wfr_rows = L.wfr_cols = L.wx_off = L.total_wide = 0; L.wide_w_lo = 1; L.wide_w_hi = 0; L.narrow_off = 0; L.w_mx_off = L.w_phase_off = 0;
-    { const char *nw_ = getenv("ABPOA_HIP_NOWIDE"), *mw_ = getenv("ABPOA_HIP_TEAM");
+    { const char *nw_ = opt_env("ABPOA_HIP_NOWIDE"), *mw_ = opt_env("ABPOA_HIP_TEAM");
       if (L.fr_cols && L.q_cap && !(nw_ && atoi(nw_))) {
           // wavefronts per alignment: 1.  Teams of 2 / 4 (ABPOA_HIP_TEAM=2|4, dp_team_rows.hip) give identical results but are slower on gfx950
           // as measured (3.9 k vs 3.1 k cycles per 5-chunk row): a row's ~370 instructions of scalar bookkeeping are repeated by every wavefront
@@ -148,7 +149,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           L.wide_nw = 1;
           if (mw_ && (atoi(mw_) == 1 || atoi(mw_) == 2 || atoi(mw_) == 4)) L.wide_nw = atoi(mw_);
           // (rows wider than the 448-column ring -- reads of 20 kb and more: w = 10 + 0.01 L -- take the kernel's long-read form: 704 columns, 8 - 11 chunks a row)
-          L.wfr_cols = (est_cols > WIDE_RING_COLS && !(getenv("ABPOA_HIP_NOXL") && atoi(getenv("ABPOA_HIP_NOXL")))) ? WIDE_RING_COLS_XL : WIDE_RING_COLS; L.wfr_rows = 16;
+          L.wfr_cols = (est_cols > WIDE_RING_COLS && !(opt_env("ABPOA_HIP_NOXL") && atoi(opt_env("ABPOA_HIP_NOXL")))) ? WIDE_RING_COLS_XL : WIDE_RING_COLS; L.wfr_rows = 16;
           if (sc->m > 16) L.wide_nw = 0;      // (4-bit query codes)
           L.w_mx_off = (int)align_up((size_t)(max_qlen + 2) / 2, 16); L.w_phase_off = L.w_mx_off + (int)align_up(4 * sc->m * (sc->m + 1), 16);
           // ring words per column of the wide kernels: as the narrow loop's, but two instead of three for convex int32 (rows_fast.h EPACK: E as 16-bit
@@ -156,8 +157,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           const int fww = (P == 5 && max_bits == 32) ? 2 : fw;
           if (P == 5 && (sc->gap_open1 + sc->gap_ext1 >= 65535 || sc->gap_open2 + sc->gap_ext2 >= 65535)) L.wide_nw = 0;      // (0xffff: "E is inf" in the compact spill records)
           L.wide_w_lo = 40; L.wide_w_hi = (L.wfr_cols - 2 * 8 - 1) / 2;
-          { const char *lo_ = getenv("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
-          const char *rr_env_ = getenv("ABPOA_HIP_RING_ROWS");
+          { const char *lo_ = opt_env("ABPOA_HIP_WIDE_LO"); if (lo_ && atoi(lo_) > 0) L.wide_w_lo = atoi(lo_); }
+          const char *rr_env_ = opt_env("ABPOA_HIP_RING_ROWS");
           if (rr_env_ && atoi(rr_env_) >= 4) L.wfr_rows = atoi(rr_env_) >= 16 ? 16 : (atoi(rr_env_) >= 8 ? 8 : 4); else rr_env_ = nullptr;
           // (up to 120 KB per wavefront: a convex int32 ring of 16 rows is 58 KB; above 64 KB the launch raises the kernel's dynamic-LDS limit)
           const int budget = 120 * 1024 - L.w_phase_off - 512;
@@ -207,7 +208,7 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
         full_cells_[i] = width * pv * d.n_rows;
         int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
         // (tests: force the overflow -> full-width retry path)
-        { const char *pct_ = getenv("ABPOA_HIP_ARENA_PCT"); if (pct_ && atoi(pct_) > 0 && atoi(pct_) < 100) est = std::max<int64_t>(pn, est * atoi(pct_) / 100); }
+        { const char *pct_ = opt_env("ABPOA_HIP_ARENA_PCT"); if (pct_ && atoi(pct_) > 0 && atoi(pct_) < 100) est = std::max<int64_t>(pn, est * atoi(pct_) / 100); }
         d.plane_cap = std::min<int64_t>(full_cells_[i], width * pv + est * pv * (d.n_rows - 1));
         est_cells_[i] = d.plane_cap;
         // direction-plane arenas (dir_plane.h; run() decides whether a pass uses them): words of DB bytes per column for every row, score records for the
@@ -261,9 +262,9 @@ int BatchStream::run() {
     // direction-plane arenas for the fast row loops (dir_plane.h) unless the caller wants the score planes back (trace), the penalties do not fit the
     // words, or ABPOA_HIP_NODIR=1; an alignment whose backtrack meets the one case the words cannot decide is redone with score records
     // (tests: ABPOA_HIP_DIRTRACE=1 keeps the direction plane in trace mode; the trace then carries the WORDS of every cell in plane 0)
-    const bool dirtrace = trace && getenv("ABPOA_HIP_DIRTRACE") && atoi(getenv("ABPOA_HIP_DIRTRACE"));
+    const bool dirtrace = trace && opt_env("ABPOA_HIP_DIRTRACE") && atoi(opt_env("ABPOA_HIP_DIRTRACE"));
     bool dir = (!trace || dirtrace) && banded && sc->align_mode == ABPOA_HIP_GLOBAL_MODE && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2, sc->gap_ext2) &&
-               !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) && !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
+               !(opt_env("ABPOA_HIP_NODIR") && atoi(opt_env("ABPOA_HIP_NODIR"))) && !(opt_env("ABPOA_HIP_TEAM") && atoi(opt_env("ABPOA_HIP_TEAM")) > 1);
     // alignment-level eligibility for the register-resident row loop: every row active, band state at its reset value
     for (int i = 0; i < n; ++i) {
         AlnDesc &d = desc_[i]; bool ok = banded || (sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0);      // (unbanded local: the local row loop; band state is not used)
@@ -319,13 +320,13 @@ int BatchStream::run() {
         if (b.lds.wide_nw > 1) dir = false;
         // (ABPOA_HIP_DIR_WIDE=1: words for the wide-band alignments too -- the device-resident driver does that by itself when the record arenas of a
         //  job do not fit the device; here it is a test switch)
-        const bool dir_wide = dir && getenv("ABPOA_HIP_DIR_WIDE") && atoi(getenv("ABPOA_HIP_DIR_WIDE")) > 0;
+        const bool dir_wide = dir && opt_env("ABPOA_HIP_DIR_WIDE") && atoi(opt_env("ABPOA_HIP_DIR_WIDE")) > 0;
         for (size_t t = 0; t < todo.size(); ++t) {
             AlnDesc &d = desc_[todo[t]];
             // direction-plane arenas for the narrow-band alignments of a dir pass; the wide-band ones keep score records (dp_common.h takes_dir / takes_wide)
             // (an alignment the general kernel will run -- seeded band of the -s retry, a row with more predecessors than a word names, no fast row loop in the
             //  plan -- stores its planes: the records' estimate, not the words'; host mirror of dp_common.h takes_fast)
-            const int dbg_ = getenv("ABPOA_HIP_DBG") ? atoi(getenv("ABPOA_HIP_DBG")) : 0;
+            const int dbg_ = opt_env("ABPOA_HIP_DBG") ? atoi(opt_env("ABPOA_HIP_DBG")) : 0;
             const bool fast_a = (d.flags & ALN_FAST_OK) && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) &&
                                 b.lds.fr_cols > 0 &&
                                 d.qlen <= b.lds.q_cap && !(dbg_ & 64);
@@ -341,7 +342,7 @@ int BatchStream::run() {
         b.want_trace = trace ? 1 : 0; b.fresh_band = fresh ? 1 : 0;
         b.dir_mode = dir ? (dir_wide ? 2 : 1) : 0; b.row_sdist = di + o_sdist_; b.row_pd = (const uint32_t *)(di + o_pd_);
         b.want_lr = (trace || (flags_ & BS_WANT_BAND_STATE)) ? 1 : 0;
-        { const char *dbg_ = getenv("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
+        { const char *dbg_ = opt_env("ABPOA_HIP_DBG"); b.dbg = dbg_ ? atoi(dbg_) : 0; }
         b.mat = (const int32_t *)(di + o_mat_); b.aln = (const AlnDesc *)(di + o_desc_); b.out = (AlnOut *)(dout + o_rec_);
         b.query = di + o_query_; b.row_base = di + o_base_; b.row_node_id = (const int32_t *)(di + o_nid_); b.row_remain = (const int32_t *)(di + o_rem_);
         b.row_active = di + o_act_; b.pred_off = (const int32_t *)(di + o_poff_); b.pred_row = (const int32_t *)(di + o_pred_);
@@ -478,6 +479,8 @@ int BatchStream::fetch_trace(int i, const uint8_t *row_active, abpoa_hip_trace_t
 using namespace abpoa_hip;
 
 extern "C" {
+int abpoa_hip_set_option(const char *name, const char *value) { return abpoa_hip::set_option(name, value) == 0 ? ABPOA_HIP_OK : ABPOA_HIP_EINVAL; }
+int abpoa_hip_list_options(const char **names, const char **help, int cap) { return abpoa_hip::list_options(names, help, cap); }
 
 int abpoa_hip_device_count(void) {
     int n = 0;
@@ -486,6 +489,7 @@ int abpoa_hip_device_count(void) {
 }
 
 int abpoa_hip_init(int device) {
+    abpoa_hip::refresh_options();
     std::lock_guard<std::mutex> lk(g.mu);
     if (g.ready && g.device == device) return ABPOA_HIP_OK;
     if (g.ready) { set_err("engine already bound to device %d", g.device); return ABPOA_HIP_EINVAL; }
@@ -570,6 +574,7 @@ static int validate(const abpoa_hip_scoring_t *sc, const abpoa_hip_problem_t *p,
 
 int abpoa_hip_align_batch(const abpoa_hip_scoring_t *sc, int n, const abpoa_hip_problem_t *pb,
                           abpoa_hip_result_t *res, unsigned flags) {
+    abpoa_hip::refresh_options();
     if (n < 0 || !sc || (n > 0 && (!pb || !res))) { set_err("bad arguments"); return ABPOA_HIP_EINVAL; }
     if (n == 0) return ABPOA_HIP_OK;
     for (int i = 0; i < n; ++i) memset(&res[i], 0, sizeof(res[i]));

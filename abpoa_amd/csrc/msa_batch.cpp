@@ -16,6 +16,7 @@
 #include <string.h>
 #include <thread>
 #include <vector>
+#include "engine_options.h"
 #include "msa_batch.h"
 #include "poa_graph.h"
 
@@ -31,7 +32,7 @@ uint64_t digest_round(uint64_t before, int read_index, int n_cigar, uint64_t sum
         << 32) | (uint32_t)n_cigar)); }
 uint64_t fnv64(const void *p, size_t n, uint64_t h = 1469598103934665603ull) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
 }
-bool cigar_digest_on() { static const bool on = getenv("ABPOA_HIP_CIGAR_DIGEST") && atoi(getenv("ABPOA_HIP_CIGAR_DIGEST")); return on; }
+bool cigar_digest_on() { static const bool on = opt_env("ABPOA_HIP_CIGAR_DIGEST") && atoi(opt_env("ABPOA_HIP_CIGAR_DIGEST")); return on; }
 // (the digest function is poa_device.h's: the device driver folds the same per-word mixes in its fuse phase)
 void cigar_digest_add(const uint8_t *seq0, int len0, int read_index, const uint64_t *cigar, int n_cigar) {
     const uint64_t key = fnv64(seq0, (size_t)len0);
@@ -233,7 +234,7 @@ int run_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_rea
     if (n_threads <= 0) n_threads = effective_host_cores();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_sets) n_threads = n_sets;
-    if (n_groups <= 0) { const char *e_ = getenv("ABPOA_HIP_GROUPS"); if (e_) n_groups = atoi(e_); }
+    if (n_groups <= 0) { const char *e_ = opt_env("ABPOA_HIP_GROUPS"); if (e_) n_groups = atoi(e_); }
     if (n_groups <= 0) n_groups = n_sets >= 512 ? 4 : (n_sets >= 128 ? 2 : 1);
     if (n_groups > n_threads) n_groups = n_threads;
     const bool want_msa = flags & ABPOA_HIP_OUT_MSA, want_cons = (flags & ABPOA_HIP_OUT_CONS) || !want_msa;

@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 #include <hip/hip_runtime.h>
+#include "engine_options.h"
 #include "batch_stream.h"
 #include "msa_device.h"
 #include "poa_device.h"
@@ -47,12 +48,12 @@ size_t up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // prints where each allocation landed.  (The HIP device is per host thread; a queue thread that forgot hipSetDevice would put its pools on device 0.)
 thread_local int t_queue_device = -1;
 int audit_allocation(const void *ptr, size_t bytes, const char *what) {
-    static const bool on = getenv("ABPOA_HIP_DEVICE_AUDIT") && atoi(getenv("ABPOA_HIP_DEVICE_AUDIT"));
+    static const bool on = opt_env("ABPOA_HIP_DEVICE_AUDIT") && atoi(opt_env("ABPOA_HIP_DEVICE_AUDIT"));
     if (!on || t_queue_device < 0) return 0;
     int cur = -1; (void)hipGetDevice(&cur);
     hipPointerAttribute_t at; memset(&at, 0, sizeof(at));
     const hipError_t e = hipPointerGetAttributes(&at, ptr);
-    if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] audit: %s, %zu bytes: device %d (queue device %d, thread's current device %d)\n", what,
+    if (opt_env("ABPOA_HIP_VERBOSE")) fprintf(stderr, "[abpoa-hip] audit: %s, %zu bytes: device %d (queue device %d, thread's current device %d)\n", what,
             bytes, e == hipSuccess ? at.device : -1, t_queue_device, cur);
     if (e != hipSuccess || cur != t_queue_device || (at.type == hipMemoryTypeDevice && at.device != t_queue_device)) {
         set_err("device audit: %s of %zu bytes on device %d, queue serves device %d, thread's current device %d", what, bytes,
@@ -114,17 +115,17 @@ void release_msa_device_caches() {
 // What the device-resident driver takes: every gap model and alignment mode (run_msa_device picks the fast row loops or the general kernel per job), any
 // alphabet of up to 27 codes, consensus and / or MSA output, per-base weights, the strand retry.
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
-    const char *e = getenv("ABPOA_HIP_HOSTGRAPH");
+    const char *e = opt_env("ABPOA_HIP_HOSTGRAPH");
     if (e && atoi(e)) return false;
     if (sc->m - 1 > POA_ALN_MAX || sc->m < 2) return false;
     // (-s on the host driver, as before round 4)
-    if ((flags & ABPOA_HIP_AMB_STRAND) && getenv("ABPOA_HIP_NO_DEVICE_STRAND") && atoi(getenv("ABPOA_HIP_NO_DEVICE_STRAND"))) return false;
-    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && getenv("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_LOCAL"))) return false;
+    if ((flags & ABPOA_HIP_AMB_STRAND) && opt_env("ABPOA_HIP_NO_DEVICE_STRAND") && atoi(opt_env("ABPOA_HIP_NO_DEVICE_STRAND"))) return false;
+    if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && opt_env("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(opt_env("ABPOA_HIP_NO_DEVICE_LOCAL"))) return false;
     // every gap model and alignment mode: the fast row loops where they apply (banded global, short local), the general kernel otherwise (linear gaps,
     // extension mode with or without z-drop, global mode without a band, long local reads).  ABPOA_HIP_NO_DEVICE_GENERAL=1 sends those back to the host driver.
     const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && (((sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) && sc->wb >= 0)
             || sc->align_mode == ABPOA_HIP_LOCAL_MODE);
-    if (!fast && getenv("ABPOA_HIP_NO_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_NO_DEVICE_GENERAL"))) return false;
+    if (!fast && opt_env("ABPOA_HIP_NO_DEVICE_GENERAL") && atoi(opt_env("ABPOA_HIP_NO_DEVICE_GENERAL"))) return false;
     return true;
 }
 
@@ -202,13 +203,13 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols
                 && max_qlen <= pl.q_cap;
         general = !(fast_global || fast_local);
-        if (getenv("ABPOA_HIP_DEVICE_GENERAL") && atoi(getenv("ABPOA_HIP_DEVICE_GENERAL"))) general = true;      // (tests: the general kernel for every job)
+        if (opt_env("ABPOA_HIP_DEVICE_GENERAL") && atoi(opt_env("ABPOA_HIP_DEVICE_GENERAL"))) general = true;      // (tests: the general kernel for every job)
         if (force_general) general = true;
     }
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
     const bool dir = !local && !extend && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
-            sc->gap_ext2) && !(getenv("ABPOA_HIP_NODIR") && atoi(getenv("ABPOA_HIP_NODIR"))) &&
-                     !(getenv("ABPOA_HIP_TEAM") && atoi(getenv("ABPOA_HIP_TEAM")) > 1);
+            sc->gap_ext2) && !(opt_env("ABPOA_HIP_NODIR") && atoi(opt_env("ABPOA_HIP_NODIR"))) &&
+                     !(opt_env("ABPOA_HIP_TEAM") && atoi(opt_env("ABPOA_HIP_TEAM")) > 1);
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
 
     std::vector<PoaSet> ps(n_sets);
@@ -233,7 +234,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     // (route: the part of `extra` that counts for the choice of the row loop)
     std::vector<int> extra(n_sets, 0), route(n_sets, 0); int max_extra = 0, weff_lo = INT_MAX, weff_hi = 0;
     // (experiments: sets with less extra keep the narrow loop)
-    const int route_min = getenv("ABPOA_HIP_EXTRA_ROUTE_MIN") ? atoi(getenv("ABPOA_HIP_EXTRA_ROUTE_MIN")) : 0;
+    const int route_min = opt_env("ABPOA_HIP_EXTRA_ROUTE_MIN") ? atoi(opt_env("ABPOA_HIP_EXTRA_ROUTE_MIN")) : 0;
     if (!local && !general && sc->wb >= 0) for (int s = 0; s < n_sets; ++s) {
         int mx = 0, mn = INT_MAX; for (int r = 0; r < sets[s].n_reads; ++r) { mx = std::max(mx, sets[s].lens[r]); mn = std::min(mn, sets[s].lens[r]); }
         if (sets[s].n_reads < 2) continue;
@@ -250,8 +251,8 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the
     // read-sets are in flight instead of two passes with half the SIMDs idle.  ABPOA_HIP_DIR_WIDE=1 / 0: always / never.
     bool dir_wide = false, any_wide_set = false;
-    { const char *e_ = getenv("ABPOA_HIP_DIR_WIDE"); if (dir && e_ && atoi(e_) > 0) dir_wide = true; }
-    const bool dir_wide_auto = dir && !getenv("ABPOA_HIP_DIR_WIDE");
+    { const char *e_ = opt_env("ABPOA_HIP_DIR_WIDE"); if (dir && e_ && atoi(e_) > 0) dir_wide = true; }
+    const bool dir_wide_auto = dir && !opt_env("ABPOA_HIP_DIR_WIDE");
     // ... and whenever the pass is large enough for two wavefronts per SIMD (the LDS plan then takes a 4-row ring: eight workgroups per CU): the
     // backtrack over words is 2.5x faster there than over records (configs[3] x 2048: 243 vs 609 ms per step), more than the row loop loses (1910 vs 1670 ms)
     if (dir_wide_auto && wide_ring_rows <= 4 && wide_hi >= wide_lo) dir_wide = true;
@@ -355,12 +356,12 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
             need = 0; given_back = 0;
             const size_t want2[4] = {L.in_dev_bytes, L.graph_bytes, L.rows_bytes, (size_t)plane_tot};
             for (int i = 0; i < 4; ++i) if (want2[i] > have[i]) { need += want2[i]; given_back += have[i]; }
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr,
+            if (opt_env("ABPOA_HIP_VERBOSE")) fprintf(stderr,
                     "[abpoa-hip] device %d: %d sets: score-record arenas do not fit, direction words for the wide-band sets " "too (arenas %.1f GB)\n", device,
                     n_sets, plane_tot / 1e9);
         }
         if (need > free_b + given_back) {
-            if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr,
+            if (opt_env("ABPOA_HIP_VERBOSE")) fprintf(stderr,
                     "[abpoa-hip] device %d: %d sets need %.1f GB in growing buffers (arenas %.1f GB), %.1f GB free + %.1f " "GB given back: splitting\n",
                     device, n_sets, need / 1e9, plane_tot / 1e9, free_b / 1e9, given_back / 1e9);
             set_err("device-resident job needs %zu more bytes, %zu free", need, free_b + given_back); return ABPOA_HIP_ENOMEM;
@@ -430,9 +431,9 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     p.order_lds = (p.order_mode || want_msa) ? std::min(((max_node_cap + 3) & ~3), 6000) : 0;
     // (the all-in-LDS order walk: what is left of 40 KB -- four workgroups per CU -- after 13 bytes a node goes to aligned-list entries, 2 bytes each)
     p.order_ecap = p.order_mode ? std::max(1024, std::min(65535, (40 * 1024 - 128 - 13 * p.order_lds) / 2)) : 0;
-    { const char *e_ = getenv("ABPOA_HIP_ORDER_LDS"); if (e_ && !atoi(e_)) p.order_ecap = 0; }      // (ABPOA_HIP_ORDER_LDS=0: the general walk everywhere)
+    { const char *e_ = opt_env("ABPOA_HIP_ORDER_LDS"); if (e_ && !atoi(e_)) p.order_ecap = 0; }      // (ABPOA_HIP_ORDER_LDS=0: the general walk everywhere)
     // (tests: graphs above this many nodes take the walks with tables in memory)
-    { const char *e_ = getenv("ABPOA_HIP_ORDER_CAP"); if (e_ && atoi(e_) >= 0) p.order_lds = std::min(p.order_lds, atoi(e_) & ~3); }
+    { const char *e_ = opt_env("ABPOA_HIP_ORDER_CAP"); if (e_ && atoi(e_) >= 0) p.order_lds = std::min(p.order_lds, atoi(e_) & ~3); }
     // per-row records of the prepare kernel in LDS (5 bytes a row, 40 KB at most: four workgroups per CU still fit)
     p.pad = max_node_cap <= 8000 ? ((max_node_cap + 3) & ~3) : 0;
     p.sets = (const PoaSet *)(di + L.o_sets); p.state = (PoaState *)(dg + L.o_state);
@@ -494,7 +495,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     b.o1 = sc->gap_open1; b.e1 = sc->gap_ext1; b.o2 = sc->gap_open2; b.e2 = sc->gap_ext2;
     b.align_mode = sc->align_mode; b.gap_mode = sc->gap_mode; b.wb = sc->wb; b.zdrop = sc->zdrop; b.ret_cigar = 1; b.rev_cigar = 0;
     b.want_trace = 0; b.fresh_band = 1; b.want_lr = 0; b.dbg = 0;
-    { const char *dbg_ = getenv("ABPOA_HIP_DBG"); if (dbg_) b.dbg = atoi(dbg_); }      // (diagnostics: bit 7 keeps the row loop's counters in AlnOut.seg)
+    { const char *dbg_ = opt_env("ABPOA_HIP_DBG"); if (dbg_) b.dbg = atoi(dbg_); }      // (diagnostics: bit 7 keeps the row loop's counters in AlnOut.seg)
     b.mat = (const int32_t *)(di + L.o_mat); b.aln = p.aln; b.out = p.out;
     b.dir_mode = (dir && b.lds.wide_nw <= 1) ? (dir_wide ? 2 : 1) : 0; b.row_sdist = p.row_sdist; b.row_pd = p.row_pd;
     b.query = p.reads; b.row_base = p.row_base; b.row_node_id = p.row_node_id; b.row_remain = p.row_remain; b.row_active = p.row_base;
@@ -519,9 +520,9 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     // ---- all-rounds kernel (poa_rounds.hip) for jobs whose reads all take the narrow row loop: round 1 runs as separate launches (the upload of the
     //      later reads hides behind it), rounds 2 .. n in ONE launch in which every read-set advances on its own.  ABPOA_HIP_LOCKSTEP=1: one launch
     //      per phase and round throughout (what the wide-band jobs use, and the per-round diagnostics below).
-    const bool dbg_sync = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
-    bool use_rounds = !local && rounds_possible && !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(getenv("ABPOA_HIP_LOCKSTEP")
-            && atoi(getenv("ABPOA_HIP_LOCKSTEP")));
+    const bool dbg_sync = opt_env("ABPOA_HIP_DEVSYNC") && atoi(opt_env("ABPOA_HIP_DEVSYNC"));
+    bool use_rounds = !local && rounds_possible && !dbg_sync && b.lds.wide_nw == 0 && !(b.dbg & 64) && max_reads > 2 && !(opt_env("ABPOA_HIP_LOCKSTEP")
+            && atoi(opt_env("ABPOA_HIP_LOCKSTEP")));
     DevBatch b_r = b; size_t rounds_lds = 0;
     if (use_rounds) {
         // (prepare: 5 bytes per row; fuse: 16 bytes per thread)
@@ -543,7 +544,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         int n_cu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cu =
                 pr.multiProcessorCount; }
         if (nb < 1 || n_sets > nb * n_cu) use_rounds = false;
-        if (getenv("ABPOA_HIP_VERBOSE")) fprintf(stderr,
+        if (opt_env("ABPOA_HIP_VERBOSE")) fprintf(stderr,
                 "[abpoa-hip] all-rounds kernel: %s, %zu B dynamic + %d B static LDS per workgroup, %d workgroups per CU, " "backtrack window %d B\n",
                 use_rounds ? "on" : "off", rounds_lds, st_lds, nb, b_r.lds.bt_bytes_tail);
     }
@@ -623,7 +624,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     }
     const double t_done = now_s();
     // (library built with -DABPOA_HIP_ORDER_PROF: the order walk's passes and ticks per kind, mean per set)
-    if (getenv("ABPOA_HIP_ORDER_PROF") && p.order_mode) {
+    if (opt_env("ABPOA_HIP_ORDER_PROF") && p.order_mode) {
         const PoaState *hs_ = (const PoaState *)(C.graph.host + L.o_state); double a_[4] = {0, 0, 0, 0};
         for (int s = 0; s < n_sets; ++s) for (int i = 0; i < 4; ++i) a_[i] += (double)hs_[s].t_phase[i];
         fprintf(stderr, "[abpoa-hip] order walk per set: %.0f single-node passes x %.0f ticks, %.0f parallel passes x %.0f ticks\n", a_[2] / n_sets,
@@ -696,7 +697,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         for (int s = 0; s < n_sets; ++s) if (need_fb[s]) { const int r = hs[s].pad;
                 fallback_reason->push_back(r >= 1000 ? (r - 1000 == ABPOA_HIP_STATUS_OVERFLOW ? 9 : 10) : (r >= 1 && r <= 8 ? r : 0)); }
     }
-    if (getenv("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
+    if (opt_env("ABPOA_HIP_VERBOSE") && !fallback->empty()) {
         int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int n_slots = 0;
         int dp_arena = 0, dp_scores = 0, dp_other = 0;      // DP status: arena too small for the rows' bands / direction words could not decide / anything else

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include "engine_options.h"
 #include "msa_device_debug.h"
 
 namespace abpoa_hip {
@@ -42,7 +43,7 @@ DeviceDebug::DeviceDebug(const PoaDev *p, const std::vector<PoaSet> *ps, const a
         bool want_msa,
                          bool amb, hipStream_t stream)
     : p_(p), ps_(ps), sets_(sets), n_sets_(n_sets), m_(m), aln_cap_(aln_cap), max_reads_(max_reads), want_msa_(want_msa), amb_(amb), st_(stream) {
-    on_ = getenv("ABPOA_HIP_DEVSYNC") && atoi(getenv("ABPOA_HIP_DEVSYNC"));
+    on_ = opt_env("ABPOA_HIP_DEVSYNC") && atoi(opt_env("ABPOA_HIP_DEVSYNC"));
     if (on_) { graphs_.resize(std::min(n_sets, 4)); for (size_t i = 0; i < graphs_.size(); ++i) graphs_[i].reset(sets[i].n_reads, want_msa); }
 }
 
@@ -152,7 +153,7 @@ void DeviceDebug::graph_check(int k) {
 
 // load balance of the round: ticks of the mean and of the slowest alignment (ABPOA_HIP_IMBAL; the censuses need the diagnostic builds)
 void DeviceDebug::balance_report(int k, const DevBatch &b, hipEvent_t rows_begin, hipEvent_t rows_end) {
-    if (!on_ || !getenv("ABPOA_HIP_IMBAL")) return;
+    if (!on_ || !opt_env("ABPOA_HIP_IMBAL")) return;
     const PoaDev &p = *p_; const std::vector<PoaSet> &ps = *ps_; const abpoa_hip_readset_t *sets = sets_; const int n_sets = n_sets_, aln_cap = aln_cap_,
             max_reads = max_reads_; const bool amb = amb_;
     std::vector<PoaGraph> &dbg_graphs = graphs_; (void)n_sets; (void)aln_cap; (void)max_reads; (void)amb; (void)ps; (void)sets;
@@ -193,7 +194,7 @@ void DeviceDebug::balance_report(int k, const DevBatch &b, hipEvent_t rows_begin
                 n_al ? t_al / n_al : 0.0, n_sh, n_sh ? t_sh / n_sh : 0.0);
     }
     // (library built with -DABPOA_HIP_ROW_CENSUS) rows and ticks per body of the narrow row loop, mean per alignment
-    if ((b.dbg & 128) && getenv("ABPOA_HIP_ROW_CENSUS")) {
+    if ((b.dbg & 128) && opt_env("ABPOA_HIP_ROW_CENSUS")) {
         double rw[6] = {0, 0, 0, 0, 0, 0}, tk[6] = {0, 0, 0, 0, 0, 0}; for (const AlnOut &o_ : ho) for (int q_ = 0; q_ < 6; ++q_) {
                 rw[q_] += (double)(o_.seg[q_] >> 40); tk[q_] += (double)(o_.seg[q_] & ((1ll << 40) - 1)); }
         const char *nm_[5] = {"1 predecessor", "2 predecessors", "3-4 predecessors", "exact bodies", "tile switches"};
@@ -210,14 +211,14 @@ void DeviceDebug::balance_report(int k, const DevBatch &b, hipEvent_t rows_begin
         fprintf(stderr, " exact-body rows: > 4 predecessors %.0f, straight-line body declined %.0f, predecessor beyond the ring %.0f\n", why[0] / n_sets,
                 why[1] / n_sets, why[2] / n_sets);
     }
-    if ((b.dbg & 128) && getenv("ABPOA_HIP_WIDE_COUNTERS")) { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_;
+    if ((b.dbg & 128) && opt_env("ABPOA_HIP_WIDE_COUNTERS")) { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_;
             const AlnOut &o_ = ho[w_];
         fprintf(stderr,
                 "[poa-device] round %d slowest row loop: set %d ticks %lld rows %d | all-chunk body %lld | not eligible "
                         "%lld | ring-geometry %lld | > 5 chunks %lld | slow vectors straddle %lld | key window / wrap %lld\n", k, w_, (long long)o_.clk_dp,
                         o_.n_rows_done, (long long)o_.seg[0], (long long)o_.seg[1], (long long)o_.seg[2], (long long)o_.seg[3], (long long)o_.seg[4],
                         (long long)o_.seg[5]); }
-    if (getenv("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr,
+    if (opt_env("ABPOA_HIP_WIDE_COUNTERS")) fprintf(stderr,
             "[poa-device] round %d wide-loop rows per alignment (diagnostic build): all-chunk body %.0f | not eligible "
                     "(preds > 8 / distance) %.0f | ring-geometry %.0f | > 5 chunks %.0f | slow vectors straddle %.0f | key " "window / wrap %.0f\n", k,
                     sg[0] / n_sets, sg[1] / n_sets, sg[2] / n_sets, sg[3] / n_sets, sg[4] / n_sets, sg[5] / n_sets);

@@ -5,6 +5,7 @@
 #include <memory>
 #include <thread>
 #include <mutex>
+#include "engine_options.h"
 #include "batch_stream.h"
 #include "msa_batch.h"
 #include "msa_device.h"
@@ -46,8 +47,8 @@ abpoa_hip_msa_timing_t g_timing;
 
 namespace abpoa_hip {
 namespace {
-bool env_on(const char *name) { const char *e = getenv(name); return e && atoi(e) != 0; }
-int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+bool env_on(const char *name) { const char *e = opt_env(name); return e && atoi(e) != 0; }
+int env_int(const char *name, int dflt) { const char *e = opt_env(name); return e ? atoi(e) : dflt; }
 bool strict_mode() { return env_on("ABPOA_HIP_STRICT"); }
 void free_all(abpoa_hip_msa_t *out, int n) { for (int s = 0; s < n; ++s) abpoa_hip_free_msa(&out[s]); }
 
@@ -91,7 +92,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
     //  node slots are never what sends a set to the host driver; round-4 fuzzing: 22 of 813 sets, all for that reason -- protein sets at 15 % error)
     const double factors[4] = {3.0, 4.5, 6.0, 4096.0};
     constexpr int NPASS = 4;
-    const bool verbose = getenv("ABPOA_HIP_VERBOSE") != nullptr;
+    const bool verbose = opt_env("ABPOA_HIP_VERBOSE") != nullptr;
     const int key = job_shape_key(sets, idx);
     int first_pass = 0;
     {   // (profiling runs of one step: start where a warmed-up process would)
@@ -175,7 +176,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
 // device); unset = the device the engine was initialised on.
 std::vector<int> device_list() {
     std::vector<int> d;
-    const char *e = getenv("ABPOA_GPU_DEVICES");
+    const char *e = opt_env("ABPOA_GPU_DEVICES");
     int n = 0;
     (void)hipGetDeviceCount(&n);
     if (e && *e) {
@@ -291,7 +292,7 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         }
         if (rc_dev != ABPOA_HIP_OK) { free_all(out, n_sets); return rc_dev; }
         if (n_q > 1) tot.device_s = tot.total_s = *std::max_element(q_busy.begin(), q_busy.end());      // queues ran side by side: the busiest one is the wall time
-        if (n_q > 1 && getenv("ABPOA_HIP_VERBOSE")) {
+        if (n_q > 1 && opt_env("ABPOA_HIP_VERBOSE")) {
             fprintf(stderr, "[abpoa-hip] %d device queues, %zu batches; busy seconds per queue:", n_q, batches.size());
             for (int q = 0; q < n_q; ++q) fprintf(stderr, " dev%d %.3f", devs[q], q_busy[q]);
             fprintf(stderr, "\n");
@@ -308,7 +309,7 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         tm.host_sort_s = tot.prepare_ms / 1e3; tm.host_fuse_s = tot.fuse_ms / 1e3;      // device kernels now: graph -> rows, cigar -> graph
         tm.n_host_sets = (int32_t)todo.size();                                          // how many sets take the host driver
         if (todo.empty()) return ABPOA_HIP_OK;
-        if (getenv("ABPOA_HIP_VERBOSE"))
+        if (opt_env("ABPOA_HIP_VERBOSE"))
             fprintf(stderr, "[abpoa-hip] %zu of %d read-sets outgrew a device capacity: host driver for those\n", todo.size(), n_sets);
         if (strict_mode()) {
             free_all(out, n_sets);
@@ -345,6 +346,7 @@ void abpoa_hip_get_host_reasons(int32_t *out12) {
     for (int i = 0; i < abpoa_hip::MSA_HOST_REASONS; ++i) out12[i] = abpoa_hip::g_host_reasons[i];
 }
 int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
+    abpoa_hip::refresh_options();
     return abpoa_hip::msa_batch_impl(sc, n_sets, sets, out, flags, n_threads, abpoa_hip::g_timing, -1, -1);
 }
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = abpoa_hip::g_timing; }
@@ -370,6 +372,7 @@ void abpoa_hip_ctx_destroy(abpoa_hip_ctx_t *c) {
     delete c;      // (the queue's pools stay cached for the next context that takes the slot; abpoa_hip_trim releases them)
 }
 int abpoa_hip_msa_batch_ctx(abpoa_hip_ctx_t *c, const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
+    abpoa_hip::refresh_options();
     if (!c) return ABPOA_HIP_EINVAL;
     abpoa_hip::clear_thread_error();
     const int rc = abpoa_hip::msa_batch_impl(sc, n_sets, sets, out, flags, n_threads, c->timing, c->device, c->slot);

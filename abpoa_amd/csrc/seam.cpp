@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include "engine_options.h"
 #include "../../include/abpoa_hip.h"
 #include "../../include/abpoa_seam.h"
 
@@ -29,6 +30,7 @@ void abpoa_free_simd_matrix(abpoa_seam_matrix_t *abm) {
 
 int simd_abpoa_align_sequence_to_subgraph(abpoa_seam_t *ab, abpoa_seam_para_t *abpt, int beg_node_id, int end_node_id,
                                           uint8_t *query, int qlen, abpoa_seam_res_t *res) {
+    abpoa_hip::refresh_options();
     abpoa_seam_graph_t *g = ab->abg;
     if (beg_node_id < 0 || beg_node_id >= g->node_n || end_node_id < 0 || end_node_id >= g->node_n) seam_fatal(__func__, "Wrong node id");
     const int beg_index = g->node_id_to_index[beg_node_id], end_index = g->node_id_to_index[end_node_id];

@@ -85,4 +85,5 @@ CONFIGS = {
     3: dict(n_reads=50, length=10000, err=0.15, alphabet=NT),     # convex defaults, -b 10 -f 0.01
     4: dict(n_reads=50, length=10000, err=0.05, alphabet=NT),     # global affine, 100k sets
     5: dict(n_reads=30, length=500, alphabet=AA, rates=(0.05, 0.03, 0.03)),  # local, BLOSUM62, MSA output
+    6: dict(n_reads=50, length=20000, err=0.10, alphabet=NT),     # (not in BASELINE.json) long reads: convex defaults, band half-width 210 -- rows of 7 - 9 chunks
 }

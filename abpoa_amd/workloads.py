@@ -19,9 +19,11 @@ WORKLOADS = {
                  desc="50 reads x 10 kb, 5% err, global affine"),
     "cfg5": dict(cfg=5, params=dict(aln_mode=1, is_aa=True, score_matrix=BLOSUM62), ref_opts=["-m", "1", "-c", "-t", BLOSUM62, "-r", "1"],
                  out_msa=True, desc="30 seqs x 500 aa, local convex BLOSUM62 (-m 1 -c -t BLOSUM62.mtx -r 1), MSA output"),
+    # not a BASELINE.json configuration: ONT reads of 20 kb (missing 4 -- the wide row loop ended at 448 columns)
+    "cfg3l": dict(cfg=6, params=dict(), ref_opts=[], out_msa=False, desc="50 reads x 20 kb, 10% err, global convex defaults (-b 10 -f 0.01): long reads"),
 }
 # sets (index 0 .. n-1, seed 1) with a committed reference digest
-DIGEST_SETS = {"cfg2": 8000, "cfg3": 2048, "cfg4": 2048, "cfg5": 1000}
+DIGEST_SETS = {"cfg2": 8000, "cfg3": 2048, "cfg4": 2048, "cfg5": 1000, "cfg3l": 256}
 
 
 def ref_options(wl, portable=False):

@@ -224,6 +224,14 @@ void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out);
  * device memory even alone).  Process-wide like the timing record. */
 void abpoa_hip_get_host_reasons(int32_t *out12);
 
+/* ---- switches (additive) -----------------------------------------------------------------------------------------------------------------
+ * The library's behaviour switches (device list, strict mode, verbose output; test hooks that force a code path; diagnostics) form one table
+ * (abpoa_amd/csrc/engine_options.cpp; abpoa_hip_list_options returns it).  Their values are read ONCE at every entry point of this header -- from the
+ * environment variable of the same name unless abpoa_hip_set_option gave one (value NULL: back to the environment) -- and hold for the whole call on every
+ * thread.  Unknown names are refused (ABPOA_HIP_EINVAL); nothing outside the table is ever read from the environment. */
+int abpoa_hip_set_option(const char *name, const char *value);
+int abpoa_hip_list_options(const char **names, const char **help, int cap);      /* returns the number of switches; fills up to cap entries */
+
 /* ---- contexts (additive; SURVEY.md 8b: "the replacement should be re-entrant per abpoa_t") --------------------------------------------------
  * abpoa_hip_msa_batch keeps its timing record and last error per PROCESS and drives the device queues named by ABPOA_GPU_DEVICES: one caller at a
  * time.  A context is the same entry with the per-caller state in a handle: its own device queue (stream, pool cache, argument record), timing and

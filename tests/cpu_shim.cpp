@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 #include "../abpoa_amd/csrc/msa_batch.h"
+#include "../abpoa_amd/csrc/engine_options.h"
 extern "C" {
 #include "../oracle/abpoa_dp_oracle.h"
 }
@@ -83,6 +84,7 @@ abpoa_hip_msa_timing_t g_timing;
 
 extern "C" {
 int abpoa_hip_msa_batch(const abpoa_hip_scoring_t *sc, int n_sets, const abpoa_hip_readset_t *sets, abpoa_hip_msa_t *out, unsigned flags, int n_threads) {
+    abpoa_hip::refresh_options();
     return abpoa_hip::run_msa_batch(sc, n_sets, sets, out, flags, n_threads, n_sets >= 4 ? 2 : 1, make_oracle_aligner, &g_timing);
 }
 void abpoa_hip_get_msa_timing(abpoa_hip_msa_timing_t *out) { *out = g_timing; }

@@ -388,7 +388,7 @@ def cpu_shim_lib():
         os.makedirs(bdir, exist_ok=True)
         so = os.path.join(bdir, "libcpu_shim.so")
         srcs = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.cpp"),
-                os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.cpp")]
+                os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.cpp"), os.path.join(ROOT, "abpoa_amd", "csrc", "engine_options.cpp")]
         deps = srcs + [os.path.join(ORACLE_DIR, "abpoa_dp_oracle.c"), os.path.join(ORACLE_DIR, "dir_model.c"), os.path.join(ORACLE_DIR, "abpoa_dp_oracle.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "dir_plane.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "poa_graph.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "msa_batch.h"), os.path.join(ROOT, "abpoa_amd", "csrc", "batch_types.h"),
                        os.path.join(ROOT, "include", "abpoa_hip.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):

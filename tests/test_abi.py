@@ -85,3 +85,27 @@ def test_no_device_fails_loudly():
     assert b"no HIP device" in lib.abpoa_hip_last_error()
     with pytest.raises(ffi.EngineError):
         api.msa_batch([["ACGT", "ACGT"]], api.Params())
+
+
+def test_switches_form_one_table_and_nothing_else_reads_the_environment():
+    """Round 5 hygiene: every behaviour switch of the library is a row of abpoa_amd/csrc/engine_options.cpp, read once per C-ABI entry into
+    a snapshot (environment, overridden by abpoa_hip_set_option); no other source file of the engine calls getenv."""
+    import glob
+    lib = ffi.lib()
+    lib.abpoa_hip_list_options.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int]; lib.abpoa_hip_list_options.restype = C.c_int
+    n = lib.abpoa_hip_list_options(None, None, 0)
+    names, helps = (C.c_char_p * n)(), (C.c_char_p * n)()
+    assert lib.abpoa_hip_list_options(names, helps, n) == n and n >= 30
+    table = {names[i].decode(): helps[i].decode() for i in range(n)}
+    assert "ABPOA_HIP_STRICT" in table and "ABPOA_GPU_DEVICES" in table and all(h[:1] in "PTD" for h in table.values())
+    lib.abpoa_hip_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    assert lib.abpoa_hip_set_option(b"ABPOA_HIP_NO_SUCH_SWITCH", b"1") != 0
+    assert lib.abpoa_hip_set_option(b"ABPOA_HIP_VERBOSE", b"1") == 0 and lib.abpoa_hip_set_option(b"ABPOA_HIP_VERBOSE", None) == 0
+    csrc = os.path.join(H.ROOT, "abpoa_amd", "csrc")
+    used = set()
+    for fn in glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(fn).read()
+        if not fn.endswith("engine_options.cpp"):
+            assert "getenv(" not in text.replace("opt_env(", ""), f"{os.path.basename(fn)} reads the environment directly"
+            used |= set(re.findall(r'(?:opt_env|env_int|env_on)\("(ABPOA_[A-Z_0-9]+)"', text))
+    assert used <= set(table), f"switches read but not in the table: {sorted(used - set(table))}"

@@ -251,7 +251,7 @@ def test_host_layer_under_address_and_ub_sanitizers(tmp_path):
     os.makedirs(bdir, exist_ok=True)
     exe = os.path.join(bdir, "abpoa_batch_asan")
     csrc, odir = os.path.join(ROOT, "abpoa_amd", "csrc"), os.path.join(ROOT, "oracle")
-    srcs_cpp = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(csrc, "poa_graph.cpp"), os.path.join(csrc, "msa_batch.cpp")]
+    srcs_cpp = [os.path.join(ROOT, "tests", "cpu_shim.cpp"), os.path.join(csrc, "poa_graph.cpp"), os.path.join(csrc, "msa_batch.cpp"), os.path.join(csrc, "engine_options.cpp")]
     srcs_c = [os.path.join(odir, "abpoa_dp_oracle.c"), os.path.join(odir, "dir_model.c"), os.path.join(ROOT, "abpoa_amd", "host", "abpoa_batch.c")]
     deps = srcs_cpp + srcs_c + [os.path.join(csrc, "poa_graph.h"), os.path.join(csrc, "msa_batch.h"), os.path.join(ROOT, "include", "abpoa_hip.h")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
