@@ -197,7 +197,9 @@ void DeviceDebug::balance_report(int k, const DevBatch &b, hipEvent_t rows_begin
     if ((b.dbg & 128) && opt_env("ABPOA_HIP_ROW_CENSUS")) {
         double rw[6] = {0, 0, 0, 0, 0, 0}, tk[6] = {0, 0, 0, 0, 0, 0}; for (const AlnOut &o_ : ho) for (int q_ = 0; q_ < 6; ++q_) {
                 rw[q_] += (double)(o_.seg[q_] >> 40); tk[q_] += (double)(o_.seg[q_] & ((1ll << 40) - 1)); }
-        const char *nm_[5] = {"1 predecessor", "2 predecessors", "3-4 predecessors", "exact bodies", "tile switches"};
+        // (a build with -DABPOA_HIP_ASM_CENSUS as well: slot 0 = the rows of the assembly loop, slot 1 = the C++ copies of the one- / two-predecessor body)
+        const bool asmc_ = opt_env("ABPOA_HIP_ROW_CENSUS") && atoi(opt_env("ABPOA_HIP_ROW_CENSUS")) == 2;
+        const char *nm_[5] = {asmc_ ? "assembly loop" : "1 predecessor", asmc_ ? "C++ 1-2 predecessors" : "2 predecessors", "3-8 predecessors (C++)", "all-chunks / exact bodies", "tile switches"};
         fprintf(stderr, "[poa-device] round %d narrow-loop census per alignment:", k);
         for (int q_ = 0; q_ < 5; ++q_) fprintf(stderr, " %s %.0f x %.0f ticks |", nm_[q_], rw[q_] / n_sets, rw[q_] > 0 ? tk[q_] / rw[q_] : 0.0);
         { int w_ = 0; for (int s_ = 0; s_ < n_sets; ++s_) if (ho[s_].clk_dp > ho[w_].clk_dp) w_ = s_; const AlnOut &o_ = ho[w_];

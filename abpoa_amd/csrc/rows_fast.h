@@ -100,9 +100,14 @@ __device__ __forceinline__ void slow_f_vectors(int vbase, int end_sn, int max_pr
 // 0 wide body, 1 not eligible (predecessor count / distance), 2 ring / geometry, 3 wider than NW chunks, 4 slow vectors span two wavefronts, 5 wrap guard
 // -DABPOA_HIP_ROW_CENSUS (same hand-over): rows and clock ticks per body of the NARROW loop -- seg[i] = rows << 40 | ticks for i = 0 one predecessor
 // (tight loop), 1 two predecessors (tight loop), 2 three / four predecessors (straight-line body), 3 the exact bodies (fast / general); 4 = tile switches
+#ifdef ABPOA_HIP_ASM_CENSUS      // (-DABPOA_HIP_ROW_CENSUS -DABPOA_HIP_ASM_CENSUS: the census WITH the assembly loop -- slot 0 = its rows, slot 1 = the C++ copies of the one- / two-predecessor body)
+#define CENSUS_SLOT(I) ((I) == 0 ? 1 : (I))
+#else
+#define CENSUS_SLOT(I) (I)
+#endif
 #ifdef ABPOA_HIP_ROW_CENSUS
 #define CENSUS_T0() const long long cen_t0 = (long long)__builtin_amdgcn_s_memtime();
-#define CENSUS(I) { fseg[I] += (1ll << 40) + ((long long)__builtin_amdgcn_s_memtime() - cen_t0); }
+#define CENSUS(I) { fseg[CENSUS_SLOT(I)] += (1ll << 40) + ((long long)__builtin_amdgcn_s_memtime() - cen_t0); }
 #else
 #define CENSUS_T0()
 #define CENSUS(I)
@@ -1235,11 +1240,14 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             // row it does not take and says why; that row goes through the bodies below, then the loop is entered again.  (Not in the diagnostic builds, whose
             // ablation bits / clocks / censuses live in the C++ bodies; ABPOA_HIP_DBG bit 11 keeps the compiler's loop, for comparison.)
             bool cxx_tight = true;
-#if !defined(ABPOA_HIP_ABLATE) && !defined(ABPOA_HIP_PROFILE) && !defined(ABPOA_HIP_ROW_CENSUS) && !defined(ABPOA_HIP_NO_ASM_TIGHT)
+#if !defined(ABPOA_HIP_ABLATE) && !defined(ABPOA_HIP_PROFILE) && (!defined(ABPOA_HIP_ROW_CENSUS) || defined(ABPOA_HIP_ASM_CENSUS)) && !defined(ABPOA_HIP_NO_ASM_TIGHT)
             if constexpr (!WPLAN && I16 && GAP == 1 && DIR) {
                 if (asm_tight_on && cur + NV * (r_hi - row) <= cap_turbo) {
                     int code, sM, sTB, sRT, sP0, sM0, sG0, sSL0, sA, sB, sESN, sBSN, sPB0, sPE0, sNV1, sC0, sP1, sM1, sG1, sSL1, sPB1, sPE1, sP2, sSL2, sPB2, sPE2, sP3, sSL3, sPB3, sPE3;
                     long long inb, amok, msk;
+#ifdef ABPOA_HIP_ASM_CENSUS
+                    const int asm_row0 = row; const long long asm_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
                     int infw_v = infw, inf_v = inf; asm("" : "+v"(infw_v), "+v"(inf_v));
                     const int mxb = (int)(unsigned)(size_t)(lds_int_t *)s_mx, qb = (int)(unsigned)(size_t)(lds_int_t *)(const void *)s_query;
                     asm volatile(TIGHT_ASM_I16_AFFINE_DIR
@@ -1255,6 +1263,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                           "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc", "m0", "memory");
                     ok_ = code == 1 ? 0 : (code == 2 ? -1 : 1);
                     cxx_tight = false;
+#ifdef ABPOA_HIP_ASM_CENSUS
+                    fseg[0] += ((long long)(row - asm_row0) << 40) + ((long long)__builtin_amdgcn_s_memtime() - asm_t0);
+#endif
                 }
             }
 #endif

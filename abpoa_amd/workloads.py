@@ -23,7 +23,7 @@ WORKLOADS = {
     "cfg3l": dict(cfg=6, params=dict(), ref_opts=[], out_msa=False, desc="50 reads x 20 kb, 10% err, global convex defaults (-b 10 -f 0.01): long reads"),
 }
 # sets (index 0 .. n-1, seed 1) with a committed reference digest
-DIGEST_SETS = {"cfg2": 8000, "cfg3": 2048, "cfg4": 2048, "cfg5": 1000, "cfg3l": 256}
+DIGEST_SETS = {"cfg2": 8000, "cfg3": 2048, "cfg4": 2048, "cfg5": 1000, "cfg3l": 64}
 
 
 def ref_options(wl, portable=False):

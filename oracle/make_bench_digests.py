@@ -52,7 +52,7 @@ def main():
             old = json.load(open(fn_old))
             if old.get("seed") == 1 and old.get("options") == ref_options(wl, portable=True):
                 have = old["sha256"][:n]
-        with tempfile.TemporaryDirectory(prefix="abpoa_dig_") as tmp, ThreadPoolExecutor(max_workers=7) as ex:
+        with tempfile.TemporaryDirectory(prefix="abpoa_dig_") as tmp, ThreadPoolExecutor(max_workers=2 if wl == "cfg3l" else 7) as ex:      # (the reference holds rows x (qlen + 1) x planes: ~25 GB per process on 50 x 20 kb reads)
             shas = have + list(ex.map(lambda i: one(wl, i, tmp), range(len(have), n)))
         rec = {"workload": wl, "seed": 1, "options": ref_options(wl, portable=True), "n_sets": n,
                "generator": "oracle/make_bench_digests.py (abPOA v1.4.1, oracle/_ref/abpoa_ref)", "sha256": shas}

@@ -35,6 +35,6 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "kernel
        "commit": (subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or (open(os.path.join(root, ".git_head")).read().strip() if os.path.exists(os.path.join(root, ".git_head")) else "") or os.environ.get("ABPOA_COMMIT") or "working tree"),
        "how": "tools/pmc_insts.sh: rocprofv3 --kernel-trace --pmc <4 counters>, two passes over `bench.py --workload %s --steps 1 --warmup 0`" % wl}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-json.dump(rec, open(os.path.join(root, "gpurun_out", f"r4_pmc_insts_{wl}.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(root, "gpurun_out", f"{bench.ROUND}_pmc_insts_{wl}.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in rec.items() if k != "all_kernels"}, indent=1))
 PY

@@ -1,6 +1,6 @@
 # HBM traffic of the row-loop kernels on a bench workload: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (they do not fit one
 # pass; no tracing flag besides --kernel-trace), the same bench command each time.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts
-# 128-byte requests at 64 bytes -> x2; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Writes profiles/r4_pmc_traffic_<workload>.json,
+# 128-byte requests at 64 bytes -> x2; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Writes profiles/<round>_pmc_traffic_<workload>.json,
 # which bench.py reports as roofline.traffic while the row-loop sources are unchanged (hash kept in the record).
 # usage (on the GPU box): bash tools/pmc_traffic.sh cfg2|cfg3|cfg4|cfg5 [read-sets]
 cd /tmp && export TMPDIR=/tmp
@@ -50,6 +50,6 @@ rec = {"workload": wl, "read_sets": line["config"]["read_sets_per_gpu"], "rounds
        "all_kernels_MB_per_launch": {k: {"fetch_x2": round(2 * v["FETCH_SIZE"] / 1024 / max(1, rounds), 1), "write": round(v["WRITE_SIZE"] / 1024 / max(1, rounds), 1)} for k, v in per_kernel.items()},
        "how": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --workload %s --steps 1 --warmup 0`" % wl}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-json.dump(rec, open(os.path.join(root, "gpurun_out", f"r4_pmc_traffic_{wl}.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(root, "gpurun_out", f"{bench.ROUND}_pmc_traffic_{wl}.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY
