@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 #include "abpoa_hip.h"
 
@@ -352,6 +353,8 @@ int main(int argc, char **argv) {
     for (int q = 0; q < sticky_n; ++q) free(sticky[q]);
     free(sticky); free(mat);
     fflush(stdout);
-    if (gpu_up) abpoa_hip_shutdown();
+    /* every result is out: leave without tearing the engine down piece by piece (abpoa_hip_shutdown would hipFree ~150 GB of pools one by one and the HIP
+     * runtime's exit handlers would follow; the driver reclaims a dead process's memory in one go: ~0.4 s of a 10 s job) */
+    if (gpu_up) _exit(ferror(stdout) ? 1 : 0);
     return 0;
 }

@@ -108,7 +108,7 @@ def main():
         for k_, v_ in why.items():
             hist[k_] = hist.get(k_, 0) + v_
         if it % 20 == 19:
-            print(f"{it + 1} iterations ok ({n_dev} sets on the device, {n_host} through the host driver)", flush=True)
+            print(f"{it + 1} iterations ok ({n_dev} sets on the device, {n_host} through the host driver{': ' + str(hist) if hist else ''})", flush=True)
     print(f"fuzz ok: {a.iters} iterations, {n_dev} sets on the device, {n_host} through the host driver, {n_err} sets on which both sides report the same error status")
     print(f"why sets left the device: {hist if hist else 'none did'}")
 
