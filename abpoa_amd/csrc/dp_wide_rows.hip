@@ -8,8 +8,14 @@
 
 namespace abpoa_hip {
 
+// (-DABPOA_HIP_WIDE_W3: the experiment of LOG.md round 5 -- three wavefronts per SIMD: 168 VGPRs, twelve workgroups per CU with a 2-row ring)
+#ifdef ABPOA_HIP_WIDE_W3
+#define WIDE_BOUNDS(NW) __launch_bounds__(NW * 64, 3)
+#else
+#define WIDE_BOUNDS(NW) __launch_bounds__(NW * 64)
+#endif
 template <int GAP, int BITS, int NW, bool DIR = false>
-__global__ void __launch_bounds__(NW * 64) dp_wide_kernel(const DevBatch b) {
+__global__ void WIDE_BOUNDS(NW) dp_wide_kernel(const DevBatch b) {
     const int a = blockIdx.x;
     if (a >= b.n) return;
     const AlnDesc d = b.aln[a];

@@ -88,6 +88,12 @@ void BatchStream::close() {
 
 // LDS carve-up of one wavefront (engine.h LdsPlan) for a launch whose largest query is max_qlen, widest score type max_bits
 // and widest expected band est_cols columns.
+// (-DABPOA_HIP_WIDE_W3, experiment: three wavefronts per SIMD in the wide loop -- twelve workgroups per CU, ring depth down to 2)
+#ifdef ABPOA_HIP_WIDE_W3
+constexpr int WIDE_PER_CU_MAX = 12, WIDE_RING_MIN = 2;
+#else
+constexpr int WIDE_PER_CU_MAX = 8, WIDE_RING_MIN = 4;
+#endif
 void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int64_t est_cols, int n_aln, LdsPlan *Lp) {
     LdsPlan &L = *Lp;
     const int P = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 3 : 5);
@@ -170,12 +176,12 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           // shallower ring sends more rows to the HBM gather (predecessor older than the ring: 0.5 % / 14 % / ~45 % of the rows of a 15 %-error
           // graph at depth 16 / 8 / 4; rows +1.6 % / +6.5 %).
           const int extra_ = L.wide_nw > 1 ? 16 * 16 + 64 : 0;      // (exchange slots: teams only)
-          auto per_cu_ = [&](int rows_) { return std::min<int64_t>(8, 128 / ((L.w_phase_off + (int64_t)rows_ * fww * (L.wfr_cols + 4) * 4 + extra_ + 1279) / 1280)); };
+          auto per_cu_ = [&](int rows_) { return std::min<int64_t>(WIDE_PER_CU_MAX, 128 / ((L.w_phase_off + (int64_t)rows_ * fww * (L.wfr_cols + 4) * 4 + extra_ + 1279) / 1280)); };
           if (!(rr_env_)) {
               const int top_ = L.wfr_rows; int best_ = top_;
-              for (int r_ = top_; r_ >= 4; r_ /= 2) {
+              for (int r_ = top_; r_ >= WIDE_RING_MIN; r_ /= 2) {
                   if (per_cu_(r_) > per_cu_(best_)) best_ = r_;
-                  if (per_cu_(r_) * 256 >= std::min(n_aln, 8 * 256)) { best_ = r_; break; }
+                  if (per_cu_(r_) * 256 >= std::min(n_aln, WIDE_PER_CU_MAX * 256)) { best_ = r_; break; }
               }
               L.wfr_rows = best_;
           }
@@ -519,7 +525,7 @@ void abpoa_hip__dir_counts(long long *out) { out[0] = __atomic_exchange_n(&g_dir
 void abpoa_hip__wide_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, int n_aln, int *out) {
     abpoa_hip::LdsPlan L; const int pn = max_bits == 16 ? 16 : 8; const int w = sc->wb + (int)(sc->wf * (float)max_qlen);
     abpoa_hip::make_lds_plan(sc, max_qlen, max_bits, std::min<int64_t>((int64_t)((max_qlen + pn) / pn) * pn, 2LL * w + 3 * pn + 32), n_aln, &L);
-    out[0] = L.wide_nw; out[1] = L.wfr_rows; out[2] = L.total_wide; out[3] = L.total_wide > 0 ? std::min(8, 128 / ((L.total_wide + 1279) / 1280)) : 0;
+    out[0] = L.wide_nw; out[1] = L.wfr_rows; out[2] = L.total_wide; out[3] = L.total_wide > 0 ? std::min(WIDE_PER_CU_MAX, 128 / ((L.total_wide + 1279) / 1280)) : 0;
     out[4] = L.w_phase_off; out[5] = L.wide_w_lo; out[6] = L.wide_w_hi;
 }
 void abpoa_hip__debug_clocks(long long *out) { for (int i = 0; i < 10; ++i) { out[i] = g_dbg[i]; g_dbg[i] = 0; } }

@@ -139,7 +139,11 @@ int msa_device_resident_sets(const abpoa_hip_scoring_t *sc, int n_sets, const ab
     int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr;
             if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
     // (LDS is handed out in pieces of 1280 B, 128 per CU: tools/probes/lds_granule.hip; 166-192 VGPRs: two wavefronts per SIMD at most)
+#ifdef ABPOA_HIP_WIDE_W3
+    const int per_cu = std::max(1, std::min(12, 128 / ((pl.total_wide + 1279) / 1280)));
+#else
     const int per_cu = std::max(1, std::min(8, 128 / ((pl.total_wide + 1279) / 1280)));
+#endif
     return per_cu * cus;
 }
 
