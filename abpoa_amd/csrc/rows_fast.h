@@ -1315,10 +1315,22 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }
                 if (nch_ >= 2) {
                     int ok2;
+                    // (one body per chunk count from 4 on: a 4-chunk row in the 5-chunk body computes a fifth chunk of lanes nobody keeps -- a fifth of the row's
+                    //  vector instructions; 10 kb reads at 5 % error sit at exactly 4 chunks most of the time)
                     if (nch_ <= 3) ok2 = ilp_chunks(std::integral_constant<int, 3>{}, nch_, row, ti);
+#ifndef ABPOA_HIP_WIDE_PAIRED_NCH
+                    else if (nch_ == 4) ok2 = ilp_chunks(std::integral_constant<int, 4>{}, nch_, row, ti);
+                    else if (nch_ == 5) ok2 = ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti);
+                    else if (nch_ == 6) ok2 = ilp_chunks(std::integral_constant<int, 6>{}, nch_, row, ti);
+#else
                     else if (nch_ <= 5) ok2 = ilp_chunks(std::integral_constant<int, 5>{}, nch_, row, ti);
+#endif
                     else if (nch_ <= 7) ok2 = ilp_chunks(std::integral_constant<int, 7>{}, nch_, row, ti);
-                    else if constexpr (XL) ok2 = nch_ <= 9 ? ilp_chunks(std::integral_constant<int, 9>{}, nch_, row, ti) : ilp_chunks(std::integral_constant<int, 11>{}, nch_, row, ti);
+                    else if constexpr (XL) {
+                        if (nch_ == 8) ok2 = ilp_chunks(std::integral_constant<int, 8>{}, nch_, row, ti);
+                        else if (nch_ == 9) ok2 = ilp_chunks(std::integral_constant<int, 9>{}, nch_, row, ti);
+                        else ok2 = ilp_chunks(std::integral_constant<int, 11>{}, nch_, row, ti);
+                    }
                     else ok2 = 0;
                     if (ok2 == 1) { WCOUNT(0); commit_row(ti, true); FSTAMP(5) ++row; continue; }
                     WCOUNT(5);
