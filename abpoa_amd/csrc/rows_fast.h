@@ -263,6 +263,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         return q;
     };
     MetaA a1 = load_a(0); MetaB b1 = load_b(a1); MetaA a2 = load_a(64);
+    int tv_r1 = 0, tv_r2 = 0;      // (assembly loop: the static terms of the band, rows_tight_asm.h TA_BAND_*)
     int tv_meta = 0, tv_rterm = 0, tv_ps = 0, tv_p0 = 0, tv_p1 = 0, tv_p2 = 0, tv_p3 = 0;
     int tv_p4 = 0, tv_p5 = 0, tv_p6 = 0, tv_p7 = 0;      // (wide rows only)
     int tv_tb = 0;          // turbo rows: dist(pred 0) | dist(pred 1) << 8 | (base * (m + 1) * 4) << 16
@@ -292,6 +293,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         tv_tb = ((myrow - b1.p[0]) & 0xff) | (((myrow - b1.p[1]) & 0xff) << 8) | (((a1.base & 0xff) * m1 * 4) << 16);
         tv_rterm = qlen - (a1.rem - remain_end - 1); tv_ps = a1.ps;
+        tv_r1 = imin(gn, tv_rterm) - w; tv_r2 = tv_rterm + w;
         tv_p0 = b1.p[0]; tv_p1 = b1.p[1]; tv_p2 = b1.p[2]; tv_p3 = b1.p[3];
         tv_p4 = b1.p[4]; tv_p5 = b1.p[5]; tv_p6 = b1.p[6]; tv_p7 = b1.p[7];
         a1 = a2; b1 = load_b(a1); a2 = load_a(t0 + 128);
@@ -1243,7 +1245,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
 #if !defined(ABPOA_HIP_ABLATE) && !defined(ABPOA_HIP_PROFILE) && (!defined(ABPOA_HIP_ROW_CENSUS) || defined(ABPOA_HIP_ASM_CENSUS)) && !defined(ABPOA_HIP_NO_ASM_TIGHT)
             if constexpr (!WPLAN && I16 && GAP == 1 && DIR) {
                 if (asm_tight_on && cur + NV * (r_hi - row) <= cap_turbo) {
-                    int code, sM, sTB, sRT, sP0, sM0, sG0, sSL0, sA, sB, sESN, sBSN, sPB0, sPE0, sNV1, sC0, sP1, sM1, sG1, sSL1, sPB1, sPE1, sP2, sSL2, sPB2, sPE2, sP3, sSL3, sPB3, sPE3;
+                    int code, sM, sTB, sRT, sR2, sP0, sM0, sG0, sSL0, sA, sB, sESN, sBSN, sPB0, sPE0, sNV1, sC0, sP1, sM1, sG1, sSL1, sPB1, sPE1, sP2, sSL2, sPB2, sPE2, sP3, sSL3, sPB3, sPE3;
                     long long inb, amok, msk;
 #ifdef ABPOA_HIP_ASM_CENSUS
                     const int asm_row0 = row; const long long asm_t0 = (long long)__builtin_amdgcn_s_memtime();
@@ -1252,13 +1254,13 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     const int mxb = (int)(unsigned)(size_t)(lds_int_t *)s_mx, qb = (int)(unsigned)(size_t)(lds_int_t *)(const void *)s_query;
                     asm volatile(TIGHT_ASM_I16_AFFINE_DIR
                         : [row] "+s"(row), [cur] "+s"(cur), [qcb] "+s"(qc_beg_sn), [code] "=&s"(code), [geo] "+v"(vg_geo), [mi] "+v"(vg_mi), [off] "+v"(vg_off), [qoff0] "+v"(qoff0),
-                          [qoff1] "+v"(qoff1), [sM] "=&s"(sM), [sTB] "=&s"(sTB), [sRT] "=&s"(sRT), [sP0] "=&s"(sP0), [sM0] "=&s"(sM0), [sG0] "=&s"(sG0), [sSL0] "=&s"(sSL0), [sA] "=&s"(sA),
+                          [qoff1] "+v"(qoff1), [sM] "=&s"(sM), [sTB] "=&s"(sTB), [sRT] "=&s"(sRT), [sR2] "=&s"(sR2), [sP0] "=&s"(sP0), [sM0] "=&s"(sM0), [sG0] "=&s"(sG0), [sSL0] "=&s"(sSL0), [sA] "=&s"(sA),
                           [sB] "=&s"(sB), [sESN] "=&s"(sESN), [sBSN] "=&s"(sBSN), [sPB0] "=&s"(sPB0), [sPE0] "=&s"(sPE0), [sNV1] "=&s"(sNV1), [sC0] "=&s"(sC0), [sP1] "=&s"(sP1),
                           [sM1] "=&s"(sM1), [sG1] "=&s"(sG1), [sSL1] "=&s"(sSL1), [sPB1] "=&s"(sPB1), [sPE1] "=&s"(sPE1), [sP2] "=&s"(sP2), [sSL2] "=&s"(sSL2), [sPB2] "=&s"(sPB2),
                           [sPE2] "=&s"(sPE2), [sP3] "=&s"(sP3), [sSL3] "=&s"(sSL3), [sPB3] "=&s"(sPB3), [sPE3] "=&s"(sPE3), [inb] "=&s"(inb), [amok] "=&s"(amok), [msk] "=&s"(msk)
-                        : [lane] "v"(lane), [tvmeta] "v"(tv_meta), [tvtb] "v"(tv_tb), [tvrt] "v"(tv_rterm), [tvp2] "v"(tv_p2), [tvp3] "v"(tv_p3), [vslot] "v"(vslot), [le1] "v"(le1), [cf1] "v"(cf1), [inj1] "v"(inj1), [kN] "v"(kN),
-                          [kE] "v"(kE), [vvl] "v"(vvl), [vl] "v"(l), [infwv] "v"(infw_v), [infv] "v"(inf_v), [gn] "s"(gn), [w] "s"(w), [qlen] "s"(qlen), [rc] "s"(RC), [mxb] "s"(mxb), [fastlo] "s"(fast_lo),
-                          [e1] "s"(e1), [oe1] "s"(oe1), [infk] "s"(inf + 32768), [planes] "s"(io.planes), [rhi] "s"(r_hi), [qb] "s"(qb), [m] "s"(m), [perm] "s"(0x05040100)
+                        : [lane] "v"(lane), [tvmeta] "v"(tv_meta), [tvtb] "v"(tv_tb), [tvr1] "v"(tv_r1), [tvr2] "v"(tv_r2), [tvp2] "v"(tv_p2), [tvp3] "v"(tv_p3), [vslot] "v"(vslot), [le1] "v"(le1), [cf1] "v"(cf1), [inj1] "v"(inj1), [kN] "v"(kN),
+                          [kE] "v"(kE), [vvl] "v"(vvl), [vl] "v"(l), [infwv] "v"(infw_v), [infv] "v"(inf_v), [c1] "s"(1 - w), [c2] "s"(1 + w), [qlen] "s"(qlen), [rc] "s"(RC), [mxb] "s"(mxb), [fastlo] "s"(fast_lo),
+                          [e1] "s"(e1), [oe1] "s"(oe1), [infk] "s"((int)((((unsigned)(inf + 32768)) << 16) | 0xffffu)), [planes] "s"(io.planes), [rhi] "s"(r_hi), [qb] "s"(qb), [m] "s"(m), [perm] "s"(0x05040100)
                         : "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
                           "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc", "m0", "memory");
                     ok_ = code == 1 ? 0 : (code == 2 ? -1 : 1);

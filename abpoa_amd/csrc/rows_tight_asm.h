@@ -74,14 +74,13 @@
 #define vD01 "v[98:99]"
 
 // band of the row, reference :710-720, in two halves so that the ring reads -- which need the band START only -- go out before the band END and the row's
-// conditions are computed (LDS latency under ~17 scalar instructions instead of ~5):  TA_BAND_BEG: mn + 1 in sA -> beg_sn before the max with min_pb;
-// TA_BAND_END: mx + 1 in sB -> end_sn in sESN
+// conditions are computed (LDS latency under ~17 scalar instructions instead of ~5):  TA_BAND_BEG: mn + 1 - w in sA -> beg_sn before the max with min_pb;
+// TA_BAND_END: mx + 1 + w in sB -> end_sn in sESN.  The row's static terms come from two tile registers, R1 = min(rows, qlen - remaining) - w (in sRT) and
+// R2 = (qlen - remaining) + w (in sR2): beg = max(0, min(mn + 1 - w, R1)), end = min(qlen, max(mx + 1 + w, R2)) -- min / max commute with the shift by w
 #define TA_BAND_BEG                                                                                          \
-    "s_min_i32 %[sA], %[gn], %[sA]\n\t"   "s_min_i32 %[sA], %[sA], %[sRT]\n\t"  "s_sub_i32 %[sA], %[sA], %[w]\n\t"      \
-    "s_max_i32 %[sA], %[sA], 0\n\t"       "s_lshr_b32 %[sA], %[sA], 4\n\t"
+    "s_min_i32 %[sA], %[sA], %[sRT]\n\t"  "s_max_i32 %[sA], %[sA], 0\n\t"       "s_lshr_b32 %[sA], %[sA], 4\n\t"
 #define TA_BAND_END                                                                                          \
-    "s_max_i32 %[sB], %[sB], %[sRT]\n\t"  "s_add_i32 %[sB], %[sB], %[w]\n\t"    "s_min_i32 %[sB], %[sB], %[qlen]\n\t"   \
-    "s_lshr_b32 %[sESN], %[sB], 4\n\t"
+    "s_max_i32 %[sB], %[sB], %[sR2]\n\t"  "s_min_i32 %[sB], %[sB], %[qlen]\n\t" "s_lshr_b32 %[sESN], %[sB], 4\n\t"
 // the query-code cache (before the reads: the substitution score's address comes from it); LBL = path suffix
 #define TA_QCACHE(LBL)                                                                                       \
     "s_cmp_lg_u32 %[sBSN], %[qcb]\n\t"     "s_cbranch_scc1 L_ref" LBL "_%=\n\t"                              \
@@ -204,8 +203,8 @@
     "v_readlane_b32 %[sA], " vAK ", 63\n\t"                                                                  \
     "s_bitset1_b32 %[sB], 24\n\t"                                                                            \
     "v_writelane_b32 %[geo], %[sB], m0\n\t"     "v_writelane_b32 %[off], %[cur], m0\n\t"                     \
-    "s_lshr_b32 %[sM0], %[sA], 16\n\t"          "s_and_b32 %[sA], %[sA], 63\n\t"      "s_add_i32 %[sA], %[sA], %[sC0]\n\t" \
-    "s_cmp_gt_i32 %[sM0], %[infk]\n\t"          "s_cselect_b32 %[sA], %[sA], -1\n\t"                         \
+    "s_and_b32 %[sM0], %[sA], 63\n\t"           "s_add_i32 %[sM0], %[sM0], %[sC0]\n\t"                       \
+    "s_cmp_gt_u32 %[sA], %[infk]\n\t"           "s_cselect_b32 %[sA], %[sM0], -1\n\t"      /* (row maximum above "inf": the whole key against (inf + 32768) << 16 | 0xffff) */ \
     "v_writelane_b32 %[mi], %[sA], m0\n\t"                                                                   \
     "s_add_i32 %[cur], %[cur], %[sNV1]\n\t"     "s_add_i32 %[cur], %[cur], 1\n\t"                            \
     "s_add_i32 %[row], %[row], 1\n\t"           "s_cmp_lt_i32 %[row], %[rhi]\n\t"     "s_cbranch_scc1 L_row_%=\n\t"
@@ -262,7 +261,7 @@
     TA_FOLD("%[sP1]", "%[sSL1]", "%[sPB1]", "%[sPE1]")                                                       \
     TA_FOLD("%[sP2]", "%[sSL2]", "%[sPB2]", "%[sPE2]")                                                       \
     IF4(TA_FOLD("%[sP3]", "%[sSL3]", "%[sPB3]", "%[sPE3]"))                                                  \
-    "s_add_i32 %[sA], %[sA], 1\n\t"               "s_add_i32 %[sB], %[sB], 1\n\t"                            \
+    "s_add_i32 %[sA], %[sA], %[c1]\n\t"               "s_add_i32 %[sB], %[sB], %[c2]\n\t"                            \
     TA_BAND_BEG                                                                                              \
     "s_min_u32 %[sESN], %[sPB0], %[sPB1]\n\t"     "s_min_u32 %[sESN], %[sESN], %[sPB2]\n\t"   IF4("s_min_u32 %[sESN], %[sESN], %[sPB3]\n\t") \
     "s_max_u32 %[sBSN], %[sA], %[sESN]\n\t"                                                                  \
@@ -331,14 +330,15 @@
     "s_mov_b32 %[code], 3\n\t"                                                                               \
     TA_LOOP_HEAD                                                                                             \
     "L_row_%=:\n\t"                                                                                          \
-    "v_readlane_b32 %[sM], %[tvmeta], %[row]\n\t"   "v_readlane_b32 %[sTB], %[tvtb], %[row]\n\t"   "v_readlane_b32 %[sRT], %[tvrt], %[row]\n\t" \
+    "v_readlane_b32 %[sM], %[tvmeta], %[row]\n\t"   "v_readlane_b32 %[sTB], %[tvtb], %[row]\n\t"   "v_readlane_b32 %[sRT], %[tvr1], %[row]\n\t" \
+    "v_readlane_b32 %[sR2], %[tvr2], %[row]\n\t"                                                            \
     "s_and_b32 m0, %[row], 63\n\t"                                                                           \
     "s_and_b32 %[sA], %[sTB], 0xff\n\t"         "s_sub_i32 %[sP0], %[row], %[sA]\n\t"                        \
     "v_readlane_b32 %[sM0], %[mi], %[sP0]\n\t"  "v_readlane_b32 %[sG0], %[geo], %[sP0]\n\t"   "v_readlane_b32 %[sSL0], %[vslot], %[sP0]\n\t" \
     "s_bitcmp1_b32 %[sM], 17\n\t"               "s_cbranch_scc0 L_n17_%=\n\t"                                \
     "s_bitcmp1_b32 %[sM], 9\n\t"                "s_cbranch_scc1 L_two_%=\n\t"                                \
     /* ---------------- one predecessor */                                                                   \
-    "s_add_i32 %[sB], %[sM0], 1\n\t"            "s_mov_b32 %[sA], %[sB]\n\t"                                 \
+    "s_add_i32 %[sA], %[sM0], %[c1]\n\t"        "s_add_i32 %[sB], %[sM0], %[c2]\n\t"                                 \
     TA_BAND_BEG                                                                                              \
     "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_max_u32 %[sBSN], %[sA], %[sPB0]\n\t"                      \
     TA_QCACHE("1")                                                                                           \
@@ -354,7 +354,7 @@
     "s_bfe_u32 %[sA], %[sTB], 0x80008\n\t"      "s_sub_i32 %[sP1], %[row], %[sA]\n\t"                        \
     "v_readlane_b32 %[sM1], %[mi], %[sP1]\n\t"  "v_readlane_b32 %[sG1], %[geo], %[sP1]\n\t"   "v_readlane_b32 %[sSL1], %[vslot], %[sP1]\n\t" \
     "s_min_i32 %[sA], %[sM0], %[sM1]\n\t"       "s_max_i32 %[sB], %[sM0], %[sM1]\n\t"                        \
-    "s_add_i32 %[sA], %[sA], 1\n\t"             "s_add_i32 %[sB], %[sB], 1\n\t"                              \
+    "s_add_i32 %[sA], %[sA], %[c1]\n\t"             "s_add_i32 %[sB], %[sB], %[c2]\n\t"                              \
     TA_BAND_BEG                                                                                              \
     "s_and_b32 %[sPB0], %[sG0], 0xfff\n\t"      "s_and_b32 %[sPB1], %[sG1], 0xfff\n\t"                       \
     "s_min_u32 %[sESN], %[sPB0], %[sPB1]\n\t"   "s_max_u32 %[sBSN], %[sA], %[sESN]\n\t"                      \
