@@ -113,19 +113,7 @@
     "v_lshl_add_u32 " vQA ", %[qoff0], 2, %[mxb]\n\t"                                                        \
     "s_branch L_refd" LBL "_%=\n\t"
 // column, substitution score and the first predecessor's ring words (two LDS reads in flight)
-// (-DABPOA_HIP_ASM_PROBE=1 | 2: five wait states off / on the row-to-row dependency chain -- what an instruction costs where; timing experiment)
-#if defined(ABPOA_HIP_ASM_PROBE) && ABPOA_HIP_ASM_PROBE == 2
-#define TA_PROBE_CHAIN "s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t"
-#else
-#define TA_PROBE_CHAIN
-#endif
-#if defined(ABPOA_HIP_ASM_PROBE) && ABPOA_HIP_ASM_PROBE == 1
-#define TA_PROBE_OFF "s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t"
-#else
-#define TA_PROBE_OFF
-#endif
 #define TA_READS                                                                                             \
-    TA_PROBE_CHAIN                                                                                           \
     "s_lshl_b32 %[sC0], %[sBSN], 4\n\t"    "v_add_u32 " vCOL ", %[sC0], %[lane]\n\t"                         \
     "s_ashr_i32 %[sA], %[sTB], 16\n\t"     "v_add_u32 " vX ", %[sA], " vQA "\n\t"    "ds_read_b32 " vQ ", " vX "\n\t"   \
     "s_lshl_b32 %[sA], %[sPB0], 4\n\t"     "v_xad_u32 " vX ", %[sA], -1, " vCOL "\n\t"  "v_med3_i32 " vX ", " vX ", -2, %[rc]\n\t" \
@@ -209,7 +197,6 @@
 #define TA_TAIL(S)                                                                                           \
     "v_lshl_or_b32 " vU ", " vD ", 3, " vU "\n\t"   "v_lshl_or_b32 " vWD ", " vU ", 8, " vKF "\n\t"           \
     S("v_lshl_or_b32 " vWD ", " vSH ", 14, " vWD "\n\t")                                                     \
-    TA_PROBE_OFF                                                                                             \
     "global_store_short " vRO ", " vWD ", %[planes]\n\t"                                                     \
     "v_cndmask_b32_e64 " vHE ", %[infwv], " vHE ", %[inb]\n\t"                                                   \
     "ds_write2st64_b32 " vQD ", " vHE ", %[infwv] offset1:1\n\t"                                             \
