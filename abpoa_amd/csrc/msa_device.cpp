@@ -211,7 +211,12 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         if (force_general) general = true;
     }
     // direction-plane arenas (dir_plane.h) whenever the penalties allow it: 2 / 4 bytes per cell instead of 8 - 32; ABPOA_HIP_NODIR=1 keeps the score records
-    const bool dir = !local && !extend && !general && !amb && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
+    // the last pass of the ladder (msa_hip.cpp device_passes): edge slots for one edge per read at every node -- a node takes at most one new in-edge and one new
+    // out-edge per read, so a set can no longer run out of them (the terminals keep their pools: reads that start / end on different nodes); score records
+    // instead of direction words there (dir_plane.h names a predecessor by its list index in four bits)
+    const bool roomy = node_factor >= 4096.0;
+    const int in_cap = roomy ? std::max((int)POA_IN_CAP, std::min(250, max_reads + 1)) : POA_IN_CAP, out_cap = roomy ? std::max((int)POA_OUT_CAP, std::min(250, max_reads + 1)) : POA_OUT_CAP;
+    const bool dir = !local && !extend && !general && !amb && in_cap <= POA_IN_CAP && dir_plane_usable(sc->gap_mode, sc->gap_open1, sc->gap_ext1, sc->gap_open2,
             sc->gap_ext2) && !(opt_env("ABPOA_HIP_NODIR") && atoi(opt_env("ABPOA_HIP_NODIR"))) &&
                      !(opt_env("ABPOA_HIP_TEAM") && atoi(opt_env("ABPOA_HIP_TEAM")) > 1);
     const int DB = sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 2 : 4;
@@ -326,11 +331,11 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     const size_t dl_bytes = o;
     L.o_order0 = take(4 * node_tot); L.o_order1 = take(4 * node_tot); L.o_base = take(node_tot); L.o_nout = take(node_tot);
     L.o_out = take(4 * node_tot * POA_HOT); L.o_outw = take(4 * node_tot * POA_HOT); L.o_nread = take(4 * node_tot);
-    L.o_outx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT)); L.o_outwx = take(4 * node_tot * (POA_OUT_CAP - POA_HOT));
-    L.o_inx = take(4 * node_tot * (POA_IN_CAP - POA_HOT));
+    L.o_outx = take(4 * node_tot * (size_t)(out_cap - POA_HOT)); L.o_outwx = take(4 * node_tot * (size_t)(out_cap - POA_HOT));
+    L.o_inx = take(4 * node_tot * (size_t)(in_cap - POA_HOT));
     L.o_nin = take(node_tot); L.o_naln = take(node_tot); L.o_in = take(4 * node_tot * POA_HOT); L.o_aln = take(4 * node_tot * (size_t)aln_cap);
     L.o_row = take(4 * node_tot);
-    L.o_rid = take(8 * node_tot * POA_OUT_CAP * (size_t)rid_words); L.o_mrank = take(want_msa ? 4 * node_tot : 0);
+    L.o_rid = take(8 * node_tot * (size_t)out_cap * (size_t)rid_words); L.o_mrank = take(want_msa ? 4 * node_tot : 0);
     L.o_msaoff = take(want_msa ? 8 * (size_t)n_sets : 0);
     L.o_tout = take(4 * term_tot); L.o_toutw = take(4 * term_tot); L.o_tin = take(4 * term_tot);
     L.graph_bytes = o;
@@ -425,6 +430,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     p.e2 = sc->gap_ext2;
     p.wb = sc->wb; p.wf = sc->wf; p.gap_mode = sc->gap_mode; p.max_qlen = max_qlen;
     p.last_pass = node_factor >= 6.0 ? 1 : 0;      // (msa_hip.cpp device_passes: 3x, 4.5x, 6x)
+    p.in_cap = in_cap; p.out_cap = out_cap;
     p.dig_on = cigar_digest_on() ? 1 : 0;      // (tests: the fuse phase folds every graph cigar into PoaState.cigar_dig)
     // (the reference's own row order where the best cell is the FIRST row that reaches the maximum: local and extension mode, ref :1012-1026; the remaining
     //  length where something reads it: the adaptive band and the z-drop test)
@@ -693,8 +699,8 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     });
     dbg.msa_check(hs, out);
     dbg.consensus_check(hs, out);
-    // (a set whose edge or aligned lists are full gains nothing from a pass with more node slots: -(s + 1) tells the caller to hand it to the host driver at
-    //  once)
+    // (a set with a node out of edge slots gains nothing from a pass with more node slots: -(s + 1) tells the caller to take it to the last pass -- `roomy`
+    //  above -- at once, and to the host driver if that was this one: a terminal with more than POA_TERM_MAX edges)
     for (int s = 0; s < n_sets; ++s) if (need_fb[s]) fallback->push_back(need_fb[s] == 2 ? -(s + 1) : s);
     if (fallback_reason) {
         fallback_reason->clear();
@@ -717,7 +723,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         if (hist[5]) fprintf(stderr, "[abpoa-hip]   DP status: arena too small for the bands %d, direction words undecided %d, other %d\n", dp_arena,
                 dp_scores, dp_other);
         fprintf(stderr, "[abpoa-hip] fallback reasons: node cap at init %d, pred CSR cap %d, cigar cap %d, node slots in the fuse "
-                "phase %d, edge / aligned slots of a node full (host driver at once) %d, DP status %d, projected node growth "
+                "phase %d, edge slots of a node full (redone in the last pass) %d, DP status %d, projected node growth "
                 "(early exit at read 10) %d, other %d\n", hist[1], hist[2], hist[3], hist[4], n_slots, hist[5], hist[7], hist[6] + hist[0]);
     }
     if (stats) {

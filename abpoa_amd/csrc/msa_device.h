@@ -25,9 +25,9 @@ struct DeviceRunStats {
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
 
 // Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
-// them) and must be redone (with a larger node_factor, or by the host driver; an entry -(s + 1) is set s with a full edge / aligned list: more node slots
-// would not help, host driver at once).  node_factor: node slots per set = factor x
-// longest read.  ABPOA_HIP_ENOMEM: the job does not fit the device (split it); EINVAL: not a job for the device driver.
+// them) and must be redone (with a larger node_factor, or by the host driver; an entry -(s + 1) is set s with a node out of edge slots: more node slots
+// would not help, the last pass does).  node_factor: node slots per set = factor x
+// longest read; 4096 and more: the last pass -- every node also has an edge slot per read (score records instead of direction words).  ABPOA_HIP_ENOMEM: the job does not fit the device (split it); EINVAL: not a job for the device driver.
 // device < 0: the device the engine was initialised on.  slot: which of the per-worker pool caches to use (one worker = one device queue of
 // the multi-GPU batch call; workers may share a device); a slot runs one job at a time.
 constexpr int MSA_DEVICE_SLOTS = 16;

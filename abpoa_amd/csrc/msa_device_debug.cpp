@@ -14,13 +14,13 @@ namespace abpoa_hip {
 // successors' values only, so the visiting order does not matter as long as successors come first.
 void consensus_flat(int n, const int32_t *order, const uint8_t *base, const uint8_t *nout, const int32_t *out_id, const int32_t *out_w,
                     const int32_t *n_read, std::vector<int> *ids, std::vector<uint8_t> *bases, std::vector<int> *cov, std::vector<int> &score,
-                            std::vector<int> &max_out) {
+                            std::vector<int> &max_out, int out_cap) {
     ids->clear(); bases->clear(); cov->clear();
     if (n <= 2) return;
     score.assign(n, 0); max_out.assign(n, -1);
     for (int r = n - 1; r >= 0; --r) {
         const int cur = order[r];
-        const int32_t *oi = out_id + (size_t)cur * POA_OUT_CAP, *ow = out_w + (size_t)cur * POA_OUT_CAP; const int no = nout[cur];
+        const int32_t *oi = out_id + (size_t)cur * out_cap, *ow = out_w + (size_t)cur * out_cap; const int no = nout[cur];
         if (cur == 1) { max_out[cur] = -1; score[cur] = 0; }
         else if (cur == 0) {
             int path_score = -1, path_max_w = -1, max_id = -1;
@@ -109,7 +109,7 @@ void DeviceDebug::graph_check(int k) {
                     ? sets[s].weights[k] : nullptr));
         }
         if (hst.status != POA_ST_OK) continue;
-        std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * POA_IN_CAP), outv(n * POA_OUT_CAP), outw(n * POA_OUT_CAP),
+        std::vector<uint8_t> base(n), nin(n), nout(n), naln(n); std::vector<int32_t> in(n * (int)p.in_cap), outv(n * (int)p.out_cap), outw(n * (int)p.out_cap),
                 aln((size_t)n * aln_cap), nread(n), row(n), order(n);
         auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per,
                 (size_t)n * elem * per, hipMemcpyDeviceToHost); };
@@ -122,8 +122,8 @@ void DeviceDebug::graph_check(int k) {
             for (int u_ = 0; u_ < n; ++u_) for (int t_ = 0; t_ < cap_; ++t_) dst[(size_t)u_ * cap_ + t_] = t_ < POA_HOT ? h_[(size_t)u_ * POA_HOT + t_]
                     : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
         };
-        dl_list(in.data(), p.nd_in, p.nd_inx, POA_IN_CAP); dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(), p.nd_outw, p.nd_outwx,
-                POA_OUT_CAP); dl(aln.data(), p.nd_aln, 4, aln_cap);
+        dl_list(in.data(), p.nd_in, p.nd_inx, (int)p.in_cap); dl_list(outv.data(), p.nd_out, p.nd_outx, (int)p.out_cap); dl_list(outw.data(), p.nd_outw, p.nd_outwx,
+                (int)p.out_cap); dl(aln.data(), p.nd_aln, 4, aln_cap);
         dl(nread.data(), p.nd_nread, 4, 1); dl(row.data(), p.nd_row, 4, 1); dl(order.data(), p.row_node[hst.order_buf], 4, 1);
         int bad = 0;
         auto complain = [&](const char *what, int a, int b_) { if (bad++ < 8) fprintf(stderr, "[poa-device]   set %d round %d: %s (%d, %d)\n", s, k, what, a,
@@ -136,13 +136,13 @@ void DeviceDebug::graph_check(int k) {
             const PoaNode &h = G.node(u);
             if (h.base != base[u]) complain("base differs", u, base[u]);
             if (h.in_id.size() != nin[u]) complain("in-degree differs", u, nin[u]);
-            else for (int t = 0; t < std::min<int>(nin[u], POA_IN_CAP); ++t) { if (h.in_id[t] != in[u * POA_IN_CAP + t]) complain("in edge differs", u, t);
-                    if (row[in[u * POA_IN_CAP
-                    + t]] >= row[u]) complain("order violated (pred row >= row)", in[u * POA_IN_CAP + t], u); }
+            else for (int t = 0; t < std::min<int>(nin[u], (int)p.in_cap); ++t) { if (h.in_id[t] != in[u * (int)p.in_cap + t]) complain("in edge differs", u, t);
+                    if (row[in[u * (int)p.in_cap
+                    + t]] >= row[u]) complain("order violated (pred row >= row)", in[u * (int)p.in_cap + t], u); }
             if (h.out_id.size() != nout[u]) complain("out-degree differs", u, nout[u]);
-            else for (int t = 0; t < std::min<int>(nout[u], POA_OUT_CAP); ++t) { if (h.out_id[t] != outv[u * POA_OUT_CAP + t]) complain("out edge differs", u,
+            else for (int t = 0; t < std::min<int>(nout[u], (int)p.out_cap); ++t) { if (h.out_id[t] != outv[u * (int)p.out_cap + t]) complain("out edge differs", u,
                     t);
-                    if (h.out_w[t] != outw[u * POA_OUT_CAP + t]) complain("out weight differs", u, t); }
+                    if (h.out_w[t] != outw[u * (int)p.out_cap + t]) complain("out weight differs", u, t); }
             if (h.aligned.size() != naln[u]) complain("aligned count differs", u, naln[u]);
             else for (int t = 0; t < naln[u]; ++t) if (h.aligned[t] != aln[(size_t)u * aln_cap + t]) complain("aligned node differs", u, t);
             if (h.n_read != nread[u]) complain("n_read differs", u, nread[u]);
@@ -254,7 +254,7 @@ void DeviceDebug::consensus_check(const PoaState *hs, const abpoa_hip_msa_t *out
     for (int s = 0; s < std::min(n_sets, 4); ++s) {
         if (hs[s].status != POA_ST_OK) continue;
         const PoaSet &S = ps[s]; const int n = hs[s].n_nodes;
-        std::vector<uint8_t> base(n), nout(n); std::vector<int32_t> outv((size_t)n * POA_OUT_CAP), outw((size_t)n * POA_OUT_CAP), nread(n), order(n);
+        std::vector<uint8_t> base(n), nout(n); std::vector<int32_t> outv((size_t)n * (int)p.out_cap), outw((size_t)n * (int)p.out_cap), nread(n), order(n);
         auto dl = [&](void *dst, const void *pool, size_t elem, size_t per) { (void)hipMemcpy(dst, (const uint8_t *)pool + (size_t)S.node0 * elem * per,
                 (size_t)n * elem * per, hipMemcpyDeviceToHost); };
         // edge lists come back as hot + cold halves and are merged into [node][CAP] arrays
@@ -266,13 +266,13 @@ void DeviceDebug::consensus_check(const PoaState *hs, const abpoa_hip_msa_t *out
                     : c_[(size_t)u_ * (cap_ - POA_HOT) + t_ - POA_HOT];
         };
         dl(base.data(), p.nd_base, 1, 1); dl(nout.data(), p.nd_nout, 1, 1);
-        if (nout[0] > POA_OUT_CAP) { fprintf(stderr, "[poa-device]   set %d: consensus check skipped (the source has %d out-edges: the check's arrays hold "
-                "%d per node)\n", s, (int)nout[0], POA_OUT_CAP); continue; }
-        dl_list(outv.data(), p.nd_out, p.nd_outx, POA_OUT_CAP); dl_list(outw.data(),
-                p.nd_outw, p.nd_outwx, POA_OUT_CAP);
+        if (nout[0] > (int)p.out_cap) { fprintf(stderr, "[poa-device]   set %d: consensus check skipped (the source has %d out-edges: the check's arrays hold "
+                "%d per node)\n", s, (int)nout[0], (int)p.out_cap); continue; }
+        dl_list(outv.data(), p.nd_out, p.nd_outx, (int)p.out_cap); dl_list(outw.data(),
+                p.nd_outw, p.nd_outwx, (int)p.out_cap);
         dl(nread.data(), p.nd_nread, 4, 1); dl(order.data(), p.row_node[hs[s].order_buf], 4, 1);
         std::vector<int> ids, cov, sc_, mo; std::vector<uint8_t> bases;
-        consensus_flat(n, order.data(), base.data(), nout.data(), outv.data(), outw.data(), nread.data(), &ids, &bases, &cov, sc_, mo);
+        consensus_flat(n, order.data(), base.data(), nout.data(), outv.data(), outw.data(), nread.data(), &ids, &bases, &cov, sc_, mo, (int)p.out_cap);
         bool same = (int)ids.size() == out[s].cons_len;
         for (size_t i = 0; same && i < ids.size(); ++i) same = ids[i] == out[s].cons_node_id[i] && bases[i] == out[s].cons_base[i]
                 && cov[i] == out[s].cons_cov[i];

@@ -10,9 +10,9 @@
 
 namespace abpoa_hip {
 
-// Heaviest-bundling consensus from flat [node][POA_OUT_CAP] edge arrays (the host-side check of poa_consensus_kernel)
+// Heaviest-bundling consensus from flat [node][out_cap] edge arrays (the host-side check of poa_consensus_kernel)
 void consensus_flat(int n, const int32_t *order, const uint8_t *base, const uint8_t *nout, const int32_t *out_id, const int32_t *out_w, const int32_t *n_read,
-                    std::vector<int> *ids, std::vector<uint8_t> *bases, std::vector<int> *cov, std::vector<int> &score, std::vector<int> &max_out);
+                    std::vector<int> *ids, std::vector<uint8_t> *bases, std::vector<int> *cov, std::vector<int> &score, std::vector<int> &max_out, int out_cap);
 
 class DeviceDebug {
 public:

@@ -105,9 +105,13 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
         if (it != g_hint.end()) first_pass = it->second;
     }
     bool most_outgrew = false;
-    std::vector<int> hopeless;      // sets a later pass cannot hold either (run_msa_device marks them): the caller's, with what the last pass leaves
+    // sets with a node out of edge slots (run_msa_device marks them): more node slots do not help, the LAST pass does -- it has an edge slot per read at
+    // every node (msa_device.cpp `roomy`) -- so they skip the passes in between; what the last pass marks is the caller's
+    std::vector<int> deferred, hopeless;
     int n_small = 0, n_done = 0;      // (sets that would also have fitted the 3x estimate / sets that finished)
-    for (int pass = first_pass; pass < NPASS && R.device_ok && !todo.empty(); ++pass) {
+    for (int pass = first_pass; pass < NPASS && R.device_ok && (!todo.empty() || !deferred.empty()); ++pass) {
+        if (todo.empty()) pass = NPASS - 1;
+        if (pass == NPASS - 1) { todo.insert(todo.end(), deferred.begin(), deferred.end()); deferred.clear(); std::sort(todo.begin(), todo.end()); }
         left.clear();
         size_t chunk = todo.size();
         bool halved = false;          // (the pass did not fit the device memory in the pieces first tried)
@@ -138,7 +142,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
                 break;
             }
             for (size_t i = 0; i < nb; ++i) out[todo[at + i]] = sub_out[i];
-            for (int f : fb) { if (f >= 0) left.push_back(todo[at + f]); else hopeless.push_back(todo[at + (-f - 1)]); }      // (f < 0: a full edge list -- no further device pass)
+            for (int f : fb) { if (f >= 0) left.push_back(todo[at + f]); else (pass < NPASS - 1 ? deferred : hopeless).push_back(todo[at + (-f - 1)]); }      // (f < 0: a full edge list)
             for (size_t i = 0; i < fb.size() && i < fb_why.size(); ++i) R.why[todo[at + (fb[i] < 0 ? -fb[i] - 1 : fb[i])]] = fb_why[i];
             add_stats(R.tot, ds);
             n_small += ds.n_fit_3x;
@@ -157,7 +161,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
         }
         // most sets of the previous pass outgrew it and this one held most of them (in the pieces first tried): jobs of this shape start here next time
         const bool outgrew_now = left.size() * 2 >= todo.size();
-        if (R.device_ok && pass > 0 && most_outgrew && !outgrew_now && !halved) { std::lock_guard<std::mutex> lk(g_hint_mu); g_hint[key] = pass; }
+        if (R.device_ok && pass > 0 && pass < NPASS - 1 && most_outgrew && !outgrew_now && !halved) { std::lock_guard<std::mutex> lk(g_hint_mu); g_hint[key] = pass; }
         if (R.device_ok) most_outgrew = outgrew_now;
         // the hint is dropped again when a job that started higher because of it turns out to fit 3x (a cleaner job of the same shape): more
         // graph and arena memory for nothing otherwise, for as long as the process lives
@@ -168,6 +172,7 @@ PassOut device_passes(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *
         if (R.device_ok) todo.swap(left);
     }
     R.left = todo;
+    R.left.insert(R.left.end(), deferred.begin(), deferred.end());      // (only when the device path gave up on the job)
     R.left.insert(R.left.end(), hopeless.begin(), hopeless.end());
     return R;
 }

@@ -22,13 +22,13 @@ __device__ __forceinline__ int ld_fresh(const int32_t *p) { return __hip_atomic_
 // capacity on exist for the source's out-edges and the sink's in-edges only (PoaSet.term0: the set's slice of the terminal pools)
 constexpr int POA_TERM_MAX = 250;      // edges of the source / into the sink at most (the counts are bytes)
 __device__ __forceinline__ int32_t &in_slot(const PoaDev &p, const PoaSet &S, int64_t X, int t) {
-    return t < POA_HOT ? p.nd_in[X * POA_HOT + t] : (t < POA_IN_CAP ? p.nd_inx[X * (POA_IN_CAP - POA_HOT) + t - POA_HOT] : p.t_in[S.term0 + t - POA_IN_CAP]);
+    return t < POA_HOT ? p.nd_in[X * POA_HOT + t] : (t < p.in_cap ? p.nd_inx[X * (p.in_cap - POA_HOT) + t - POA_HOT] : p.t_in[S.term0 + t - p.in_cap]);
 }
 __device__ __forceinline__ int32_t &out_slot(const PoaDev &p, const PoaSet &S, int64_t X, int t) {
-    return t < POA_HOT ? p.nd_out[X * POA_HOT + t] : (t < POA_OUT_CAP ? p.nd_outx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT] : p.t_out[S.term0 + t - POA_OUT_CAP]);
+    return t < POA_HOT ? p.nd_out[X * POA_HOT + t] : (t < p.out_cap ? p.nd_outx[X * (p.out_cap - POA_HOT) + t - POA_HOT] : p.t_out[S.term0 + t - p.out_cap]);
 }
 __device__ __forceinline__ int32_t &outw_slot(const PoaDev &p, const PoaSet &S, int64_t X, int t) {
-    return t < POA_HOT ? p.nd_outw[X * POA_HOT + t] : (t < POA_OUT_CAP ? p.nd_outwx[X * (POA_OUT_CAP - POA_HOT) + t - POA_HOT] : p.t_outw[S.term0 + t - POA_OUT_CAP]);
+    return t < POA_HOT ? p.nd_outw[X * POA_HOT + t] : (t < p.out_cap ? p.nd_outwx[X * (p.out_cap - POA_HOT) + t - POA_HOT] : p.t_outw[S.term0 + t - p.out_cap]);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }      // a value that is the same in every lane -> scalar register
 __device__ __forceinline__ int shfl(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
@@ -358,17 +358,17 @@ __device__ __forceinline__ void poa_fuse_body(const PoaDev &p, const int s, cons
         else {
             const int ni = to_new ? 0 : (int)p.nd_nin[T];
             // (the source may have any number of out-edges, the sink of in-edges: reads that start / end on different nodes; PoaSet.term0)
-            if (no >= (from == 0 ? imin_(POA_TERM_MAX, POA_OUT_CAP + S.n_reads + 2) : POA_OUT_CAP) || ni >= (to == 1 ? imin_(POA_TERM_MAX, POA_IN_CAP + S.n_reads + 2) : POA_IN_CAP)) { fail = true;
+            if (no >= (from == 0 ? imin_(POA_TERM_MAX, p.out_cap + S.n_reads + 2) : p.out_cap) || ni >= (to == 1 ? imin_(POA_TERM_MAX, p.in_cap + S.n_reads + 2) : p.in_cap)) { fail = true;
                     fail_slots = true; return; }
             out_slot(p, S, F, no) = to; outw_slot(p, S, F, no) = w; p.nd_nout[F] = (uint8_t)(no + 1);
             in_slot(p, S, T, ni) = from; p.nd_nin[T] = (uint8_t)(ni + 1);
             hit = no;
             // (a new edge: no read went through it yet.  The source's edges beyond the capacity keep no read ids: nothing reads the source's -- the MSA rows
             //  come from the out-edges of nodes 2.., reference abpoa_output.c:142-150)
-            if (hit < POA_OUT_CAP) for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + w_] = 0;
+            if (hit < p.out_cap) for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[(F * p.out_cap + hit) * p.rid_words + w_] = 0;
         }
         // read k went through this edge (reference :453-472; a node is the tail of at most one edge per read, so no other lane touches these words)
-        if (p.rid_words && hit < POA_OUT_CAP) p.nd_rid[(F * POA_OUT_CAP + hit) * p.rid_words + (k >> 6)] |= 1ull << (k & 63);
+        if (p.rid_words && hit < p.out_cap) p.nd_rid[(F * p.out_cap + hit) * p.rid_words + (k >> 6)] |= 1ull << (k & 63);
         p.nd_nread[F] = (from_new ? 0 : p.nd_nread[F]) + 1;
     };
     // all wavefronts walk the query together, GT positions per pass: per-position work (node lookup, new node, edge) is private to

@@ -73,6 +73,8 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
                                    // kernel (rows_general.h: linear gaps, extension mode, no band, long local reads) -- prepare also writes the successor CSR it reads
     int32_t last_pass, pad_lp;     // last_pass: the largest node capacity there is -- no early exit on projected growth (the projection errs on ragged read-sets,
                                    // whose reads add their nodes in bursts; a set that really outgrows this pass goes to the host driver either way)
+    int32_t in_cap, out_cap;       // edge slots per inner node (hot + cold): POA_IN_CAP / POA_OUT_CAP in every pass but the last, which has room for one edge per read
+                                   // (msa_device.cpp: a set whose node ran out of edge slots is redone there; no direction words then -- dir_plane.h names a predecessor in four bits)
     int32_t order_lds, dig_on;     // order_lds: node capacity of the order / rank kernels' LDS tables (0: the tables live in the set's scratch slice); dig_on: PoaState.cigar_dig is kept
     const PoaSet *sets; PoaState *state;
     const int64_t *read_off; const int32_t *read_len; const uint8_t *reads;       // resident reads: codes 0..m-1
@@ -80,12 +82,12 @@ struct PoaDev {                    // everything the poa_* kernels need; passed 
     // graph, indexed node0 + node id
     uint8_t *nd_base, *nd_nin, *nd_nout, *nd_naln;
     int32_t *nd_in, *nd_out, *nd_outw;              // hot slots  [node][POA_HOT]: in ids, out ids, out weights
-    int32_t *nd_inx, *nd_outx, *nd_outwx;           // cold slots [node][CAP - POA_HOT]
+    int32_t *nd_inx, *nd_outx, *nd_outwx;           // cold slots [node][in_cap / out_cap - POA_HOT]
     // The source's out-edges beyond POA_OUT_CAP and the sink's in-edges beyond POA_IN_CAP (reads that do not all start / end on the same node: every read adds
     // at most one of each, so n_reads + 2 entries per set hold them all); slot t >= CAP of node 0 / node 1 is entry t - CAP of the set's slice (poa_bodies.h out_slot / in_slot)
     int32_t *t_out, *t_outw, *t_in;
     int32_t *nd_aln;                                // [node][aln_cap]
-    uint64_t *nd_rid;                               // [node][POA_OUT_CAP][rid_words]: reads that went through the out-edge (reference abpoa_node_t.read_ids)
+    uint64_t *nd_rid;                               // [node][out_cap][rid_words]: reads that went through the out-edge (reference abpoa_node_t.read_ids)
     int32_t *nd_nread, *nd_row;
     int32_t *row_node[2];          // row order (double buffered), indexed node0 + row
     int32_t *scratch;

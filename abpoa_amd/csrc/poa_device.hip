@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64) poa_init_kernel(const PoaDev p) {
         in_slot(p, S, N0 + u, 0) = in0; out_slot(p, S, N0 + u, 0) = out0; outw_slot(p, S, N0 + u, 0) = !wq ? 1 : (u == 0 ? wq[0] : (u == 1 ? 0 : wq[i == L - 1 ? L - 1 : i + 1]));
         p.nd_nread[N0 + u] = nout;          // every edge added from a node counts one read through it
         // read 0 went through the node's one edge
-        if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * POA_OUT_CAP) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }
+        if (p.rid_words && nout) { for (int w_ = 0; w_ < p.rid_words; ++w_) p.nd_rid[((N0 + u) * p.out_cap) * p.rid_words + w_] = w_ == 0 ? 1ull : 0ull; }
         // row order: source, the chain, sink
         const int row = u == 0 ? 0 : (u == 1 ? n - 1 : u - 1);
         p.nd_row[N0 + u] = row; p.row_node[0][N0 + row] = u;
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(GT) poa_msa_fill_kernel(const PoaDev p) {
     for (int u = 2 + tid; u < n; u += GT) {
         const int col = p.msa_rank[N0 + u] - 1, no = p.nd_nout[N0 + u]; const uint8_t b = p.nd_base[N0 + u];
         for (int e = 0; e < no; ++e) for (int w_ = 0; w_ < p.rid_words; ++w_) {
-            unsigned long long num = p.nd_rid[((N0 + u) * POA_OUT_CAP + e) * p.rid_words + w_];
+            unsigned long long num = p.nd_rid[((N0 + u) * p.out_cap + e) * p.rid_words + w_];
             while (num) { const int r = w_ * 64 + __builtin_ctzll(num); num &= num - 1; if (r < S.n_reads) out[(int64_t)r * len + col] = b; }
         }
     }

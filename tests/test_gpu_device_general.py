@@ -329,8 +329,8 @@ def test_random_option_mixes_on_ragged_reads(engine):
 
 
 def test_more_start_nodes_than_the_terminal_pools_hold(engine):
-    """300 reads that all start on different nodes: the source would need 300 out-edges, the pools stop at 250 (the counts are bytes) -- the set is handed to the host
-    driver at once (no retry passes: more node slots would not help) and the result is the reference's all the same; its neighbour in the job stays on the device."""
+    """300 reads that all start on different nodes: the source would need 300 out-edges, the pools stop at 250 (the counts are bytes) -- the set goes to the last
+    pass of the ladder, overflows there too and is handed to the host driver; the result is the reference's all the same; its neighbour in the job stays on the device."""
     import helpers as H
     from abpoa_amd import api, synth
     shim = H.cpu_shim_lib()
@@ -343,6 +343,26 @@ def test_more_start_nodes_than_the_terminal_pools_hold(engine):
     ref = api.msa_batch(sets, p, out_cons=True, out_msa=False, n_threads=4, lib=shim)
     for a, b in zip(dev, ref):
         assert a.status == 0 and a.cons_seq == b.cons_seq and a.cons_cov == b.cons_cov
+
+
+def test_inner_nodes_with_more_edges_than_the_edge_slots(engine):
+    """25 reads that each delete a different number of bases behind (in front of) the same node: that node collects 26 out-edges (in-edges), more than the 16 (15)
+    slots a node has in the regular passes.  Such sets used to go to the host driver; now the pass that finds the full list sends them straight to the last
+    pass of the ladder, whose layout has a slot per read at every node (msa_device.cpp `roomy`; ABPOA_HIP_VERBOSE shows `pass 1 ... 2 sets outgrew` then
+    `pass 4 ... 0 sets`), and nothing leaves the device.  Global affine / convex, local, extension; consensus and MSA; against the oracle-backed run."""
+    import helpers as H
+    from abpoa_amd import api, synth
+    shim = H.cpu_shim_lib()
+    base = synth.make_read_set(211, 0, 1, 420, 0.0)[0]
+    fan_out = [base] + [base[:200] + base[200 + k:] for k in range(1, 26)]
+    fan_in = [base] + [base[:200 - k] + base[200:] for k in range(1, 26)]
+    sets = [fan_out, fan_in, fan_out + fan_in[1:], list(synth.make_read_set(211, 1, 12, 300, 0.05))]
+    for kw in (dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict(), dict(aln_mode=1), dict(aln_mode=2)):
+        p = api.Params(**kw)
+        dev = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+        assert api.msa_timing()["n_host_sets"] == 0, (kw, api.host_reasons())
+        ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+        _same(dev, ref, f"fan of edges {kw}")
 
 
 def test_hundreds_of_reads_per_set(engine):

@@ -105,6 +105,8 @@ def main():
             print(ex, flush=True)
             sys.exit(1)
         n_dev += d; n_host += h; n_err += e
+        if h:
+            print(f"  iteration {it} (seed {a.seed * 100000 + it}): {h} set(s) through the host driver: {why}", flush=True)
         for k_, v_ in why.items():
             hist[k_] = hist.get(k_, 0) + v_
         if it % 20 == 19:
