@@ -78,6 +78,42 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         }
     };
 
+    // Linear gaps (reference :762-778): the row's H is max(h, H[col-1] - e) taken vector by vector with SIMD_SET_F on H itself.  For the vectors that use the plain scan
+    // (set_num == pn: up to max_pre_end_sn) and while nothing can wrap, max-plus arithmetic distributes over the whole 64-lane chunk:
+    //   H[c] = max( max_{c' <= c} (h[c'] + c' e) - c e ,  first - c e ,  inf - INJ[l] e )      (first enters at lane 0; the last lane of a vector has no injection,
+    // so the vector-to-vector carry H[pn-1] - e is the clean prefix term) -- ONE 64-lane prefix-max scan instead of 64 / pn log-step scans with a readlane between them.
+    // The vectors beyond every predecessor's band (set_num 1 / 0) keep the literal masked scan.
+    const int le1 = lane * (int)e1;
+    auto linear_h = [&](int c, int beg_sn_, int end_sn_, int max_pre_, T h, T &first) __attribute__((always_inline)) -> T {
+        if (c == 0) first = (T)__builtin_amdgcn_readlane((int)h, 0);
+        const int vb = beg_sn_ + c * NV;
+        const int nvec = imin(NV, end_sn_ - vb + 1);
+        int nfast = local ? nvec : imin(nvec, max_pre_ - vb + 1);
+        if (nfast < 0) nfast = 0;
+        if (nfast > 0 && ((int)first < fast_lo || __any(vvl < nfast && (int)h < fast_lo))) nfast = 0;
+        if (b.dbg & 4) nfast = 0;
+        if (nfast > 0) {
+            int g = (int)h + le1;
+            g = lane == 0 ? imax(g, (int)first) : g;
+            const int Hc = imax(wave_scan_max_i32(g) - le1, inj1);
+            if (vvl < nfast) h = (T)Hc;
+            first = (T)(__builtin_amdgcn_readlane(Hc, nfast * PN - 1) - (int)e1);
+        }
+#pragma unroll
+        for (int vv = 0; vv < NV; ++vv) {
+            if (vv >= nfast && vb + vv <= end_sn_) {
+                const int vg = vb + vv;
+                int set_num = PN;
+                if (!local && vg > max_pre_) set_num = (vg == max_pre_ + 1) ? 1 : 0;
+                T hv = tmax<T>(h, l == 0 ? first : inf);
+                hv = set_f<T>(hv, l, set_num, e1, inf);
+                if (vvl == vv) h = hv;
+                first = wsub<T>((T)__builtin_amdgcn_readlane((int)hv, vv * PN + PN - 1), e1);
+            }
+        }
+        return h;
+    };
+
     long long cursor = 0;          // next free arena cell
     long long n_cells = 0;
     int status = 0;
@@ -298,10 +334,10 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
                         const bool inH0 = in_band && v >= bs0 && v <= esh0, inH1 = in_band && v >= bs1 && v <= esh1;
                         const bool inE0 = in_band && v >= bs0 && v <= ese0, inE1 = in_band && v >= bs1 && v <= ese1;
                         const T h0 = rp0[ok0 ? x0 : 0], h1 = rp1[ok1 ? x1 : 0];
+                        const T q = (in_band && qc >= 0) ? (T)qv : (T)0;
                         const T a0 = rp0[ring_cols + (inE0 ? x0 + 1 : 0)], a1 = rp1[ring_cols + (inE1 ? x1 + 1 : 0)];
                         T c0 = 0, c1 = 0;
                         if (GAP == 2) { c0 = rp0[2 * ring_cols + (inE0 ? x0 + 1 : 0)]; c1 = rp1[2 * ring_cols + (inE1 ? x1 + 1 : 0)]; }
-                        const T q = (in_band && qc >= 0) ? (T)qv : (T)0;
                         T Mv = inH0 ? (ok0 ? h0 : inf) : inf;
                         Mv = inH1 ? tmax<T>(Mv, ok1 ? h1 : inf) : Mv;
                         T E1v = inE0 ? a0 : inf; E1v = inE1 ? tmax<T>(E1v, a1) : E1v;
@@ -550,20 +586,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
             T Hout, E1out = 0, E2out = 0, F1 = inf, F2 = inf;
             if (GAP == 0) {
                 // reference :762-778
-                T h = Mv;
-                if (c == 0) first = (T)__builtin_amdgcn_readlane((int)h, 0);
-#pragma unroll
-                for (int vv = 0; vv < NV; ++vv) {
-                    const int vg = beg_sn + c * NV + vv;
-                    if (vg <= end_sn) {
-                        int set_num = PN;
-                        if (!local && vg > max_pre_end_sn) set_num = (vg == max_pre_end_sn + 1) ? 1 : 0;
-                        T hv = tmax<T>(h, l == 0 ? first : inf);
-                        hv = set_f<T>(hv, l, set_num, e1, inf);
-                        if (vvl == vv) h = hv;
-                        first = wsub<T>((T)__builtin_amdgcn_readlane((int)hv, vv * PN + PN - 1), e1);
-                    }
-                }
+                const T h = linear_h(c, beg_sn, end_sn, max_pre_end_sn, Mv, first);
                 Hout = local ? tmax<T>((T)0, h) : h;
             } else {
                 T h = wadd<T>(Mv, q);                                   // reference :854-856 / :972-974
