@@ -136,7 +136,8 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             // (8-byte records: a slice starts and ends on an even column -- it is up to two columns wider than WC, and the rows of a window must leave room for
             //  that: sized by WC alone, 48 rows of 34 records overran a 12 KB window by 96 records and the topmost row read back zeros -- EBACKTRACK on ragged reads
             //  in the wide loop; the retry passes hid it)
-            constexpr int EVEN = (CW * (int)sizeof(T) == 8) ? 1 : 0;
+            // (linear gaps: records of 2 / 4 bytes -- slices start and end on multiples of 8 / 4 columns)
+            constexpr int EVEN = (CW > 0 && CW * (int)sizeof(T) < 16) ? 16 / (CW * (int)sizeof(T)) - 1 : 0;
             const int R = narrow ? r_full : imin(n64, imax(4, max_rec / (WC + 2 * EVEN)));
             const int lo = hi - R + 1, nrow = R, li = lane - (lo - lo64);           // li: index of this lane's row inside the window
             const bool rv = rv64 && li >= 0;
@@ -277,7 +278,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             //      wrote on its straight-line path (0 = not known).  While a match is what the reference tries first (:130-160 with M allowed
             //      and indel_first == 0) and the flag is set, a step is ONE LDS round trip (flag, query code, the row's edge records) and a
             //      handful of scalar instructions; anything else leaves the loop for the full step below.
-            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
+            if (GAP != 0 && (cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
                 int mi_ = i, mj = j, pi_ = i, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr;
                 const int nc0 = n_cigar;
                 int slots = n_cigar == 0 ? 64 : ((64 - (n_cigar & 63)) & 63);           // words that still fit before the VGPR pair has to be written out
@@ -326,10 +327,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             bool need = false;
             const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
             // (every lane reads the same cell: keep the walk's state in SGPRs)
-            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0,
-                    F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;
+            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = GAP != 0 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E1]) : 0, E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0,
+                    F1ij = GAP != 0 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F1]) : 0, F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
-            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]),
+            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = GAP != 0 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]) : 0,
                     F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
             if (local && Hij == 0) { local_done = true; break; }            // reference :126: the local walk ends on a zero cell
             const int qc = __builtin_amdgcn_readfirstlane(qcode(j - 1));
@@ -344,7 +345,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 load_window_cols(i, j); cr_row = -1; if (!win_narrow) { bt_walk_narrow = false; break; } continue;
             }
             const T *rk = bt + er.z + (in_j ? sk : 0) * CW, *rkm1 = bt + er.z + (in_jm1 ? sk - 1 : 0) * CW;
-            const int Hk_j = (int)rk[0], E1k_j = (int)rk[PL_E1], E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
+            const int Hk_j = (int)rk[0], E1k_j = GAP != 0 ? (int)rk[PL_E1] : 0, E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
             const int sc_ = s_mat[m * bs_ + qc];
             start_i = i; start_j = j; ++bt_steps;
             const unsigned long long mA = __ballot(in_jm1 && Hk_jm1 + sc_ == Hij);
@@ -357,6 +358,12 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 --j; ++n_aln; n_match += (bs_ == qc);
                 if (set_indel) indel_first = 0;
             };
+            if constexpr (GAP == 0) {      // linear gaps, reference :109-190: match (unless an indel is tried first), deletion from the first predecessor that fits, insertion, match
+                if (indel_first == 0) do_match(0);
+                if (!hit) { const unsigned long long mD = __ballot(in_j && Hk_j - (int)e1 == Hij); if (mD) { k_sel = __builtin_ctzll(mD); hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); } }
+                if (!hit && st_jm1 && Hijm1 - (int)e1 == Hij) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; hit = 1; }
+                if (!hit && indel_first == 1) do_match(1);
+            } else {
             if ((cur_op & OP_M) && indel_first == 0) do_match(0);
             if (!hit && (cur_op & OP_E)) {
                 const bool viaM = cur_op & OP_M;
@@ -387,6 +394,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
+            }
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
             if (k_sel >= 0) {                                                    // move to the chosen predecessor: its record comes along
                 i = __builtin_amdgcn_readlane(er.x, k_sel);
@@ -402,7 +410,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }
             // ---- match run, as in the whole-row loop above; here a row's staged cells are the column slice cr2 = first column | count << 16
-            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
+            if (GAP != 0 && (cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
                 int mi_ = i, mj = j, pi_ = i, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr; int mc2 = cr2;
                 const int nc0 = n_cigar;
                 int slots = n_cigar == 0 ? 64 : ((64 - (n_cigar & 63)) & 63);           // words that still fit before the VGPR pair has to be written out
@@ -451,10 +459,10 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             bool need = !win_narrow && ((unsigned)si >= (unsigned)nsi || (st_jm1 && si - 1 < 0));     // a cell of the own row outside the staged slice
             const T *ri = bt + offi + ((unsigned)si < (unsigned)nsi ? si : 0) * CW;
             // (every lane reads the same cell: keep the walk's state in SGPRs)
-            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_E1]), E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0,
-                    F1ij = __builtin_amdgcn_readfirstlane((int)ri[PL_F1]), F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;
+            const int Hij = __builtin_amdgcn_readfirstlane((int)ri[0]), E1ij = GAP != 0 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E1]) : 0, E2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_E2]) : 0,
+                    F1ij = GAP != 0 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F1]) : 0, F2ij = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)ri[PL_F2]) : 0;
             const T *rim1 = bt + offi + ((st_jm1 && si - 1 >= 0) ? si - 1 : 0) * CW;
-            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]),
+            const int Hijm1 = __builtin_amdgcn_readfirstlane((int)rim1[0]), F1ijm1 = GAP != 0 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F1]) : 0,
                     F2ijm1 = GAP == 2 ? __builtin_amdgcn_readfirstlane((int)rim1[PL_F2]) : 0;
             // reference :126: the local walk ends on a zero cell (a cell outside the staged slice is re-read after the reload below)
             if (local && Hij == 0 && (win_narrow || (unsigned)si < (unsigned)nsi)) { local_done = true; break; }
@@ -471,7 +479,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 load_window_cols(i, j); cr_row = -1; continue;
             }
             const T *rk = bt + er.z + (in_j ? sk : 0) * CW, *rkm1 = bt + er.z + (in_jm1 ? sk - 1 : 0) * CW;
-            const int Hk_j = (int)rk[0], E1k_j = (int)rk[PL_E1], E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
+            const int Hk_j = (int)rk[0], E1k_j = GAP != 0 ? (int)rk[PL_E1] : 0, E2k_j = GAP == 2 ? (int)rk[PL_E2] : 0, Hk_jm1 = (int)rkm1[0];
             const int sc_ = s_mat[m * bs_ + qc];
             start_i = i; start_j = j; ++bt_steps;
             const unsigned long long mA = __ballot(in_jm1 && Hk_jm1 + sc_ == Hij);
@@ -484,6 +492,12 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 --j; ++n_aln; n_match += (bs_ == qc);
                 if (set_indel) indel_first = 0;
             };
+            if constexpr (GAP == 0) {      // linear gaps, reference :109-190: match (unless an indel is tried first), deletion from the first predecessor that fits, insertion, match
+                if (indel_first == 0) do_match(0);
+                if (!hit) { const unsigned long long mD = __ballot(in_j && Hk_j - (int)e1 == Hij); if (mD) { k_sel = __builtin_ctzll(mD); hit = 1; push(ABPOA_HIP_CDEL, 1, id, j - 1); } }
+                if (!hit && st_jm1 && Hijm1 - (int)e1 == Hij) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; hit = 1; }
+                if (!hit && indel_first == 1) do_match(1);
+            } else {
             if ((cur_op & OP_M) && indel_first == 0) do_match(0);
             if (!hit && (cur_op & OP_E)) {
                 const bool viaM = cur_op & OP_M;
@@ -514,6 +528,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
                 if (hit) { push(ABPOA_HIP_CINS, 1, id, j - 1); --j; ++n_aln; }
             }
             if (!hit && (cur_op & OP_M) && indel_first == 1) do_match(1);
+            }
             if (!hit && status == 0) status = ABPOA_HIP_EBACKTRACK;
             if (k_sel >= 0) {                                                    // move to the chosen predecessor: its record comes along
                 i = __builtin_amdgcn_readlane(er.x, k_sel);

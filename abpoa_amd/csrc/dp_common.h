@@ -299,7 +299,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 // Which row loop an alignment takes (must agree between the two kernels and with engine.cpp's count).
 __device__ __forceinline__ bool takes_fast(const DevBatch &b, const AlnDesc &d) {
-    return b.gap_mode != ABPOA_HIP_LINEAR_GAP && b.wb >= 0 && (b.align_mode == ABPOA_HIP_GLOBAL_MODE || b.align_mode == ABPOA_HIP_EXTEND_MODE) && (d.flags & ALN_FAST_OK) && b.lds.fr_cols > 0 &&
+    return fast_global_job(b.gap_mode, b.align_mode, b.wb, b.e1) && fast_global_aln(b.gap_mode, d.w, d.pad0) && (d.flags & ALN_FAST_OK) && b.lds.fr_cols > 0 &&
            d.qlen <= b.lds.q_cap && !(b.dbg & 64);
 }
 

@@ -26,6 +26,7 @@ static hipError_t launch_rows_gap(const DevBatch &b, hipStream_t stream) {
     return e;
 }
 hipError_t launch_fast_rows(const DevBatch &b, hipStream_t stream) {
+    if (b.gap_mode == ABPOA_HIP_LINEAR_GAP) return launch_rows_gap<0, false>(b, stream);      // (H records only: no direction words)
     if (b.dir_mode) return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_rows_gap<1, true>(b, stream) : launch_rows_gap<2, true>(b, stream);
     return b.gap_mode == ABPOA_HIP_AFFINE_GAP ? launch_rows_gap<1, false>(b, stream) : launch_rows_gap<2, false>(b, stream);
 }

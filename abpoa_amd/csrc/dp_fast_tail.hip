@@ -24,6 +24,7 @@ static hipError_t launch_tail_gap(const DevBatch &b, hipStream_t stream) {
     return e;
 }
 hipError_t launch_fast_tail(const DevBatch &b, hipStream_t stream) {
+    if (b.gap_mode == ABPOA_HIP_LINEAR_GAP) return launch_tail_gap<0, false>(b, stream);
     if (b.dir_mode == 2) {
         // every alignment of the launch walks direction words: no query, no score matrix in LDS -- the walk's image and its window start at byte 0 -- and the
         // window is what lets the whole launch be resident (LDS comes in pieces of 1280 B, 128 per CU; at most eight workgroups per CU: a walk is a chain

@@ -34,7 +34,7 @@ hipError_t launch_dp_fast(const DevBatch &b, hipStream_t stream, hipEvent_t afte
     if (b.n <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
     if (b.align_mode != ABPOA_HIP_LOCAL_MODE && !b.lds.narrow_off) e = launch_fast_rows(b, stream);
-    if (e == hipSuccess && b.lds.wide_nw >= 1) e = launch_wide_rows(b, stream);
+    if (e == hipSuccess && b.lds.wide_nw >= 1 && b.gap_mode != ABPOA_HIP_LINEAR_GAP) e = launch_wide_rows(b, stream);
     if (e == hipSuccess && b.lds.loc_cols > 0 && b.align_mode == ABPOA_HIP_LOCAL_MODE) e = launch_local_rows(b, stream);
     if (e == hipSuccess) e = hipEventRecord(after_rows, stream);
     if (e == hipSuccess) e = launch_fast_tail(b, stream);

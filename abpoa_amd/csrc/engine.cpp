@@ -111,8 +111,8 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
     L.bt_off = lds_fixed_bytes_bt();
     // staged arena window of the backtrack: 24 KB, less when a long query already takes much of the 40 KB a workgroup may use
     L.bt_bytes = std::max(std::max(8 * 1024, std::min(24 * 1024, (longq ? 62 : 38) * 1024 - L.phase_off - L.bt_off)), L.ring_off + ring_bytes - L.bt_off) & ~15;
-    // fast row loop: packed score ring (words per cell: int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
-    const int fw = P == 1 ? 0 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));
+    // fast row loop: packed score ring (words per cell: linear 1, int16 affine 1, int16 convex 2, int32 affine 2, int32 convex 3)
+    const int fw = P == 1 ? 1 : (max_bits == 16 ? (P == 3 ? 1 : 2) : (P == 3 ? 2 : 3));      // (linear gaps: H alone)
     L.fr_off = 0; L.fr_rows = 16; L.fr_cols = fw ? std::max(128, (int)align_up((size_t)est_cols, 64)) : 0;      // >= 128: the turbo row pads one chunk unconditionally
     const int fr_budget = (longq ? 62 : 36) * 1024 - L.phase_off;
     while (L.fr_cols && (int64_t)L.fr_rows * fw * (L.fr_cols + 4) * 4 + 64 > fr_budget && L.fr_rows > 4) L.fr_rows /= 2;
@@ -187,6 +187,7 @@ void make_lds_plan(const abpoa_hip_scoring_t *sc, int max_qlen, int max_bits, in
           }
           L.wx_off = L.fr_off + (int)align_up((size_t)L.wfr_rows * fww * (L.wfr_cols + 4) * 4, 16);
           L.total_wide = L.w_phase_off + L.wx_off + extra_;
+          if (P == 1) L.wide_nw = 0;      // (linear gaps: the narrow loop only -- dp_common.h takes_fast)
       } }
 }
 
@@ -333,7 +334,7 @@ int BatchStream::run() {
             // (an alignment the general kernel will run -- seeded band of the -s retry, a row with more predecessors than a word names, no fast row loop in the
             //  plan -- stores its planes: the records' estimate, not the words'; host mirror of dp_common.h takes_fast)
             const int dbg_ = opt_env("ABPOA_HIP_DBG") ? atoi(opt_env("ABPOA_HIP_DBG")) : 0;
-            const bool fast_a = (d.flags & ALN_FAST_OK) && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) &&
+            const bool fast_a = (d.flags & ALN_FAST_OK) && fast_global_job(sc->gap_mode, sc->align_mode, sc->wb, sc->gap_ext1) && fast_global_aln(sc->gap_mode, d.w, d.pad0) &&
                                 b.lds.fr_cols > 0 &&
                                 d.qlen <= b.lds.q_cap && !(dbg_ & 64);
             const bool dir_a = dir && fast_a && (dir_wide || !(b.lds.wide_nw >= 1 && d.w >= b.lds.wide_w_lo && d.w <= b.lds.wide_w_hi));
@@ -378,8 +379,8 @@ int BatchStream::run() {
         }
         HIP_TRY(hipEventRecord(ev_[1], stream_), ABPOA_HIP_ELAUNCH);
         int n_fast = 0;       // mirrors takes_fast() in dp_kernel.hip
-        if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && banded && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) && b.lds.fr_cols > 0 && !(b.dbg & 64))
-            for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.qlen <= b.lds.q_cap) ? 1 : 0;
+        if (fast_global_job(sc->gap_mode, sc->align_mode, sc->wb, sc->gap_ext1) && b.lds.fr_cols > 0 && !(b.dbg & 64))
+            for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.qlen <= b.lds.q_cap && fast_global_aln(sc->gap_mode, d.w, d.pad0)) ? 1 : 0;
         if (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_LOCAL_MODE && sc->wb < 0 && b.lds.loc_cols > 0 && !(b.dbg & 64))      // mirrors takes_local() in rows_local.h
             for (const AlnDesc &d : pass) n_fast += ((d.flags & ALN_FAST_OK) && d.bits == 16 && (d.qlen / 16 + 1) * 16 <= b.lds.loc_cols && d.qlen <= b.lds.q_cap) ? 1 : 0;
         HIP_TRY(launch_dp(b, n_fast, stream_, ev_[4]), ABPOA_HIP_ELAUNCH);

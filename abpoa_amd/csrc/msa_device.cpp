@@ -123,8 +123,7 @@ bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags) {
     if (sc->align_mode == ABPOA_HIP_LOCAL_MODE && opt_env("ABPOA_HIP_NO_DEVICE_LOCAL") && atoi(opt_env("ABPOA_HIP_NO_DEVICE_LOCAL"))) return false;
     // every gap model and alignment mode: the fast row loops where they apply (banded global, short local), the general kernel otherwise (linear gaps,
     // extension mode with or without z-drop, global mode without a band, long local reads).  ABPOA_HIP_NO_DEVICE_GENERAL=1 sends those back to the host driver.
-    const bool fast = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && (((sc->align_mode == ABPOA_HIP_GLOBAL_MODE || sc->align_mode == ABPOA_HIP_EXTEND_MODE) && sc->wb >= 0)
-            || sc->align_mode == ABPOA_HIP_LOCAL_MODE);
+    const bool fast = fast_global_job(sc->gap_mode, sc->align_mode, sc->wb, sc->gap_ext1) || (sc->gap_mode != ABPOA_HIP_LINEAR_GAP && sc->align_mode == ABPOA_HIP_LOCAL_MODE);
     if (!fast && opt_env("ABPOA_HIP_NO_DEVICE_GENERAL") && atoi(opt_env("ABPOA_HIP_NO_DEVICE_GENERAL"))) return false;
     return true;
 }
@@ -202,8 +201,16 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         const int64_t width_ = (int64_t)((max_qlen + pn_) / pn_) * pn_, w_ = sc->wb + (int)(sc->wf * (float)max_qlen);
         make_lds_plan(sc, max_qlen, mb, (local || unbanded) ? width_ : std::min<int64_t>(width_, 2LL * w_ + 3 * pn_ + 32), n_sets, &pl);
         // (extension mode, round 5: the same banded rows plus the running best cell / z-drop of reference :1018-1026 -- rows_fast.h commit_row)
-        const bool fast_global = sc->gap_mode != ABPOA_HIP_LINEAR_GAP && (sc->align_mode == ABPOA_HIP_GLOBAL_MODE || extend) && !unbanded && pl.fr_cols > 0
-                && max_qlen <= pl.q_cap;
+        bool fast_global = fast_global_job(sc->gap_mode, sc->align_mode, sc->wb, sc->gap_ext1) && pl.fr_cols > 0 && max_qlen <= pl.q_cap;
+        // (linear gaps, round 5: the narrow row loop only -- every alignment of the job must take it, dp_common.h takes_fast: band half-widths below the wide
+        //  loop's, no read-set with ragged ends; anything else is the general kernel's as before)
+        if (fast_global && sc->gap_mode == ABPOA_HIP_LINEAR_GAP) {
+            if (w_ >= LINEAR_FAST_W) fast_global = false;
+            for (int s = 0; s < n_sets && fast_global; ++s) {
+                int mx = 0, mn = INT_MAX; for (int r = 0; r < sets[s].n_reads; ++r) { mx = std::max(mx, sets[s].lens[r]); mn = std::min(mn, sets[s].lens[r]); }
+                if (sets[s].n_reads >= 2 && mx - mn > std::max(64, mx / 8)) fast_global = false;      // (the `extra` rule below)
+            }
+        }
         const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols
                 && max_qlen <= pl.q_cap;
         general = !(fast_global || fast_local);

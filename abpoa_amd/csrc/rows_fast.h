@@ -28,7 +28,8 @@ namespace abpoa_hip {
 // Arena format of the fast loop: one record of CW values per column -- {H, E1, F1, -} (affine) or {H, E1, E2, F1, F2, -, -, -}
 // (convex), plane id = index in the record -- so that a row chunk is ONE wide store per lane instead of 3-5 two-byte ones
 // (vector-memory instruction issue, not bytes, is what a lone wave pays for).
-template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 1 ? 4 : 8; };
+// (linear gaps, GAP == 0: the record is the cell's H alone -- the same bytes as the general kernel's plane-major rows, whose backtrack walks them)
+template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 0 ? 1 : (GAP == 1 ? 4 : 8); };
 // Direction-plane arenas (DIR = true, dir_plane.h): a row owns ONE word per column -- 2 bytes (affine) or 4 (convex) -- that records every
 // decision the backtrack takes at that cell; only rows whose scores a later reader needs from HBM (a successor beyond the LDS score ring,
 // the global best at the sink's predecessors, a row too wide for the ring) also keep their cell records, IN FRONT of the words (a row's arena
@@ -139,6 +140,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     constexpr int CWR = CSP ? (I16 ? (GAP == 2 ? 4 : 2) : 2) : CW;
     constexpr bool CPK = CSP && !I16 && GAP == 2;
     static_assert(!(DIR && NW > 1), "teams of wavefronts keep the score-record arenas");
+    static_assert(!(GAP == 0 && (DIR || NW > 1 || WIDEB)), "linear gaps: the narrow loop with H records only");
     constexpr int DB = DirFmt<T, GAP>::DB, CAPF1 = GAP == 1 ? DIRA_CAP1 : DIRC_CAP1, CAPF2 = DIRC_CAP2;
     auto dir_units = [](int nv) __attribute__((always_inline)) { return DirFmt<T, GAP>::units(nv); };
     // arena units of a row of nv vectors (spill: the row also keeps its score records)
@@ -150,7 +152,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // "both inf" where H is inf (outside the band, padding).  Two words instead of three: a ring of 8 rows for a 10 kb convex alignment is 29 KB, and
     // four workgroups share a CU (40 KB each) instead of three.  Row 0 -- E = inf beside real H -- stays out of such a ring: its successors read its records.
     constexpr bool EPACK = WPLAN && !I16 && GAP == 2;
-    constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? (EPACK ? 2 : 3) : 2);
+    constexpr int NPW = I16 ? (GAP == 2 ? 2 : 1) : (GAP == 2 ? (EPACK ? 2 : 3) : (GAP == 0 ? 1 : 2));      // (linear gaps: H alone; int16: in the low half of the word)
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
     constexpr int GEO_RING = 1 << 24;
     const int lane = threadIdx.x & 63, l = lane % PN, vvl = lane / PN;
@@ -201,7 +203,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto ring_put = [&](int slot, int x, int H, int E1, int E2) __attribute__((always_inline)) {
         int *q = fr + slot * (NPW * RCS) + 2 + x;
         if (I16) { q[0] = (int)(((unsigned)H & 0xffffu) | ((unsigned)E1 << 16)); if (GAP == 2) q[RCS] = E2; }
-        else { q[0] = H; q[RCS] = E1; if (GAP == 2) q[2 * RCS] = E2; }
+        else { q[0] = H; if (GAP != 0) q[RCS] = E1; if (GAP == 2) q[2 * RCS] = E2; }
     };
 
     // extension mode (reference :1018-1026, set_extend_max_score): the rows are the global rows; after every row the running best cell (strictly greater: the
@@ -226,7 +228,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         T *H = io.planes;
         for (int i = tid; i < W0; i += NT) {
             int h, x1 = inf, x2 = inf, f1 = inf, f2 = inf;
-            if (GAP == 1) { const int g = wr(-o1 - e1 * i); h = i == 0 ? 0 : g; x1 = i == 0 ? wr(-oe1) : inf; f1 = i == 0 ? inf : g; }
+            if (GAP == 0) h = wr(-e1 * i);      // (reference :553-607 lg_first_row)
+            else if (GAP == 1) { const int g = wr(-o1 - e1 * i); h = i == 0 ? 0 : g; x1 = i == 0 ? wr(-oe1) : inf; f1 = i == 0 ? inf : g; }
             else {
                 const int g1 = wr(-o1 - e1 * i), g2 = wr(-o2 - e2 * i);
                 h = i == 0 ? 0 : imax(g1, g2); x1 = i == 0 ? wr(-oe1) : inf; x2 = i == 0 ? wr(-oe2) : inf; f1 = i == 0 ? inf : g1; f2 = i == 0 ? inf : g2;
@@ -234,6 +237,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             T *cellp = H + (long long)i * CWR;
             if constexpr (CPK) { cellp[0] = (T)h; cellp[1] = (T)(i == 0 ? (int)((unsigned)(h - x1) | ((unsigned)(h - x2) << 16)) : -1); }      // (E = inf beside a real H: 0xffff)
             else if constexpr (CSP) { cellp[0] = (T)h; cellp[PL_E1] = (T)x1; if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[3] = (T)0; } }
+            else if constexpr (GAP == 0) cellp[0] = (T)h;
             else {
                 cellp[0] = (T)h; cellp[PL_E1] = (T)x1; cellp[PL_F1] = (T)f1;
                 if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
@@ -329,10 +333,18 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // one predecessor's contribution from the score ring (k == 0: unmasked, see the header comment)
     // kb: 1 + list index of the first predecessor that supplies the maximum of H[.][col-1] (kidx = this one's 1 + list index): the match flag
     // kE1 / kE2 (DIR): 1 + list index of the first predecessor that holds the maximum of E1 / E2 entering the cell (dir_plane.h)
-    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v, int &kb, int kidx, int &kE1, int &kE2) __attribute__((always_inline)) {
+    auto from_ring = [&](int k, int p, int g_, int col, int &Mv, int &E1v, int &E2v, int &kb, int kidx, int &kE1, int &kE2, int q = 0) __attribute__((always_inline)) {
         const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
         const int x = col - pb * PN;
         const int *src = ring_at(__builtin_amdgcn_readlane(vslot, p), med3i(x - 1, -2, RC));
+        if constexpr (GAP == 0) {      // linear gaps (reference :722-761): max(H[col-1] + q, H[col] - e) over the predecessor's vectors [max(pb, beg_sn), min(pe + 1, end_sn)], "inf" outside -- the first one too
+            const int w0 = src[0], w1 = src[1];
+            const int hm1 = I16 ? (int)(short)w0 : w0, h0 = I16 ? (int)(short)w1 : w1;
+            const int t = imax(wr(hm1 + q), wr(h0 - e1));
+            const bool inH = (unsigned)x < (unsigned)(Wp + PN);
+            Mv = k == 0 ? (inH ? t : inf) : (inH ? imax(Mv, t) : Mv);
+            return;
+        }
         int hm1, ev1, ev2 = inf;
         if (I16) { const int w0 = src[0], w1 = src[1]; hm1 = (int)(short)w0; ev1 = w1 >> 16; if (GAP == 2) ev2 = src[RCS + 1]; }
         else if (EPACK) { hm1 = src[0]; const int h0 = src[1]; const unsigned dd = (unsigned)src[RCS + 1]; ev1 = h0 - (int)(dd & 0xffffu); ev2 = h0 - (int)(dd >> 16); }
@@ -350,6 +362,46 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     auto chunk_tail = [&](int c, int nch, int Wr, int Mv, int E1v, int E2v, int q, int kb, int &first, int &first2, T *H, int my_slot, int kE1 = 1, int kE2 = 1) __attribute__((always_inline)) {
         const int rel = c * 64 + lane, col = beg_sn * PN + rel, vb = beg_sn + c * NV, v = vb + vvl;
         const bool in_band = rel < Wr;
+        if constexpr (GAP == 0) {
+            // linear gaps (reference :762-778): Mv already is max over the predecessors of max(H[col-1] + q, H[col] - e); the in-row term runs on H itself.  Vectors that use
+            // the plain scan (up to max_pre_end_sn), while nothing can wrap: H[c] = max(prefix max of (h + c e) - c e, inf - INJ e) over the whole chunk with the carry
+            // entering at lane 0; the vectors beyond (set_num 1 / 0) and everything near the wrap limit: the literal masked scan
+            int hl = Mv;
+            if (c == 0) first = __builtin_amdgcn_readlane(hl, 0);
+            const int nvec = imin(NV, end_sn - vb + 1);
+            int nfast = imax(0, imin(nvec, max_pe - vb + 1));
+            if (nfast > 0 && (first < fast_lo || __any(vvl < nfast && hl < fast_lo))) nfast = 0;
+            if (nfast > 0) {
+                int g = hl + le1; g = lane == 0 ? imax(g, first) : g;
+                const int Hc = imax(wave_scan_max_i32(g) - le1, inj1);
+                hl = vvl < nfast ? Hc : hl;
+                first = __builtin_amdgcn_readlane(Hc, nfast * PN - 1) - e1;
+            }
+#pragma unroll
+            for (int vv = 0; vv < NV; ++vv) {
+                if (vv >= nfast && vb + vv <= end_sn) {
+                    const int vg = vb + vv;
+                    const int set_num = vg > max_pe ? (vg == max_pe + 1 ? 1 : 0) : PN;
+                    T hv = tmax<T>((T)hl, l == 0 ? (T)first : (T)inf);
+                    hv = set_f<T>(hv, l, set_num, (T)e1, (T)inf);
+                    if (vvl == vv) hl = (int)hv;
+                    first = (int)wsub<T>((T)__builtin_amdgcn_readlane((int)hv, vv * PN + PN - 1), (T)e1);
+                }
+            }
+            const int Hout = hl;
+            if (!ABL(1)) H[rel] = (T)Hout;      // (lanes past the band write cells the next row overwrites: same wave, program order)
+            if (to_ring && !ABL(2)) { int *qd = fr + my_slot + 2 + rel; qd[0] = in_band ? (I16 ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)inf << 16)) : Hout) : infw; }
+            if (!ABL(4)) {
+                const bool is_end = (v == end_sn);
+                int cand = Hout;
+                if (end_sn == qlen_sn) cand = (is_end && col > qlen) ? inf : cand;
+                if (I16) {
+                    const unsigned key = ((unsigned)cand << 16) + (unsigned)(kconst - vb) + (is_end ? 2048u : 0u);
+                    am_key = (in_band && key > am_key) ? key : am_key;
+                } else if (in_band && (!am_any || (is_end ? cand >= am_val : cand > am_val))) { am_val = cand; am_v = v; am_isend = is_end; am_any = true; }
+            }
+            return;
+        }
         const int h = wr(Mv + q);
         int hs = h; if (GAP == 2) hs = imax(imax(h, E1v), E2v);
         if (c == 0) { first = __builtin_amdgcn_readlane(h, 0); first2 = first; }
@@ -462,7 +514,107 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
     // arg-max key constants (normal / end_sn vector): lane residue, vector priority, and -- never decisive, it only saves the decoding -- the lane
     const int kN = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | ((unsigned)(NV - 1 - vvl) << 8) | (unsigned)lane),
             kE = (int)(0x80000000u | ((unsigned)(PN - 1 - l) << 12) | (8u << 8) | (unsigned)lane);
-    auto turbo_body = [&](auto npc, auto slowc, int row, int ti) __attribute__((always_inline)) -> int {
+    // ---- the straight-line row for LINEAR gaps (reference simd_abpoa_lg_dp :701-779; same interface and exits as turbo_body below): per predecessor ONE
+    //      ds_read2 (H[col-1], H[col]), max(H[col-1] + q, H[col] - e) under the reference's vector range, the in-row term as one 64-lane prefix-max scan on H itself
+    //      with the arg-max key riding beside it (e >= 1: a propagated term never holds the row maximum), one H store per lane.
+    auto turbo_lin = [&](auto npc, auto slowc, int row, int ti) __attribute__((always_inline)) -> int {
+        constexpr bool SLOWV = decltype(slowc)::value;
+        constexpr int NPC = decltype(npc)::value, NPL = NPC == 1 ? 1 : (NPC == 2 ? 2 : (NPC == 4 ? 4 : 8));
+        const int tb = __builtin_amdgcn_readlane(tv_tb, ti);
+        int px[NPL], gx[NPL];
+        px[0] = row - (tb & 0xff);
+        if constexpr (NPC >= 2) px[1] = row - ((tb >> 8) & 0xff);
+        if constexpr (NPC >= 4) { px[2] = __builtin_amdgcn_readlane(tv_p2, ti); px[3] = np > 3 ? __builtin_amdgcn_readlane(tv_p3, ti) : px[2]; }      // (a missing fourth repeats the third)
+        if constexpr (NPC == 8) { px[4] = __builtin_amdgcn_readlane(tv_p4, ti); px[5] = __builtin_amdgcn_readlane(tv_p5, ti); px[6] = __builtin_amdgcn_readlane(tv_p6, ti); px[7] = __builtin_amdgcn_readlane(tv_p7, ti); }
+        int mn = 0, mx = 0, min_pb = 0, ring = -1; max_pe = 0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            gx[k] = __builtin_amdgcn_readlane(vg_geo, px[k] & 63); const int mk = __builtin_amdgcn_readlane(vg_mi, px[k] & 63);
+            if (k == 0) { mn = mx = mk; min_pb = gx[0] & 0xfff; max_pe = (gx[0] >> 12) & 0xfff; }
+            else { mn = imin(mn, mk); mx = imax(mx, mk); min_pb = imin(min_pb, gx[k] & 0xfff); max_pe = imax(max_pe, (gx[k] >> 12) & 0xfff); }
+            ring &= gx[k];
+        }
+        mn = sgpr(mn); mx = sgpr(mx);
+        set_band(std::true_type{}, mn, mx, min_pb);
+        const int nvr = end_sn - beg_sn + 1;
+        const int okbits = (nvr - NV - 1) & ((SLOWV ? beg_sn : end_sn) - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7);      // (as turbo_body)
+        if (__builtin_expect(okbits >= 0, 0)) return (!SLOWV && ((nvr - NV - 1) & (beg_sn - max_pe - 1) & (cur - cap_turbo - 1) & (ring << 7)) < 0) ? 0 : -1;
+        const int Wr = nvr * PN;
+        if (__builtin_expect(beg_sn != qc_beg_sn, 0)) {
+            qc_beg_sn = beg_sn;
+            const int c0 = beg_sn * PN + lane, c1 = c0 + 64;
+            qoff0 = (c0 >= 1 && c0 <= qlen) ? qat(c0 - 1) : m; qoff1 = (c1 >= 1 && c1 <= qlen) ? qat(c1 - 1) : m;
+        }
+        const int q = *(const int *)((const char *)s_mx + (tb >> 16) + qoff0 * 4);
+        const int colrel = beg_sn * PN + lane;
+        int ra[NPL], rb[NPL], xk[NPL], Wk[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {      // every predecessor's words in flight together
+            const int pbk = gx[k] & 0xfff; Wk[k] = (((gx[k] >> 12) & 0xfff) - pbk + 1) * PN; xk[k] = colrel - pbk * PN;
+            const int *src = ring_at(__builtin_amdgcn_readlane(vslot, px[k]), med3i(xk[k] - 1, -2, RC));
+            ra[k] = src[0]; rb[k] = src[1];
+        }
+        const bool in_band = lane < Wr;
+        const int key_c = (vvl == nvr - 1) ? kE : kN;
+        const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * lane;
+        const unsigned rec_off = (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)sizeof(T));
+        asm volatile("" :: "v"(key_c), "v"(qd_addr), "v"(rec_off));
+        __builtin_amdgcn_sched_barrier(0);
+        int h = inf;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            asm volatile("" : "+v"(ra[k]), "+v"(rb[k]));
+            const int hm1 = I16 ? (int)(short)ra[k] : ra[k], h0 = I16 ? (int)(short)rb[k] : rb[k];
+            const int t = imax(hm1 + q, h0 - e1);                  // (no wrap: checked below, and "inf" leaves room for q and e)
+            const bool inH = (unsigned)xk[k] < (unsigned)(Wk[k] + PN);
+            h = k == 0 ? (inH ? t : inf) : (inH ? imax(h, t) : h);
+        }
+        const bool near_wrap = __any(in_band && h < fast_lo);
+        const bool am_ok = in_band && colrel <= qlen;
+        unsigned akey = I16 ? (am_ok ? ((unsigned)h << 16) + (unsigned)key_c : 0u) : 0u;
+        int aval = am_ok ? h : INT_MIN;
+        int s_ = h + le1;                                          // (lane 0: its own value is the reference's `first`)
+        if (I16) wave_scan2_iu(s_, akey); else wave_scan2_ii(s_, aval);
+        int Hout = imax(s_ - le1, inj1);
+        if (__builtin_expect(near_wrap, 0)) return -1;
+        if (SLOWV && end_sn > max_pe) {                             // vectors beyond every predecessor's band: the literal masked scan on H (set_num 1 / 0, reference :766-772)
+            const int nfast = max_pe - beg_sn + 1;                  // 1 <= nfast < nvr
+            int first = __builtin_amdgcn_readlane(Hout, nfast * PN - 1) - e1, hl = vvl < nfast ? Hout : h;
+#pragma unroll
+            for (int vv = 1; vv < NV; ++vv) {
+                if (vv >= nfast && vv < nvr) {
+                    const int set_num = vv == nfast ? 1 : 0;
+                    T hv = tmax<T>((T)hl, l == 0 ? (T)first : (T)inf);
+                    hv = set_f<T>(hv, l, set_num, (T)e1, (T)inf);
+                    if (vvl == vv) hl = (int)hv;
+                    first = (int)wsub<T>((T)__builtin_amdgcn_readlane((int)hv, vv * PN + PN - 1), (T)e1);
+                }
+            }
+            Hout = hl;
+        }
+        // ---- from here on the row is committed
+        off_pn = cur; cur += row_units(nvr, false);
+        *(T *)((char *)io.planes + (size_t)rec_off) = (T)Hout;     // (lanes past the band write cells the next row overwrites)
+        {
+            int *qd = (int *)ring_at(qd_addr, 0);
+            qd[0] = in_band ? (I16 ? (int)__builtin_amdgcn_perm((unsigned)inf, (unsigned)Hout, 0x05040100u) : Hout) : infw;
+            qd[64] = infw;                                          // (RC <= 128 for these rows: tv_meta bit 17)
+        }
+        if (I16) {
+            const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)akey, 63);
+            rowmax = (int)(kb >> 16) - 32768;
+            mi = (rowmax > inf) ? beg_sn * PN + (int)(kb & 63) : -1;
+        } else {
+            const int vmax = __builtin_amdgcn_readlane(aval, 63);
+            rowmax = vmax;
+            const unsigned key = (am_ok && h == vmax) ? (((unsigned)(PN - 1 - l) << 12) | (unsigned)((vvl == nvr - 1) ? 8 : NV - 1 - vvl)) : 0u;
+            const unsigned kb = wave_max_u32_s(key);
+            const int vrel = (kb & 8) ? nvr - 1 : NV - 1 - (int)(kb & 7);
+            mi = (vmax > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
+        }
+        return 1;
+    };
+    auto turbo_aff = [&](auto npc, auto slowc, int row, int ti) __attribute__((always_inline)) -> int {
         constexpr bool SLOWV = decltype(slowc)::value;      // handles vectors beyond every predecessor's band (the tight loop's copies do not: they decline and the row comes back here)
         constexpr int NPC = decltype(npc)::value;
         const int tb = __builtin_amdgcn_readlane(tv_tb, ti);
@@ -683,6 +835,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             mi = (vmax > inf) ? (beg_sn + vrel) * PN + (PN - 1 - (int)((kb >> 12) & 0xf)) : -1;
         }
         return 1;
+    };
+    auto turbo_body = [&](auto npc, auto slowc, int row, int ti) __attribute__((always_inline)) -> int {
+        if constexpr (GAP == 0) return turbo_lin(npc, slowc, row, ti); else return turbo_aff(npc, slowc, row, ti);
     };
 
     constexpr int NWP = NW <= 2 ? 2 : (NW <= 4 ? 4 : 8);            // exchange entries read per lane group
@@ -1070,9 +1225,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (c >= 2) qc = (col >= 1 && col <= qlen) ? qat(col - 1) : m;
             const int q = mrow[qc];
             int Mv = lane, E1v = inf, E2v = inf, kb = 0, kE1 = 1, kE2 = 1;
-            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v, kb, 1, kE1, kE2);
-            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v, kb, 2, kE1, kE2);
-            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v, kb, 3, kE1, kE2); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v, kb, 4, kE1, kE2); }
+            if (!ABL(16)) from_ring(0, pr[0], pgeo[0], col, Mv, E1v, E2v, kb, 1, kE1, kE2, q);
+            if (NPC >= 2 && !ABL(16)) from_ring(1, pr[1], pgeo[1], col, Mv, E1v, E2v, kb, 2, kE1, kE2, q);
+            if (NPC >= 4) { if (np > 2) from_ring(2, pr[2], pgeo[2], col, Mv, E1v, E2v, kb, 3, kE1, kE2, q); if (np > 3) from_ring(3, pr[3], pgeo[3], col, Mv, E1v, E2v, kb, 4, kE1, kE2, q); }
             FSTAMP(1)
             chunk_tail(c, nch, Wr, Mv, E1v, E2v, q, kb, first, first2, H, my_slot, kE1, kE2);
         }
@@ -1112,7 +1267,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             for (int k = 0; k < np; ++k) {
                 int g_, mi_, off_; const int p = __builtin_amdgcn_readfirstlane(gld_i32(io.pred_row + ps + k)); geo_of(p, row, g_, mi_, off_);
                 if ((g_ & GEO_RING) && row - p < RR) {
-                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1, kE1, kE2); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1, kE1, kE2);
+                    if (k == 0) from_ring(0, p, g_, col, Mv, E1v, E2v, kb, 1, kE1, kE2, q); else from_ring(1, p, g_, col, Mv, E1v, E2v, kb, k + 1, kE1, kE2, q);
                 } else {
                     const int pb = g_ & 0xfff, pe = (g_ >> 12) & 0xfff, Wp = (pe - pb + 1) * PN;
                     const int x = col - pb * PN;
@@ -1120,6 +1275,12 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                     const T *Hp = io.planes + (long long)(uint32_t)(off_ - (DIR ? (pe - pb + 1) * CWR : 0)) * PN;      // (DIR: its score records, in front of its direction words)
                     int hval = inf, ev1 = inf, ev2 = inf;
                     if (inH && (unsigned)(x - 1) < (unsigned)Wp) hval = gld_cell((GLOBAL_AS const T *)(Hp + (long long)(x - 1) * CWR));
+                    if constexpr (GAP == 0) {      // linear gaps: max(H[col-1] + q, H[col] - e) inside the predecessor's vector range, "inf" outside (the first predecessor too)
+                        int vert = inf; if (inH && (unsigned)x < (unsigned)Wp) vert = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR));
+                        const int t = imax(wr(hval + q), wr(vert - e1));
+                        Mv = k == 0 ? (inH ? t : inf) : (inH ? imax(Mv, t) : Mv);
+                        continue;
+                    }
                     if constexpr (CPK) { if (inE) { const int h0 = gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR));
                             const unsigned dd = (unsigned)gld_cell((GLOBAL_AS const T *)(Hp + (long long)x * CWR + 1));
                                                     ev1 = (dd & 0xffffu) == 0xffffu ? inf : h0 - (int)(dd & 0xffffu); ev2 = (dd >> 16) == 0xffffu ? inf : h0 - (int)(dd >> 16); } }
@@ -1225,7 +1386,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             // ---- tight loop over consecutive straight-line rows: only these merge at its back edge (in one loop with the other row
             //      bodies every row paid ~30 register copies for the merge of all paths)
             int ok_ = 1;
-            if constexpr (!WPLAN) if (__builtin_expect(two_chunk_streak, 0)) {      // the band is 65-128 columns wide at the moment: straight to the two-chunk body
+            if constexpr (!WPLAN && GAP != 0) if (__builtin_expect(two_chunk_streak, 0)) {      // the band is 65-128 columns wide at the moment: straight to the two-chunk body
                 const int ti_ = row & 63, meta_ = __builtin_amdgcn_readlane(tv_meta, ti_);
                 if constexpr (DIR) row_spill = (meta_ >> 21) & 1;
                 if ((meta_ >> 19) & 1) {
@@ -1306,7 +1467,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 const int ok3 = np == 1 ? turbo_body(std::integral_constant<int, 1>{}, std::true_type{}, row, ti) : turbo_body(std::integral_constant<int, 2>{}, std::true_type{}, row, ti);
                 if (ok3 == 1) { commit_row(ti, true); CENSUS(np == 1 ? 0 : 1) ++row; continue; }
             }
-            if (!WPLAN && ((meta >> 19) & 1)) {                       // narrow kernel, the straight-line bodies declined (a band of 65-128 columns for a stretch of
+            if (GAP != 0 && !WPLAN && ((meta >> 19) & 1)) {           // narrow kernel, the straight-line bodies declined (a band of 65-128 columns for a stretch of
                                                                       // rows, a predecessor beyond the score ring, ...): the all-chunks body with two chunks
                 const int nch_ = ilp_band(row, ti);
                 if (nch_ == -2) { status = ABPOA_HIP_STATUS_OVERFLOW; break; }

@@ -134,12 +134,12 @@ def test_device_row_order_graph_and_msa_checks_after_every_read(engine):
 
 
 def test_strict_mode_reports_instead_of_slowing_down(engine, monkeypatch):
-    """ABPOA_HIP_STRICT=1: a job whose options are the host driver's (here: linear gaps) fails with ABPOA_HIP_ESTRICT instead of running at host-driver
+    """ABPOA_HIP_STRICT=1: a job whose options are the host driver's (here: linear gaps without a band) fails with ABPOA_HIP_ESTRICT instead of running at host-driver
     speed unnoticed; without the switch it runs and reports every set in abpoa_hip_msa_timing_t.n_host_sets.  A device-driver job is unaffected."""
     from abpoa_amd import api, ffi, synth
     sets = [synth.make_read_set(53, i, 6, 200, 0.05) for i in range(4)]
-    monkeypatch.setenv("ABPOA_HIP_NO_DEVICE_GENERAL", "1")      # (linear gaps: the general kernel's job, which this switch keeps on the host driver)
-    lin = api.Params(gap_open1=0, gap_open2=0, gap_ext1=2)
+    monkeypatch.setenv("ABPOA_HIP_NO_DEVICE_GENERAL", "1")      # (linear gaps without a band: the general kernel's job, which this switch keeps on the host driver)
+    lin = api.Params(gap_open1=0, gap_open2=0, gap_ext1=2, extra_b=-1)
     r = api.msa_batch(sets, lin, n_threads=4)
     assert all(x.status == 0 for x in r) and api.msa_timing()["n_host_sets"] == len(sets)
     monkeypatch.setenv("ABPOA_HIP_STRICT", "1")
