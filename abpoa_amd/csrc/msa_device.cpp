@@ -262,7 +262,9 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         weff_hi = std::max(weff_hi, sc->wb + (int)(sc->wf * (float)mx) + route[s] / 2);
     }
     if (weff_hi == 0) { weff_lo = 0; }
-    const bool rounds_possible = dir && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo) && max_extra == 0;
+    // (linear gaps on the fast loops keep H records -- no direction words -- and take the all-rounds kernel with them)
+    const bool lin_fast = !general && !local && sc->gap_mode == ABPOA_HIP_LINEAR_GAP && !amb;
+    const bool rounds_possible = (dir || lin_fast) && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo) && max_extra == 0;
     // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
     // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the
     // read-sets are in flight instead of two passes with half the SIMDs idle.  ABPOA_HIP_DIR_WIDE=1 / 0: always / never.

@@ -90,16 +90,22 @@ __global__ void __launch_bounds__(GT, 4) poa_rounds_kernel(const int slot, const
             const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags;
             // (the host launches this kernel only for jobs whose reads all take the narrow loop)
             if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {
-                if (b.dir_mode) {
+                bool done_dir = false;
+                if constexpr (GAP != 0) if (b.dir_mode) {      // (linear gaps keep H records: no direction words)
                     if (bits == 16) { c2 = rounds_rows<int16_t, GAP, true>(slot, s); rounds_tail<int16_t, GAP, true>(slot, s, pair ? 0 : -1, sh_walk, k); }
                     else { c2 = rounds_rows<int32_t, GAP, true>(slot, s); rounds_tail<int32_t, GAP, true>(slot, s, pair ? 0 : -1, sh_walk, k); }
-                } else if (bits == 16) { c2 = rounds_rows<int16_t, GAP, false>(slot, s); rounds_tail<int16_t, GAP, false>(slot, s, -1, sh_walk, k); }
+                    done_dir = true;
+                }
+                if (done_dir) {}
+                else if (bits == 16) { c2 = rounds_rows<int16_t, GAP, false>(slot, s); rounds_tail<int16_t, GAP, false>(slot, s, -1, sh_walk, k); }
                 else { c2 = rounds_rows<int32_t, GAP, false>(slot, s); rounds_tail<int32_t, GAP, false>(slot, s, -1, sh_walk, k); }
             } else if ((tid & 63) == 0) b.out[s].status = ABPOA_HIP_EINVAL;       // -> poa_fuse_body marks the set for the fall-back
-        } else if (b.dir_mode && pair) {      // the other three wavefronts: helpers of the backtrack (backtrack_dir.h)
+        } else if (GAP != 0 && b.dir_mode && pair) {      // the other three wavefronts: helpers of the backtrack (backtrack_dir.h)
+            if constexpr (GAP != 0) {
             const int bits = b.aln[s].bits, w = b.aln[s].w, flags = b.aln[s].flags, hr = (((int)(tid >> 6) - worker) & (GW - 1));
             if ((flags & ALN_FAST_OK) && !(b.lds.wide_nw >= 1 && w >= b.lds.wide_w_lo && w <= b.lds.wide_w_hi)) {
                 if (bits == 16) rounds_tail<int16_t, GAP, true>(slot, s, hr, sh_walk, k); else rounds_tail<int32_t, GAP, true>(slot, s, hr, sh_walk, k);
+            }
             }
         }
         __syncthreads();                                    // graph cigar and result record are complete
@@ -123,18 +129,21 @@ hipError_t launch_poa_rounds(const PoaDev &p, const DevBatch &b, int32_t *cu_tic
     e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rounds), &a, sizeof(a), sizeof(RoundsArgs) * (size_t)slot, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     if (lds_bytes > 65536) {      // (above 64 KB the kernel's dynamic-LDS limit has to be raised; without it the launch gets 64 KB and the phases read and write past it)
-        e = hipFuncSetAttribute(b.gap_mode == ABPOA_HIP_AFFINE_GAP ? (const void *)poa_rounds_kernel<1> : (const void *)poa_rounds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                (int)lds_bytes);
+        e = hipFuncSetAttribute(b.gap_mode == ABPOA_HIP_LINEAR_GAP ? (const void *)poa_rounds_kernel<0> : (b.gap_mode == ABPOA_HIP_AFFINE_GAP ? (const void *)poa_rounds_kernel<1> : (const void *)poa_rounds_kernel<2>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) hipLaunchKernelGGL(poa_rounds_kernel<1>, dim3(p.n_sets), dim3(GT), lds_bytes, s, slot, k_lo);
+    if (b.gap_mode == ABPOA_HIP_LINEAR_GAP) hipLaunchKernelGGL(poa_rounds_kernel<0>, dim3(p.n_sets), dim3(GT), lds_bytes, s, slot, k_lo);
+    else if (b.gap_mode == ABPOA_HIP_AFFINE_GAP) hipLaunchKernelGGL(poa_rounds_kernel<1>, dim3(p.n_sets), dim3(GT), lds_bytes, s, slot, k_lo);
     else hipLaunchKernelGGL(poa_rounds_kernel<2>, dim3(p.n_sets), dim3(GT), lds_bytes, s, slot, k_lo);
     return hipGetLastError();
 }
 // workgroups of the all-rounds kernel one CU holds with `lds_bytes` of dynamic LDS (registers and LDS), and its static LDS
 int poa_rounds_residency(int gap_mode, size_t lds_bytes, int *static_lds) {
     int nb = 0; hipFuncAttributes fa; memset(&fa, 0, sizeof(fa));
-    if (gap_mode == ABPOA_HIP_AFFINE_GAP) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<1>, GT, lds_bytes);
+    if (gap_mode == ABPOA_HIP_LINEAR_GAP) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<0>, GT, lds_bytes);
+            (void)hipFuncGetAttributes(&fa, (const void *)poa_rounds_kernel<0>); }
+    else if (gap_mode == ABPOA_HIP_AFFINE_GAP) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<1>, GT, lds_bytes);
             (void)hipFuncGetAttributes(&fa, (const void *)poa_rounds_kernel<1>); }
     else { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_rounds_kernel<2>, GT, lds_bytes); (void)hipFuncGetAttributes(&fa, (const void *)poa_rounds_kernel<2>); }
     if (static_lds) *static_lds = (int)fa.sharedSizeBytes;

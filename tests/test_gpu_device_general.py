@@ -82,7 +82,7 @@ def test_general_kernel_equals_the_fast_row_loops_on_their_jobs(engine, monkeypa
     from abpoa_amd import api
     shim = H.cpu_shim_lib()
     sets = _nt_sets(79, 8)
-    for kw in (dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2)):
+    for kw in (dict(), dict(gap_open1=4, gap_open2=0, gap_ext1=2), dict(gap_open1=0, gap_open2=0, gap_ext1=2)):
         p = api.Params(**kw)
         monkeypatch.setenv("ABPOA_HIP_DEVICE_GENERAL", "0")
         fast = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
@@ -92,6 +92,36 @@ def test_general_kernel_equals_the_fast_row_loops_on_their_jobs(engine, monkeypa
         ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
         _same(gen, ref, f"general kernel {kw}")
         _same(fast, ref, f"fast loops {kw}")
+
+
+LINEAR_FAST = [
+    ("e2_1kb_5pct", dict(gap_ext1=2), 12, 1000, 0.05),
+    ("e2_1kb_15pct", dict(gap_ext1=2), 10, 900, 0.15),          # many rows with three and more predecessors, bands that open beyond 64 columns
+    ("e1_600_10pct", dict(gap_ext1=1), 16, 600, 0.10),          # the smallest extension the fast loops take (the row arg-max is read before the in-row scan)
+    ("e5_2500_8pct", dict(gap_ext1=5, mismatch=7), 6, 2500, 0.08),      # w = 35: the widest band of the narrow loop
+    ("int32_scores_800", dict(gap_ext1=3, match=45, mismatch=60), 8, 800, 0.07),      # 800 x 45 leaves int16
+    ("e0_general_kernel", dict(gap_ext1=0), 6, 300, 0.05),      # extension 0: ties between a cell and its left neighbour -- stays with the general kernel
+]
+
+
+@pytest.mark.parametrize("name,kw,n_reads,length,err", LINEAR_FAST, ids=[v[0] for v in LINEAR_FAST])
+def test_linear_gaps_on_the_fast_row_loops(engine, monkeypatch, name, kw, n_reads, length, err):
+    """Banded global alignment with linear gaps (reference simd_abpoa_lg_dp, src/simd_abpoa_align.c:701-779, backtrack :109-190) on the narrow row loop
+    (rows_fast.h GAP = 0: one 64-lane prefix-max scan on H per row, H-only records, lane-parallel linear backtrack steps): consensus and MSA rows equal the
+    oracle-backed run AND the general kernel's (ABPOA_HIP_DEVICE_GENERAL=1) on 5 - 15 % reads, int16 and int32 scores, extension penalties 1 - 5."""
+    import helpers as H
+    from abpoa_amd import api, synth
+    shim = H.cpu_shim_lib()
+    sets = [synth.make_read_set(97, i, n_reads + i, length + 13 * i, err) for i in range(4)]
+    p = api.Params(gap_open1=0, gap_open2=0, **kw)
+    monkeypatch.setenv("ABPOA_HIP_DEVICE_GENERAL", "0")
+    fast = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 0
+    monkeypatch.setenv("ABPOA_HIP_DEVICE_GENERAL", "1")
+    gen = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+    _same(gen, ref, f"linear {name}: general kernel")
+    _same(fast, ref, f"linear {name}: fast row loops")
 
 
 def test_general_jobs_can_be_kept_off_the_device(engine, monkeypatch):

@@ -269,7 +269,7 @@ CIGAR_JOBS = {
 
 @pytest.mark.parametrize("job,env", [("narrow_affine", {}), ("narrow_affine", {"ABPOA_HIP_LOCKSTEP": "1"}), ("narrow_convex_noisy", {}), ("narrow_convex_noisy", {"ABPOA_HIP_LOCKSTEP": "1"}),
                                      ("narrow_1500", {}), ("narrow_1500", {"ABPOA_HIP_DBG": "1024"}), ("narrow_1500", {"ABPOA_HIP_DEVICE_GENERAL": "1"}),
-                                     ("linear_banded", {}), ("extend_convex", {}), ("affine_unbanded", {}),
+                                     ("linear_banded", {}), ("linear_banded", {"ABPOA_HIP_LOCKSTEP": "1"}), ("linear_banded", {"ABPOA_HIP_DEVICE_GENERAL": "1"}), ("extend_convex", {}), ("affine_unbanded", {}),
                                      ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "0"}), ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "1"}), ("wide_affine_5", {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"}),
                                      ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "0"}), ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "1"}), ("wide_convex_15", {"ABPOA_HIP_DIR_WIDE": "1", "ABPOA_HIP_RING_ROWS": "4"})],
                          ids=lambda v: v if isinstance(v, str) else ("default" if not v else "_".join(f"{k[10:].lower()}{x}" for k, x in v.items())))
@@ -309,5 +309,6 @@ def test_device_driver_cigars_equal_the_oracle_backed_run(engine, job, env):
     e = dict(os.environ, ABPOA_HIP_CIGAR_DIGEST="1", **env)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=900)
     assert r.returncode == 0 and "CIGARS EQUAL" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-    narrow_all_rounds = job.startswith("narrow") and "ABPOA_HIP_LOCKSTEP" not in env and "ABPOA_HIP_DEVICE_GENERAL" not in env
+    # (banded linear jobs: the fast row loops and the all-rounds kernel since round 5 -- H records, lane-parallel linear backtrack steps)
+    narrow_all_rounds = (job.startswith("narrow") or job == "linear_banded") and "ABPOA_HIP_LOCKSTEP" not in env and "ABPOA_HIP_DEVICE_GENERAL" not in env
     assert ("ROUNDS_LAUNCHES 0" not in r.stdout) == narrow_all_rounds, r.stdout

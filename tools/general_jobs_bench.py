@@ -8,7 +8,7 @@ for name, kw in (("linear", dict(gap_open1=0, gap_open2=0, gap_ext1=2)), ("exten
     p = api.Params(**kw)
     for host in (0, 1):
         os.environ["ABPOA_HIP_NO_DEVICE_GENERAL"] = str(host)
-        if name in ("affine_banded_fast", "linear"): os.environ["ABPOA_HIP_HOSTGRAPH"] = str(host)      # (jobs of the fast row loops: the host driver by its own switch)
+        os.environ["ABPOA_HIP_HOSTGRAPH"] = str(host) if name in ("affine_banded_fast", "linear") else "0"      # (jobs of the fast row loops: the host driver by its own switch)
         api.msa_batch(sets[:32], p, n_threads=16)
         t = time.time(); r = api.msa_batch(sets, p, n_threads=16); dt = time.time() - t
         tm = api.msa_timing()
