@@ -305,7 +305,16 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
             int32_t inf_dummy; const int bits = abpoa_hip_score_bits(sc, (int)cap, mx, &inf_dummy); const int pn = bits == 16 ? 16 : 8;
             const int64_t width = (int64_t)((mx + pn) / pn) * pn;
             const int w = sc->wb + (int)(sc->wf * (float)mx);
-            const int64_t est = std::min<int64_t>(width, est_cols(width, w, pn) + extra[s]);
+            int64_t est = std::min<int64_t>(width, est_cols(width, w, pn) + extra[s]);
+            // (a set comes back to a later pass also because its ROWS were wider than the estimate -- extension mode on reads that end early, the band pushed off
+            //  its anchor -- and for a set of a few reads the node slots of every pass are the same number, the sum of its reads: the later passes grow the columns
+            //  with the slots, the last one takes whole rows while that stays under 1 GB per set; found by tools/fuzz_device_vs_oracle.py seed 770500103)
+            if (node_factor > 3.0) {
+                const double cellb = dir ? (double)(DB + 8) : (double)CW * (bits / 8);
+                int64_t e2 = roomy ? width : std::min<int64_t>(width, (int64_t)((double)est * node_factor / 3.0));
+                if (roomy && (double)e2 * (double)cap * cellb > 1e9) e2 = std::min<int64_t>(width, est * 4);
+                est = std::max(est, e2);
+            }
             // (direction words for every row, score records for the first row and for about one row in four -- rows a successor beyond the score ring or the
             //  global best will read from HBM; half of the rows where the wide loop's ring is only four rows deep; a set that needs more is flagged and
             //  redone like any other capacity miss)

@@ -462,3 +462,16 @@ def test_seeded_fuzz_sweep_of_the_device_driver(engine):
     assert set(hist) <= {"edge / aligned slots of a node", "node slots while fusing", "node slots at the first read", "projected graph growth", "cigar slots",
                          "predecessor-list slots", "DP arena too small for the bands"}, hist
     assert n_host <= 0.1 * (n_dev + n_host), (n_dev, n_host, hist)
+
+
+def test_rows_wider_than_the_band_estimate_stay_on_the_device(engine):
+    """A set of three reads in extension mode with linear gaps whose rows are much wider than 2 w (the band pushed off its anchor): the DP arena of the first
+    pass is too small, and for a set of a few reads every pass of the ladder has the same node slots (the sum of its reads) -- the later passes grow the
+    columns of the arena estimate as well.  Found by tools/fuzz_device_vs_oracle.py --seed 7705 (iteration 103): the set used to end on the host driver."""
+    import importlib.util
+    import os
+    import helpers as H
+    spec = importlib.util.spec_from_file_location("fuzz_device_vs_oracle", os.path.join(H.ROOT, "tools", "fuzz_device_vs_oracle.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    d, h, _, why = fz.iteration(770500103, H.cpu_shim_lib())
+    assert h == 0 and d == 4, (d, h, why)
