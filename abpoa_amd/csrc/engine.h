@@ -117,12 +117,12 @@ struct DevBatch {
 };
 
 // Which jobs / alignments the banded global row loops (rows_fast.h) take -- shared by the kernels (dp_common.h takes_fast) and their host mirrors.
-// (linear gaps, round 5: global mode, gap extension >= 1 -- the row arg-max is taken before the in-row scan -- and band half-widths of the narrow loop only:
-//  linear_fast_job / LINEAR_FAST_W; the wide kernels have no linear form, extension / local / band-less linear jobs stay with the general kernel)
+// (linear gaps, round 5: gap extension >= 1 -- the row arg-max is taken before the in-row scan -- and band half-widths of the narrow loop only: LINEAR_FAST_W; the
+//  wide kernels have no linear form; local / band-less linear jobs stay with the general kernel)
 constexpr int LINEAR_FAST_W = 40;      // = LdsPlan.wide_w_lo's default
 __host__ __device__ inline bool fast_global_job(int gap_mode, int align_mode, int wb, int e1) {
     if (wb < 0) return false;
-    if (gap_mode == ABPOA_HIP_LINEAR_GAP) return align_mode == ABPOA_HIP_GLOBAL_MODE && e1 >= 1;
+    if (gap_mode == ABPOA_HIP_LINEAR_GAP && e1 < 1) return false;
     return align_mode == ABPOA_HIP_GLOBAL_MODE || align_mode == ABPOA_HIP_EXTEND_MODE;
 }
 __host__ __device__ inline bool fast_global_aln(int gap_mode, int w, int pad0) { return gap_mode != ABPOA_HIP_LINEAR_GAP || w + (pad0 >> 1) < LINEAR_FAST_W; }

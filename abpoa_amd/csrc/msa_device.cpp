@@ -263,7 +263,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     }
     if (weff_hi == 0) { weff_lo = 0; }
     // (linear gaps on the fast loops keep H records -- no direction words -- and take the all-rounds kernel with them)
-    const bool lin_fast = !general && !local && sc->gap_mode == ABPOA_HIP_LINEAR_GAP && !amb;
+    const bool lin_fast = !general && !local && !extend && sc->gap_mode == ABPOA_HIP_LINEAR_GAP && !amb;      // (extension mode: the row order is rebuilt before every read)
     const bool rounds_possible = (dir || lin_fast) && max_reads > 2 && !(w_max >= wide_lo && wide_hi >= wide_lo) && max_extra == 0;
     // Wide-band sets (10 kb reads) keep score records while the record arenas of the whole job fit the device -- their all-chunks row loop is 18-21 % slower
     // with the words, more than the backtrack gains -- and switch to direction words when they do not: an eighth of the bytes per cell, so twice the

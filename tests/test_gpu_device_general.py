@@ -101,6 +101,8 @@ LINEAR_FAST = [
     ("e5_2500_8pct", dict(gap_ext1=5, mismatch=7), 6, 2500, 0.08),      # w = 35: the widest band of the narrow loop
     ("int32_scores_800", dict(gap_ext1=3, match=45, mismatch=60), 8, 800, 0.07),      # 800 x 45 leaves int16
     ("e0_general_kernel", dict(gap_ext1=0), 6, 300, 0.05),      # extension 0: ties between a cell and its left neighbour -- stays with the general kernel
+    ("extend_e2_700", dict(gap_ext1=2, aln_mode=EXTEND), 9, 700, 0.08),      # extension mode: the global rows + the running best cell (rows_fast.h commit_row)
+    ("extend_zdrop_e3_500", dict(gap_ext1=3, aln_mode=EXTEND, zdrop=30), 9, 500, 0.12),
 ]
 
 
