@@ -206,10 +206,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
         //  loop's, no read-set with ragged ends; anything else is the general kernel's as before)
         if (fast_global && sc->gap_mode == ABPOA_HIP_LINEAR_GAP) {
             if (w_ >= LINEAR_FAST_W) fast_global = false;
-            for (int s = 0; s < n_sets && fast_global; ++s) {
-                int mx = 0, mn = INT_MAX; for (int r = 0; r < sets[s].n_reads; ++r) { mx = std::max(mx, sets[s].lens[r]); mn = std::min(mn, sets[s].lens[r]); }
-                if (sets[s].n_reads >= 2 && mx - mn > std::max(64, mx / 8)) fast_global = false;      // (the `extra` rule below)
-            }
+            for (int s = 0; s < n_sets && fast_global; ++s) if (msa_device_set_is_ragged(sets[s])) fast_global = false;      // (the `extra` rule below)
         }
         const bool fast_local = local && sc->gap_mode != ABPOA_HIP_LINEAR_GAP && mb == 16 && pl.loc_cols > 0 && (max_qlen / 16 + 1) * 16 <= pl.loc_cols
                 && max_qlen <= pl.q_cap;

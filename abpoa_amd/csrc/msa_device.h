@@ -23,6 +23,16 @@ struct DeviceRunStats {
 // output, alphabets of up to 27 codes, per-base weights, the strand retry (-s).  env ABPOA_HIP_HOSTGRAPH=1 forces the host driver;
 // ABPOA_HIP_NO_DEVICE_LOCAL / _GENERAL / _STRAND=1 send that class of jobs there
 bool msa_device_eligible(const abpoa_hip_scoring_t *sc, unsigned flags);
+// A read-set whose reads differ much in length (more than an eighth of the longest, at least 64 bases): its band sits that far from the alignment's path in every
+// row (reference abpoa_align.h:34-35), so its rows are wider than 2 w by the difference -- run_msa_device gives it `band_extra` columns and the wide row loop.
+// A job that has such sets cannot take the all-rounds kernel: abpoa_hip_msa_batch runs them as a batch of their own (msa_hip.cpp deal_batches).
+inline bool msa_device_set_is_ragged(const abpoa_hip_readset_t &S) {
+    if (S.n_reads < 2) return false;
+    int mx = 0, mn = 0x7fffffff;
+    for (int r = 0; r < S.n_reads; ++r) { mx = S.lens[r] > mx ? S.lens[r] : mx; mn = S.lens[r] < mn ? S.lens[r] : mn; }
+    const int tol = mx / 8 > 64 ? mx / 8 : 64;
+    return mx - mn > tol;
+}
 
 // Consensus of every set in out[]; sets whose graph outgrew a device capacity are listed in `fallback` (out[] zeroed for
 // them) and must be redone (with a larger node_factor, or by the host driver; an entry -(s + 1) is set s with a node out of edge slots: more node slots

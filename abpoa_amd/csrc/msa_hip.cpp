@@ -202,11 +202,26 @@ std::vector<int> device_list() {
 
 // Batches for the device queues: sets sorted by estimated DP cost (sum of read lengths x reads), heaviest first, dealt round-robin so that
 // every batch holds the same mix; the queues pull batches from one shared counter (a fast device simply takes more of them).
-std::vector<std::vector<int>> deal_batches(const abpoa_hip_readset_t *sets, int n_sets, int n_q) {
+// Banded global / extension jobs: the read-sets with ragged read ends (msa_device.h msa_device_set_is_ragged) of a batch become a batch of their own -- the
+// uniform sets then keep the all-rounds kernel (narrow bands: one launch for all rounds, ~1.4x the lock-step launches' rate on 1 kb reads), which a job with a
+// single ragged set would lose for all of them.  (ABPOA_HIP_NO_RAGGED_SPLIT=1: one batch, as before round 5.)
+void split_ragged(std::vector<std::vector<int>> &batches, const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *sets) {
+    if (!sc || sc->wb < 0 || sc->align_mode == ABPOA_HIP_LOCAL_MODE || env_on("ABPOA_HIP_NO_RAGGED_SPLIT")) return;
+    std::vector<std::vector<int>> out_;
+    for (auto &b_ : batches) {
+        std::vector<int> uni, rag;
+        for (int i : b_) (msa_device_set_is_ragged(sets[i]) ? rag : uni).push_back(i);
+        if (uni.empty() || rag.empty()) { out_.push_back(std::move(b_)); continue; }
+        out_.push_back(std::move(uni)); out_.push_back(std::move(rag));
+    }
+    batches.swap(out_);
+}
+std::vector<std::vector<int>> deal_batches(const abpoa_hip_scoring_t *sc, const abpoa_hip_readset_t *sets, int n_sets, int n_q) {
     std::vector<std::vector<int>> batches;
     if (n_q == 1) {
         batches.emplace_back(n_sets);
         for (int s = 0; s < n_sets; ++s) batches[0][s] = s;
+        split_ragged(batches, sc, sets);
         return batches;
     }
     std::vector<int64_t> cost(n_sets);
@@ -226,6 +241,7 @@ std::vector<std::vector<int>> deal_batches(const abpoa_hip_readset_t *sets, int 
     batches.resize(nb);
     for (int i = 0; i < n_sets; ++i) batches[i % nb].push_back(order[i]);
     for (auto &b_ : batches) std::sort(b_.begin(), b_.end());        // (caller order inside a batch)
+    split_ragged(batches, sc, sets);
     return batches;
 }
 }  // namespace
@@ -260,7 +276,7 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         if ((int)devs.size() > CTX_SLOT_LO) devs.resize(CTX_SLOT_LO);
         if (ctx_slot >= 0) devs.assign(1, ctx_device);      // a context: its own device, its own queue
         const int n_q = (int)devs.size();
-        const std::vector<std::vector<int>> batches = deal_batches(sets, n_sets, n_q);
+        const std::vector<std::vector<int>> batches = deal_batches(sc, sets, n_sets, n_q);
         std::atomic<int> next{0};
         std::vector<PassOut> results(batches.size());
         std::vector<double> q_busy(n_q, 0.0);

@@ -477,3 +477,32 @@ def test_rows_wider_than_the_band_estimate_stay_on_the_device(engine):
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     d, h, _, why = fz.iteration(770500103, H.cpu_shim_lib())
     assert h == 0 and d == 4, (d, h, why)
+
+
+def test_ragged_sets_of_a_mixed_job_run_as_a_batch_of_their_own(engine, monkeypatch):
+    """A banded global job of uniform read-sets with two ragged ones among them: abpoa_hip_msa_batch hands the ragged sets to the device passes as a batch of
+    their own (msa_hip.cpp split_ragged), so the uniform ones keep the all-rounds kernel; results in caller order, equal to the oracle-backed run's and to the
+    one-batch form (ABPOA_HIP_NO_RAGGED_SPLIT=1: lock-step launches for everything, no all-rounds launch)."""
+    import numpy as np
+    import helpers as H
+    from abpoa_amd import api, ffi, synth
+    shim = H.cpu_shim_lib()
+    rng = np.random.default_rng(3)
+    sets = []
+    for i in range(12):
+        reads = list(synth.make_read_set(61, i, 8 + i % 5, 500 + 20 * i, 0.06))
+        if i in (2, 9):
+            reads = [reads[0]] + [r[int(rng.integers(20, 90)):len(r) - int(rng.integers(20, 90))] for r in reads[1:]]
+        sets.append(reads)
+    p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
+    lib = ffi.lib()
+    lib.abpoa_hip_reset_stats()
+    apart = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 0 and ffi.stats()["rounds_launches"] >= 1
+    monkeypatch.setenv("ABPOA_HIP_NO_RAGGED_SPLIT", "1")
+    lib.abpoa_hip_reset_stats()
+    one = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4)
+    assert api.msa_timing()["n_host_sets"] == 0 and ffi.stats()["rounds_launches"] == 0
+    ref = api.msa_batch(sets, p, out_cons=True, out_msa=True, n_threads=4, lib=shim)
+    _same(apart, ref, "ragged sets apart")
+    _same(one, ref, "one batch")
