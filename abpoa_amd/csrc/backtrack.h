@@ -13,7 +13,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
     constexpr int PN = Width<T>::PN;
     constexpr int P = CW > 0 ? CW : (GAP == 0 ? 1 : (GAP == 1 ? 3 : 5));      // values per column in the arena
     constexpr int PL_E1 = 1, PL_E2 = 2, PL_F1 = GAP == 1 ? 2 : 3, PL_F2 = 4;
-    constexpr int PL_FLAG = GAP == 1 ? 3 : (sizeof(T) == 2 ? 6 : 5);      // cell records only: the row loop's match flag (0 = not known)
+    constexpr int PL_FLAG = GAP == 0 ? 1 : (GAP == 1 ? 3 : (sizeof(T) == 2 ? 6 : 5));      // cell records only: the row loop's match flag (0 = not known)
     const int lane = threadIdx.x & 63;
     const int gn = d.n_rows, qlen = d.qlen, m = b.m;
     const bool local = b.align_mode == ABPOA_HIP_LOCAL_MODE;
@@ -278,7 +278,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             //      wrote on its straight-line path (0 = not known).  While a match is what the reference tries first (:130-160 with M allowed
             //      and indel_first == 0) and the flag is set, a step is ONE LDS round trip (flag, query code, the row's edge records) and a
             //      handful of scalar instructions; anything else leaves the loop for the full step below.
-            if (GAP != 0 && (cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
+            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
                 int mi_ = i, mj = j, pi_ = i, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr;
                 const int nc0 = n_cigar;
                 int slots = n_cigar == 0 ? 64 : ((64 - (n_cigar & 63)) & 63);           // words that still fit before the VGPR pair has to be written out
@@ -410,7 +410,7 @@ __device__ __forceinline__ void finish_alignment(const DevBatch &b, const AlnDes
             if (i > bt_hi || i < bt_lo) { load_window_cols(i, j); cr_row = -1; }
             if (cr_row != i) { cr = uniform4(B.rinfo[i - bt_lo]); cr2 = __builtin_amdgcn_readfirstlane(B.rinfo2[i - bt_lo]); cr_row = i; }
             // ---- match run, as in the whole-row loop above; here a row's staged cells are the column slice cr2 = first column | count << 16
-            if (GAP != 0 && (cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
+            if ((cur_op & OP_M) && indel_first == 0 && q_in_lds && cap_safe) {
                 int mi_ = i, mj = j, pi_ = i, nm_v = 0, w_lo = 0, w_hi = 0; int4 mc = cr; int mc2 = cr2;
                 const int nc0 = n_cigar;
                 int slots = n_cigar == 0 ? 64 : ((64 - (n_cigar & 63)) & 63);           // words that still fit before the VGPR pair has to be written out

@@ -211,7 +211,8 @@ int BatchStream::prepare(const abpoa_hip_scoring_t *sc, int n, const BatchShape 
         const int pn = d.bits == 16 ? 16 : 8;
         const int64_t width = (int64_t)((d.qlen + pn) / pn) * pn;
         // values per DP column in the arena: P planes (general kernel) or one padded cell record (fast loop: 4 / 8 values)
-        const int pv = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
+        // (linear gaps: one plane in the general kernel, {H, match flag} in the fast loops)
+        const int pv = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 2 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
         full_cells_[i] = width * pv * d.n_rows;
         int64_t est = banded ? std::min<int64_t>(width, 2LL * d.w + 3 * pn + 32) : width;
         // (tests: force the overflow -> full-width retry path)

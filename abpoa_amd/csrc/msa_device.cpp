@@ -183,7 +183,7 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
     const double t_begin = now_s();
     // values per DP column in an arena of score records: one padded cell record of the fast loops (4 / 8 values) = the planes of the general kernel (engine.cpp
     //  pv)
-    const int CW = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 1 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);
+    const int CW = sc->gap_mode == ABPOA_HIP_LINEAR_GAP ? 2 : (sc->gap_mode == ABPOA_HIP_AFFINE_GAP ? 4 : 8);      // (linear gaps: {H, match flag} in the fast loops, H alone in the general kernel)
     const bool unbanded = sc->wb < 0;
     // ---- sizes
     int max_reads = 0, max_qlen = 0; int64_t tot_reads = 0, tot_bases = 0, max_cap0 = 0;

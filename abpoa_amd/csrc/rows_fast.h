@@ -28,8 +28,8 @@ namespace abpoa_hip {
 // Arena format of the fast loop: one record of CW values per column -- {H, E1, F1, -} (affine) or {H, E1, E2, F1, F2, -, -, -}
 // (convex), plane id = index in the record -- so that a row chunk is ONE wide store per lane instead of 3-5 two-byte ones
 // (vector-memory instruction issue, not bytes, is what a lone wave pays for).
-// (linear gaps, GAP == 0: the record is the cell's H alone -- the same bytes as the general kernel's plane-major rows, whose backtrack walks them)
-template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 0 ? 1 : (GAP == 1 ? 4 : 8); };
+// (linear gaps, GAP == 0: {H, match flag})
+template <typename T, int GAP> struct FastFmt { static constexpr int CW = GAP == 0 ? 2 : (GAP == 1 ? 4 : 8); };
 // Direction-plane arenas (DIR = true, dir_plane.h): a row owns ONE word per column -- 2 bytes (affine) or 4 (convex) -- that records every
 // decision the backtrack takes at that cell; only rows whose scores a later reader needs from HBM (a successor beyond the LDS score ring,
 // the global best at the sink's predecessors, a row too wide for the ring) also keep their cell records, IN FRONT of the words (a row's arena
@@ -237,7 +237,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             T *cellp = H + (long long)i * CWR;
             if constexpr (CPK) { cellp[0] = (T)h; cellp[1] = (T)(i == 0 ? (int)((unsigned)(h - x1) | ((unsigned)(h - x2) << 16)) : -1); }      // (E = inf beside a real H: 0xffff)
             else if constexpr (CSP) { cellp[0] = (T)h; cellp[PL_E1] = (T)x1; if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[3] = (T)0; } }
-            else if constexpr (GAP == 0) cellp[0] = (T)h;
+            else if constexpr (GAP == 0) { cellp[0] = (T)h; cellp[1] = (T)0; }
             else {
                 cellp[0] = (T)h; cellp[PL_E1] = (T)x1; cellp[PL_F1] = (T)f1;
                 if (GAP == 2) { cellp[PL_E2] = (T)x2; cellp[PL_F2] = (T)f2; }
@@ -389,7 +389,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
                 }
             }
             const int Hout = hl;
-            if (!ABL(1)) H[rel] = (T)Hout;      // (lanes past the band write cells the next row overwrites: same wave, program order)
+            if (!ABL(1)) { if (I16) *(int *)(H + (long long)rel * CW) = Hout & 0xffff; else { int2 rec; rec.x = Hout; rec.y = 0; *(int2 *)(H + (long long)rel * CW) = rec; } }      // ({H, flag 0 = not known}; lanes past the band write cells the next row overwrites)
             if (to_ring && !ABL(2)) { int *qd = fr + my_slot + 2 + rel; qd[0] = in_band ? (I16 ? (int)(((unsigned)Hout & 0xffffu) | ((unsigned)inf << 16)) : Hout) : infw; }
             if (!ABL(4)) {
                 const bool is_end = (v == end_sn);
@@ -557,17 +557,18 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const bool in_band = lane < Wr;
         const int key_c = (vvl == nvr - 1) ? kE : kN;
         const int qd_addr = __builtin_amdgcn_readlane(vslot, ti) + 4 * lane;
-        const unsigned rec_off = (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)sizeof(T));
+        const unsigned rec_off = (unsigned)(cur * (int)(PN * sizeof(T)) + lane * (int)(CW * sizeof(T)));
         asm volatile("" :: "v"(key_c), "v"(qd_addr), "v"(rec_off));
         __builtin_amdgcn_sched_barrier(0);
-        int h = inf;
+        int h = inf, dmax = INT_MIN, kfirst = 0;      // (dmax / kfirst: the largest diagonal term and 1 + list index of the first predecessor that holds it -- the record's match flag)
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             asm volatile("" : "+v"(ra[k]), "+v"(rb[k]));
             const int hm1 = I16 ? (int)(short)ra[k] : ra[k], h0 = I16 ? (int)(short)rb[k] : rb[k];
-            const int t = imax(hm1 + q, h0 - e1);                  // (no wrap: checked below, and "inf" leaves room for q and e)
+            const int dg = hm1 + q, t = imax(dg, h0 - e1);         // (no wrap: checked below, and "inf" leaves room for q and e)
             const bool inH = (unsigned)xk[k] < (unsigned)(Wk[k] + PN);
             h = k == 0 ? (inH ? t : inf) : (inH ? imax(h, t) : h);
+            if (k == 0) { dmax = inH ? dg : INT_MIN; kfirst = 1; } else { kfirst = (inH && dg > dmax) ? k + 1 : kfirst; dmax = inH ? imax(dmax, dg) : dmax; }
         }
         const bool near_wrap = __any(in_band && h < fast_lo);
         const bool am_ok = in_band && colrel <= qlen;
@@ -594,7 +595,9 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         }
         // ---- from here on the row is committed
         off_pn = cur; cur += row_units(nvr, false);
-        *(T *)((char *)io.planes + (size_t)rec_off) = (T)Hout;     // (lanes past the band write cells the next row overwrites)
+        // {H, 1 + index of the first predecessor k (list order) with H[k][col-1] + q == H[col], 0 = none}: the backtrack's match runs (backtrack.h PL_FLAG)
+        { const int mflag = dmax == Hout ? kfirst : 0; char *const dp = (char *)io.planes + (size_t)rec_off;
+          if (I16) *(int *)dp = (int)__builtin_amdgcn_perm((unsigned)mflag, (unsigned)Hout, 0x05040100u); else { int2 rec; rec.x = Hout; rec.y = mflag; *(int2 *)dp = rec; } }
         {
             int *qd = (int *)ring_at(qd_addr, 0);
             qd[0] = in_band ? (I16 ? (int)__builtin_amdgcn_perm((unsigned)inf, (unsigned)Hout, 0x05040100u) : Hout) : infw;
