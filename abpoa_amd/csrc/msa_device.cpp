@@ -306,7 +306,11 @@ static int run_msa_device_body(const abpoa_hip_scoring_t *sc_in, int n_sets, con
             // (a set comes back to a later pass also because its ROWS were wider than the estimate -- extension mode on reads that end early, the band pushed off
             //  its anchor -- and for a set of a few reads the node slots of every pass are the same number, the sum of its reads: the later passes grow the columns
             //  with the slots, the last one takes whole rows while that stays under 1 GB per set; found by tools/fuzz_device_vs_oracle.py seed 770500103)
-            if (node_factor > 3.0) {
+            int64_t sum_len = 0; for (int r = 0; r < sets[s].n_reads; ++r) sum_len += sets[s].lens[r];
+            const bool slots_fixed = 2 + sum_len <= 2 + (int64_t)(3.0 * mx) + 1024;      // (a few reads: the 3x estimate already is the bound, no pass has more node slots or rows)
+            // (sets whose slots DO grow keep the plain estimate in passes 2 and 3: 10 kb reads at 15 % error start at 4.5x / 6x, and wider arenas would halve the
+            //  read-sets a pass holds -- configs[2] 405 -> 281 read-sets/s when this first went in for every set)
+            if (node_factor > 3.0 && (roomy || slots_fixed)) {
                 const double cellb = dir ? (double)(DB + 8) : (double)CW * (bits / 8);
                 int64_t e2 = roomy ? width : std::min<int64_t>(width, (int64_t)((double)est * node_factor / 3.0));
                 if (roomy && (double)e2 * (double)cap * cellb > 1e9) e2 = std::min<int64_t>(width, est * 4);
