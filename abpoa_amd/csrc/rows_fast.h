@@ -364,8 +364,8 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         const bool in_band = rel < Wr;
         if constexpr (GAP == 0) {
             // linear gaps (reference :762-778): Mv already is max over the predecessors of max(H[col-1] + q, H[col] - e); the in-row term runs on H itself.  Vectors that use
-            // the plain scan (up to max_pre_end_sn), while nothing can wrap: H[c] = max(prefix max of (h + c e) - c e, inf - INJ e) over the whole chunk with the carry
-            // entering at lane 0; the vectors beyond (set_num 1 / 0) and everything near the wrap limit: the literal masked scan
+            // the plain scan (up to max_pre_end_sn), while nothing can wrap: H[c] = max(prefix max of (h + c e) - c e, inf) over the whole chunk with the carry
+            // entering at lane 0 (the clamp at inf is the reference's: `first` holds inf in its lanes 1 .. pn - 1; tests/test_linear_closed_form.py); the vectors beyond (set_num 1 / 0) and everything near the wrap limit: the literal masked scan
             int hl = Mv;
             if (c == 0) first = __builtin_amdgcn_readlane(hl, 0);
             const int nvec = imin(NV, end_sn - vb + 1);
@@ -373,7 +373,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
             if (nfast > 0 && (first < fast_lo || __any(vvl < nfast && hl < fast_lo))) nfast = 0;
             if (nfast > 0) {
                 int g = hl + le1; g = lane == 0 ? imax(g, first) : g;
-                const int Hc = imax(wave_scan_max_i32(g) - le1, inj1);
+                const int Hc = imax(wave_scan_max_i32(g) - le1, inf);
                 hl = vvl < nfast ? Hc : hl;
                 first = __builtin_amdgcn_readlane(Hc, nfast * PN - 1) - e1;
             }
@@ -576,7 +576,7 @@ __device__ __forceinline__ void rows_fast(const DevBatch &b, const AlnDesc &d, c
         int aval = am_ok ? h : INT_MIN;
         int s_ = h + le1;                                          // (lane 0: its own value is the reference's `first`)
         if (I16) wave_scan2_iu(s_, akey); else wave_scan2_ii(s_, aval);
-        int Hout = imax(s_ - le1, inj1);
+        int Hout = imax(s_ - le1, inf);                             // (the reference clamps every lane at inf: `first` holds inf in its lanes 1 .. pn - 1; tests/test_linear_closed_form.py)
         if (__builtin_expect(near_wrap, 0)) return -1;
         if (SLOWV && end_sn > max_pe) {                             // vectors beyond every predecessor's band: the literal masked scan on H (set_num 1 / 0, reference :766-772)
             const int nfast = max_pe - beg_sn + 1;                  // 1 <= nfast < nvr

@@ -80,8 +80,9 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
 
     // Linear gaps (reference :762-778): the row's H is max(h, H[col-1] - e) taken vector by vector with SIMD_SET_F on H itself.  For the vectors that use the plain scan
     // (set_num == pn: up to max_pre_end_sn) and while nothing can wrap, max-plus arithmetic distributes over the whole 64-lane chunk:
-    //   H[c] = max( max_{c' <= c} (h[c'] + c' e) - c e ,  first - c e ,  inf - INJ[l] e )      (first enters at lane 0; the last lane of a vector has no injection,
-    // so the vector-to-vector carry H[pn-1] - e is the clean prefix term) -- ONE 64-lane prefix-max scan instead of 64 / pn log-step scans with a readlane between them.
+    //   H[c] = max( max_{c' <= c} (h[c'] + c' e) - c e ,  first - c e ,  inf )      (first enters at lane 0; the clamp at `inf` is the reference's: `first` holds inf in
+    // its lanes 1 .. pn - 1 and `max(H, first)` lifts those lanes before the scan, lane 0 gets inf from the scan's shifted-in lane -- NOT the affine F scan's
+    // `inf - INJ e`; tests/test_linear_closed_form.py) -- ONE 64-lane prefix-max scan instead of 64 / pn log-step scans with a readlane between them.
     // The vectors beyond every predecessor's band (set_num 1 / 0) keep the literal masked scan.
     const int le1 = lane * (int)e1;
     auto linear_h = [&](int c, int beg_sn_, int end_sn_, int max_pre_, T h, T &first) __attribute__((always_inline)) -> T {
@@ -95,7 +96,7 @@ __device__ __forceinline__ void align_one(const DevBatch &b, const AlnDesc &d, A
         if (nfast > 0) {
             int g = (int)h + le1;
             g = lane == 0 ? imax(g, (int)first) : g;
-            const int Hc = imax(wave_scan_max_i32(g) - le1, inj1);
+            const int Hc = imax(wave_scan_max_i32(g) - le1, (int)inf);      // (the clamp: see the comment above)
             if (vvl < nfast) h = (T)Hc;
             first = (T)(__builtin_amdgcn_readlane(Hc, nfast * PN - 1) - (int)e1);
         }

@@ -59,6 +59,38 @@ def test_direction_words_match_the_model(engine, monkeypatch, env):
     assert n >= 4
 
 
+@pytest.mark.parametrize("e1,wb", [(2, 10), (1, 3), (4, 2), (3, 6)], ids=["e2_b10", "e1_b3", "e4_b2", "e3_b6"])
+def test_linear_rows_plane_level_on_the_golden_graphs(engine, e1, wb):
+    """Linear gaps on the fast row loops (rows_fast.h GAP = 0) at plane level: the graphs and queries of the banded global goldens, re-scored with linear gaps
+    (reference simd_abpoa_lg_dp, src/simd_abpoa_align.c:701-779) and narrow bands -b 2 .. 10 -f 0 -- bands so tight that stretches of a row are reached by no
+    real score, where the reference's `max(H, first)` clamps every lane at `inf` (tests/test_linear_closed_form.py) -- every H cell, band, row arg-max, best
+    score, cigar and the max_pos_left/right state against the C oracle."""
+    n = 0
+    cases = []
+    for label, path in CASES:
+        if not label.split("/")[0].endswith("_gb"):
+            continue
+        g = dict(H.read_abpg(path))
+        if int(np.asarray(g["align_mode"]).reshape(-1)[0]) != 0 or int(np.asarray(g["wb"]).reshape(-1)[0]) < 0:
+            continue
+        g["gap_mode"] = np.array([0], np.int32); g["gap_open1"] = np.array([0], np.int32); g["gap_open2"] = np.array([0], np.int32)
+        g["gap_ext1"] = np.array([e1], np.int32); g["wb"] = np.array([wb], np.int32); g["wf"] = np.array([0.0], np.float32)
+        cases.append((label, H.FlatCase(g)))
+    assert len(cases) >= 10
+    outs = []
+    for i in range(0, len(cases), 16):
+        grp = [c for _, c in cases[i:i + 16] if c.sc.m == cases[i][1].sc.m]
+        if len(grp) != len(cases[i:i + 16]):      # (run_hip takes one alphabet per call)
+            for _, c in cases[i:i + 16]:
+                outs.append(H.run_hip([c])[0])
+        else:
+            outs.extend(H.run_hip(grp))
+    for (label, case), h in zip(cases, outs):
+        H.compare_outs(h, H.run_oracle(case), label=f"linear e={e1} b={wb} hip-vs-oracle {label}")
+        n += 1
+    assert n == len(cases)
+
+
 @pytest.mark.parametrize("team", ["0", "1"], ids=["one_wavefront", "team_of_four"])
 def test_local_row_loops_plane_level(engine, monkeypatch, team):
     """Both forms of the local row loop (rows_local.h) -- one wavefront with every chunk of a row in registers, and the team of four wavefronts that split
