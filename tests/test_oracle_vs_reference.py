@@ -44,6 +44,18 @@ def test_synthetic_1kb(tmp_path, gap):
     _check(tmp_path, "u", fa, g + ["-b", "-1"], "4")
 
 
+@pytest.mark.parametrize("e1,wb", [(2, 10), (1, 3), (4, 2), (3, 6)], ids=["e2_b10", "e1_b3", "e4_b2", "e3_b6"])
+def test_linear_gaps_with_narrow_bands(tmp_path, e1, wb):
+    """Linear gaps with bands of -b 2 .. 10 -f 0: rows with stretches no real score reaches (the reference clamps those lanes at `inf`, src/simd_abpoa_align.c:773-775) --
+    the regime of tests/test_gpu_parity.py::test_linear_rows_plane_level_on_the_golden_graphs, which compares the fast row loops with this oracle."""
+    g = ["-O", "0,0", "-E", str(e1), "-b", str(wb), "-f", "0"]
+    _check(tmp_path, "seq", os.path.join(H.REFERENCE_TREE, "test_data/seq.fa"), g, "all")
+    _check(tmp_path, "het", os.path.join(H.REFERENCE_TREE, "test_data/heter.fa"), g, "2,7,14")
+    fa = str(tmp_path / "s.fa")
+    synth.write_fasta(fa, synth.make_read_set(17, 2, 8, 700, 0.12))
+    _check(tmp_path, "syn", fa, g, "3,7")
+
+
 def test_synthetic_10kb_int32(tmp_path):
     fa = str(tmp_path / "s.fa")
     synth.write_fasta(fa, synth.make_read_set(11, 0, 9, 10000, 0.15))
