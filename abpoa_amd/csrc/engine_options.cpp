@@ -32,6 +32,7 @@ const Row kTable[] = {
     {"ABPOA_HIP_RING_ROWS", "T  depth of the wide loop's score ring (4 | 8 | 16)"},
     {"ABPOA_HIP_EXTRA_ROUTE_MIN", "T  ragged sets with fewer extra columns keep the narrow loop"},
     {"ABPOA_HIP_NO_RAGGED_SPLIT", "T  1: read-sets with ragged read ends stay in the batch of the uniform ones (no all-rounds kernel for such a job)"},
+    {"ABPOA_HIP_RAGGED_CONCURRENT", "T  1: the ragged batch of a mixed job runs on a second queue of the device beside the uniform batch (measured: see LOG.md)"},
     {"ABPOA_HIP_PASS_SETS", "T  read-sets per pass of the device-resident driver"},
     {"ABPOA_HIP_FIRST_PASS", "T  start the node-slot ladder at pass 1 / 2 / 3 (profiling runs of one step)"},
     {"ABPOA_HIP_NO_PASS_HINT", "T  1: always start the ladder at 3x"},

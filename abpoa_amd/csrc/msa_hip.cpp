@@ -275,8 +275,10 @@ int msa_batch_impl(const abpoa_hip_scoring_t *sc_in, int n_sets, const abpoa_hip
         std::vector<int> devs = device_list();
         if ((int)devs.size() > CTX_SLOT_LO) devs.resize(CTX_SLOT_LO);
         if (ctx_slot >= 0) devs.assign(1, ctx_device);      // a context: its own device, its own queue
-        const int n_q = (int)devs.size();
+        int n_q = (int)devs.size();
         const std::vector<std::vector<int>> batches = deal_batches(sc, sets, n_sets, n_q);
+        // (experiment, ABPOA_HIP_RAGGED_CONCURRENT=1: the ragged batch of a mixed job on a second queue of the same device, beside the uniform batch's all-rounds kernel)
+        if (n_q == 1 && ctx_slot < 0 && batches.size() == 2 && env_on("ABPOA_HIP_RAGGED_CONCURRENT")) { devs.push_back(devs[0]); n_q = 2; }
         std::atomic<int> next{0};
         std::vector<PassOut> results(batches.size());
         std::vector<double> q_busy(n_q, 0.0);

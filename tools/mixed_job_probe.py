@@ -20,11 +20,11 @@ for i in range(n):
 p = api.Params(gap_open1=4, gap_open2=0, gap_ext1=2)
 enc = api.EncodedSets(sets, p.m)
 keep = None
-for split in (1, 0):
-    os.environ["ABPOA_HIP_NO_RAGGED_SPLIT"] = "0" if split else "1"
+for split in (1, 0, 2):      # 2: the ragged batch on a second queue of the device (ABPOA_HIP_RAGGED_CONCURRENT=1)
+    os.environ["ABPOA_HIP_NO_RAGGED_SPLIT"] = "0" if split else "1"; os.environ["ABPOA_HIP_RAGGED_CONCURRENT"] = "1" if split == 2 else "0"
     api.msa_batch(None, p, encoded=enc, n_threads=16)
     t = time.time(); r = api.msa_batch(None, p, encoded=enc, n_threads=16); dt = time.time() - t
-    print(f"{'ragged sets apart' if split else 'one batch        '} {n / dt:8.1f} read-sets/s  n_host_sets {api.msa_timing()['n_host_sets']}  all-rounds launches {ffi.stats()['rounds_launches']}", flush=True)
+    print(f"{('one batch        ', 'ragged sets apart', 'apart, two queues')[split]} {n / dt:8.1f} read-sets/s  n_host_sets {api.msa_timing()['n_host_sets']}  all-rounds launches {ffi.stats()['rounds_launches']}", flush=True)
     cons = [x.cons_seq for x in r]
     if keep is None: keep = cons
     else: print("   same consensus:", keep == cons)
