@@ -33,6 +33,8 @@ def build_parser():
     ap.add_argument("-E", "--gap-ext", default="2,1")
     ap.add_argument("-b", "--extra-b", type=int, default=10)
     ap.add_argument("-f", "--extra-f", type=float, default=0.01)
+    ap.add_argument("-z", "--zdrop", type=int, default=-1)
+    ap.add_argument("-e", "--bonus", type=int, default=-1)      # (accepted; as in the reference, nothing in the DP reads it)
     ap.add_argument("-c", "--amino-acid", action="store_true")
     ap.add_argument("-l", "--in-list", action="store_true")
     ap.add_argument("-o", "--output", default=None)
@@ -51,7 +53,7 @@ def main(argv=None, lib=None, out=None):
     o1, o2 = _pair(a.gap_open, 24)
     e1, e2 = _pair(a.gap_ext, 1)
     params = api.Params(aln_mode=a.aln_mode, is_aa=a.amino_acid, match=a.match, mismatch=a.mismatch, score_matrix=a.matrix,
-                        gap_open1=o1, gap_open2=o2, gap_ext1=e1, gap_ext2=e2, extra_b=a.extra_b, extra_f=a.extra_f)
+                        gap_open1=o1, gap_open2=o2, gap_ext1=e1, gap_ext2=e2, extra_b=a.extra_b, extra_f=a.extra_f, zdrop=a.zdrop)
     files = [ln.strip() for ln in open(a.input) if ln.strip()] if a.in_list else [a.input]
     names, sets, weights = [], [], []
     sticky = {}      # a nameless record shows the last name seen at its position in an earlier file of the list (the reference's abpoa_seq_t lives across the files: src/abpoa_seq.c:123-130)

@@ -13,12 +13,13 @@
  *   abpoa_batch [options] <in.fa|in.fq|list.txt>      (plain or gzip'ed; FASTA / FASTQ)
  *     -m INT   0 global, 1 local, 2 extension          -M INT match [2]      -X INT mismatch [4]      -t FILE score matrix
  *     -O INT[,INT] gap open [4,24]   -E INT[,INT] gap extension [2,1]   -b INT [10] / -f FLOAT [0.01] adaptive band (b < 0: off)
+ *     -z INT z-drop of extension mode [-1: off]   -e INT end bonus (accepted; as in the reference, nothing in the DP reads it)
  *     -c amino acids   -l the input is a list of files   -o FILE output [stdout]   -r INT 0 consensus, 1 MSA, 2 both
  *     -s ambiguous strand   -Q base qualities as edge weights   -T INT host threads [all]   -v version
  *     --piece INT files per GPU call with -l [2048]   --readers INT reader threads [8]      (no reference counterpart)
  * Degenerate inputs as the reference treats them: a file without records prints nothing; a record without bases after the first one is an MSA row
  * of gaps and adds nothing to the graph; a first record without bases ends the run as abpoa_add_graph_sequence does (src/abpoa_graph.c:487).
- * Options of the reference that the engine does not cover (-S -k -w -n -p -i -g -d -q -z -e, -r 3/4/5) are refused, not ignored.
+ * Options of the reference that the engine does not cover (-S -k -w -n -p -i -g -d -q, -r 3/4/5) are refused, not ignored.
  *
  * Plain C99 + zlib; links against libabpoa_hip.so only.  Own code throughout: no klib / kseq.
  */
@@ -218,7 +219,7 @@ int main(int argc, char **argv) {
     const int timing = getenv("ABPOA_BATCH_TIMING") != NULL;      /* per piece on stderr: wait for the readers, the batch call, output */
     const double t_start = now_s();
     int mode = 0, match = 2, mismatch = 4, o1 = 4, o2 = 24, e1 = 2, e2 = 1, wb = 10, m = 5, in_list = 0, out_cons = 1, out_msa = 0, amb = 0, use_qv = 0, threads = 0, c;
-    int piece_sets = 2048, readers = 8;
+    int piece_sets = 2048, readers = 8, zdrop = -1;
     float wf = 0.01f; const char *mat_fn = NULL; char *s;
     while ((c = getopt_long(argc, argv, "m:M:X:t:O:E:b:f:z:e:QSk:w:n:i:clpso:r:g:d:q:T:hvV:", long_opt, NULL)) >= 0) {
         switch (c) {
@@ -230,6 +231,8 @@ int main(int argc, char **argv) {
             case 'E': e1 = (int)strtol(optarg, &s, 10); if (*s == ',') e2 = (int)strtol(s + 1, &s, 10); break;
             case 'b': wb = atoi(optarg); break;
             case 'f': wf = (float)atof(optarg); break;
+            case 'z': zdrop = atoi(optarg); break;      /* extension mode: the row loop ends when the row maximum falls this far below the best one (ref src/simd_abpoa_align.c:1018-1026) */
+            case 'e': break;                            /* end bonus: parsed by the reference, read by nothing in its DP (ref src/simd_abpoa_align.c:1069 "TODO") */
             case 'Q': use_qv = 1; break;
             case 'c': m = 27; break;
             case 'l': in_list = 1; break;
@@ -242,8 +245,8 @@ int main(int argc, char **argv) {
                         else { fprintf(stderr, "abpoa_batch: -r %d (GFA / FASTQ output) is outside this engine\n", r); return 2; } } break;
             case 'v': printf("abpoa_batch (MI355X engine; output of abPOA 1.4.1)\n"); return 0;
             case 'V': break;
-            case 'h': fprintf(stderr, "usage: abpoa_batch [-m -M -X -t -O -E -b -f -c -l -o -r -s -Q -T --piece --readers] <in.fa|in.fq|list.txt>   (see the head of abpoa_batch.c)\n"); return 1;
-            default: fprintf(stderr, "abpoa_batch: option -%c is outside this engine (seeding, guide tree, incremental graphs, plots, multiple consensus, z-drop)\n", c); return 2;
+            case 'h': fprintf(stderr, "usage: abpoa_batch [-m -M -X -t -O -E -b -f -z -e -c -l -o -r -s -Q -T --piece --readers] <in.fa|in.fq|list.txt>   (see the head of abpoa_batch.c)\n"); return 1;
+            default: fprintf(stderr, "abpoa_batch: option -%c is outside this engine (seeding, guide tree, incremental graphs, plots, multiple consensus)\n", c); return 2;
         }
     }
     if (argc - optind != 1) { fprintf(stderr, "usage: abpoa_batch [options] <in.fa|in.fq|list.txt>\n"); return 1; }
@@ -258,7 +261,7 @@ int main(int argc, char **argv) {
     sc.m = m; sc.mat = mat; sc.max_mat = max_mat; sc.min_mis = min_mis;
     sc.gap_open1 = o1; sc.gap_ext1 = e1; sc.gap_open2 = o2; sc.gap_ext2 = e2;
     sc.align_mode = mode; sc.gap_mode = o1 == 0 ? ABPOA_HIP_LINEAR_GAP : ((o1 > 0 && o2 == 0) ? ABPOA_HIP_AFFINE_GAP : ABPOA_HIP_CONVEX_GAP);
-    sc.wb = mode == ABPOA_HIP_LOCAL_MODE ? -1 : wb; sc.wf = wf; sc.zdrop = -1; sc.ret_cigar = 1; sc.rev_cigar = 0;
+    sc.wb = mode == ABPOA_HIP_LOCAL_MODE ? -1 : wb; sc.wf = wf; sc.zdrop = zdrop; sc.ret_cigar = 1; sc.rev_cigar = 0;
     const unsigned flags = (out_cons ? ABPOA_HIP_OUT_CONS : 0u) | (out_msa ? ABPOA_HIP_OUT_MSA : 0u) | (amb ? ABPOA_HIP_AMB_STRAND : 0u);
 
     FILE *lf = in_list ? fopen(argv[optind], "r") : NULL;

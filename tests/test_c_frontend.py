@@ -91,9 +91,10 @@ def test_c_front_end_list_is_one_batch_and_equals_the_reference_cli(tmp_path):
     if not os.path.exists(REF):
         pytest.skip("compiled reference not present: the golden outputs above are the check")
     job = _list_job(tmp_path)
-    for opts in (["-O", "4,0", "-E", "2"], ["-r", "2"], ["-r", "1", "-b", "20", "-f", "0.05"]):
+    # (-z: the z-drop of extension mode, reference src/simd_abpoa_align.c:1018-1026; -e: the end bonus, which the reference parses and nothing in its DP reads)
+    for opts in (["-O", "4,0", "-E", "2"], ["-r", "2"], ["-r", "1", "-b", "20", "-f", "0.05"], ["-m", "2", "-z", "10", "-r", "2"], ["-m", "2", "-z", "40", "-e", "7", "-O", "0,0", "-E", "3"]):
         ref = subprocess.run([REF] + opts + ["-l", job], capture_output=True, text=True, timeout=600)
-        assert ref.returncode == 0
+        assert ref.returncode == 0, (opts, ref.stderr[-300:])
         assert _run(exe, opts + ["-l", job]) == ref.stdout, opts
 
 
