@@ -135,3 +135,59 @@ def test_against_reference_cli(tmp_path, opts, pk, kw):
         names = [f"r{i}" for i in range(n)]
         r = api.msa_batch([reads], api.Params(**pk), lib=H.cpu_shim_lib(), **kw)[0]
         assert api.format_output(r, names, kw.get("out_cons", True), kw.get("out_msa", False)) == exp
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="reference build not available")
+def test_seeded_sweep_of_the_oracle_backed_host_layer_against_the_reference_cli(tmp_path):
+    """What the GPU fuzz sweeps compare the device with -- the CPU build of the host layer with the oracle as its aligner -- against the compiled reference
+    binary on the same kind of option / shape mixes (tools/fuzz_device_vs_oracle.py: nucleotides or amino acids, linear / affine / convex gaps, global /
+    local / extension mode, band on / off / narrow, z-drop, -s), output text byte for byte (`-r 2`: MSA rows and consensus).  An input on which the
+    reference itself fails (its backtrack after a z-drop break) is skipped and counted."""
+    import numpy as np
+    from abpoa_amd import workloads
+    ref_bin = os.path.join(H.REF_DIR, "abpoa_ref")
+    comp = str.maketrans("ACGTN", "TGCAN")
+    n_ok = n_ref_failed = 0
+    for it in range(160):
+        rng = np.random.default_rng(9100 + it)
+        aa = rng.random() < 0.2
+        n = int(rng.integers(2, 26)); ln = int(rng.integers(40, 700)); err = float(rng.uniform(0.01, 0.15))
+        reads = list(synth.make_read_set(9100 + it, 0, n, ln, alphabet=synth.AA, rates=(err, err / 3, err / 3))) if aa else list(synth.make_read_set(9100 + it, 0, n, ln, err))
+        if rng.random() < 0.4:      # ragged ends
+            reads = [reads[0]] + [r[int(rng.integers(0, len(r) // 8 + 1)):len(r) - int(rng.integers(0, len(r) // 8 + 1))] for r in reads[1:]]
+        gap = [dict(gap_open1=0, gap_open2=0, gap_ext1=int(rng.integers(1, 5))), dict(gap_open1=int(rng.integers(2, 12)), gap_open2=0, gap_ext1=int(rng.integers(1, 4))), dict(),
+               dict(gap_open1=int(rng.integers(3, 8)), gap_open2=int(rng.integers(12, 40)), gap_ext1=int(rng.integers(2, 4)), gap_ext2=1)][int(rng.integers(0, 4))]
+        mode = int(rng.integers(0, 3))
+        kw = dict(gap, aln_mode=mode)
+        if mode != 1:
+            r_ = rng.random()
+            if r_ < 0.2:
+                kw["extra_b"] = -1
+            elif r_ < 0.5:
+                kw.update(extra_b=int(rng.integers(2, 60)), extra_f=float(rng.choice([0.0, 0.01, 0.03])))
+        if mode == 2 and rng.random() < 0.4:
+            kw["zdrop"] = int(rng.integers(10, 100))
+        amb = (not aa) and rng.random() < 0.3
+        if amb:
+            reads = [(r[::-1].translate(comp) if (j and rng.random() < 0.3) else r) for j, r in enumerate(reads)]
+        p = api.Params(is_aa=True, score_matrix=workloads.BLOSUM62, **kw) if aa else api.Params(**kw)
+        opts = ["-m", str(mode), "-O", f"{p.gap_open1},{p.gap_open2}", "-E", f"{p.gap_ext1},{p.gap_ext2}", "-b", str(kw.get("extra_b", 10)), "-f", str(kw.get("extra_f", 0.01)), "-r", "2"]
+        if "zdrop" in kw:
+            opts += ["-z", str(kw["zdrop"])]
+        if aa:
+            opts += ["-c", "-t", workloads.BLOSUM62]
+        if amb:
+            opts += ["-s"]
+        fa = str(tmp_path / f"f{it}.fa")
+        synth.write_fasta(fa, reads)
+        ref = subprocess.run([ref_bin] + opts + [fa], capture_output=True, text=True, timeout=300)
+        r = api.msa_batch([reads], p, out_cons=True, out_msa=True, lib=H.cpu_shim_lib(), n_threads=2, amb_strand=amb)[0]
+        if ref.returncode != 0:
+            n_ref_failed += 1
+            assert r.status != 0, (it, opts, "the reference fails on this input, the host layer does not")
+            continue
+        assert r.status == 0, (it, opts, r.status)
+        assert api.format_output(r, [f"r{i}" for i in range(len(reads))], True, True) == ref.stdout, (it, opts, [len(x) for x in reads])
+        n_ok += 1
+    print(f"sweep: {n_ok} outputs identical to abpoa_ref, {n_ref_failed} inputs on which the reference itself fails")
+    assert n_ok >= 140 and n_ref_failed <= 20, (n_ok, n_ref_failed)
