@@ -50,6 +50,9 @@ class msa_aligner:
                                  extra_b=extra_b, extra_f=extra_f)
         self._lib = _lib
 
+    def __bool__(self):      # (reference pyabpoa.pyx:142-143: the aligner exists)
+        return True
+
     def _wrap(self, seqs, r, out_cons, out_msa):
         n = len(seqs)
         if r.status != 0:
