@@ -34,6 +34,22 @@ class msa_result:
             print(s)
 
 
+def set_seq_int_dict(m):
+    """(letter -> code, code -> letter) as the reference binding's helper of the same name gives them (pyabpoa.pyx:69-86): both cases of every letter of the
+    alphabet, U as T; unknown letters map to the last code m - 1, unknown codes to '-'.  Built from this package's own tables (seqio.py)."""
+    from collections import defaultdict
+    from . import seqio
+    if m not in (5, 27):
+        raise Exception('Unexpected m: {}'.format(m))
+    letters = (seqio.NT_DECODE if m == 5 else seqio.AA_DECODE)[:m]
+    seq2int, int2seq = defaultdict(lambda: m - 1), defaultdict(lambda: '-')
+    for code, ch in enumerate(letters):
+        seq2int[ch] = code; seq2int[ch.lower()] = code; int2seq[code] = ch
+    if m == 5:
+        seq2int['U'] = seq2int['u'] = seq2int['T']
+    return seq2int, int2seq
+
+
 class msa_aligner:
     def __init__(self, aln_mode='g', is_aa=False, match=2, mismatch=4, score_matrix=b'', gap_open1=4, gap_open2=24,
                  gap_ext1=2, gap_ext2=1, extra_b=10, extra_f=0.01, _lib=None):

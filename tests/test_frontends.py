@@ -94,3 +94,16 @@ def test_cli_list_mode_is_one_batch(tmp_path):
 
 def test_cli_refuses_unsupported_output_modes():
     assert cli.main(["-r", "3", os.path.join(D, "data", "seq.fa")], lib=H.cpu_shim_lib(), out=io.StringIO()) == 2
+
+
+def test_pyabpoa_set_seq_int_dict():
+    """The binding's module-level helper (reference python/pyabpoa.pyx:69-86): codes of both cases, U as T, defaults for unknown letters / codes."""
+    from abpoa_amd import pyabpoa as pa
+    s2i, i2s = pa.set_seq_int_dict(5)
+    assert [s2i[c] for c in "ACGTNacgtnUu"] == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 3, 3] and s2i["X"] == 4 and i2s[3] == "T" and i2s[9] == "-"
+    s2i, i2s = pa.set_seq_int_dict(27)
+    assert "".join(i2s[i] for i in range(27)) == "ACGTNBDEFHIJKLMOPQRSUVWXYZ*" and s2i["w"] == s2i["W"] == 22 and s2i["?"] == 26 and i2s[30] == "-"
+    import pytest
+    with pytest.raises(Exception):
+        pa.set_seq_int_dict(4)
+    assert bool(pa.msa_aligner(_lib=object()))
