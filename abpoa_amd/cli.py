@@ -47,8 +47,8 @@ def build_parser():
 
 def main(argv=None, lib=None, out=None):
     a = build_parser().parse_args(argv)
-    if a.result not in (0, 1, 2):
-        sys.stderr.write("abpoa_amd: -r %d (GFA / FASTQ output) is outside this engine\n" % a.result)
+    if a.result not in (0, 1, 2, 5):
+        sys.stderr.write("abpoa_amd: -r %d (GFA output) is outside this engine\n" % a.result)
         return 2
     o1, o2 = _pair(a.gap_open, 24)
     e1, e2 = _pair(a.gap_ext, 1)
@@ -67,7 +67,7 @@ def main(argv=None, lib=None, out=None):
         names.append(n)
         sets.append(s)
         weights.append([seqio.qv_weights(x, y) for x, y in zip(s, q)])
-    out_cons, out_msa = a.result in (0, 2), a.result in (1, 2)
+    out_cons, out_msa, out_fq = a.result in (0, 2, 5), a.result in (1, 2), a.result == 5
     res = api.msa_batch(sets, params, out_cons=out_cons, out_msa=out_msa, n_threads=a.threads, lib=lib,
                         weights=weights if a.use_qual_weight else None, amb_strand=a.amb_strand)
     sink = out or (open(a.output, "w") if a.output else sys.stdout)
@@ -76,7 +76,15 @@ def main(argv=None, lib=None, out=None):
             if r.status != 0:
                 sys.stderr.write("abpoa_amd: alignment failed (status %d)\n" % r.status)
                 return 1
-            sink.write(api.format_output(r, n, out_cons, out_msa))
+            txt = api.format_output(r, n, out_cons, out_msa)
+            if out_fq and r.cons_len > 0:      # -r 5: the consensus as FASTQ, a quality per base from its coverage (reference src/abpoa_output.c:270-276, :516-525)
+                import math
+                q = []
+                for cov in r.cons_cov:
+                    x = 13.8 * (1.25 * cov / len(n) - 0.25); pe = 1 - 1.0 / (1.0 + math.pow(2.718281828459045, -1 * x))
+                    q.append(chr(33 + int(-10 * math.log10(pe) + 0.499)))
+                txt = "@" + txt[1:] + "+Consensus_sequence\n" + "".join(q) + "\n"
+            sink.write(txt)
     finally:
         if a.output and not out:
             sink.close()

@@ -14,16 +14,17 @@
  *     -m INT   0 global, 1 local, 2 extension          -M INT match [2]      -X INT mismatch [4]      -t FILE score matrix
  *     -O INT[,INT] gap open [4,24]   -E INT[,INT] gap extension [2,1]   -b INT [10] / -f FLOAT [0.01] adaptive band (b < 0: off)
  *     -z INT z-drop of extension mode [-1: off]   -e INT end bonus (accepted; as in the reference, nothing in the DP reads it)
- *     -c amino acids   -l the input is a list of files   -o FILE output [stdout]   -r INT 0 consensus, 1 MSA, 2 both
+ *     -c amino acids   -l the input is a list of files   -o FILE output [stdout]   -r INT 0 consensus, 1 MSA, 2 both, 5 consensus as FASTQ
  *     -s ambiguous strand   -Q base qualities as edge weights   -T INT host threads [all]   -v version
  *     --piece INT files per GPU call with -l [2048]   --readers INT reader threads [8]      (no reference counterpart)
  * Degenerate inputs as the reference treats them: a file without records prints nothing; a record without bases after the first one is an MSA row
  * of gaps and adds nothing to the graph; a first record without bases ends the run as abpoa_add_graph_sequence does (src/abpoa_graph.c:487).
- * Options of the reference that the engine does not cover (-S -k -w -n -p -i -g -d -q, -r 3/4/5) are refused, not ignored.
+ * Options of the reference that the engine does not cover (-S -k -w -n -p -i -g -d -q, -r 3/4) are refused, not ignored.
  *
  * Plain C99 + zlib; links against libabpoa_hip.so only.  Own code throughout: no klib / kseq.
  */
 #include <getopt.h>
+#include <math.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -219,7 +220,7 @@ int main(int argc, char **argv) {
     const int timing = getenv("ABPOA_BATCH_TIMING") != NULL;      /* per piece on stderr: wait for the readers, the batch call, output */
     const double t_start = now_s();
     int mode = 0, match = 2, mismatch = 4, o1 = 4, o2 = 24, e1 = 2, e2 = 1, wb = 10, m = 5, in_list = 0, out_cons = 1, out_msa = 0, amb = 0, use_qv = 0, threads = 0, c;
-    int piece_sets = 2048, readers = 8, zdrop = -1;
+    int piece_sets = 2048, readers = 8, zdrop = -1, out_fq = 0;
     float wf = 0.01f; const char *mat_fn = NULL; char *s;
     while ((c = getopt_long(argc, argv, "m:M:X:t:O:E:b:f:z:e:QSk:w:n:i:clpso:r:g:d:q:T:hvV:", long_opt, NULL)) >= 0) {
         switch (c) {
@@ -242,7 +243,8 @@ int main(int argc, char **argv) {
             case 1002: readers = atoi(optarg); break;
             case 'o': if (strcmp(optarg, "-") != 0 && freopen(optarg, "wb", stdout) == NULL) DIE("failed to open the output file %s", optarg); break;
             case 'r': { const int r = atoi(optarg); if (r == 0) { out_cons = 1; out_msa = 0; } else if (r == 1) { out_cons = 0; out_msa = 1; } else if (r == 2) { out_cons = out_msa = 1; }
-                        else { fprintf(stderr, "abpoa_batch: -r %d (GFA / FASTQ output) is outside this engine\n", r); return 2; } } break;
+                        else if (r == 5) { out_cons = 1; out_msa = 0; out_fq = 1; }      /* consensus as FASTQ: a quality per base from its coverage */
+                        else { fprintf(stderr, "abpoa_batch: -r %d (GFA output) is outside this engine\n", r); return 2; } } break;
             case 'v': printf("abpoa_batch (MI355X engine; output of abPOA 1.4.1)\n"); return 0;
             case 'V': break;
             case 'h': fprintf(stderr, "usage: abpoa_batch [-m -M -X -t -O -E -b -f -z -e -c -l -o -r -s -Q -T --piece --readers] <in.fa|in.fq|list.txt>   (see the head of abpoa_batch.c)\n"); return 1;
@@ -334,8 +336,16 @@ int main(int argc, char **argv) {
                     put_codes(o->msa_base + (size_t)n_kept[i] * o->msa_len, o->msa_len, letter);
                 }
             } else if (out_cons && o->cons_len > 0) {                    /* (abpoa_output_fx_consensus prints nothing without a consensus) */
-                printf(">Consensus_sequence\n");
+                printf(out_fq ? "@Consensus_sequence\n" : ">Consensus_sequence\n");
                 put_codes(o->cons_base, o->cons_len, letter);
+                if (out_fq) {      /* -r 5 (ref src/abpoa_output.c:270-276, :516-525): phred + 33 of a logistic in the share of the reads that pass through the base */
+                    printf("+Consensus_sequence\n");
+                    for (int j = 0; j < o->cons_len; ++j) {
+                        const double x = 13.8 * (1.25 * o->cons_cov[j] / r->n - 0.25), pe = 1 - 1.0 / (1.0 + pow(2.718281828459045, -1 * x));
+                        putchar(33 + (int)(-10 * log10(pe) + 0.499));
+                    }
+                    putchar('\n');
+                }
             }
         }
         if (timing) fprintf(stderr, "[abpoa_batch] piece of %d files at %.2f s: waited %.2f s for the readers, batch call %.2f s, output %.2f s\n", cur->n, t0 - t_start, t1 - t0, t2 - t1,

@@ -119,7 +119,13 @@ def cases(tmp):
             f.write(f"@q{i}\n{r}\n+\n{q}\n")
     out.append(("out_qv_cons", qfq, AG + ["-Q"], "none", 0, None))
     out.append(("out_qv_msa", qfq, ["-Q", "-r", "2"], "none", 0, None))
+    # -r 5: the consensus as FASTQ (a quality per base from its coverage, reference src/abpoa_output.c:270-276)
+    out.append(("out_fq_seq", seq, AG + ["-r", "5"], "none", 0, None))
+    out.append(("out_fq_heter", het, ["-r", "5"], "none", 0, None))
     return out
+
+
+ONLY = set(sys.argv[1:])      # (names given on the command line: only those containers are rewritten)
 
 
 def main():
@@ -128,7 +134,9 @@ def main():
     tmp = tempfile.mkdtemp()
     for name, fa, opts, reads, planes, sub in cases(tmp):
         d = os.path.join(tmp, name)
-        if name.startswith(("out_rc_", "out_qv_")):      # options the dump harness does not parse: the reference's own command line prints the text
+        if ONLY and name not in ONLY:
+            continue
+        if name.startswith(("out_rc_", "out_qv_", "out_fq_")):      # options the dump harness does not parse: the reference's own command line prints the text
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, "output.txt"), "w") as fo:
                 subprocess.run([os.path.join(H.REF_DIR, "abpoa_ref")] + opts + [fa], stdout=fo, check=True)

@@ -28,7 +28,7 @@ def _cpu_binary():
     exe, src = os.path.join(bdir, "abpoa_batch_cpu"), os.path.join(ROOT, "abpoa_amd", "host", "abpoa_batch.c")
     shim = os.path.join(bdir, "libcpu_shim.so")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(shim)):
-        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-L" + bdir, "-lcpu_shim", "-lz", "-lpthread",
+        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-L" + bdir, "-lcpu_shim", "-lz", "-lpthread", "-lm",
                                "-Wl,-rpath," + bdir])
     return exe
 
@@ -44,6 +44,8 @@ CASES = [
     (["-r", "1", os.path.join(D, "data", "test.fa")], "out_test_msa"),
     (["-r", "2", os.path.join(D, "data", "test.fa")], "out_test_cons_msa"),
     ([os.path.join(D, "data", "heter.fa")], "out_heter_cons"),
+    (["-O", "4,0", "-E", "2", "-r", "5", os.path.join(D, "data", "seq.fa")], "out_fq_seq"),             # the consensus as FASTQ (reference src/abpoa_output.c:270-276, :516-525)
+    (["-r", "5", os.path.join(D, "data", "heter.fa")], "out_fq_heter"),
     (["-m", "1", "-c", "-t", BLOSUM, "-r", "1", os.path.join(D, "aa_blosum_loc", "input.fa")], "aa_blosum_loc"),
     (["-O", "4,0", "-E", "2", "-Q", os.path.join(D, "out_qv_cons", "input.fq")], "out_qv_cons"),
     (["-O", "4,0", "-E", "2", "-Q", "-r", "2", os.path.join(D, "out_qv_msa", "input.fq")], "out_qv_msa"),
@@ -92,7 +94,8 @@ def test_c_front_end_list_is_one_batch_and_equals_the_reference_cli(tmp_path):
         pytest.skip("compiled reference not present: the golden outputs above are the check")
     job = _list_job(tmp_path)
     # (-z: the z-drop of extension mode, reference src/simd_abpoa_align.c:1018-1026; -e: the end bonus, which the reference parses and nothing in its DP reads)
-    for opts in (["-O", "4,0", "-E", "2"], ["-r", "2"], ["-r", "1", "-b", "20", "-f", "0.05"], ["-m", "2", "-z", "10", "-r", "2"], ["-m", "2", "-z", "40", "-e", "7", "-O", "0,0", "-E", "3"]):
+    for opts in (["-O", "4,0", "-E", "2"], ["-r", "2"], ["-r", "1", "-b", "20", "-f", "0.05"], ["-m", "2", "-z", "10", "-r", "2"], ["-m", "2", "-z", "40", "-e", "7", "-O", "0,0", "-E", "3"],
+                 ["-r", "5"], ["-r", "5", "-O", "4,0", "-E", "2", "-m", "1"]):      # (-r 5: the consensus as FASTQ, a quality per base from its coverage, reference src/abpoa_output.c:270-276)
         ref = subprocess.run([REF] + opts + ["-l", job], capture_output=True, text=True, timeout=600)
         assert ref.returncode == 0, (opts, ref.stderr[-300:])
         assert _run(exe, opts + ["-l", job]) == ref.stdout, opts
@@ -178,7 +181,7 @@ def test_c_front_end_streams_the_list_in_pieces(tmp_path):
 def test_c_front_end_refuses_what_the_engine_does_not_build():
     exe = _cpu_binary()
     seq = os.path.join(D, "data", "seq.fa")
-    for bad in (["-r", "3"], ["-S"], ["-d", "2"], ["-p"]):
+    for bad in (["-r", "3"], ["-r", "4"], ["-S"], ["-d", "2"], ["-p"]):
         p = subprocess.run([exe] + bad + [seq], capture_output=True, text=True, timeout=60)
         assert p.returncode == 2 and "outside this engine" in p.stderr and p.stdout == ""
 

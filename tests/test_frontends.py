@@ -82,6 +82,8 @@ def test_cli_matches_reference_outputs():
     assert _cli(["-r", "1", test]) == _golden("out_test_msa")
     assert _cli(["-r", "2", test]) == _golden("out_test_cons_msa")
     assert _cli([heter]) == _golden("out_heter_cons")
+    assert _cli(["-O", "4,0", "-E", "2", "-r", "5", seq]) == _golden("out_fq_seq")      # the consensus as FASTQ: a quality per base from its coverage (reference src/abpoa_output.c:270-276)
+    assert _cli(["-r", "5", heter]) == _golden("out_fq_heter")
     assert _cli(["-m", "1", "-c", "-t", os.path.join(D, "data", "BLOSUM62.mtx"), "-r", "1", os.path.join(D, "aa_blosum_loc", "input.fa")]) == _golden("aa_blosum_loc")
 
 
